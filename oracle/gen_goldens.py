@@ -1,0 +1,301 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference (never shipped, never read at test
+time), drives it with oracle/detrand.py inputs and oracle/params.py weights loaded via
+``load_state_dict``, and stores *outputs only* (the inputs are regenerated from seeds).
+Two shims: ``Tensor.cuda``/``Module.cuda`` become the identity,
+because dsmil.py and rlmil.py hard-code ``.cuda()``.
+
+    python -m oracle.gen_goldens        # from the repo root
+"""
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+sys.path.insert(0, REF)
+from models import abmil as r_abmil, clam as r_clam, dsmil as r_dsmil, cl as r_cl, rlmil as r_rlmil  # noqa: E402
+from utils import losses as r_losses, datasets as r_datasets  # noqa: E402
+sys.path.pop(0)
+
+from oracle import detrand, params as P  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+T = torch.from_numpy
+
+
+def _summ(g):
+    """Fingerprint of a tensor: L2 norm, max |.|, first 32 values."""
+    g = g.detach().double().flatten()
+    return np.concatenate([[g.norm().item(), g.abs().max().item()], g[:32].numpy()])
+
+
+def g1_abmil():
+    seed, B, N, d = 985, 4, 256, 512
+    m = r_abmil.ABMIL(d, L=512, D=128, dim_out=128)
+    m.load_state_dict(P.to_torch(P.abmil(seed)))
+    x = T(P.bags(seed, "g1.x", B, N, d))
+    out, det = m(x)
+    out.sum().backward()
+    # attention weights: re-run the reference's own sub-modules per bag
+    A = []
+    with torch.no_grad():
+        for b in range(B):
+            H = m.encoder(x[b])
+            a = torch.softmax(m.attention(H).t(), dim=1)
+            A.append(a / np.sqrt(a.shape[-1]))
+    res = {"out": out.detach().numpy(), "A": torch.cat(A).numpy()}
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _summ(v.grad)
+    # single-bag path (x.shape[0]==1 branch, abmil.py:57-58)
+    o1, _ = m(x[:1])
+    res["out_single"] = o1.detach().numpy()
+    np.savez(os.path.join(OUT, "g1_abmil.npz"), **res)
+
+
+def g2_ntxent():
+    res = {}
+    for B in (2, 4, 64):
+        for tau in (1.0, 0.5):
+            zi = T(detrand.normal(7, f"g2.zi.{B}", (B, 128))).requires_grad_()
+            zj = T(detrand.normal(7, f"g2.zj.{B}", (B, 128))).requires_grad_()
+            loss = r_losses.NT_Xent(B, tau)(zi, zj)
+            loss.backward()
+            res[f"loss.{B}.{tau}"] = loss.detach().numpy()
+            res[f"dzi.{B}.{tau}"] = zi.grad.numpy()
+            res[f"dzj.{B}.{tau}"] = zj.grad.numpy()
+    np.savez(os.path.join(OUT, "g2_ntxent.npz"), **res)
+
+
+def g3_pretrain():
+    """C1-shaped pre-train step: CL(ABMIL) + Full_layer + NT_Xent, T=1 and T=3, sub-bags injected."""
+    seed, B, N, d = 985, 4, 256, 512
+    res = {}
+    for Tn in (1, 3):
+        enc = r_abmil.ABMIL(d, L=512, D=128, dim_out=128)
+        enc.load_state_dict(P.to_torch(P.abmil(seed)))
+        model = r_cl.CL(enc, projection_dim=128, n_features=512)
+        fc = r_rlmil.Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(seed)))
+        crit = r_losses.NT_Xent(B, 1.0)
+        losses, rewards, sim_last = [], [], None
+        for t in range(Tn):                                  # mirrors train_MuRCL.py:242-288
+            xv = [T(P.bags(seed, f"g3.x.{t}.{v}", B, N, d)) for v in range(2)]
+            outs, states = model(xv)
+            outs = [fc(o, restart=(t == 0)) for o in outs]
+            losses.append(crit(outs[0], outs[1]))
+            sim = torch.cosine_similarity(outs[0], outs[1]).view(1, -1)
+            if t > 0:
+                rewards.append((sim_last - sim).detach().numpy())
+            sim_last = sim
+        loss = sum(losses) / Tn
+        loss.backward()
+        res[f"T{Tn}.loss"] = loss.detach().numpy()
+        res[f"T{Tn}.losses"] = np.array([l.item() for l in losses])
+        if rewards:
+            res[f"T{Tn}.rewards"] = np.concatenate(rewards, 0)
+        for k, v in list(model.named_parameters()) + [("fc::" + k, v) for k, v in fc.named_parameters()]:
+            if v.grad is not None:
+                res[f"T{Tn}.grad.{k}"] = _summ(v.grad)
+    np.savez(os.path.join(OUT, "g3_pretrain.npz"), **res)
+
+
+def _topk_margin(A, k):
+    s = torch.sort(A.flatten(), descending=True)[0]
+    return min((s[k - 1] - s[k]).item(), (s[-k - 1] - s[-k]).item()) / s[0].item()
+
+
+def g4_clam():
+    seed, B, N, d = 11, 3, 300, 512
+    res = {}
+    x = T(P.bags(seed, "g4.x", B, N, d))
+    for subtyping in (False, True):
+        m = r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2,
+                           subtyping=subtyping, in_dim=d)
+        m.load_state_dict(P.to_torch(P.clam_sb(seed)))
+        m.eval()
+        tag = f"sub{int(subtyping)}"
+        for label in (0, 1):
+            xx = x.clone().requires_grad_()
+            M, A_or, rd = None, None, None
+            Ms, losses, preds, tgts = [], [], [], []
+            for b in range(B):
+                Mb, rdb = m.bag_forward(xx[b], label=torch.tensor([label]), instance_eval=True)
+                Ms.append(Mb)
+                losses.append(rdb["instance_loss"])
+                preds.append(rdb["inst_preds"])
+                tgts.append(rdb["inst_labels"])
+            res[f"{tag}.l{label}.M"] = torch.cat(Ms).detach().numpy()
+            res[f"{tag}.l{label}.inst_loss"] = np.array([float(l) for l in losses])
+            res[f"{tag}.l{label}.preds"] = np.stack(preds)
+            res[f"{tag}.l{label}.targets"] = np.stack(tgts)
+        with torch.no_grad():
+            raw = torch.cat([m.bag_forward(x[b], attention_only=True) for b in range(B)])   # [B,N]
+            A = torch.softmax(raw, 1)
+            for b in range(B):
+                assert _topk_margin(A[b], 8) > 1e-4, "golden top-k margin too small"
+            res[f"{tag}.raw"] = raw.numpy()
+            res[f"{tag}.A"] = A.numpy()
+            res[f"{tag}.top_p"] = torch.topk(A, 8)[1].numpy()
+            res[f"{tag}.top_n"] = torch.topk(-A, 8)[1].numpy()
+            # batch forward path (clam.py:183-211)
+            Mb, _ = m(x)
+            res[f"{tag}.M_batch"] = Mb.numpy()
+    # grads of a combined objective in eval mode (bag + instance loss), label 1, subtyping
+    m = r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=d)
+    m.load_state_dict(P.to_torch(P.clam_sb(seed)))
+    m.eval()
+    tot = 0
+    for b in range(B):
+        Mb, rdb = m.bag_forward(x[b], label=torch.tensor([1]), instance_eval=True)
+        tot = tot + Mb.sum() + rdb["instance_loss"]
+    tot.backward()
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _summ(v.grad)
+    np.savez(os.path.join(OUT, "g4_clam.npz"), **res)
+
+
+def g5_dsmil():
+    seed, B, N, d, C = 5, 3, 200, 512, 2
+    m = r_dsmil.build_dsmil(d, C)
+    m.load_state_dict(P.to_torch(P.dsmil(seed, d, C)))
+    x = T(P.bags(seed, "g5.x", B, N, d))
+    res = {}
+    classes, bag, _ = m(x)                                   # batch path -> lists
+    res["classes"] = torch.stack(classes).detach().numpy()
+    res["bag"] = bag.detach().numpy()
+    c = torch.stack(classes)
+    srt = torch.sort(c, 1, descending=True)
+    assert ((srt[0][:, 0] - srt[0][:, 1]).abs() > 1e-5).all(), "arg-max margin too small"
+    res["m_ids"] = srt[1][:, 0, :].numpy()
+    c1, b1, _ = m(x[:1])                                     # single-bag path
+    res["classes_single"] = c1.detach().numpy()
+    res["bag_single"] = b1.detach().numpy()
+    (bag.sum() + sum(cc.max(0)[0].sum() for cc in classes)).backward()
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _summ(v.grad)
+    np.savez(os.path.join(OUT, "g5_dsmil.npz"), **res)
+
+
+def _ref_get_feats(feats, clusters, actions, feat_size):
+    fl = [T(f).unsqueeze(0) for f in feats]
+    out = r_datasets.get_feats(fl, clusters, T(np.asarray(actions, np.float32)), feat_size)
+    return out.numpy()
+
+
+def g6_get_feats():
+    """Index selection cases.  Feature value of patch i is i+1 in column 0, so the
+    selected ids can be read back from the reference's output tensor exactly."""
+    res = {}
+    cases = {}
+    # (a) N >> feat_size, random clusters / actions
+    N, K, fs = 4000, 10, 256
+    cl = P.cluster_lists(3, "g6.a", N, K)
+    cases["a"] = (N, [cl, P.cluster_lists(3, "g6.a2", N, K)], detrand.uniform(3, "g6.a.act", (2, K)), fs)
+    # (b) N < feat_size: negative-slice quirk
+    sizes = (10, 15, 5)
+    ids = np.arange(30)
+    clb = [ids[:10].tolist(), ids[10:25].tolist(), ids[25:].tolist()]
+    cases["b"] = (30, [clb], np.full((1, 3), 0.5, np.float32), 40)
+    # (c) action edges 0 and 1 (+ tiny/empty clusters)
+    N, K, fs = 1000, 6, 128
+    clc = P.cluster_lists(4, "g6.c", N, K - 1) + [[]]
+    cases["c"] = (N, [clc, clc, clc],
+                  np.array([[0] * K, [1] * K, [0, 1, 0.999999, 1e-7, 0.5, 0.3]], np.float32), fs)
+    # (d) half-way rounding: n_j * ratio exactly .5 -> round-half-even; N=64, fs=16 -> ratio .25
+    cld, start = [], 0
+    for n in (2, 6, 10, 14, 18, 14):
+        cld.append(list(range(start, start + n)))
+        start += n
+    cases["d"] = (64, [cld, cld], detrand.uniform(5, "g6.d.act", (2, 6)), 16)
+    # (e) total > feat_size after rounding -> truncation branch (:304-305)
+    cle, start = [], 0
+    for n in (6, 6, 6, 6, 6, 6, 6, 6, 6, 6):
+        cle.append(list(range(start, start + n)))
+        start += n
+    cases["e"] = (60, [cle], detrand.uniform(6, "g6.e.act", (1, 10)), 36)   # ratio .6 -> 3.6 -> 4 each = 40 > 36
+    for name, (N, cls, act, fs) in cases.items():
+        feats = []
+        for _ in cls:
+            f = np.zeros((N, 4), np.float32)
+            f[:, 0] = np.arange(N) + 1
+            f[:, 1] = 7.0
+            feats.append(f)
+        out = _ref_get_feats(feats, cls, act, fs)
+        res[f"{name}.ids_plus1"] = out[:, :, 0].astype(np.int64)      # 0 == padded row
+        res[f"{name}.N"] = np.array(N)
+        res[f"{name}.fs"] = np.array(fs)
+        res[f"{name}.act"] = np.asarray(act, np.float32)
+        res[f"{name}.cluster_flat"] = np.array([np.concatenate([np.asarray(c, np.int64) for c in cl] or [[]]) for cl in cls][0])
+        res[f"{name}.cluster_sizes"] = np.array([[len(c) for c in cl] for cl in cls])
+    np.savez(os.path.join(OUT, "g6_get_feats.npz"), **res)
+
+
+def g7_mixup():
+    B, N, d = 5, 16, 8
+    x = T(detrand.normal(9, "g7.x", (B, N, d)))
+    u = T(detrand.uniform(9, "g7.u", (B, 1)))
+    perm = T(detrand.permutation(9, "g7.perm", B))
+    with mock.patch("torch.rand", lambda *a, **k: u), mock.patch("torch.randperm", lambda *a, **k: perm):
+        out, lam, idx = r_datasets.mixup(x, 0.9)
+    np.savez(os.path.join(OUT, "g7_mixup.npz"), out=out.numpy(), lam=lam.numpy(), perm=idx.numpy(), u=u.numpy())
+
+
+def g8_ppo():
+    seed, B, S, H, K, Tm = 21, 6, 512, 512, 10, 3
+    std = 0.5
+    res = {}
+    ppo = r_rlmil.PPO(512, S, H, False, action_std=std, lr=1e-3, gamma=0.1, K_epochs=1, action_size=K)
+    sd = P.to_torch(P.actor_critic(seed, S, H, K))
+    ppo.policy.load_state_dict(sd)
+    ppo.policy_old.load_state_dict(sd)
+    mem = r_rlmil.Memory()
+    MVN = torch.distributions.multivariate_normal.MultivariateNormal
+    for t in range(Tm):
+        st = T(detrand.normal(seed, f"g8.s{t}", (B, S)))
+        eps = T(detrand.normal(seed, f"g8.e{t}", (B, K)))
+        with mock.patch.object(MVN, "sample", lambda self, *a, **k: self.loc + std * eps):
+            a = ppo.select_action(st, mem, restart_batch=(t == 0))
+        res[f"act.{t}"] = a.numpy()
+        res[f"logp.{t}"] = mem.logprobs[-1].detach().numpy()
+        res[f"hidden.{t}"] = mem.hidden[-1].detach().numpy()[0]
+        mem.rewards.append(T(detrand.normal(seed, f"g8.r{t}", (1, B)) * 0.1))
+    with torch.no_grad():
+        lp, v, ent = ppo.policy.evaluate(torch.stack(mem.states, 0), torch.stack(mem.actions, 0))
+    res["eval.logp"], res["eval.value"], res["eval.entropy"] = lp.numpy(), v.numpy(), ent.numpy()
+    ppo.update(mem)
+    for k, v in ppo.policy.state_dict().items():
+        res["post." + k] = _summ(v)
+    np.savez(os.path.join(OUT, "g8_ppo.npz"), **res)
+
+
+def g9_full_layer():
+    seed, B = 13, 4
+    fc = r_rlmil.Full_layer(512, 1024, True, 128)
+    fc.load_state_dict(P.to_torch(P.full_layer(seed)))
+    res = {}
+    with torch.no_grad():
+        for t in range(3):
+            for v in range(2):
+                x = T(detrand.normal(seed, f"g9.x.{t}.{v}", (B, 512)))
+                res[f"z.{t}.{v}"] = fc(x, restart=(t == 0)).numpy()
+                res[f"h.{t}.{v}"] = fc.hidden[0].numpy()
+    np.savez(os.path.join(OUT, "g9_full_layer.npz"), **res)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer):
+        fn()
+        print("wrote", fn.__name__)

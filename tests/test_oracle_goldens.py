@@ -1,0 +1,232 @@
+"""Pin the CPU oracle (oracle/) against outputs of the reference itself.
+
+The goldens in tests/golden/ were produced by oracle/gen_goldens.py, which imports and
+runs /root/reference in the build container.  Nothing here reads the reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detrand, mil_oracle as O, params as P, select_oracle as S
+
+T = torch.from_numpy
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _summ(g):
+    """Fingerprint of a tensor: L2 norm, max |.|, first 32 values."""
+    g = g.detach().double().flatten()
+    return np.concatenate([[g.norm().item(), g.abs().max().item()], g[:32].numpy()])
+
+
+def _leaf(d):
+    return {k: v.clone().requires_grad_() for k, v in P.to_torch(d).items()}
+
+
+def _check_grads(gold, prefix, named, rtol=2e-4):
+    n = 0
+    for k, v in named.items():
+        key = prefix + k
+        if key in gold.files:
+            assert v.grad is not None, key
+            got, want = _summ(v.grad), gold[key]
+            if k.endswith("attention.2.bias") or k.endswith("attention_c.bias"):
+                # d softmax / d(uniform shift) == 0 exactly: both sides hold only rounding noise
+                ref_scale = _summ(named[k[:-4] + "weight"].grad)[0]
+                assert got[0] < 1e-4 * ref_scale and want[0] < 1e-4 * ref_scale, key
+                n += 1
+                continue
+            np.testing.assert_allclose(got[:2], want[:2], rtol=rtol, err_msg=key)
+            np.testing.assert_allclose(got[2:], want[2:], rtol=rtol, atol=rtol * want[1], err_msg=key)
+            n += 1
+    assert n > 0
+
+
+def test_g1_abmil(golden):
+    g = golden("g1_abmil")
+    p = _leaf(P.abmil(985))
+    x = T(P.bags(985, "g1.x", 4, 256, 512))
+    out, A, s, M = O.abmil_forward(p, x)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], **TOL)
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(O.abmil_forward(p, x[:1])[0].detach().numpy(), g["out_single"], **TOL)
+    out.sum().backward()
+    _check_grads(g, "grad.", p)
+    assert p["fc.weight"].grad is None          # abmil.py:33 is never applied
+
+
+@pytest.mark.parametrize("B", [2, 4, 64])
+@pytest.mark.parametrize("tau", [1.0, 0.5])
+def test_g2_ntxent(golden, B, tau):
+    g = golden("g2_ntxent")
+    zi = T(detrand.normal(7, f"g2.zi.{B}", (B, 128))).requires_grad_()
+    zj = T(detrand.normal(7, f"g2.zj.{B}", (B, 128))).requires_grad_()
+    loss = O.nt_xent(zi, zj, tau)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"loss.{B}.{tau}"], rtol=1e-5)
+    np.testing.assert_allclose(zi.grad.numpy(), g[f"dzi.{B}.{tau}"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(zj.grad.numpy(), g[f"dzj.{B}.{tau}"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("Tn", [1, 3])
+def test_g3_pretrain_step(golden, Tn):
+    g = golden("g3_pretrain")
+    mp, fp = _leaf(P.abmil(985)), _leaf(P.full_layer(985))
+    views = [[T(P.bags(985, f"g3.x.{t}.{v}", 4, 256, 512)) for v in range(2)] for t in range(Tn)]
+    loss, losses, rewards, _ = O.pretrain_step(mp, fp, views, 1.0)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"T{Tn}.loss"], rtol=1e-5)
+    np.testing.assert_allclose([l.item() for l in losses], g[f"T{Tn}.losses"], rtol=1e-5)
+    if Tn > 1:
+        np.testing.assert_allclose(torch.stack(rewards).numpy(), g[f"T{Tn}.rewards"], rtol=1e-3, atol=2e-7)
+    _check_grads(g, f"T{Tn}.grad.encoder.", mp)
+    _check_grads(g, f"T{Tn}.grad.fc::", fp)
+
+
+@pytest.mark.parametrize("subtyping", [False, True])
+def test_g4_clam(golden, subtyping):
+    g = golden("g4_clam")
+    tag = f"sub{int(subtyping)}"
+    p = P.to_torch(P.clam_sb(11))
+    x = T(P.bags(11, "g4.x", 3, 300, 512))
+    M, A, s, h = O.clam_sb_forward(p, x)
+    np.testing.assert_allclose(s.numpy(), g[f"{tag}.raw"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(A.numpy(), g[f"{tag}.A"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(M.numpy(), g[f"{tag}.M_batch"], **TOL)
+    np.testing.assert_array_equal(torch.topk(A, 8)[1].numpy(), g[f"{tag}.top_p"])
+    np.testing.assert_array_equal(torch.topk(-A, 8)[1].numpy(), g[f"{tag}.top_n"])
+    for label in (0, 1):
+        np.testing.assert_allclose(M.numpy(), g[f"{tag}.l{label}.M"], **TOL)
+        for b in range(3):
+            loss, preds, tg, ids = O.clam_instance_eval(p, A[b], h[b], label, 2, 8, subtyping)
+            np.testing.assert_allclose(loss.item(), g[f"{tag}.l{label}.inst_loss"][b], rtol=1e-5)
+            np.testing.assert_array_equal(preds.numpy(), g[f"{tag}.l{label}.preds"][b])
+            np.testing.assert_array_equal(tg.numpy(), g[f"{tag}.l{label}.targets"][b])
+
+
+def test_g4_clam_grads(golden):
+    g = golden("g4_clam")
+    p = _leaf(P.clam_sb(11))
+    x = T(P.bags(11, "g4.x", 3, 300, 512))
+    M, A, s, h = O.clam_sb_forward(p, x)
+    tot = M.sum()
+    for b in range(3):
+        tot = tot + O.clam_instance_eval(p, A[b], h[b], 1, 2, 8, True)[0]
+    tot.backward()
+    _check_grads(g, "grad.", p)
+
+
+def test_g5_dsmil(golden):
+    g = golden("g5_dsmil")
+    p = _leaf(P.dsmil(5))
+    x = T(P.bags(5, "g5.x", 3, 200, 512))
+    c, bag, A, m = O.dsmil_forward(p, x)
+    np.testing.assert_allclose(c.detach().numpy(), g["classes"], **TOL)
+    np.testing.assert_array_equal(m.numpy(), g["m_ids"])
+    np.testing.assert_allclose(bag.detach().numpy(), g["bag"], **TOL)
+    c1, b1, _, _ = O.dsmil_forward(p, x[:1])
+    np.testing.assert_allclose(c1[0].detach().numpy(), g["classes_single"], **TOL)
+    np.testing.assert_allclose(b1.detach().numpy(), g["bag_single"], **TOL)
+    (bag.sum() + c.max(1)[0].sum()).backward()
+    _check_grads(g, "grad.", p)
+    assert p["b_classifier.fcc.weight"].grad is None      # dsmil.py:62,80 unused
+
+
+def _g6_clusters(g, name):
+    flat, sizes = g[f"{name}.cluster_flat"], g[f"{name}.cluster_sizes"]
+    return flat, sizes
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e"])
+def test_g6_get_feats_indices(golden, name):
+    g = golden("g6_get_feats")
+    N, fs, act = int(g[f"{name}.N"]), int(g[f"{name}.fs"]), g[f"{name}.act"]
+    want = g[f"{name}.ids_plus1"]
+    cls = _g6_rebuild(name)
+    assert len(cls) == want.shape[0]
+    feats = []
+    for _ in cls:
+        f = np.zeros((N, 4), np.float32)
+        f[:, 0] = np.arange(N) + 1
+        f[:, 1] = 7.0
+        feats.append(f)
+    out, kept = S.get_feats(feats, cls, act, fs)
+    np.testing.assert_array_equal(out[:, :, 0].astype(np.int64), want)
+    for b, ids in enumerate(kept):                       # padded tail is exactly zero
+        assert (out[b, len(ids):] == 0).all()
+        assert (out[b, :len(ids), 1] == 7.0).all()
+
+
+def _g6_rebuild(name):
+    """Same cluster constructions as oracle/gen_goldens.py:g6_get_feats."""
+    if name == "a":
+        return [P.cluster_lists(3, "g6.a", 4000, 10), P.cluster_lists(3, "g6.a2", 4000, 10)]
+    if name == "b":
+        ids = list(range(30))
+        return [[ids[:10], ids[10:25], ids[25:]]]
+    if name == "c":
+        c = P.cluster_lists(4, "g6.c", 1000, 5) + [[]]
+        return [c, c, c]
+    sizes = (2, 6, 10, 14, 18, 14) if name == "d" else (6,) * 10
+    cl, start = [], 0
+    for n in sizes:
+        cl.append(list(range(start, start + n)))
+        start += n
+    return [cl, cl] if name == "d" else [cl]
+
+
+def test_g6_negative_slice_quirk():
+    """n=(10,15,5), feat_size 40, a=0.5 -> ids [8,9,22,23,24,29]."""
+    ids = list(range(30))
+    got = S.select_indices(30, [ids[:10], ids[10:25], ids[25:]], [0.5, 0.5, 0.5], 40)
+    assert got == [8, 9, 22, 23, 24, 29]
+
+
+def test_g7_mixup(golden):
+    g = golden("g7_mixup")
+    x = detrand.normal(9, "g7.x", (5, 16, 8))
+    lam = (np.float32(0.9) + g["u"] * np.float32(1 - 0.9)).astype(np.float32)
+    np.testing.assert_array_equal(lam, g["lam"])
+    np.testing.assert_array_equal(g["perm"], detrand.permutation(9, "g7.perm", 5))
+    np.testing.assert_allclose(S.mixup(x, lam, g["perm"]), g["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_g8_ppo(golden):
+    g = golden("g8_ppo")
+    seed, B, S_, H, K, Tm, std = 21, 6, 512, 512, 10, 3, 0.5
+    p = _leaf(P.actor_critic(seed, S_, H, K))
+    hidden = torch.zeros(B, H)
+    states, actions, logps, rewards = [], [], [], []
+    with torch.no_grad():
+        for t in range(Tm):
+            st = T(detrand.normal(seed, f"g8.s{t}", (B, S_)))
+            eps = T(detrand.normal(seed, f"g8.e{t}", (B, K)))
+            a, lp, hidden = O.ppo_act(p, st, hidden, eps, std)
+            np.testing.assert_allclose(a.numpy(), g[f"act.{t}"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(lp.numpy(), g[f"logp.{t}"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(hidden.numpy(), g[f"hidden.{t}"], rtol=1e-4, atol=1e-6)
+            states.append(st), actions.append(a), logps.append(lp)
+            rewards.append(T(detrand.normal(seed, f"g8.r{t}", (1, B)) * 0.1))
+        lp, v, ent = O.ppo_evaluate(p, torch.stack(states), torch.stack(actions), std)
+    np.testing.assert_allclose(lp.numpy(), g["eval.logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(v.numpy(), g["eval.value"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ent.numpy(), g["eval.entropy"], rtol=1e-6)
+    # one PPO.update with K_epochs=1, Adam lr 1e-3 (rlmil.py:152-184)
+    R = O.ppo_returns(rewards, 0.1)
+    loss = O.ppo_loss(p, torch.stack(states), torch.stack(actions), torch.stack(logps), R, std)
+    loss.backward()
+    newp = O.adam_step({k: v.detach() for k, v in p.items()}, {k: v.grad for k, v in p.items()}, {}, 1e-3)
+    for k, v in newp.items():
+        np.testing.assert_allclose(_summ(v), g["post." + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_g9_full_layer_interleaved_hidden(golden):
+    g = golden("g9_full_layer")
+    p = P.to_torch(P.full_layer(13))
+    hidden = None
+    for t in range(3):
+        for v in range(2):
+            x = T(detrand.normal(13, f"g9.x.{t}.{v}", (4, 512)))
+            z, hidden = O.full_layer_step(p, x, None if t == 0 else hidden)
+            np.testing.assert_allclose(z.numpy(), g[f"z.{t}.{v}"], rtol=1e-4, atol=2e-6)
+            np.testing.assert_allclose(hidden.numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
