@@ -1,0 +1,94 @@
+/* murcl_amd C-ABI: the MI355X (gfx950) drop-in boundary for MuRCL's data-parallel hot path.
+ *
+ * The reference (wwu98934/MuRCL) is pure Python/PyTorch and has no FFI layer; its boundary for
+ * this path is the nn.Module API of models/{abmil,clam,dsmil,cl,rlmil}.py, utils/losses.py and
+ * utils/datasets.{get_feats,mixup}.  murcl_amd mirrors those modules in Python (murcl_amd/models,
+ * murcl_amd/utils) and every tensor op inside them lands on one of the entry points below, loaded
+ * with ctypes from libmurcl_amd.so.  Each entry cites the reference lines it replaces (paths
+ * relative to the reference repo).
+ *
+ * Conventions: plain device pointers and sizes, no torch types; all tensors row-major and
+ * contiguous unless a leading dimension is given; `stream` is the hipStream_t to launch on (the
+ * caller passes torch.cuda.current_stream()); nothing allocates, frees or synchronises; workspaces
+ * are caller-provided.  Return 0 on success, a hipError_t (>0) if a launch failed, <0 for
+ * unsupported arguments.  dtype codes: 0 = f32, 1 = bf16 (f32 accumulate everywhere).
+ */
+#ifndef MURCL_AMD_H
+#define MURCL_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* murcl_stream_t;
+
+#define MURCL_F32 0
+#define MURCL_BF16 1
+
+/* epilogues of murcl_gemm_nt */
+#define MURCL_EPI_NONE 0
+#define MURCL_EPI_BIAS 1        /* + bias[n]                                  */
+#define MURCL_EPI_BIAS_RELU 2   /* relu(. + bias[n])                          */
+#define MURCL_EPI_MASK 3        /* . * (mask[m][n] > 0)           (ReLU')     */
+#define MURCL_EPI_RANK1_MASK 4  /* (. + rowscale[m]*rank1[m/rows_per_bag][n]) * (mask > 0) */
+
+/* C[M,N] = epi(A[M,K] . B[N,K]^T): nn.Linear forward (abmil.py:12-21,23-27,29-32; clam.py:69,40-48;
+ * dsmil.py:9,15,55-59; rlmil.py:41-54,199-200) and its input gradient (B = W^T).  K must be a
+ * multiple of 128 bytes of dtype_in.  colsum_ws ([ceil(M/128),N] f32, may be NULL) receives per
+ * row-tile column sums of the output (bias gradients, reduced by murcl_colsum). */
+int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int dtype_in, int dtype_out, int epilogue, const float* bias, const void* mask, int ldmask,
+                  const float* rowscale, const float* rank1, int rows_per_bag, float* colsum_ws, int accumulate,
+                  murcl_stream_t stream);
+
+/* C[N1,N2] (f32, pre-zeroed or accumulated into) += A[M,N1]^T . B[M,N2]: weight gradients, i.e. what
+ * autograd's mm_backward computes for every Linear above; reduction over the patch dimension M is
+ * split over `splits` workgroup groups (<=0: auto). */
+int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
+                  int dtype, int splits, murcl_stream_t stream);
+
+/* K2 -- ABMIL attention pooling, abmil.py:38-42:  scores[b,n] = wb.tanh(Wa H[b,n]+ba)+bb,
+ * A = softmax_N(scores)/sqrt(N), M[b] = A[b].H[b];  ml[b] = (max, sum exp) of the soft-max.
+ * H [B,N,L] and Wa [D,L] in `dtype`; L = 512, D = 128.  part_ws: B*n_chunks*(L+2) floats with
+ * n_chunks from murcl_abmil_pool_workspace. */
+int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_chunks);
+int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* bb,
+                         float* scores, float* A, float* M, float* ml, float* part_ws, int B, int N, int L, int D,
+                         int dtype, int exact_tanh, murcl_stream_t stream);
+/* backward of the above w.r.t. the pre-tanh activations: dT[b,n,:] = ds_n * wb * (1 - t^2) with
+ * ds_n = p_n (dM.H_n / sqrt(N) - dM.M), plus dba += sum dT, dwb += sum ds_n t_n, dbb += sum ds_n
+ * (f32 accumulators, atomically added).  dH and dWa follow from dT through murcl_gemm_nt
+ * (MURCL_EPI_RANK1_MASK with rowscale = A, rank1 = dM) and murcl_gemm_tn. */
+int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
+                         const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
+                         float* dbb, int B, int N, int L, int D, int dtype, int exact_tanh, murcl_stream_t stream);
+
+/* K8/K9 -- NT_Xent.forward + its gradient + torch.cosine_similarity of the positive pairs in one
+ * launch (utils/losses.py:24-41; train_MuRCL.py:249,253,277,282).  z [n,P] f32 = cat(z_i,z_j),
+ * n = 2B, P = 128.  dz (may be NULL) receives d loss / d z for bags in [grad_lo,grad_hi) of both
+ * views, zero elsewhere.  sim (may be NULL) [B]. */
+long murcl_ntxent_workspace_bytes(int n);
+int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz, float* sim,
+                         int grad_lo, int grad_hi, void* workspace, murcl_stream_t stream);
+
+/* helpers */
+int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, murcl_stream_t stream);
+int murcl_transpose_cast(const float* x, void* y, int R, int C, int dtype_out, murcl_stream_t stream);
+int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, murcl_stream_t stream);
+int murcl_relu_bwd(const float* dy, const float* y, float* dx, long n, murcl_stream_t stream);
+
+/* K7/K10 -- one nn.GRU time step's gate math (rlmil.py:47,78,199,213-217); the two projections are
+ * murcl_gemm_nt calls.  gates [B,3H] = (r,z,n) saved for backward. */
+int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, float* hnew, float* gates, int B, int H,
+                        murcl_stream_t stream);
+int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
+                        float* dgh, float* dhprev, int B, int H, murcl_stream_t stream);
+
+/* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182). */
+int murcl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, murcl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

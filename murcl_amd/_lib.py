@@ -1,0 +1,76 @@
+"""ctypes binding of libmurcl_amd.so (the C-ABI declared in include/murcl_amd.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a launch fails, the call
+raises.  torch must be imported first so the library binds to the HIP runtime torch loaded.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads libamdhip64.so.7 before our library resolves it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmurcl_amd.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_RANK1_MASK = 0, 1, 2, 3, 4
+
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
+
+SIGNATURES = {
+    "murcl_gemm_nt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
+    "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
+    "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_ntxent_workspace_bytes": [_I],
+    "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _P, _P],
+    "murcl_cast": [_P, _P, _L, _I, _I, _P],
+    "murcl_transpose_cast": [_P, _P, _I, _I, _I, _P],
+    "murcl_colsum": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_relu_bwd": [_P, _P, _P, _L, _P],
+    "murcl_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "murcl_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
+}
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m murcl_amd.build` "
+                "(murcl_amd has no CPU/PyTorch fallback for its kernels)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, _I)
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"murcl_amd: {what} failed with code {rc}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"murcl_amd kernels take float32 or bfloat16, got {t.dtype}")

@@ -1,0 +1,178 @@
+// Small bandwidth-bound helpers: dtype casts / weight transposes, column sums (bias grads),
+// ReLU backward, GRU gate math (K7/K10, models/rlmil.py:47,78,199,213-217), fused Adam.
+#include "common.h"
+
+// ---------------------------------------------------------------- casts
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) store4<bf16_t>(y + i, *(const f32x4*)(x + i));
+    if (i < n && i + 3 >= n)
+        for (long k = i; k < n; ++k) y[k] = f2bf(x[k]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = bf2f(x[i]);
+}
+extern "C" int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, hipStream_t s) {
+    if (n <= 0) return 0;
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid), dim3(256), 0, s, (const float*)x, (bf16_t*)y, n);
+    else if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (float*)y, n);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
+// y[C,R] (dtype T) = x[R,C]^T (f32): 32x32 LDS tiles
+template <typename T>
+__global__ void transpose_cast_kernel(const float* __restrict__ x, T* __restrict__ y, int R, int C) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) t[k][tx] = x[(size_t)(r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) y[(size_t)(c0 + k) * R + r0 + tx] = from_f<T>(t[tx][k]);
+}
+extern "C" int murcl_transpose_cast(const float* x, void* y, int R, int C, int dtype_out, hipStream_t s) {
+    if (R <= 0 || C <= 0) return 0;
+    dim3 grid((C + 31) / 32, (R + 31) / 32);
+    if (dtype_out == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, R, C);
+    else if (dtype_out == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, R, C);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld, int accumulate) {
+    // block = 64 columns x 4 row-lanes; grid.x over column groups
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int r = rl; r < R; r += 4) s += to_f<T>(x[(size_t)r * ld + c]);
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s) {
+    if (N <= 0) return 0;
+    dim3 grid((N + 63) / 64);
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, R, N, ld, accumulate);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, R, N, ld, accumulate);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- ReLU backward: dx = dy * (y > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+extern "C" int murcl_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, s, dy, y, dx, n);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- GRU gates (PyTorch order r, z, n)
+// gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both [B,3H].  gates out: [B,3H] = (r, z, n) for backward.
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                     const float* __restrict__ hprev, float* __restrict__ hnew,
+                                     float* __restrict__ gates, int B, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H) return;
+    const int b = (int)(idx / H), k = (int)(idx % H);
+    const float* gib = gi + (size_t)b * 3 * H;
+    const float* ghb = gh + (size_t)b * 3 * H;
+    const float r = 1.f / (1.f + expf(-(gib[k] + ghb[k])));
+    const float z = 1.f / (1.f + expf(-(gib[H + k] + ghb[H + k])));
+    const float nn = tanhf(gib[2 * H + k] + r * ghb[2 * H + k]);
+    const float hp = hprev ? hprev[idx] : 0.f;
+    hnew[idx] = (1.f - z) * nn + z * hp;
+    float* g = gates + (size_t)b * 3 * H;
+    g[k] = r; g[H + k] = z; g[2 * H + k] = nn;
+}
+// dgi, dgh [B,3H]; dhprev_direct [B,H] = dh * z
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ gates,
+                                     const float* __restrict__ gh, const float* __restrict__ hprev,
+                                     float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhprev,
+                                     int B, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H) return;
+    const int b = (int)(idx / H), k = (int)(idx % H);
+    const float* g = gates + (size_t)b * 3 * H;
+    const float r = g[k], z = g[H + k], nn = g[2 * H + k];
+    const float ghn = gh[(size_t)b * 3 * H + 2 * H + k];
+    const float hp = hprev ? hprev[idx] : 0.f;
+    const float d = dh[idx];
+    const float dn = d * (1.f - z) * (1.f - nn * nn);
+    const float dz = d * (hp - nn) * z * (1.f - z);
+    const float dr = dn * ghn * r * (1.f - r);
+    float* a = dgi + (size_t)b * 3 * H;
+    float* c = dgh + (size_t)b * 3 * H;
+    a[k] = dr; a[H + k] = dz; a[2 * H + k] = dn;
+    c[k] = dr; c[H + k] = dz; c[2 * H + k] = dn * r;
+    if (dhprev) dhprev[idx] = d * z;
+}
+extern "C" int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, float* hnew, float* gates,
+                                   int B, int H, hipStream_t s) {
+    const long n = (long)B * H;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gi, gh, hprev, hnew, gates, B, H);
+    return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
+                                   float* dgh, float* dhprev, int B, int H, hipStream_t s) {
+    const long n = (long)B * H;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, L2 weight decay)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+extern "C" int murcl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, hipStream_t s) {
+    if (n <= 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    return MURCL_CHECK_LAUNCH();
+}

@@ -1,0 +1,422 @@
+// Dense projection GEMMs of the MIL aggregators on CDNA4 matrix cores.
+//
+//   gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)      forward Linear (abmil.py:12-21, clam.py:69,
+//                                                    dsmil.py:15,66-67) and dgrad (with W^T as B)
+//   gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2]       wgrad, reduction over the patch dimension
+//
+// Tiling (both): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 4x4 MFMA 16x16 tiles), K slabs of 128 bytes per row staged HBM->LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a double buffer.  bf16 inputs use v_mfma_f32_16x16x32_bf16,
+// f32 inputs the exact-f32 v_mfma_f32_16x16x4_f32 (parity path).  LDS images are XOR-swizzled on
+// the 16-byte chunk index; the swizzle is applied to the per-lane *source* address (the LDS-DMA
+// destination is lane-linear) and again on the fragment reads.
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_RANK1_MASK = 4 };
+
+struct GemmEpi {
+    const float* bias;      // [N]
+    const void* mask;       // [M,ldmask] same dtype as A: output is zeroed where mask <= 0 (ReLU')
+    int ldmask;
+    const float* rowscale;  // [M]           a[m]
+    const float* rank1;     // [M/rows_per_bag, N]   out += a[m] * rank1[bag(m)][n]  (before mask)
+    int rows_per_bag;
+    float* colsum_ws;       // [ceil(M/128), N] per-tile column sums of the output, or nullptr
+    int accumulate;         // C += result (f32 output only)
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mma16(typename Frag<T>::type a, typename Frag<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mma16<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mma16<float>(f32x4 a, f32x4 b, f32x4 c) {
+    // lane quarter q holds k = 4q..4q+3 of this 16-wide k group; MFMA e pairs element e of both
+    // operands, so the k order is permuted identically on both sides (sum is order-independent
+    // up to fp32 rounding).
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+    return c;
+}
+
+// ------------------------------------------------------------------------------------- NT
+template <typename T, typename OutT, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                      OutT* __restrict__ C, int M, int N, int K, int lda,
+                                                      int ldb, int ldc, GemmEpi e) {
+    typedef typename Frag<T>::type frag_t;
+    constexpr int BKE = 128 / (int)sizeof(T);          // K elements per slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB | B 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt_n = (N + 127) >> 7, nt_m = (M + 127) >> 7;
+    const int swz = xcd_remap(blockIdx.x, nt_n * nt_m);
+    const int tm = swz / nt_n, tn = swz - tm * nt_n;    // the nt_n column tiles of a row panel are adjacent
+    const int m0 = tm << 7, n0 = tn << 7;
+    const unsigned lds0 = lds_off(smem);
+
+    // per-thread staging sources: chunk ci = t*256+tid -> row ci>>3, LDS pos ci&7, global chunk pos^(row&7)
+    const char* asrc[4];
+    const char* bsrc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int ci = t * 256 + tid, row = ci >> 3, c = (ci & 7) ^ (row & 7);
+        int ar = min(m0 + row, M - 1), br = min(n0 + row, N - 1);
+        asrc[t] = (const char*)(A + (size_t)ar * lda) + c * 16;
+        bsrc[t] = (const char*)(B + (size_t)br * ldb) + c * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+        const unsigned la = lds0 + buf * 32768, lb = la + 16384;
+        const size_t koff = (size_t)ks * 128;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            glds16(asrc[t] + koff, la + (t * 256 + wave * 64) * 16);
+            glds16(bsrc[t] + koff, lb + (t * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wr = wave >> 1, wc = wave & 1, q4 = lane >> 4, r16 = lane & 15;
+
+    auto compute = [&](int buf) {
+        const char* la = smem + buf * 32768;
+        const char* lb = la + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wr * 64 + i * 16 + r16;
+                af[i] = *(const frag_t*)(la + row * 128 + (((4 * kk + q4) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = wc * 64 + j * 16 + r16;
+                bfr[j] = *(const frag_t*)(lb + row * 128 + (((4 * kk + q4) ^ (row & 7)) << 4));
+            }
+            // swapped roles: MFMA rows <- B (n), cols <- A (m): a lane ends with 4 consecutive n
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<T>(bfr[j], af[i], acc[i][j]);
+        }
+    };
+
+    const int nk = K / BKE;
+    stage(0, 0);
+    WAIT_VMCNT(0);
+    LDS_BARRIER();
+    for (int ks = 0; ks < nk - 1; ++ks) {
+        stage((ks + 1) & 1, ks + 1);      // that buffer's last reads retired before the previous barrier
+        compute(ks & 1);
+        WAIT_VMCNT(0);
+        LDS_BARRIER();
+    }
+    compute((nk - 1) & 1);
+
+    // ---- epilogue: lane holds C[m = m0+wr*64+i*16+r16][n = n0+wc*64+j*16+4*q4 + 0..3]
+    float* cs = (float*)smem;             // [128] column sums (LDS reuse after the last compute)
+    if (e.colsum_ws) {
+        __syncthreads();
+        if (tid < 128) cs[tid] = 0.f;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + 4 * q4;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = (n + r < N) ? e.bias[n + r] : 0.f;
+        }
+        f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + r16;
+            f32x4 v = acc[i][j];
+            const bool mok = m < M;
+            const bool full = mok && (n + 3 < N);
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += bias4;
+            if (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (EPI == EPI_RANK1_MASK && mok) {
+                const float a = e.rowscale[m];
+                const float* rk = e.rank1 + (size_t)(m / e.rows_per_bag) * N + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) v[r] += a * rk[r];
+            }
+            if ((EPI == EPI_MASK || EPI == EPI_RANK1_MASK) && mok) {
+                const T* mp = (const T*)e.mask + (size_t)m * e.ldmask + n;
+                if (full) {
+                    f32x4 h = load4<T>(mp);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = h[r] > 0.f ? v[r] : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) v[r] = to_f<T>(mp[r]) > 0.f ? v[r] : 0.f;
+                }
+            }
+            if (mok) {
+                OutT* cp = C + (size_t)m * ldc + n;
+                if (full) {
+                    if (e.accumulate) {
+                        f32x4 old = load4<OutT>(cp);
+                        v += old;
+                    }
+                    store4<OutT>(cp, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) cp[r] = from_f<OutT>(v[r] + (e.accumulate ? to_f<OutT>(cp[r]) : 0.f));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[r] += (n + r < N) ? v[r] : 0.f;
+            }
+        }
+        if (e.colsum_ws) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = csum[r];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                if (r16 == 0) atomicAdd(&cs[wc * 64 + j * 16 + 4 * q4 + r], s);
+            }
+        }
+    }
+    if (e.colsum_ws) {
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) e.colsum_ws[(size_t)tm * N + n0 + tid] = cs[tid];
+    }
+}
+
+template <typename T, typename OutT>
+static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, int lda, int ldb, int ldc, int epi,
+                         const GemmEpi& e, hipStream_t s) {
+    const int grid = ((M + 127) / 128) * ((N + 127) / 128);
+#define NT_CASE(E)                                                                                             \
+    case E: {                                                                                                  \
+        auto k = gemm_nt_kernel<T, OutT, E>;                                                                   \
+        static bool once = false;                                                                              \
+        if (!once) {                                                                                           \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);            \
+            once = true;                                                                                       \
+        }                                                                                                      \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 65536, s, A, B, C, M, N, K, lda, ldb, ldc, e);           \
+        break;                                                                                                 \
+    }
+    switch (epi) {
+        NT_CASE(EPI_NONE)
+        NT_CASE(EPI_BIAS)
+        NT_CASE(EPI_BIAS_RELU)
+        NT_CASE(EPI_MASK)
+        NT_CASE(EPI_RANK1_MASK)
+        default: return -2;
+    }
+#undef NT_CASE
+    return MURCL_CHECK_LAUNCH();
+}
+
+// C-ABI: see include/murcl_amd.h
+extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                             int dtype_in, int dtype_out, int epilogue, const float* bias, const void* mask,
+                             int ldmask, const float* rowscale, const float* rank1, int rows_per_bag,
+                             float* colsum_ws, int accumulate, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    const int bke = dtype_in == MURCL_DTYPE_BF16 ? 64 : 32;
+    if (K <= 0 || K % bke) return -1;                    // K must be a whole number of 128-byte slabs
+    if ((lda * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16 || (ldb * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16)
+        return -1;
+    if (accumulate && dtype_out != MURCL_DTYPE_F32) return -1;
+    GemmEpi e{bias, mask, ldmask, rowscale, rank1, rows_per_bag > 0 ? rows_per_bag : 1, colsum_ws, accumulate};
+    if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16)
+        return launch_nt_epi<bf16_t, bf16_t>((const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, lda, ldb, ldc,
+                                             epilogue, e, stream);
+    if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_F32)
+        return launch_nt_epi<bf16_t, float>((const bf16_t*)A, (const bf16_t*)B, (float*)C, M, N, K, lda, ldb, ldc,
+                                            epilogue, e, stream);
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32)
+        return launch_nt_epi<float, float>((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc,
+                                           epilogue, e, stream);
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------- TN (wgrad)
+// Slab = 16 KiB per operand: bf16 64 rows(m) x 128 cols, f32 32 rows x 128 cols.
+template <typename T> struct TnTraits;
+template <> struct TnTraits<bf16_t> {
+    static constexpr int ROWS = 64, ROWB = 256;
+    __device__ static __forceinline__ int swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+};
+template <> struct TnTraits<float> {
+    static constexpr int ROWS = 32, ROWB = 512;
+    __device__ static __forceinline__ int swz(int row) { return (row & 1) << 2; }
+};
+
+// fragment for output-tile index t (16 columns of the slab), k-group kk:
+//  bf16: two transposed 4x16 reads -> k = 32kk + 8q + 0..7 of column 16t + (lane&15)
+__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int t, int kk, int lane, bf16_t) {
+    const int g = lane >> 4, u = lane & 15, rq = u >> 2, p = u & 3;
+    const int row = 32 * kk + 8 * g + rq;
+    const int chunk = 2 * t + (p >> 1);
+    const char* a0 = tile + row * 256 + ((chunk ^ TnTraits<bf16_t>::swz(row)) << 4) + ((p & 1) << 3);
+    const int row1 = row + 4;
+    const char* a1 = tile + row1 * 256 + ((chunk ^ TnTraits<bf16_t>::swz(row1)) << 4) + ((p & 1) << 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+//  f32: four scalar reads -> k = 16kk + 4e + q (e = 0..3) of column 16t + (lane&15)
+__device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int lane, float) {
+    const int q = lane >> 4, col = 16 * t + (lane & 15);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = 16 * kk + 4 * e + q;
+        v[e] = *(const float*)(tile + row * 512 + ((((col >> 2) ^ TnTraits<float>::swz(row)) << 4) | ((col & 3) << 2)));
+    }
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                      float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
+                                                      int ldc, int m_per_split) {
+    typedef typename Frag<T>::type frag_t;
+    typedef TnTraits<T> TT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB | B 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t1 = blockIdx.x, t2 = blockIdx.y, sp = blockIdx.z;
+    const int n10 = t1 << 7, n20 = t2 << 7;
+    const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
+    if (mbeg >= mend) return;
+    const unsigned lds0 = lds_off(smem);
+    constexpr int CPR = TT::ROWB / 16;            // 16-byte chunks per slab row (16 or 32)
+    constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
+
+    // chunk ci = t*256+tid -> row ci/CPR, LDS pos ci%CPR, source chunk pos^swz(row)
+    int srow[4], acol[4], bcol[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int ci = t * 256 + tid, row = ci / CPR, c = (ci % CPR) ^ TT::swz(row);
+        srow[t] = row;
+        acol[t] = min(n10 + c * EPC, N1 - EPC);   // clamp: columns past N1/N2 are never stored
+        bcol[t] = min(n20 + c * EPC, N2 - EPC);
+    }
+    auto stage = [&](int buf, int mrow0) {
+        const unsigned la = lds0 + buf * 32768, lb = la + 16384;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // rows past mend are clamped to a valid row and zero-weighted below via kvalid
+            int m = min(mrow0 + srow[t], M - 1);
+            glds16(A + (size_t)m * lda + acol[t], la + (t * 256 + wave * 64) * 16);
+            glds16(B + (size_t)m * ldb + bcol[t], lb + (t * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wr = wave >> 1, wc = wave & 1;
+
+    auto compute = [&](int buf) {
+        const char* la = smem + buf * 32768;
+        const char* lb = la + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tn_frag(la, wr * 4 + i, kk, lane, T());
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(lb, wc * 4 + j, kk, lane, T());
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma16<T>(af[i], bfr[j], acc[i][j]);
+        }
+    };
+
+    const int nslab = (mend - mbeg + TT::ROWS - 1) / TT::ROWS;
+    stage(0, mbeg);
+    WAIT_VMCNT(0);
+    LDS_BARRIER();
+    for (int s = 0; s < nslab; ++s) {
+        const bool more = s + 1 < nslab;
+        if (more) stage((s + 1) & 1, mbeg + (s + 1) * TT::ROWS);
+        const int rows_here = min(TT::ROWS, mend - (mbeg + s * TT::ROWS));
+        if (rows_here < TT::ROWS) {
+            // ragged tail: zero the invalid rows of the A image (B may hold anything finite... but
+            // clamped duplicates could be inf/nan-free garbage times zero = 0 only if finite), so
+            // zero both images' tail rows.
+            char* la = smem + (s & 1) * 32768;
+            for (int idx = tid; idx < (TT::ROWS - rows_here) * (TT::ROWB / 16); idx += 256) {
+                int row = rows_here + idx / (TT::ROWB / 16), c = idx % (TT::ROWB / 16);
+                *(u32x4*)(la + row * TT::ROWB + c * 16) = u32x4{0, 0, 0, 0};
+                *(u32x4*)(la + 16384 + row * TT::ROWB + c * 16) = u32x4{0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+        compute(s & 1);
+        WAIT_VMCNT(0);
+        LDS_BARRIER();
+    }
+    // lane holds C[n1 = n10+wr*64+i*16+4q+r][n2 = n20+wc*64+j*16+(lane&15)]
+    const int q4 = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = n20 + wc * 64 + j * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n10 + wr * 64 + i * 16 + 4 * q4 + r;
+                if (n1 < N1 && n2 < N2) atomicAdd(C + (size_t)n1 * ldc + n2, acc[i][j][r]);
+            }
+        }
+}
+
+extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
+                             int dtype, int splits, hipStream_t stream) {
+    if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    const int es = dtype == MURCL_DTYPE_BF16 ? 2 : 4, epc = 16 / es;
+    if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
+    const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
+    const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
+    if (splits <= 0) {                       // fill the chip: ~2 workgroups per CU
+        splits = (512 + t1 * t2 - 1) / (t1 * t2);
+    }
+    int mps = (M + splits - 1) / splits;
+    mps = ((mps + rows - 1) / rows) * rows;
+    splits = (M + mps - 1) / mps;
+    dim3 grid(t1, t2, splits);
+    if (dtype == MURCL_DTYPE_BF16) {
+        auto k = gemm_tn_kernel<bf16_t>;
+        static bool once = false;
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps);
+    } else if (dtype == MURCL_DTYPE_F32) {
+        auto k = gemm_tn_kernel<float>;
+        static bool once = false;
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps);
+    } else {
+        return -1;
+    }
+    return MURCL_CHECK_LAUNCH();
+}

@@ -1,0 +1,221 @@
+// K8/K9: NT-Xent forward + backward and the per-pair cosine reward in ONE launch
+// (utils/losses.py:24-41, train_MuRCL.py:253,282-283).
+//
+//   zh_i = z_i / max(|z_i|, 1e-8);  S = zh zh^T / tau;  loss = mean_i [ lse_{j!=i} S_ij - S_{i,pos(i)} ]
+//   d loss / d zh_i = (1/(n tau)) sum_{j!=i} [ P_ij + P_ji - 2 [j == pos(i)] ] zh_j,   P_ij = exp(S_ij - lse_i)
+//
+// S is symmetric, so the column term P_ji needs only lse_j: phase 1 computes lse for every row,
+// phase 2 the gradient, separated by an agent-scope grid barrier (<= 64 workgroups of 16 rows, always
+// co-resident).  Nothing of size n x n is ever materialised (the reference builds an n x n x 128
+// broadcast temp, losses.py:29).  Rows [grad_lo, grad_hi) of each view receive a gradient (bag
+// sharding across ranks: loss rows are global, gradients local).
+#include "common.h"
+
+#define NX_P 128          // projection dim
+#define NX_ROWS 16        // rows per workgroup
+#define NX_JT 64          // columns (other embeddings) per LDS tile
+#define NX_SPIN_LIMIT (1u << 24)
+
+struct NxCtl {            // zeroed by a memset node before every launch
+    unsigned arrive[2];
+    unsigned timeout;
+    unsigned pad;
+    float loss;
+    float pad2[3];
+};
+
+__device__ __forceinline__ bool nx_grid_barrier(unsigned* counter, unsigned target, unsigned* timeout) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
+    __syncthreads();
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > NX_SPIN_LIMIT) { ok = 0; __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+__global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z, int n, int Bh, float inv_tau,
+                                                     float* __restrict__ zh, float* __restrict__ inorm,
+                                                     float* __restrict__ lse, NxCtl* ctl, float* __restrict__ dz,
+                                                     float* __restrict__ sim, float* __restrict__ loss_out,
+                                                     int grad_lo, int grad_hi) {
+    __shared__ __attribute__((aligned(16))) float zi[NX_ROWS][NX_P + 4];    // own rows (normalised)
+    __shared__ __attribute__((aligned(16))) float zj[NX_JT][NX_P + 4];      // streamed tile
+    __shared__ float st[NX_ROWS][NX_JT + 1];                                // S tile / weights
+    __shared__ float lse_j[NX_JT];
+    const int tid = threadIdx.x, i_loc = tid >> 4, c16 = tid & 15;
+    const int row0 = blockIdx.x * NX_ROWS;
+    const int nblk = gridDim.x;
+
+    // ---------------- phase 0: normalise own rows
+    {
+        const int i = row0 + i_loc;
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = (i < n) ? z[(size_t)i * NX_P + 8 * c16 + e] : 0.f;
+            ss += v[e] * v[e];
+        }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-8f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            zi[i_loc][8 * c16 + e] = v[e] * inv;
+            if (i < n) zh[(size_t)i * NX_P + 8 * c16 + e] = v[e] * inv;
+        }
+        if (c16 == 0 && i < n) inorm[i] = inv;
+    }
+    if (!nx_grid_barrier(&ctl->arrive[0], nblk, &ctl->timeout)) return;
+
+    auto load_tile = [&](int j0) {            // zj <- zh[j0 .. j0+63]
+        for (int idx = tid; idx < NX_JT * (NX_P / 4); idx += 256) {
+            const int r = idx / (NX_P / 4), c4 = idx % (NX_P / 4);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j0 + r < n) v = *(const f32x4*)(zh + (size_t)(j0 + r) * NX_P + 4 * c4);
+            *(f32x4*)&zj[r][4 * c4] = v;
+        }
+    };
+    // S_ij for this thread's row i_loc and columns j = c16 + 16*u (u = 0..3) of the tile
+    auto dots = [&](float* s4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < NX_P; k += 4) {
+            const f32x4 a = *(const f32x4*)&zi[i_loc][k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 b = *(const f32x4*)&zj[c16 + 16 * u][k];
+                s4[u] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] *= inv_tau;
+    };
+
+    // ---------------- phase 1: row log-sum-exp (j != i) and the positive logit
+    const int i_glob = row0 + i_loc;
+    const int pos = (i_glob < Bh) ? i_glob + Bh : i_glob - Bh;
+    float m_run = -INFINITY, l_run = 0.f, s_pos = 0.f;
+    for (int j0 = 0; j0 < n; j0 += NX_JT) {
+        __syncthreads();
+        load_tile(j0);
+        __syncthreads();
+        float s4[4];
+        dots(s4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + c16 + 16 * u;
+            if (j < n && j != i_glob) {
+                const float mn = fmaxf(m_run, s4[u]);
+                l_run = l_run * __expf(m_run - mn) + __expf(s4[u] - mn);
+                m_run = mn;
+            }
+            if (j == pos) s_pos = s4[u];
+        }
+    }
+    // combine the 16 threads of a row
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float m2 = __shfl_xor(m_run, o, 64), l2 = __shfl_xor(l_run, o, 64);
+        const float mn = fmaxf(m_run, m2);
+        const float a = (m_run == -INFINITY) ? 0.f : l_run * __expf(m_run - mn);
+        const float b = (m2 == -INFINITY) ? 0.f : l2 * __expf(m2 - mn);
+        l_run = a + b;
+        m_run = mn;
+        s_pos += __shfl_xor(s_pos, o, 64);
+    }
+    const float my_lse = m_run + __logf(l_run);
+    if (c16 == 0 && i_glob < n) {
+        lse[i_glob] = my_lse;
+        atomicAdd(&ctl->loss, (my_lse - s_pos) / (float)n);
+        if (i_glob < Bh && sim) sim[i_glob] = s_pos / inv_tau;      // cosine of the positive pair (K9)
+    }
+    if (!nx_grid_barrier(&ctl->arrive[1], nblk, &ctl->timeout)) return;
+    if (blockIdx.x == 0 && tid == 0) loss_out[0] = __hip_atomic_load(&ctl->loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!dz) return;
+
+    // ---------------- phase 2: gradient for rows whose bag index is in [grad_lo, grad_hi)
+    const int bag_i = (i_glob < Bh) ? i_glob : i_glob - Bh;
+    const bool want = i_glob < n && bag_i >= grad_lo && bag_i < grad_hi;
+    bool any = false;
+    for (int r = 0; r < NX_ROWS; ++r) {
+        const int ig = row0 + r, bg = ig < Bh ? ig : ig - Bh;
+        any |= (ig < n && bg >= grad_lo && bg < grad_hi);
+    }
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    if (any) {
+        const float scale = inv_tau / (float)n;
+        for (int j0 = 0; j0 < n; j0 += NX_JT) {
+            __syncthreads();
+            load_tile(j0);
+            if (tid < NX_JT) lse_j[tid] = (j0 + tid < n) ? lse[j0 + tid] : 0.f;
+            __syncthreads();
+            float s4[4];
+            dots(s4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jl = c16 + 16 * u, j = j0 + jl;
+                float w = 0.f;
+                if (j < n && j != i_glob) {
+                    w = __expf(s4[u] - my_lse) + __expf(s4[u] - lse_j[jl]);
+                    if (j == pos) w -= 2.f;
+                }
+                st[i_loc][jl] = w * scale;
+            }
+            __syncthreads();
+            // thread (i_loc, c16) accumulates columns 8*c16 .. +7
+#pragma unroll 8
+            for (int jl = 0; jl < NX_JT; ++jl) {
+                const float w = st[i_loc][jl];
+                const f32x4 b0 = *(const f32x4*)&zj[jl][8 * c16];
+                const f32x4 b1 = *(const f32x4*)&zj[jl][8 * c16 + 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { g[e] += w * b0[e]; g[4 + e] += w * b1[e]; }
+            }
+        }
+    }
+    // project through the normalisation: dz = (g - (zh.g) zh) / |z|
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot += g[e] * zi[i_loc][8 * c16 + e];
+    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+    if (i_glob < n) {
+        const float inv = inorm[i_glob];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            dz[(size_t)i_glob * NX_P + 8 * c16 + e] = want ? (g[e] - dot * zi[i_loc][8 * c16 + e]) * inv : 0.f;
+    }
+}
+
+extern "C" long murcl_ntxent_workspace_bytes(int n) { return (long)sizeof(NxCtl) + (long)n * (NX_P + 2) * 4; }
+
+// C-ABI: see include/murcl_amd.h
+extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz,
+                                    float* sim, int grad_lo, int grad_hi, void* workspace, hipStream_t stream) {
+    if (P != NX_P || n <= 0 || (n & 1)) return -1;
+    const int nblk = (n + NX_ROWS - 1) / NX_ROWS;
+    if (nblk > 256) return -1;                               // grid barrier needs co-residency
+    NxCtl* ctl = (NxCtl*)workspace;
+    float* zh = (float*)((char*)workspace + sizeof(NxCtl));
+    float* inorm = zh + (size_t)n * NX_P;
+    float* lse = inorm + n;
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(NxCtl), stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ntxent_kernel, dim3(nblk), dim3(256), 0, stream, z, n, n / 2, 1.0f / temperature, zh, inorm, lse,
+                       ctl, dz, sim, loss, grad_lo, grad_hi);
+    return MURCL_CHECK_LAUNCH();
+}

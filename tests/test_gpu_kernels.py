@@ -1,0 +1,274 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against CPU math / the oracle.
+
+fp32 kernels (exact-f32 MFMA) are held to 1e-4 relative (BASELINE.json north_star); bf16 kernels
+are compared with the same math evaluated on the bf16-rounded inputs (tolerance stated per test).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, mil_oracle as O  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(seed, name, shape, scale=1.0):
+    return torch.from_numpy(detrand.normal(seed, name, shape) * np.float32(scale))
+
+
+def _close(got, want, rtol, atol, msg=""):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{msg}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} (ref max {want.abs().max():.3e})"
+
+
+def _rel_fro(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).norm() / want.norm().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (1000, 130, 128), (64, 3072, 1024), (333, 12, 512), (4096, 512, 512)])
+def test_gemm_nt_plain_and_bias_relu(dtype, M, N, K):
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(1, f"A{M}{K}", (M, K)).to(dtype)
+    B = _rand(1, f"B{N}{K}", (N, K), 1 / math.sqrt(K)).to(dtype)
+    bias = _rand(1, f"b{N}", (N,))
+    ref = A.double() @ B.double().t()
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    C = ops.gemm_nt(A.to(dev), B.to(dev), out_dtype=torch.float32)
+    _close(C, ref, msg="plain", **tol)
+    C2, ws = ops.gemm_nt(A.to(dev), B.to(dev), epi=ops.EPI_BIAS_RELU, bias=bias.to(dev), colsum=True)
+    ref2 = torch.relu(ref + bias.double())
+    _close(C2.float(), ref2, msg="bias_relu", **tol)
+    # per-tile column sums add up to the column sums of the (rounded) output
+    _close(ws.sum(0), C2.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_mask_and_rank1(dtype):
+    from murcl_amd import ops
+    dev = _dev()
+    bags, n, K, N = 3, 200, 128, 512
+    M = bags * n
+    A = _rand(2, "A", (M, K)).to(dtype)
+    B = _rand(2, "B", (N, K), 0.1).to(dtype)
+    Hm = _rand(2, "H", (M, N)).to(dtype)
+    a = torch.from_numpy(detrand.uniform(2, "a", (M,)))
+    dM = _rand(2, "dM", (bags, N))
+    base = A.double() @ B.double().t()
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    C = ops.gemm_nt(A.to(dev), B.to(dev), epi=ops.EPI_MASK, mask=Hm.to(dev), out_dtype=torch.float32)
+    _close(C, base * (Hm.double() > 0), msg="mask", **tol)
+    C, ws = ops.gemm_nt(A.to(dev), B.to(dev), epi=ops.EPI_RANK1_MASK, mask=Hm.to(dev), rowscale=a.to(dev),
+                        rank1=dM.to(dev), rows_per_bag=n, colsum=True)
+    ref = (base + a.double()[:, None] * dM.double().repeat_interleave(n, 0)) * (Hm.double() > 0)
+    _close(C.float(), ref, msg="rank1_mask", **tol)
+    _close(ws.sum(0), C.double().sum(0).float(), rtol=1e-3, atol=0.3, msg="colsum")
+
+
+def test_gemm_nt_accumulate():
+    from murcl_amd import ops
+    dev = _dev()
+    A, B = _rand(3, "A", (128, 512)), _rand(3, "B", (384, 512), 0.05)
+    C0 = _rand(3, "C", (128, 384))
+    C = C0.to(dev).clone()
+    ops.gemm_nt(A.to(dev), B.to(dev), out=C, accumulate=True)
+    _close(C, C0.double() + A.double() @ B.double().t(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ GEMM TN
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (1000, 128, 512), (130, 3072, 512), (77, 16, 1024), (20000, 512, 128)])
+def test_gemm_tn(dtype, M, N1, N2):
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(4, f"A{M}{N1}", (M, N1)).to(dtype)
+    B = _rand(4, f"B{M}{N2}", (M, N2)).to(dtype)
+    ref = A.double().t() @ B.double()
+    C = ops.gemm_tn(A.to(dev), B.to(dev))
+    rel = _rel_fro(C, ref)
+    assert rel < (2e-6 if dtype == torch.float32 else 2e-3), rel
+    s = math.sqrt(M)
+    _close(C, ref, rtol=1e-4, atol=1e-4 * s if dtype == torch.float32 else 2e-2 * s, msg="tn")
+
+
+# ------------------------------------------------------------------ K2 attention pool
+def _k2_inputs(seed, B, N):
+    H = torch.relu(_rand(seed, "H", (B, N, 512)))
+    H = H * torch.from_numpy(detrand.uniform(seed, "sig", (B, 1, 512), 0.1, 1.9))
+    Wa = _rand(seed, "Wa", (128, 512), 2.0 / math.sqrt(512))
+    ba = _rand(seed, "ba", (128,), 0.1)
+    wb = _rand(seed, "wb", (1, 128), 4.0 / math.sqrt(128))
+    bb = _rand(seed, "bb", (1,), 0.1)
+    return H, Wa, ba, wb, bb
+
+
+@pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (3, 16), (1, 1), (5, 1000), (2, 5000), (64, 2048)])
+def test_abmil_pool_fwd_f32(B, N):
+    """fp32 path vs oracle: attention weights and pooled vector within 1e-4 (north_star)."""
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(7, B, N)
+    M_ref, A_ref, s_ref = O.abmil_attn_pool(H, Wa, ba, wb, bb)
+    s, A, M, ml = ops.abmil_pool_fwd(H.to(dev), Wa.to(dev), ba.to(dev), wb.to(dev), bb.to(dev))
+    _close(s, s_ref, rtol=1e-4, atol=1e-5, msg="scores")
+    _close(A, A_ref, rtol=1e-4, atol=1e-9, msg="A")
+    _close(M, M_ref, rtol=1e-4, atol=1e-6, msg="M")
+    np.testing.assert_allclose(A.sum(1).cpu().numpy(), np.full(B, 1 / math.sqrt(N)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (64, 2048)])
+def test_abmil_pool_fwd_bf16(B, N):
+    """bf16 storage path vs the oracle evaluated on the bf16-rounded H and Wa.
+    Tolerance: scores 2e-3 abs (fast tanh + accumulation order), A 1% rel, M 1% of max."""
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(8, B, N)
+    Hb, Wab = H.bfloat16(), Wa.bfloat16()
+    M_ref, A_ref, s_ref = O.abmil_attn_pool(Hb.float(), Wab.float(), ba, wb, bb)
+    s, A, M, ml = ops.abmil_pool_fwd(Hb.to(dev), Wab.to(dev), ba.to(dev), wb.to(dev), bb.to(dev))
+    _close(s, s_ref, rtol=0, atol=2e-3, msg="scores")
+    _close(A, A_ref, rtol=1e-2, atol=1e-9, msg="A")
+    _close(M, M_ref, rtol=1e-2, atol=1e-2 * M_ref.abs().max().item(), msg="M")
+
+
+def test_abmil_pool_fwd_online_softmax_rescale():
+    """Force the running-max rescale: one late row with a much larger score than everything before
+    it (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
+    from murcl_amd import ops
+    dev = _dev()
+    B, N = 2, 4096
+    H, Wa, ba, wb, bb = _k2_inputs(9, B, N)
+    wb = wb * 6.0
+    H[0, 3000] *= 8.0
+    H[1, 17] *= 8.0
+    M_ref, A_ref, s_ref = O.abmil_attn_pool(H, Wa, ba, wb, bb)
+    s, A, M, ml = ops.abmil_pool_fwd(H.to(dev), Wa.to(dev), ba.to(dev), wb.to(dev), bb.to(dev))
+    _close(A, A_ref, rtol=2e-4, atol=1e-9, msg="A")
+    _close(M, M_ref, rtol=2e-4, atol=1e-6, msg="M")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (16, 2048)])
+def test_abmil_pool_bwd(dtype, B, N):
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(10, B, N)
+    H, Wa = H.to(dtype), Wa.to(dtype)
+    dM = _rand(10, "dM", (B, 512))
+    # oracle gradient w.r.t. the pre-tanh activations U = H Wa^T + ba
+    Hf, Waf = H.float(), Wa.float()
+    U = (Hf @ Waf.t() + ba).requires_grad_()
+    bbr, wbr = bb.clone().requires_grad_(), wb.clone().requires_grad_()
+    s = (torch.tanh(U) @ wbr.t()).squeeze(-1) + bbr
+    A = torch.softmax(s, 1) / math.sqrt(N)
+    Mo = torch.einsum("bn,bnl->bl", A, Hf)
+    (Mo * dM).sum().backward()
+    sc, A_g, M_g, ml = ops.abmil_pool_fwd(H.to(dev), Wa.to(dev), ba.to(dev), wb.to(dev), bb.to(dev))
+    dT, dba, dwb, dbb = ops.abmil_pool_bwd(H.to(dev), Wa.to(dev), ba.to(dev), wb.to(dev), sc, ml, M_g, dM.to(dev))
+    f32 = dtype == torch.float32
+    ref = U.grad.reshape(B * N, 128)
+    scale = ref.abs().max().item()
+    _close(dT.float(), ref, rtol=1e-4 if f32 else 2e-2, atol=(1e-5 if f32 else 1e-2) * scale, msg="dT")
+    _close(dba, ref.sum(0), rtol=1e-3 if f32 else 3e-2, atol=(1e-4 if f32 else 3e-2) * ref.sum(0).abs().max().item(), msg="dba")
+    _close(dwb, wbr.grad[0], rtol=1e-3 if f32 else 3e-2, atol=(1e-4 if f32 else 3e-2) * wbr.grad.abs().max().item(), msg="dwb")
+    assert abs(dbb.item()) < 1e-3 * max(1.0, wbr.grad.abs().max().item())      # softmax shift invariance
+
+
+# ------------------------------------------------------------------ NT-Xent
+@pytest.mark.parametrize("Bh", [2, 4, 9, 64, 512])
+@pytest.mark.parametrize("tau", [1.0, 0.5, 0.07])
+def test_ntxent(Bh, tau):
+    from murcl_amd import ops
+    dev = _dev()
+    zi = _rand(11, f"zi{Bh}", (Bh, 128)).requires_grad_()
+    zj = (zi.detach() * 0.7 + 0.3 * _rand(11, f"zj{Bh}", (Bh, 128))).requires_grad_()
+    loss_ref = O.nt_xent(zi, zj, tau)
+    loss_ref.backward()
+    z = torch.cat([zi.detach(), zj.detach()]).to(dev)
+    loss, dz, sim = ops.ntxent(z, tau)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    gref = torch.cat([zi.grad, zj.grad])
+    # (P_ij - 1) cancels to ~1e-5 at small tau; fp32 exp carries ~1e-7 absolute error per weight on
+    # BOTH sides, scaled by 1/(n tau) in the gradient.
+    _close(dz, gref, rtol=1e-3, atol=2e-5 * gref.abs().max().item() + 4e-7 / (2 * Bh * tau), msg="dz")
+    _close(sim, O.row_cosine(zi.detach(), zj.detach()), rtol=1e-4, atol=1e-6, msg="sim")
+
+
+def test_ntxent_sharded_rows_match_global():
+    """Rank-local gradient slices assemble to the global gradient."""
+    from murcl_amd import ops
+    dev = _dev()
+    Bh = 32
+    z = torch.cat([_rand(12, "a", (Bh, 128)), _rand(12, "b", (Bh, 128))]).to(dev)
+    loss, dz, _ = ops.ntxent(z, 0.5)
+    parts = torch.zeros_like(dz)
+    for lo in range(0, Bh, 8):
+        l2, d2, _ = ops.ntxent(z, 0.5, grad_lo=lo, grad_hi=lo + 8)
+        assert l2.item() == pytest.approx(loss.item(), rel=1e-6)
+        parts += d2
+    _close(parts, dz, rtol=1e-6, atol=1e-9)
+
+
+# ------------------------------------------------------------------ small helpers
+def test_cast_transpose_colsum_relu():
+    from murcl_amd import ops
+    dev = _dev()
+    x = _rand(13, "x", (513, 130))
+    xb = ops.cast(x.to(dev), torch.bfloat16)
+    assert torch.equal(xb.cpu(), x.bfloat16())
+    assert torch.equal(ops.cast(xb, torch.float32).cpu(), x.bfloat16().float())
+    assert torch.equal(ops.transpose_cast(x.to(dev), torch.float32).cpu(), x.t().contiguous())
+    assert torch.equal(ops.transpose_cast(x.to(dev), torch.bfloat16).cpu(), x.t().contiguous().bfloat16())
+    _close(ops.colsum(x.to(dev)), x.double().sum(0), rtol=1e-5, atol=1e-4)
+    _close(ops.colsum(xb), x.bfloat16().double().sum(0), rtol=1e-5, atol=1e-4)
+    y = _rand(13, "y", (513, 130))
+    assert torch.equal(ops.relu_bwd(x.to(dev), y.to(dev)).cpu(), x * (y > 0))
+
+
+def test_gru_gates_fwd_bwd():
+    from murcl_amd import ops
+    dev = _dev()
+    B, H = 6, 1024
+    gi, gh = _rand(14, "gi", (B, 3 * H)).requires_grad_(), _rand(14, "gh", (B, 3 * H)).requires_grad_()
+    hp = _rand(14, "hp", (B, H)).requires_grad_()
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn = (1 - z) * n + z * hp
+    dh = _rand(14, "dh", (B, H))
+    (hn * dh).sum().backward()
+    hnew, gates = ops.gru_gates_fwd(gi.detach().to(dev), gh.detach().to(dev), hp.detach().to(dev))
+    _close(hnew, hn, rtol=1e-5, atol=1e-6)
+    dgi, dgh, dhp = ops.gru_gates_bwd(dh.to(dev), gates, gh.detach().to(dev), hp.detach().to(dev))
+    _close(dgi, gi.grad, rtol=1e-4, atol=1e-6)
+    _close(dgh, gh.grad, rtol=1e-4, atol=1e-6)
+    _close(dhp, hp.grad, rtol=1e-4, atol=1e-6)
+    # restart (no previous hidden)
+    h0, _ = ops.gru_gates_fwd(gi.detach().to(dev), gh.detach().to(dev), None)
+    _close(h0, (1 - z) * n, rtol=1e-5, atol=1e-6)
+
+
+def test_adam_matches_oracle():
+    from murcl_amd import ops
+    dev = _dev()
+    p0, g = _rand(15, "p", (1000,)), _rand(15, "g", (1000,))
+    p = p0.to(dev).clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    st, ref = {}, {"w": p0.clone()}
+    for step in range(1, 4):
+        ops.adam_step(p, g.to(dev), m, v, 1e-3, (0.9, 0.999), 1e-8, 1e-5, step)
+        ref = O.adam_step(ref, {"w": g}, st, 1e-3, weight_decay=1e-5)
+    _close(p, ref["w"], rtol=1e-5, atol=1e-7)
