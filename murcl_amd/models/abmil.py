@@ -1,0 +1,71 @@
+"""Drop-in ``ABMIL`` (reference: models/abmil.py).
+
+Same constructor, ``forward`` contract ``(out [B,L], out.detach())``, TypeError on foreign
+inputs and state-dict keys (``encoder.{0,3,6}``, ``attention.{0,2}``, ``decoder.0``, ``fc``) as
+the reference, so its checkpoints load unchanged.  The containers only *hold* parameters: a bag
+batch runs as three MFMA GEMMs with fused bias+ReLU, one streaming attention-pool kernel
+(scores, online soft-max, /sqrt(N), weighted sum in a single pass over H) and the decoder GEMM,
+for all bags of a batch at once instead of the reference's per-bag Python loop (abmil.py:47-51).
+"""
+import torch
+from torch import nn
+
+from ..functional import ABMILFn
+
+
+def _stack(spec):
+    return nn.Sequential(*[m for m in spec])
+
+
+class ABMIL(nn.Module):
+    def __init__(self, dim_in, L=512, D=128, K=1, dim_out=2, dropout=0.):
+        super().__init__()
+        self.L, self.D, self.K = L, D, K
+        self.dropout = float(dropout)
+        enc, width = [], dim_in
+        for depth in range(3):                       # indices 0,3,6 are the Linears (abmil.py:12-21)
+            enc += [nn.Linear(width, L), nn.ReLU()] + ([nn.Dropout(dropout)] if depth < 2 else [])
+            width = L
+        self.encoder = _stack(enc)
+        self.attention = _stack([nn.Linear(L, D), nn.Tanh(), nn.Linear(D, K)])
+        self.decoder = _stack([nn.Linear(L, L), nn.ReLU()])
+        self.fc = nn.Linear(L, dim_out)              # built, never applied (abmil.py:33)
+        self.compute_dtype = torch.float32           # torch.bfloat16 = throughput path
+        self.last_attention = None                   # A [B,N] of the most recent call (detached)
+
+    # -- kernels -------------------------------------------------------------------------
+    def _bags(self, x):
+        """x [B,N,d] -> [B,L] through the fused HIP path."""
+        if self.K != 1 or self.L != 512 or self.D != 128:
+            raise NotImplementedError("murcl_amd ABMIL kernels are built for L=512, D=128, K=1")
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("dropout>0 is not wired into the fused encoder (reference default 0.0)")
+        if x.dtype != self.compute_dtype:
+            from .. import ops
+            x = ops.cast(x.float().contiguous(), self.compute_dtype) if x.dtype != torch.float32 else \
+                ops.cast(x.contiguous(), self.compute_dtype)
+        e, a, d = self.encoder, self.attention, self.decoder
+        out, A = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
+                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias)
+        self.last_attention = A
+        return out
+
+    def bag_forward(self, bag):
+        return self._bags(bag.unsqueeze(0))
+
+    def batch_forward(self, batch):
+        if isinstance(batch, torch.Tensor):
+            return self._bags(batch)
+        bags = [b.squeeze(0) if b.dim() == 3 else b for b in batch]
+        if len({b.shape[0] for b in bags}) == 1:
+            return self._bags(torch.stack(bags, 0))
+        return torch.cat([self._bags(b.unsqueeze(0)) for b in bags], 0)      # ragged bags
+
+    def forward(self, x):
+        if isinstance(x, list):
+            outputs = self.batch_forward(x)
+        elif isinstance(x, torch.Tensor):
+            outputs = self._bags(x if x.dim() == 3 else x.unsqueeze(0))
+        else:
+            raise TypeError
+        return outputs, outputs.detach()

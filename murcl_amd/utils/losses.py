@@ -1,0 +1,28 @@
+"""Drop-in ``NT_Xent`` (reference: utils/losses.py).
+
+One HIP launch computes the loss, its gradient and the positive-pair cosines; no
+[2B,2B,128] broadcast temp and no boolean-mask gather as in losses.py:27-36.
+``set_shard(lo, hi)`` restricts the gradient to bags [lo,hi) when the batch given to
+``forward`` is the all-gathered global batch (one process per GPU, see murcl_amd/dist.py).
+"""
+from torch import nn
+
+from ..functional import NTXentFn
+
+
+class NT_Xent(nn.Module):
+    def __init__(self, batch_size, temperature):
+        super().__init__()
+        self.batch_size = batch_size
+        self.temperature = temperature
+        self._shard = None
+        self.last_similarity = None          # cos(z_i[b], z_j[b]) of the latest call (K9)
+
+    def set_shard(self, lo, hi):
+        self._shard = (int(lo), int(hi))
+
+    def forward(self, z_i, z_j):
+        lo, hi = self._shard if self._shard is not None else (0, z_i.shape[0])
+        loss, sim = NTXentFn.apply(z_i, z_j, float(self.temperature), lo, hi)
+        self.last_similarity = sim
+        return loss

@@ -199,7 +199,8 @@ def test_ntxent(Bh, tau):
     loss_ref.backward()
     z = torch.cat([zi.detach(), zj.detach()]).to(dev)
     loss, dz, sim = ops.ntxent(z, tau)
-    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    # loss = lse - positive logit, both O(1/tau): absolute error scales with 1/tau, not with the loss
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item()) + 2e-7 / tau
     gref = torch.cat([zi.grad, zj.grad])
     # (P_ij - 1) cancels to ~1e-5 at small tau; fp32 exp carries ~1e-7 absolute error per weight on
     # BOTH sides, scaled by 1/(n tau) in the gradient.

@@ -1,0 +1,187 @@
+"""Module-level parity on MI355X: drop-in modules vs the CPU oracle on identical seeded inputs,
+and vs the committed goldens that were produced by the reference itself.
+
+fp32 path: <=1e-4 (north_star).  bf16 path: checked against the fp32 HIP path with the
+tolerances written in each test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, mil_oracle as O, params as P  # noqa: E402
+
+T = torch.from_numpy
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _summ(g):
+    g = g.detach().double().flatten().cpu()
+    return np.concatenate([[g.norm().item(), g.abs().max().item()], g[:32].numpy()])
+
+
+def _check_summ(got, want, rtol, key):
+    np.testing.assert_allclose(got[:2], want[:2], rtol=rtol, err_msg=key)
+    np.testing.assert_allclose(got[2:], want[2:], rtol=rtol, atol=rtol * want[1], err_msg=key)
+
+
+def _abmil(seed, dtype=torch.float32):
+    from murcl_amd.models.abmil import ABMIL
+    m = ABMIL(512, L=512, D=128, dim_out=128)
+    m.load_state_dict(P.to_torch(P.abmil(seed)))          # reference state-dict keys load unchanged
+    m.compute_dtype = dtype
+    return m.to(_dev())
+
+
+def test_abmil_forward_backward_vs_reference_golden(golden):
+    """G1: the reference's own outputs for the C1 shape (4 x 256 x 512)."""
+    g = golden("g1_abmil")
+    m = _abmil(985)
+    x = T(P.bags(985, "g1.x", 4, 256, 512)).to(_dev())
+    out, det = m(x)
+    assert not det.requires_grad and out.shape == (4, 512)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), g["A"], rtol=1e-4, atol=1e-9)
+    out.sum().backward()
+    for k, v in m.named_parameters():
+        key = "grad." + k
+        if key not in g.files:
+            continue
+        if k == "attention.2.bias":
+            assert v.grad.abs().max().item() < 1e-4 * m.attention[2].weight.grad.norm().item()
+            continue
+        _check_summ(_summ(v.grad), g[key], 3e-4, key)
+    assert m.fc.weight.grad is None
+    o1, _ = m(x[:1])
+    np.testing.assert_allclose(o1.detach().cpu().numpy(), g["out_single"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N", [(2, 300), (3, 1000), (8, 2048)])
+def test_abmil_vs_oracle_full_grads(B, N):
+    m = _abmil(3)
+    p = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(3)).items()}
+    x = T(P.bags(3, f"x{B}{N}", B, N, 512))
+    w = T(detrand.normal(3, "w", (B, 512)))
+    out_ref, A_ref, _, _ = O.abmil_forward(p, x)
+    (out_ref * w).sum().backward()
+    out, _ = m(x.to(_dev()))
+    (out * w.to(_dev())).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), A_ref.detach().numpy(), rtol=1e-4, atol=1e-9)
+    for k, v in m.named_parameters():
+        if p[k].grad is None:
+            continue
+        ref = p[k].grad
+        scale = ref.abs().max().item()
+        if k == "attention.2.bias":
+            continue
+        np.testing.assert_allclose(v.grad.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=2e-4 * scale, err_msg=k)
+
+
+def test_abmil_list_and_ragged_inputs():
+    m = _abmil(4)
+    dev = _dev()
+    xs = [T(P.bags(4, f"r{i}", 1, n, 512)).to(dev) for i, n in enumerate((100, 257, 100))]
+    out, _ = m(xs)                                            # list of [1,N_i,d]
+    p = P.to_torch(P.abmil(4))
+    for i, x in enumerate(xs):
+        ref = O.abmil_forward(p, x.cpu())[0]
+        np.testing.assert_allclose(out[i:i + 1].detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(TypeError):
+        m(3.0)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 8, 512))                             # CPU tensor: no fallback
+
+
+def test_abmil_bf16_path_close_to_fp32_path():
+    """bf16 storage of patch-level tensors: out within 2% of max, A within 3% rel, grads within 5% (norm-wise)."""
+    dev = _dev()
+    x = T(P.bags(5, "xb", 8, 2048, 512)).to(dev)
+    w = T(detrand.normal(5, "w", (8, 512))).to(dev)
+    m32, m16 = _abmil(5), _abmil(5, torch.bfloat16)
+    o32, _ = m32(x)
+    (o32 * w).sum().backward()
+    o16, _ = m16(x)
+    (o16 * w).sum().backward()
+    assert (o16 - o32).abs().max().item() <= 2e-2 * o32.abs().max().item()
+    np.testing.assert_allclose(m16.last_attention.cpu().numpy(), m32.last_attention.cpu().numpy(), rtol=3e-2)
+    for (k, a), (_, b) in zip(m16.named_parameters(), m32.named_parameters()):
+        if a.grad is None or k == "attention.2.bias":
+            continue
+        rel = ((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-30)).item()
+        assert rel < 5e-2, (k, rel)
+
+
+def test_full_layer_interleaved_hidden_golden(golden):
+    """G9: the two views share one hidden state exactly like the reference's attribute."""
+    from murcl_amd.models.rlmil import Full_layer
+    g = golden("g9_full_layer")
+    fc = Full_layer(512, 1024, True, 128)
+    fc.load_state_dict(P.to_torch(P.full_layer(13)))
+    fc = fc.to(_dev())
+    with torch.no_grad():
+        for t in range(3):
+            for v in range(2):
+                x = T(detrand.normal(13, f"g9.x.{t}.{v}", (4, 512))).to(_dev())
+                z = fc(x, restart=(t == 0))
+                np.testing.assert_allclose(z.cpu().numpy(), g[f"z.{t}.{v}"], rtol=1e-4, atol=2e-6)
+                np.testing.assert_allclose(fc.hidden[0].cpu().numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("Tn", [1, 3])
+def test_pretrain_step_golden(golden, Tn):
+    """G3: CL(ABMIL) + Full_layer + NT_Xent over T patch-steps: losses, rewards, gradients vs the reference."""
+    from murcl_amd.models.cl import CL
+    from murcl_amd.models.rlmil import Full_layer
+    from murcl_amd.utils.losses import NT_Xent
+    g = golden("g3_pretrain")
+    dev = _dev()
+    model = CL(_abmil(985), projection_dim=128, n_features=512)
+    fc = Full_layer(512, 1024, True, 128)
+    fc.load_state_dict(P.to_torch(P.full_layer(985)))
+    fc = fc.to(dev)
+    crit = NT_Xent(4, 1.0)
+    losses, rewards, sim_last = [], [], None
+    for t in range(Tn):
+        xv = [T(P.bags(985, f"g3.x.{t}.{v}", 4, 256, 512)).to(dev) for v in range(2)]
+        outs, states = model(xv)
+        outs = [fc(o, restart=(t == 0)) for o in outs]
+        losses.append(crit(outs[0], outs[1]))
+        sim = crit.last_similarity
+        if t > 0:
+            rewards.append((sim_last - sim).cpu().numpy())
+        sim_last = sim
+    loss = sum(losses) / Tn
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g[f"T{Tn}.loss"], rtol=1e-4)
+    np.testing.assert_allclose([l.item() for l in losses], g[f"T{Tn}.losses"], rtol=1e-4)
+    if Tn > 1:
+        np.testing.assert_allclose(np.stack(rewards), g[f"T{Tn}.rewards"], rtol=2e-3, atol=2e-6)
+    for k, v in model.named_parameters():
+        key = f"T{Tn}.grad.{k}"
+        if key in g.files and not k.endswith("attention.2.bias"):
+            _check_summ(_summ(v.grad), g[key], 2e-3, key)
+    for k, v in fc.named_parameters():
+        _check_summ(_summ(v.grad), g[f"T{Tn}.grad.fc::{k}"], 2e-3, k)
+
+
+def test_ntxent_module_golden(golden):
+    from murcl_amd.utils.losses import NT_Xent
+    g = golden("g2_ntxent")
+    dev = _dev()
+    for B in (2, 4, 64):
+        for tau in (1.0, 0.5):
+            zi = T(detrand.normal(7, f"g2.zi.{B}", (B, 128))).to(dev).requires_grad_()
+            zj = T(detrand.normal(7, f"g2.zj.{B}", (B, 128))).to(dev).requires_grad_()
+            loss = NT_Xent(B, tau)(zi, zj)
+            loss.backward()
+            np.testing.assert_allclose(loss.item(), g[f"loss.{B}.{tau}"], rtol=1e-4)
+            np.testing.assert_allclose(zi.grad.cpu().numpy(), g[f"dzi.{B}.{tau}"], rtol=1e-3, atol=1e-7)
+            np.testing.assert_allclose(zj.grad.cpu().numpy(), g[f"dzj.{B}.{tau}"], rtol=1e-3, atol=1e-7)
