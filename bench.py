@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""MuRCL hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+Workload (BASELINE.json configs[1]): ABMIL + NT-Xent pre-train step on one view pair,
+64 bags x 2048 patches x 512-d per GPU, bf16 patch-level tensors with f32 accumulation.
+A step = CL(ABMIL) forward on both views (128 bag-forwards) -> Full_layer GRU step + projection
+-> NT-Xent -> full backward -> Adam on model + head.  Inputs are resident in HBM before the
+timed region.  With N > 1 GPUs each rank owns 64 bags (weak scaling); embeddings are
+all-gathered for the global contrastive denominator and gradients all-reduced (RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"hbm_GBps": 8000.0, "mfma_bf16_TFLOPs": 2500.0, "mfma_f32_TFLOPs": 157.3}   # MI355X_MICROARCH.md
+
+
+def build(dtype, device, bags):
+    from murcl_amd.models.abmil import ABMIL
+    from murcl_amd.models.cl import CL
+    from murcl_amd.models.rlmil import Full_layer
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.utils.losses import NT_Xent
+    torch.manual_seed(985)                                   # reference seed (train_MuRCL.py:473)
+    enc = ABMIL(512, L=512, D=128, dim_out=128)
+    enc.compute_dtype = dtype
+    model = CL(enc, projection_dim=128, n_features=512).to(device)
+    fc = Full_layer(512, 1024, True, 128).to(device)
+    opt = FlatAdam([{"params": list(model.parameters()), "lr": 1e-4},
+                    {"params": list(fc.parameters()), "lr": 5e-5}], betas=(0.9, 0.999), weight_decay=1e-5)
+    crit = NT_Xent(bags, 1.0)
+    return model, fc, opt, crit
+
+
+def synth_views(bags, n, d, dtype, device, rank):
+    """Two views of `bags` synthetic slides: |N(0,1)|*0.5 with a per-slide feature signature."""
+    g = torch.Generator(device=device)
+    g.manual_seed(985 + rank)
+    sig = torch.rand((bags, 1, d), generator=g, device=device) * 1.8 + 0.1
+    views = []
+    for _ in range(2):
+        x = torch.randn((bags, n, d), generator=g, device=device).abs_().mul_(0.5).mul_(sig)
+        views.append(x.to(dtype).contiguous())
+    return views
+
+
+def make_step(model, fc, opt, crit, views, world):
+    from murcl_amd import dist as mdist
+
+    def step():
+        opt.zero_grad()
+        outs, _ = model(views)
+        z = [fc(o, restart=True) for o in outs]
+        if world > 1:
+            loss, _ = mdist.gathered_nt_xent(z[0], z[1], 1.0)
+        else:
+            loss = crit(z[0], z[1])
+        loss.backward()
+        if world > 1:
+            mdist.all_reduce_grads(opt.flat_grads())
+        opt.step()
+        return loss
+    return step
+
+
+def cpu_baseline(bags, n, d, budget_s=12.0):
+    """The CPU oracle (a port of the reference step: oracle/mil_oracle.py) timed on this host."""
+    from oracle import mil_oracle as O, params as P
+    torch.manual_seed(0)
+    sample = 8                                              # bags per view in the bounded sample
+    mp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(985)).items()}
+    fp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.full_layer(985)).items()}
+    xs = [torch.randn(sample, n, d).abs_() * 0.5 for _ in range(2)]
+    st_m, st_f = {}, {}
+
+    def one():
+        for p in list(mp.values()) + list(fp.values()):
+            p.grad = None
+        loss, *_ = O.pretrain_step(mp, fp, [xs], 1.0)
+        loss.backward()
+        gm = {k: v.grad for k, v in mp.items() if v.grad is not None}
+        gf = {k: v.grad for k, v in fp.items() if v.grad is not None}
+        with torch.no_grad():
+            newm = O.adam_step({k: mp[k].detach() for k in gm}, gm, st_m, 1e-4, weight_decay=1e-5)
+            newf = O.adam_step({k: fp[k].detach() for k in gf}, gf, st_f, 5e-5, weight_decay=1e-5)
+            for k, v in newm.items():
+                mp[k].copy_(v)
+            for k, v in newf.items():
+                fp[k].copy_(v)
+    one()
+    t0, k = time.time(), 0
+    while time.time() - t0 < budget_s or k < 2:
+        one()
+        k += 1
+    dt = (time.time() - t0) / k
+    return dict(value=sample / dt, unit="bags/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{k} steps of the same step on {sample} bags x {n} x {d} per view (fp32, torch CPU threads="
+                       f"{torch.get_num_threads()}), {dt * 1e3:.0f} ms/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--bags", type=int, default=64)
+    ap.add_argument("--patches", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from murcl_amd import ops
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, N, D = args.bags, args.patches, 512
+    model, fc, opt, crit = build(dtype, device, B)
+    views = synth_views(B, N, D, dtype, device, rank)
+    step = make_step(model, fc, opt, crit, views, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+
+    # -- breakdown pass (untimed): find the kernel that dominates the step
+    ops.TIMERS = ops.KernelTimers()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    breakdown = ops.TIMERS.summary()
+    ops.TIMERS = None
+    dominant = max(breakdown, key=lambda k: breakdown[k]["ms_total"])
+    k2_key = f"abmil_pool_fwd<{args.dtype}>"
+
+    # -- timed region: exactly K steps; only the dominant kernel and K2 carry HIP events
+    ops.TIMERS = ops.KernelTimers(only={dominant, k2_key})
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    live = ops.TIMERS.summary()
+    ops.TIMERS = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = elapsed / args.steps * 1e3
+    value = B * world / (elapsed / args.steps)
+
+    def roof(key):
+        r = live[key]
+        sec = r["ms_total"] * 1e-3
+        if key.startswith("abmil_pool") or key.startswith("ntxent"):
+            ach, peak, unit, bound = r["bytes"] / sec / 1e9, PEAK["hbm_GBps"], "GB/s", "hbm"
+        else:
+            ach = r["flops"] / sec / 1e12
+            peak = PEAK["mfma_bf16_TFLOPs"] if "<bf16" in key else PEAK["mfma_f32_TFLOPs"]
+            unit, bound = "TFLOP/s", "mfma"
+        return dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                    traffic=_pmc_traffic(key), launches=r["calls"], avg_launch_ms=round(r["ms_avg"], 4))
+
+    out = {
+        "metric": "WSI-bags/sec pretrain step (ABMIL+NT-Xent) at N=2048,d=512",
+        "value": round(value, 2), "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"ABMIL+Full_layer+NT-Xent view-pair pretrain step (fwd+bwd+Adam), {B} bags x {N} x {D} "
+                               f"per GPU, {args.dtype} patch tensors / f32 accumulate (BASELINE configs[1])",
+                   "bags_per_gpu": B, "patches": N, "feat_dim": D, "global_bags": B * world,
+                   "sharding": "bags by WSI; all-gather of z + grad all-reduce" if world > 1 else "single GPU"},
+        "roofline": roof(dominant),
+        "roofline_k2": roof(k2_key),
+        "loss": round(float(loss.item()), 6),
+        "kernel_ms_per_step": {k: round(v["ms_total"] / 2, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B, N, D)
+    if args.breakdown:
+        for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):
+            print(f"{k:44s} calls/step {v['calls'] // 2:3d}  ms/step {v['ms_total'] / 2:8.4f}", file=sys.stderr)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(key):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), else null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,61 @@ from . import _lib
 from ._lib import BF16, F32, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_NONE, EPI_RANK1_MASK, check, dt, ptr, stream
 
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_EPI_NAME = {EPI_NONE: "NONE", EPI_BIAS: "BIAS", EPI_BIAS_RELU: "BIAS_RELU", EPI_MASK: "MASK", EPI_RANK1_MASK: "RANK1_MASK"}
+_DT_NAME = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+
+class KernelTimers:
+    """Optional HIP-event timing of individual launches on the launch stream (bench.py).
+
+    ``only`` restricts recording to some kernel keys so that the timed region carries a handful of
+    event records per step instead of one pair per launch."""
+
+    def __init__(self, only=None):
+        self.only, self.records = only, {}
+
+    def span(self, key, work=None):
+        return _Span(self, key, work) if (self.only is None or key in self.only) else _NULL
+
+    def summary(self):
+        """key -> dict(calls, ms_total, ms_avg, flops, bytes)   (call after a device synchronize)"""
+        out = {}
+        for key, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[key] = dict(calls=len(ms), ms_total=sum(ms), ms_avg=sum(ms) / len(ms),
+                            flops=sum(w.get("flops", 0) for _, _, w in recs),
+                            bytes=sum(w.get("bytes", 0) for _, _, w in recs))
+        return out
+
+
+class _Span:
+    def __init__(self, owner, key, work):
+        self.o, self.k, self.w = owner, key, work or {}
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.o.records.setdefault(self.k, []).append((self.a, self.b, self.w))
+
+
+class _Null:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+_NULL = _Null()
+TIMERS = None            # set to a KernelTimers to record
+
+
+def _span(key, work=None):
+    return TIMERS.span(key, work) if TIMERS is not None else _NULL
 
 
 def _need_cuda(*ts):
@@ -39,9 +94,13 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     if mask is not None:
         mask = _c(mask)
         assert mask.dtype == A.dtype and mask.shape == (M, N)
-    check(_lib.lib().murcl_gemm_nt(ptr(A), ptr(B), ptr(C), M, N, K, K, K, N, dt(A), dt(C), epi, ptr(bias), ptr(mask),
-                                   N, ptr(rowscale), ptr(rank1), rows_per_bag, ptr(ws), int(accumulate), stream()),
-          "gemm_nt")
+    es = A.element_size()
+    with _span(f"gemm_nt<{_DT_NAME[A.dtype]},{_DT_NAME[C.dtype]},{_EPI_NAME[epi]}>",
+               dict(flops=2.0 * M * N * K, bytes=(M * K + N * K) * es + M * N * C.element_size()
+                    + (M * N * es if mask is not None else 0))):
+        check(_lib.lib().murcl_gemm_nt(ptr(A), ptr(B), ptr(C), M, N, K, K, K, N, dt(A), dt(C), epi, ptr(bias),
+                                       ptr(mask), N, ptr(rowscale), ptr(rank1), rows_per_bag, ptr(ws), int(accumulate),
+                                       stream()), "gemm_nt")
     return (C, ws) if colsum else C
 
 
@@ -53,7 +112,10 @@ def gemm_tn(A, B, *, splits=0, out=None):
     N2 = B.shape[1]
     assert B.shape[0] == M and A.dtype == B.dtype
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
-    check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, stream()), "gemm_tn")
+    with _span(f"gemm_tn<{_DT_NAME[A.dtype]}>",
+               dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4)):
+        check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, stream()),
+              "gemm_tn")
     return C
 
 
@@ -78,9 +140,14 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
     M = torch.empty((B, L), dtype=torch.float32, device=dev)
     ml = torch.empty((B, 2), dtype=torch.float32, device=dev)
     part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
-    check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), ptr(A), ptr(M),
-                                          ptr(ml), ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
-          "abmil_pool_fwd")
+    es = H.element_size()
+    # algorithmic bytes per bag: H once + scores out + pooled M out; Wa amortised over the launch
+    with _span(f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>",
+               dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L),
+                    bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es)):
+        check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), ptr(A), ptr(M),
+                                              ptr(ml), ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
+              "abmil_pool_fwd")
     return scores, A, M, ml
 
 
@@ -97,9 +164,12 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None):
     dba = torch.zeros((D,), dtype=torch.float32, device=dev)
     dwb = torch.zeros((D,), dtype=torch.float32, device=dev)
     dbb = torch.zeros((1,), dtype=torch.float32, device=dev)
-    check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
-                                          ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), B, N, L, D, dt(H),
-                                          int(exact_tanh), stream()), "abmil_pool_bwd")
+    es = H.element_size()
+    with _span(f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
+               dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es)):
+        check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
+                                              ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), B, N, L, D, dt(H),
+                                              int(exact_tanh), stream()), "abmil_pool_bwd")
     return dT_full[:B * N], dba, dwb, dbb
 
 
@@ -116,8 +186,9 @@ def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None):
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dz = torch.empty_like(z) if want_grad else None
     sim = torch.empty((Bh,), dtype=torch.float32, device=dev)
-    check(_lib.lib().murcl_ntxent_fwd_bwd(ptr(z), n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo,
-                                          grad_hi, ptr(ws), stream()), "ntxent_fwd_bwd")
+    with _span("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4)):
+        check(_lib.lib().murcl_ntxent_fwd_bwd(ptr(z), n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo,
+                                              grad_hi, ptr(ws), stream()), "ntxent_fwd_bwd")
     return loss, dz, sim
 
 

@@ -1,0 +1,48 @@
+"""Flat-buffer Adam on the HIP kernel (torch.optim.Adam semantics; train_MuRCL.py:154-171).
+
+Parameters of each group are re-seated as views of one contiguous f32 buffer, and so are their
+``.grad``s: ``zero_grad`` is one memset, ``step`` one kernel launch per group, and a data-parallel
+gradient all-reduce is one collective over the flat gradient buffer (no per-tensor buckets).
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.groups = []
+        self.step_count = 0
+        for g in param_groups:
+            params = [p for p in g["params"] if p.requires_grad]
+            n = sum(p.numel() for p in params)
+            dev = params[0].device
+            flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+            flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                k = p.numel()
+                flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + k].view_as(p.data)
+                p.grad = flat_g[off:off + k].view_as(p.data)
+                off += k
+            self.groups.append(dict(params=params, lr=g["lr"], p=flat_p, g=flat_g,
+                                    m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p)))
+
+    @property
+    def param_groups(self):            # lr schedulers poke group['lr']
+        return self.groups
+
+    def flat_grads(self):
+        return [g["g"] for g in self.groups]
+
+    def zero_grad(self):
+        for g in self.groups:
+            g["g"].zero_()
+
+    def step(self):
+        self.step_count += 1
+        for g in self.groups:
+            ops.adam_step(g["p"], g["g"], g["m"], g["v"], g["lr"], self.betas, self.eps, self.weight_decay,
+                          self.step_count)
