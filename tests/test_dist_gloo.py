@@ -1,0 +1,72 @@
+"""world_size-2 gloo test of the sharded contrastive step.
+
+The HIP NT-Xent kernel is GPU-only, so the CPU test injects the oracle with the same
+(z, tau, grad_lo, grad_hi) -> (loss, dz, sim) contract; what is under test is the distributed
+glue: all-gather layout, shard windows, local gradient slices, flat gradient all-reduce.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_kernel(z, tau, grad_lo, grad_hi):
+    from oracle import mil_oracle as O
+    n = z.shape[0]
+    Bh = n // 2
+    with torch.enable_grad():                    # Function.forward runs with grad mode off
+        zz = z.detach().clone().requires_grad_()
+        loss = O.nt_xent(zz[:Bh], zz[Bh:], tau)
+        loss.backward()
+    dz = torch.zeros_like(z)
+    dz[grad_lo:grad_hi] = zz.grad[grad_lo:grad_hi]
+    dz[Bh + grad_lo:Bh + grad_hi] = zz.grad[Bh + grad_lo:Bh + grad_hi]
+    return loss.detach().reshape(1), dz, O.row_cosine(z[:Bh], z[Bh:])
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from murcl_amd import dist as mdist
+    from oracle import detrand
+    bl, P_ = 3, 128
+    torch.manual_seed(0)
+    W = torch.from_numpy(detrand.normal(1, "W", (P_, 16)))              # shared "model": z = x W^T
+    W.requires_grad_()
+    x_i = torch.from_numpy(detrand.normal(2, f"xi{rank}", (bl, 16)))
+    x_j = torch.from_numpy(detrand.normal(2, f"xj{rank}", (bl, 16)))
+    loss, sim = mdist.gathered_nt_xent(x_i @ W.t(), x_j @ W.t(), 0.5, kernel=_oracle_kernel)
+    loss.backward()
+    flat = W.grad.reshape(-1).clone()
+    mdist.all_reduce_grads([flat])
+    out[rank] = (loss.item(), flat.detach().numpy().copy(), sim.detach().numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_sharded_ntxent_equals_global_single_process():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    # single-process global reference: same bags, rank-major order
+    from oracle import detrand, mil_oracle as O
+    W = torch.from_numpy(detrand.normal(1, "W", (128, 16))).requires_grad_()
+    xi = torch.cat([torch.from_numpy(detrand.normal(2, f"xi{r}", (3, 16))) for r in range(world)])
+    xj = torch.cat([torch.from_numpy(detrand.normal(2, f"xj{r}", (3, 16))) for r in range(world)])
+    loss = O.nt_xent(xi @ W.t(), xj @ W.t(), 0.5)
+    loss.backward()
+    sim = O.row_cosine((xi @ W.t()).detach(), (xj @ W.t()).detach()).numpy()
+    for r in range(world):
+        l, g, s = res[r]
+        assert l == pytest.approx(loss.item(), rel=1e-6)
+        np.testing.assert_allclose(g, W.grad.reshape(-1).numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(s, sim[3 * r:3 * r + 3], rtol=1e-5)

@@ -1,0 +1,53 @@
+"""Host-side mirror of the reference interface: constructors, state-dict keys/shapes, error behaviour."""
+import pytest
+import torch
+
+from oracle import params as P
+
+
+def test_abmil_state_dict_keys_match_reference_names():
+    from murcl_amd.models.abmil import ABMIL
+    m = ABMIL(512, L=512, D=128, dim_out=128)
+    want = P.abmil(1)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(want)
+    assert all(tuple(sd[k].shape) == want[k].shape for k in sd)
+    assert sum(p.numel() for p in m.parameters()) == 1182081          # SURVEY.md section 2.3 [probe]
+    assert (m.L, m.D, m.K) == (512, 128, 1)
+
+
+def test_full_layer_state_dict_and_memory():
+    from murcl_amd.models.rlmil import Full_layer, Memory
+    f = Full_layer(512, 1024, True, 128)
+    want = P.full_layer(1)
+    assert sorted(f.state_dict()) == sorted(want)
+    assert sum(p.numel() for p in f.parameters()) == 4855936
+    mem = Memory()
+    mem.actions.append(1), mem.hidden.append(2)
+    mem.clear_memory()
+    assert all(getattr(mem, k) == [] for k in Memory.FIELDS)
+    g = Full_layer(512, 1024, False, 10)
+    assert sorted(k.split(".")[0] for k in g.state_dict()) == sorted(["fc_2", "fc_3", "fc_4", "fc_5"] * 2)
+
+
+def test_cl_wrapper_contract():
+    from murcl_amd.models.abmil import ABMIL
+    from murcl_amd.models.cl import CL
+    c = CL(ABMIL(512), projection_dim=128, n_features=512)
+    assert c.projection_dim == 128 and c.n_features == 512
+    assert all(k.startswith("encoder.") for k in c.state_dict())
+    with pytest.raises(AssertionError):
+        c(torch.zeros(1, 2, 512))
+
+
+def test_abmil_type_error_and_guards():
+    from murcl_amd.models.abmil import ABMIL
+    with pytest.raises(TypeError):
+        ABMIL(512)("not a tensor")
+    with pytest.raises(NotImplementedError):
+        ABMIL(512, L=256)._bags(torch.zeros(1, 4, 512))
+
+
+def test_shard_range():
+    from murcl_amd.dist import shard_range
+    assert [shard_range(r, 4, 16) for r in range(4)] == [(0, 16), (16, 32), (32, 48), (48, 64)]

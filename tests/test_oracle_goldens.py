@@ -1,7 +1,7 @@
 """Pin the CPU oracle (oracle/) against outputs of the reference itself.
 
 The goldens in tests/golden/ were produced by oracle/gen_goldens.py, which imports and
-runs /root/reference in the build container.  Nothing here reads the reference.
+runs the reference checkout in the build container.  Nothing here reads the reference.
 """
 import numpy as np
 import pytest
