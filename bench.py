@@ -46,11 +46,11 @@ def synth_views(bags, n, d, dtype, device, rank):
     g = torch.Generator(device=device)
     g.manual_seed(985 + rank)
     sig = torch.rand((bags, 1, d), generator=g, device=device) * 1.8 + 0.1
-    views = []
-    for _ in range(2):
+    both = torch.empty((2 * bags, n, d), dtype=dtype, device=device)     # the two views back to back
+    for v in range(2):
         x = torch.randn((bags, n, d), generator=g, device=device).abs_().mul_(0.5).mul_(sig)
-        views.append(x.to(dtype).contiguous())
-    return views
+        both[v * bags:(v + 1) * bags].copy_(x)
+    return [both[:bags], both[bags:]]
 
 
 def make_step(model, fc, opt, crit, views, world):

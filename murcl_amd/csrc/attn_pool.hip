@@ -2,38 +2,52 @@
 //
 //   s_n = wb . tanh(Wa H_n + ba) + bb ;  A = softmax_N(s) / sqrt(N) ;  M = A . H
 //
-// One pass over H.  Persistent workgroups (one per CU, 4 waves, one wave per SIMD) walk
-// (bag, row-chunk) items; H row tiles stream HBM -> LDS by LDS-DMA into a 4-slot ring with three
-// tiles (96 KiB) in flight per CU; each wave keeps its 32-column slice of Wa in registers as MFMA
-// operands for the whole launch, so per tile the matrix cores see only LDS reads of H.  Scores are
-// reduced across waves through LDS, the soft-max is kept online (running max / sum per chunk), and
-// the weighted sum M is accumulated on the VALU from the same LDS tile.  Per-chunk partials
+// One pass over H.  Persistent workgroups (one per CU, 8 waves = two per SIMD, so one wave's VALU phases
+// overlap its partner's MFMAs) walk (bag, row-chunk) items; H row tiles stream HBM -> LDS by LDS-DMA
+// into a 4-slot ring with three tiles (96 KiB) in flight per CU; each wave keeps its 16-column slice of
+// Wa in registers as MFMA operands for the whole launch, so per tile the matrix cores see only LDS reads
+// of H.  Scores are reduced across waves through LDS, the soft-max is kept online (running max / sum per
+// chunk), and the weighted sum M is accumulated on the VALU from the same LDS tile.  Per-chunk partials
 // (m, l, sum p.H) are merged per bag by abmil_pool_combine_kernel.
 //
-// LDS row image: a row of L elements is ROWB bytes = ROWB/16 chunks; chunk c of row r is stored at
-// position c ^ (r & 15) (conflict-free ds_read_b128 for 16 rows x same k-chunk).  The swizzle is
-// applied on the LDS-DMA source address and on every read.
+// LDS row image: rows are stored whole at a stride of ROWB+16 bytes (each LDS-DMA instruction writes
+// 1 KiB inside one row, so the pad is free): 16 lanes reading the same 16-byte chunk of 16 consecutive
+// rows hit 16 different bank slots, every fragment address is base + immediate, and the DMA source is
+// plain row-major (wave-uniform SGPR base + lane*16).
 #include "common.h"
 
 #define K2_L 512
 #define K2_D 128
-#define K2_SLOT 32768
-#define K2_NSLOT 4
+#define K2_TR 16                  // rows per tile (one MFMA row tile)
+#define K2_NSLOT 4                // ring slots per workgroup; three tiles in flight while one is consumed
 
+// NW waves per workgroup, each owning a DW = 128/NW column slice of Wa in registers:
+//   bf16: NW = 4 (DW = 32, 128 VGPRs of weights), TWO workgroups per CU - they desynchronise naturally, so
+//         one workgroup's barrier / LDS latencies are covered by the other's MFMA and VALU work;
+//   f32 : NW = 8 (DW = 16, 128 VGPRs of weights), one workgroup per CU (parity path).
 template <typename T> struct K2 {
-    static constexpr int ROWB = K2_L * (int)sizeof(T);       // bytes per row: 1024 / 2048
-    static constexpr int TR = K2_SLOT / ROWB;                // rows per tile: 32 / 16
-    static constexpr int NI = TR / 16;                       // 16-row MFMA tiles per tile: 2 / 1
-    static constexpr int CPR = ROWB / 16;                    // chunks per row: 64 / 128
-    static constexpr int GL = K2_SLOT / 4096;                // LDS-DMA instructions per wave per tile = 8
-    static constexpr int NKK = K2_L * (int)sizeof(T) / 64;   // 16-byte k groups per quarter: 16 / 32
+    static constexpr int NW = (sizeof(T) == 2) ? 4 : 8;
+    static constexpr int DW = K2_D / NW;                     // D columns per wave: 32 / 16
+    static constexpr int NJ = DW / 16;                       // MFMA column tiles per wave: 2 / 1
+    static constexpr int ROWB = K2_L * (int)sizeof(T);       // bytes per row in HBM: 1024 / 2048
+    static constexpr int PADB = ROWB + 16;                   // LDS row stride: +16 B rotates rows over the 16 bank slots
+    static constexpr int TR = K2_TR;
+    static constexpr int SLOT = TR * PADB;                   // 16.25 KiB / 32.25 KiB
+    static constexpr int GT = TR * ROWB / (NW * 1024);       // LDS-DMA instructions per wave per tile: 4 / 4
+    static constexpr int NKK = ROWB / 64;                    // MFMA k-steps: 16 / 32
+    static constexpr int PC = K2_L / NW;                     // pooled columns per wave: 128 / 64
+    static constexpr int NPJ = PC / 16;                      // pooling MFMA column tiles per wave: 8 / 4
+    static constexpr int WG_PER_CU = (sizeof(T) == 2) ? 2 : 1;
 };
 
-// LDS carve (bytes): ring 4*32 KiB | spart [4 waves][32 rows] f32 | sbuf [<=chunk rows] f32
-#define K2_OFF_SPART (K2_NSLOT * K2_SLOT)
-#define K2_OFF_SBUF (K2_OFF_SPART + 4 * 32 * 4)
-#define K2_MAX_CHUNK 2048
-#define K2_LDS_BYTES (K2_OFF_SBUF + K2_MAX_CHUNK * 4)
+// LDS carve (bytes): ring | spart [NW waves][16 rows] f32 | pbuf [NW waves][16] u32 | sbuf [<= chunk rows] f32
+#define K2_MAX_CHUNK 1024
+template <typename T> struct K2Lds {
+    static constexpr int OFF_SPART = K2_NSLOT * K2<T>::SLOT;
+    static constexpr int OFF_PBUF = OFF_SPART + K2<T>::NW * 16 * 4;
+    static constexpr int OFF_SBUF = OFF_PBUF + K2<T>::NW * 16 * 4;
+    static constexpr int BYTES = OFF_SBUF + K2_MAX_CHUNK * 4;
+};
 
 template <typename T> struct WFrag;
 template <> struct WFrag<bf16_t> { typedef bf16x8 type; };
@@ -50,19 +64,61 @@ template <> __device__ __forceinline__ f32x4 k2_mma<float>(f32x4 a, f32x4 b, f32
     return c;
 }
 
+// Tile issue shared by forward and backward: LDS-DMA instruction ii = j*NW + wave copies 1 KiB =
+// one row (bf16) / half a row (f32); global base is wave-uniform (SGPRs), per-lane offset = lane*16.
+template <typename T>
+__device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N, unsigned slot_lds, int wave, int lane) {
+    typedef K2<T> C_;
+    const unsigned voff = lane * 16;
+    if (row0 + C_::TR <= N) {
+        // whole tile inside the bag (all but the last tile of a ragged bag): one scalar base, constant strides
+        const char* base = (const char*)bag_base + (size_t)row0 * C_::ROWB;
+#pragma unroll
+        for (int j = 0; j < C_::GT; ++j) {
+            const int ii = j * C_::NW + wave;
+            const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
+            const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
+            glds16_u(base + (size_t)(row * C_::ROWB + half * 1024), voff, slot_lds + row * C_::PADB + half * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C_::GT; ++j) {
+            const int ii = j * C_::NW + wave;
+            const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
+            const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
+            const int grow = min(row0 + row, N - 1);              // rows past N: clamped, masked by the caller
+            glds16_u((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, voff,
+                     slot_lds + row * C_::PADB + half * 1024);
+        }
+    }
+}
+
+// Walks a workgroup's tile sequence without integer division in the loop: item = blockIdx + k*gridDim,
+// tile-in-item `tin`; (bag, chunk) are re-derived only when the item changes.
+struct K2Pos {
+    int tin, item, bag, ch;
+    __device__ __forceinline__ void init(int first_item, int S) { tin = 0; item = first_item; bag = item / S; ch = item - bag * S; }
+    __device__ __forceinline__ void next(int tiles_per_item, int stride, int S) {
+        if (++tin == tiles_per_item) { tin = 0; item += stride; bag = item / S; ch = item - bag * S; }
+    }
+};
+
 template <typename T, bool EXACT_TANH>
-__global__ __launch_bounds__(256, 1) void abmil_pool_fwd_kernel(
+__global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ bb_p, float* __restrict__ scores, float* __restrict__ part, int B, int N,
     int chunk_rows, int S) {
     typedef K2<T> C_;
+    typedef K2Lds<T> L_;
     typedef typename WFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform -> scalar address math
     const int q4 = lane >> 4, r16 = lane & 15;
     const unsigned lds0 = lds_off(smem);
-    float* spart = (float*)(smem + K2_OFF_SPART);
-    float* sbuf = (float*)(smem + K2_OFF_SBUF);
+    float* spart = (float*)(smem + L_::OFF_SPART);
+    unsigned* pbuf = (unsigned*)(smem + L_::OFF_PBUF) + wave * 16;   // wave-private
+    float* sbuf = (float*)(smem + L_::OFF_SBUF);
 
     const int n_items = B * S;
     const int tiles_per_item = chunk_rows / C_::TR;
@@ -70,142 +126,162 @@ __global__ __launch_bounds__(256, 1) void abmil_pool_fwd_kernel(
     const int my_tiles = my_items * tiles_per_item;
     if (my_tiles <= 0) return;
 
-    // ---- LDS-DMA issue for tile `seq` of this workgroup.  Instruction j of wave w fills rows
-    // (4j+w) for bf16 (one row per instruction) / half rows for f32.
+    K2Pos ip, cp;                                                    // issue / compute positions
+    ip.init(blockIdx.x, S);
+    cp.init(blockIdx.x, S);
     auto issue = [&](int seq) {
-        const int item = blockIdx.x + (seq / tiles_per_item) * gridDim.x;
-        const int bag = item / S, ch = item - bag * S;
-        const int row0 = ch * chunk_rows + (seq % tiles_per_item) * C_::TR;
-        const char* base = (const char*)(H + (size_t)bag * N * K2_L);
-        const unsigned slot = lds0 + (seq % K2_NSLOT) * K2_SLOT;
-#pragma unroll
-        for (int j = 0; j < C_::GL; ++j) {
-            const int ci = (j * 4 + wave) * 64 + lane;          // 16-byte chunk index within the tile
-            const int row = ci / C_::CPR, pos = ci % C_::CPR;
-            const int grow = min(row0 + row, N - 1);            // rows past N: clamped, masked below
-            const char* src = base + (size_t)grow * C_::ROWB + ((pos ^ (row & 15)) << 4);
-            glds16(src, slot + (j * 4 + wave) * 1024);
-        }
+        k2_issue_tile<T>(H + (size_t)ip.bag * N * K2_L, ip.ch * chunk_rows + ip.tin * C_::TR, N,
+                         lds0 + (seq & (K2_NSLOT - 1)) * C_::SLOT, wave, lane);
+        ip.next(tiles_per_item, gridDim.x, S);
     };
-
     const int pre = min(3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
 
-    // ---- this wave's Wa slice as MFMA "a" operands: rows d = 32*wave + 16j + r16
-    frag_t wa[2][C_::NKK];
-    float ba_r[2][4], wb_r[2][4];
+    // ---- this wave's DW columns of Wa as MFMA "a" operands: row d = DW*wave + 16j + r16; quarter q4 of k-step
+    // kk covers the 16-byte chunk (kk + NKK*q4) of the row (any k assignment works as long as H uses the same)
+    frag_t wa[C_::NJ][C_::NKK];
+    float ba_r[C_::NJ][4], wb_r[C_::NJ][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const T* wrow = Wa + (size_t)(32 * wave + 16 * j + r16) * K2_L;
+    for (int j = 0; j < C_::NJ; ++j) {
+        const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)((const char*)wrow + (4 * kk + q4) * 16);
+        for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ba_r[j][r] = ba[32 * wave + 16 * j + 4 * q4 + r];
-            wb_r[j][r] = wb[32 * wave + 16 * j + 4 * q4 + r];
+            ba_r[j][r] = ba[C_::DW * wave + 16 * j + 4 * q4 + r];
+            wb_r[j][r] = wb[C_::DW * wave + 16 * j + 4 * q4 + r];
         }
     }
     const float bb = bb_p[0];
-    // The loads above are ordinary (compiler-counted) loads issued AFTER the first LDS-DMA tiles; the
-    // compiler's own waits for them are conservative w.r.t. the older LDS-DMA ops.  Drain them here
-    // so that from now on the only VMEM ops in flight are the LDS-DMA tiles counted by hand.
+    // tanh is bounded, so every score satisfies |s| <= sum|wb| + |bb| =: smax.  When smax is moderate the soft-max
+    // can use smax as a FIXED reference (p = exp(s - smax) in [e^-2smax, 1], no underflow below smax = 30), which
+    // removes the running-max reduction and the accumulator rescale from the per-tile path.  Otherwise: online.
+    const float smax = wave_sum(fabsf(wb[lane]) + fabsf(wb[64 + lane])) + fabsf(bb);
+    const bool fixed_ref = smax < 30.f;
+    // retire the compiler-counted loads above; from here on the only VMEM ops in flight are LDS-DMA tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // (that also retired the first `pre` tiles; the steady-state counts below stay valid because
-    //  waiting for more than necessary is always safe.)
 
-    float m_run = -INFINITY, l_run = 0.f, macc0 = 0.f, macc1 = 0.f;
-    const int col0 = 2 * tid;                 // this thread's two pooled columns
-    const int chunk_of_col = (col0 * (int)sizeof(T)) >> 4, inchunk = (col0 * (int)sizeof(T)) & 15;
+    // Pooling runs on the matrix cores too: M[PC*w + 16j + c] += sum_r p_r H[r][.] as a 16x16 MFMA whose A operand
+    // carries p in row 0 (bf16: p = hi + lo split over rows 0 and 1, so p keeps ~16 mantissa bits; f32: exact) and
+    // zeros elsewhere, and whose B operand is the LDS tile read k-major (rows of the tile = k).
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 macc[C_::NPJ];
+#pragma unroll
+    for (int j = 0; j < C_::NPJ; ++j) macc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // byte selector building the A fragment from packed (hi | lo<<16) words: row 0 takes the low halves,
+    // row 1 the high halves, every other row zeros (v_perm_b32: 0x0c = constant zero byte)
+    const unsigned psel = (r16 == 0) ? 0x05040100u : (r16 == 1 ? 0x07060302u : 0x0c0c0c0cu);
 
     for (int seq = 0; seq < my_tiles; ++seq) {
-        // tile `seq` landed when at most (tiles issued after it) * GL LDS-DMA ops are outstanding
         const int ahead = min(2, my_tiles - 1 - seq);
-        if (ahead == 2) { WAIT_VMCNT(16); } else if (ahead == 1) { WAIT_VMCNT(8); } else { WAIT_VMCNT(0); }
+        static_assert(C_::GT == 4, "vmcnt literals below assume 4 LDS-DMA ops per wave per tile");
+        if (ahead == 2) { WAIT_VMCNT(8); } else if (ahead == 1) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();                         // all waves' pieces landed; slot (seq+3)%4 is free
         if (seq + 3 < my_tiles) issue(seq + 3);
 
-        const int tin = seq % tiles_per_item;
-        const int item = blockIdx.x + (seq / tiles_per_item) * gridDim.x;
-        const int bag = item / S, ch = item - bag * S;
-        const int row0 = ch * chunk_rows + tin * C_::TR;
-        const char* tile = smem + (seq % K2_NSLOT) * K2_SLOT;
+        const int tin = cp.tin;
+        const int row0 = cp.ch * chunk_rows + tin * C_::TR;
+        const char* tile = smem + (seq & (K2_NSLOT - 1)) * C_::SLOT;
 
-        // ---- phase A: scores for the tile, this wave's 32 columns of D
-        f32x4 acc[C_::NI][2];
+        // ---- phase A: pre-activations of the tile for this wave's DW columns of D
+        f32x4 acc[C_::NJ];
 #pragma unroll
-        for (int i = 0; i < C_::NI; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C_::NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hbase = tile + r16 * C_::PADB + C_::NKK * q4 * 16;
 #pragma unroll
         for (int kk = 0; kk < C_::NKK; ++kk) {
+            const frag_t h = *(const frag_t*)(hbase + kk * 16);
 #pragma unroll
-            for (int i = 0; i < C_::NI; ++i) {
-                const int row = 16 * i + r16;
-                const int c = 4 * kk + q4;
-                frag_t h = *(const frag_t*)(tile + row * C_::ROWB + ((c ^ (row & 15)) << 4));
-                acc[i][0] = k2_mma<T>(wa[0][kk], h, acc[i][0]);
-                acc[i][1] = k2_mma<T>(wa[1][kk], h, acc[i][1]);
+            for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][kk], h, acc[j]);
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < C_::NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = acc[j][r] + ba_r[j][r];
+                ps += wb_r[j][r] * (EXACT_TANH ? tanhf(x) : fast_tanh(x));
             }
-        }
-        // lane holds pre-activations for patch row 16i+r16, d = 32w+16j+4q+r
-#pragma unroll
-        for (int i = 0; i < C_::NI; ++i) {
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = acc[i][j][r] + ba_r[j][r];
-                    ps += wb_r[j][r] * (EXACT_TANH ? tanhf(x) : fast_tanh(x));
-                }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            if (q4 == 0) spart[wave * 32 + 16 * i + r16] = ps;
-        }
+        ps = quarters_sum(ps);                               // over the 4 lane quarters (same r16)
+        if (q4 == 0) spart[wave * 16 + r16] = ps;
         LDS_BARRIER();
 
-        // ---- phase B (every wave redundantly): tile soft-max statistics, lane r <-> row r
+        // ---- phase B (every wave redundantly): tile soft-max statistics, lane r <-> row r (lanes 0..15)
         float s = -INFINITY;
         if (lane < C_::TR) {
-            s = spart[lane] + spart[32 + lane] + spart[64 + lane] + spart[96 + lane] + bb;
+            s = bb;
+#pragma unroll
+            for (int w = 0; w < C_::NW; ++w) s += spart[w * 16 + lane];
             if (row0 + lane >= N) s = -INFINITY;             // ragged tail rows carry no weight
             if (wave == 0) sbuf[tin * C_::TR + lane] = s;
         }
-        const float tmax = wave_max(s);
-        const float m_new = fmaxf(m_run, tmax);
-        const float scale = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-        const float p = (s == -INFINITY) ? 0.f : __expf(s - m_new);
-        l_run = l_run * scale + wave_sum(p);
-        m_run = m_new;
-        macc0 *= scale;
-        macc1 *= scale;
-        // ---- pooling: M[col] += sum_r p_r H[r][col]; p_r broadcast through an SGPR
+        float p;
+        if (fixed_ref) {
+            p = (s == -INFINITY) ? 0.f : (EXACT_TANH ? __expf(s - smax) : fast_exp(s - smax));
+            l_run += p;                                       // per-lane partial (lanes 0..15), reduced at item end
+        } else {
+            const float tmax = rdlane(row16_max(s), 0);
+            const float m_new = fmaxf(m_run, tmax);
+            const float scale = (m_run == -INFINITY) ? 0.f : (EXACT_TANH ? __expf(m_run - m_new) : fast_exp(m_run - m_new));
+            p = (s == -INFINITY) ? 0.f : (EXACT_TANH ? __expf(s - m_new) : fast_exp(s - m_new));
+            l_run = l_run * scale + rdlane(row16_sum(p), 0);
+            m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < C_::TR; ++r) {
-            const float pr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), r));
-            const char* hp = tile + r * C_::ROWB + ((chunk_of_col ^ (r & 15)) << 4) + inchunk;
-            if (sizeof(T) == 2) {
-                const uint32_t u = *(const uint32_t*)hp;
-                macc0 += pr * bf_lo(u);
-                macc1 += pr * bf_hi(u);
-            } else {
-                const f32x2 v = *(const f32x2*)hp;
-                macc0 += pr * v[0];
-                macc1 += pr * v[1];
+            for (int j = 0; j < C_::NPJ; ++j) macc[j] *= scale;
+        }
+        // ---- pooling on the MFMAs: this wave owns output columns PC*wave .. +PC-1
+        if (sizeof(T) == 2) {
+            if (lane < 16) {
+                const bf16_t hi = f2bf(p);
+                pbuf[lane] = (unsigned)hi | ((unsigned)f2bf(p - bf2f(hi)) << 16);
+            }
+            // A fragment of v_mfma_f32_16x16x16_bf16: lane (q4, r16) = A[row r16][k = 4q4 + e], e = 0..3
+            const u32x4 pa = *(const u32x4*)(pbuf + 4 * q4);
+            const u32x2 afw = u32x2{__builtin_amdgcn_perm(pa[1], pa[0], psel), __builtin_amdgcn_perm(pa[3], pa[2], psel)};
+            const s16x4 af = __builtin_bit_cast(s16x4, afw);
+            // B fragment: column 16j + (lane&15) of rows 4q4 .. 4q4+3 = one transposed 4x16 read
+            const int u = lane & 15, rq = u >> 2, pp4 = u & 3;
+            const char* tb = tile + (4 * q4 + rq) * C_::PADB + (C_::PC * wave + 4 * pp4) * 2;
+#pragma unroll
+            for (int j = 0; j < C_::NPJ; ++j) {
+                const s16x4 bfm = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tb + j * 32));
+                macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, bfm, macc[j], 0, 0, 0);
+            }
+        } else {
+            // f32: 16 rows = 4 k-steps of v_mfma_f32_16x16x4_f32; A[row r16][k = q4] = p[4s+q4] in row 0 only
+            if (lane < 16) pbuf[lane] = __float_as_uint(p);
+            const char* tb = tile + q4 * C_::PADB + (C_::PC * wave + r16) * 4;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float av = (r16 == 0) ? __uint_as_float(pbuf[4 * st + q4]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) {
+                    const float bv = *(const float*)(tb + st * 4 * C_::PADB + j * 64);
+                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, macc[j], 0, 0, 0);
+                }
             }
         }
 
         if (tin == tiles_per_item - 1) {        // ---- end of item: publish partial + raw scores
-            float* pp = part + (size_t)item * (K2_L + 2);
-            if (tid == 0) { pp[0] = m_run; pp[1] = l_run; }
-            pp[2 + col0] = macc0;
-            pp[2 + col0 + 1] = macc1;
-            __syncthreads();                    // sbuf complete (wave 0 wrote it)
-            const int rbeg = ch * chunk_rows;
-            for (int r = tid; r < chunk_rows && rbeg + r < N; r += 256) scores[(size_t)bag * N + rbeg + r] = sbuf[r];
-            // the stores above are compiler-visible VMEM ops; retire them so the hand counts of
-            // LDS-DMA ops stay exact for the next item.
+            float* pp = part + (size_t)cp.item * (K2_L + 2);
+            if (q4 == 0) {                      // rows 0 (+1) of the accumulator tiles live in lane quarter 0
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) pp[2 + C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
+            }
+            {
+                const float l_tot = fixed_ref ? rdlane(row16_sum(lane < 16 ? l_run : 0.f), 0) : l_run;
+                if (tid == 0) { pp[0] = fixed_ref ? smax : m_run; pp[1] = l_tot; }
+            }
+            __syncthreads();                    // sbuf complete
+            const int rbeg = cp.ch * chunk_rows;
+            for (int r = tid; r < chunk_rows && rbeg + r < N; r += 64 * C_::NW) scores[(size_t)cp.bag * N + rbeg + r] = sbuf[r];
+            // compiler-visible stores: retire them so the hand counts of LDS-DMA ops stay exact
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            m_run = -INFINITY; l_run = 0.f; macc0 = 0.f; macc1 = 0.f;
+            m_run = -INFINITY; l_run = 0.f;
+#pragma unroll
+            for (int j = 0; j < C_::NPJ; ++j) macc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        cp.next(tiles_per_item, gridDim.x, S);
     }
 }
 
@@ -233,11 +309,11 @@ __global__ __launch_bounds__(256) void abmil_pool_combine_kernel(const float* __
     for (int n = tid; n < N; n += 256) A[(size_t)bag * N + n] = expf(scores[(size_t)bag * N + n] - m) * inv;
 }
 
-static int pick_chunk(int B, int N, int tr, int n_cu) {
-    // rows per item: multiple of the tile height, <= K2_MAX_CHUNK, small enough to give every CU work
+static int pick_chunk(int B, int N, int tr, int n_wg) {
+    // rows per item: multiple of the tile height, <= K2_MAX_CHUNK, small enough to give every workgroup >= 2 items
     int chunk = ((N + tr - 1) / tr) * tr;
     if (chunk > K2_MAX_CHUNK) chunk = K2_MAX_CHUNK;
-    while (chunk > tr && (long)B * ((N + chunk - 1) / chunk) < 2L * n_cu) {
+    while (chunk > 4 * tr && (long)B * ((N + chunk - 1) / chunk) < 2L * n_wg) {
         int c2 = ((chunk / 2 + tr - 1) / tr) * tr;
         if (c2 == chunk) break;
         chunk = c2;
@@ -246,8 +322,8 @@ static int pick_chunk(int B, int N, int tr, int n_cu) {
 }
 
 extern "C" int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_chunks) {
-    const int tr = dtype == MURCL_DTYPE_BF16 ? 32 : 16;
-    const int c = pick_chunk(B, N, tr, 256);
+    const int tr = K2_TR;
+    const int c = pick_chunk(B, N, tr, dtype == MURCL_DTYPE_BF16 ? 512 : 256);
     *chunk_rows = c;
     *n_chunks = (N + c - 1) / c;
     return 0;
@@ -262,17 +338,18 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     const int items = B * S;
-    const int grid = items < 256 ? items : 256;
+    const int max_grid = 256 * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
+    const int grid = items < max_grid ? items : max_grid;
 #define K2_LAUNCH(T, EX)                                                                                        \
     {                                                                                                           \
         auto k = abmil_pool_fwd_kernel<T, EX>;                                                                  \
         static bool once = false;                                                                               \
         if (!once) {                                                                                            \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, K2_LDS_BYTES);      \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, K2Lds<T>::BYTES);   \
             once = true;                                                                                        \
         }                                                                                                       \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), K2_LDS_BYTES, stream, (const T*)H, (const T*)Wa, ba, wb,   \
-                           bb, scores, part_ws, B, N, chunk, S);                                                \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), K2Lds<T>::BYTES, stream, (const T*)H, (const T*)Wa, \
+                           ba, wb, bb, scores, part_ws, B, N, chunk, S);                                        \
     }
     if (dtype == MURCL_DTYPE_BF16) {
         if (exact_tanh) K2_LAUNCH(bf16_t, true) else K2_LAUNCH(bf16_t, false)

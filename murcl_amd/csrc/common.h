@@ -66,6 +66,34 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// Same with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: no per-op 64-bit VALU add.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(bs), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long bs = ((unsigned long long)hi << 32) | lo;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(bs), "s"(dst) : "memory");
+}
+// Variant for bases the compiler already knows to be wave-uniform (kernel args, blockIdx / readfirstlane'd
+// values and scalar arithmetic on them): no v_readfirstlane round trip.
+__device__ __forceinline__ void glds16_u(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // Raw workgroup barrier that does NOT drain vmcnt (LDS-DMA tiles stay in flight across it):
@@ -97,8 +125,39 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 __device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2/(exp(2x)+1); exp via v_exp_f32 (2^x). abs error ~1e-7 relative to range.
-    float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    // tanh(x) = 1 - 2/(2^(2x log2 e) + 1): one v_exp_f32 + one v_rcp_f32 (1 ulp each), no IEEE
+    // division sequence.  Saturates correctly: e=inf -> 1, e=0 -> -1.
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// DPP cross-lane moves (VALU, no LDS round trip).  CTRL: quad_perm = sel0|sel1<<2|sel2<<4|sel3<<6,
+// 0x140 row_mirror, 0x141 row_half_mirror.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// all 16 lanes of each row end with the row's sum / max
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// sum over the four 16-lane rows (lanes l, l^16, l^32, l^48) with the gfx950 row/half swaps - VALU only
+__device__ __forceinline__ float quarters_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// reductions over lanes 0..31 (rows 0 and 1), result wave-uniform
+__device__ __forceinline__ float half_wave_sum(float v) { v = row16_sum(v); return rdlane(v, 0) + rdlane(v, 16); }
+__device__ __forceinline__ float half_wave_max(float v) { v = row16_max(v); return fmaxf(rdlane(v, 0), rdlane(v, 16)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

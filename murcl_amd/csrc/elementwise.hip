@@ -53,28 +53,38 @@ extern "C" int murcl_transpose_cast(const float* x, void* y, int R, int C, int d
 }
 
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
+// grid = (column groups of 64, row splits); each block reduces its row range and adds 64 values atomically.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld, int accumulate) {
-    // block = 64 columns x 4 row-lanes; grid.x over column groups
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld, int rows_per_block) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
     float s = 0.f;
     if (c < N)
-        for (int r = rl; r < R; r += 4) s += to_f<T>(x[(size_t)r * ld + c]);
+        for (int r = r0 + rl; r < r1; r += 4) s += to_f<T>(x[(size_t)r * ld + c]);
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && c < N) {
         s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[c] = accumulate ? out[c] + s : s;
+        if (gridDim.y == 1) out[c] += s; else atomicAdd(out + c, s);
     }
 }
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s) {
     if (N <= 0) return 0;
-    dim3 grid((N + 63) / 64);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int cg = (N + 63) / 64;
+    int splits = R > 64 ? (512 + cg - 1) / cg : 1;          // ~512 blocks, >= 32 rows each
+    if (splits > (R + 31) / 32) splits = (R + 31) / 32;
+    if (splits < 1) splits = 1;
+    const int rpb = (R + splits - 1) / splits;
+    dim3 grid(cg, (R + rpb - 1) / rpb);
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, R, N, ld, accumulate);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, R, N, ld, rpb);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, R, N, ld, accumulate);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, R, N, ld, rpb);
     else
         return -1;
     return MURCL_CHECK_LAUNCH();

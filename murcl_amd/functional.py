@@ -55,21 +55,30 @@ class ABMILFn(torch.autograd.Function):
         T = x.dtype
         x2 = x.reshape(B * N, d)
         c = (lambda w: w) if T == torch.float32 else (lambda w: ops.cast(w, T))
-        h1 = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)
-        h2 = ops.gemm_nt(h1, c(w2), epi=ops.EPI_BIAS_RELU, bias=b2)
-        h3 = ops.gemm_nt(h2, c(w3), epi=ops.EPI_BIAS_RELU, bias=b3)
+        L = w3.shape[0]
+        # bf16 + panel-friendly shapes: weight-stationary GEMMs that also emit 1-bit ReLU masks
+        fast = (T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
+                and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
+        if fast:
+            h1, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=True)
+            h2, m2, _ = ops.panel_gemm(h1, c(w2), ops.PG_BIAS_RELU, bias=b2, want_bitmask=True)
+            h3, m3, _ = ops.panel_gemm(h2, c(w3), ops.PG_BIAS_RELU, bias=b3, want_bitmask=True)
+        else:
+            m1 = m2 = m3 = None
+            h1 = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)
+            h2 = ops.gemm_nt(h1, c(w2), epi=ops.EPI_BIAS_RELU, bias=b2)
+            h3 = ops.gemm_nt(h2, c(w3), epi=ops.EPI_BIAS_RELU, bias=b3)
         wac = c(wa)
-        L = h3.shape[1]
         scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
         out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
-        ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac)
+        ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3)
         ctx.dims = (B, N, d)
         ctx.mark_non_differentiable(A)
         return out, A
 
     @staticmethod
     def backward(ctx, dout, _dA):
-        x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac = ctx.saved_tensors
+        x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3 = ctx.saved_tensors
         B, N, d = ctx.dims
         T = x2.dtype
         L = h3.shape[1]
@@ -82,15 +91,23 @@ class ABMILFn(torch.autograd.Function):
         dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
         dwa = ops.gemm_tn(dT, h3)
         # encoder layer 3: dZ3 = (dT Wa + A (x) dM) * relu'(H3)
-        dz3, ws = ops.gemm_nt(dT, ops.transpose_cast(wa, T), epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
-                              rank1=dM, rows_per_bag=N, colsum=True)
-        db3 = ops.colsum(ws)
-        dw3 = ops.gemm_tn(dz3, h2)
-        dz2, ws = ops.gemm_nt(dz3, ops.transpose_cast(w3, T), epi=ops.EPI_MASK, mask=h2, colsum=True)
-        db2 = ops.colsum(ws)
-        dw2 = ops.gemm_tn(dz2, h1)
-        dz1, ws = ops.gemm_nt(dz2, ops.transpose_cast(w2, T), epi=ops.EPI_MASK, mask=h1, colsum=True)
-        db1 = ops.colsum(ws)
+        if m3 is not None:
+            dz3, _, db3 = ops.panel_gemm(dT, ops.transpose_cast(wa, T), ops.PG_RANK1_MASK, bitmask=m3,
+                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
+            dw3 = ops.gemm_tn(dz3, h2)
+            dz2, _, db2 = ops.panel_gemm(dz3, ops.transpose_cast(w3, T), ops.PG_MASK, bitmask=m2, colsum=True)
+            dw2 = ops.gemm_tn(dz2, h1)
+            dz1, _, db1 = ops.panel_gemm(dz2, ops.transpose_cast(w2, T), ops.PG_MASK, bitmask=m1, colsum=True)
+        else:
+            dz3, ws = ops.gemm_nt(dT, ops.transpose_cast(wa, T), epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
+                                  rank1=dM, rows_per_bag=N, colsum=True)
+            db3 = ops.colsum(ws)
+            dw3 = ops.gemm_tn(dz3, h2)
+            dz2, ws = ops.gemm_nt(dz3, ops.transpose_cast(w3, T), epi=ops.EPI_MASK, mask=h2, colsum=True)
+            db2 = ops.colsum(ws)
+            dw2 = ops.gemm_tn(dz2, h1)
+            dz1, ws = ops.gemm_nt(dz2, ops.transpose_cast(w2, T), epi=ops.EPI_MASK, mask=h1, colsum=True)
+            db1 = ops.colsum(ws)
         dw1 = ops.gemm_tn(dz1, x2)
         dx = None
         if ctx.needs_input_grad[0]:

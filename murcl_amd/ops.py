@@ -104,6 +104,32 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     return (C, ws) if colsum else C
 
 
+PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK = 0, 1, 2
+_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK"}
+
+
+def panel_supported(M, N, K, epi, rows_per_bag=0):
+    return bool(_lib.lib().murcl_panel_gemm_supported(M, N, K, epi, rows_per_bag))
+
+
+def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
+               colsum=False):
+    """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None)."""
+    _need_cuda(A, W)
+    A, W = _c(A), _c(W)
+    M, K = A.shape
+    N = W.shape[0]
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    bm = torch.empty((M, N // 8), dtype=torch.uint8, device=A.device) if want_bitmask else None
+    cs = torch.empty((N,), dtype=torch.float32, device=A.device) if colsum else None
+    with _span(f"panel_gemm<K{K},{_PG_NAME[epi]}>",
+               dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0))):
+        check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
+                                          ptr(rowscale), ptr(rank1), rows_per_bag, ptr(cs), stream()), "panel_gemm")
+    return C, bm, cs
+
+
 def gemm_tn(A, B, *, splits=0, out=None):
     """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given)."""
     _need_cuda(A, B)

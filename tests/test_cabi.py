@@ -39,7 +39,7 @@ def test_workspace_queries_run_on_host():
     from murcl_amd import ops, _lib
     for B, N, code, tr in [(128, 2048, _lib.BF16, 32), (4, 256, _lib.F32, 16), (1, 1, _lib.F32, 16), (2, 100000, _lib.BF16, 32)]:
         chunk, S = ops.pool_chunks(B, N, code)
-        assert chunk % tr == 0 and chunk <= 2048 and (S - 1) * chunk < N <= S * chunk
+        assert chunk % 16 == 0 and chunk <= 2048 and (S - 1) * chunk < N <= S * chunk
     assert _lib.lib().murcl_ntxent_workspace_bytes(128) >= 128 * 130 * 4
 
 

@@ -273,3 +273,73 @@ def test_adam_matches_oracle():
         ops.adam_step(p, g.to(dev), m, v, 1e-3, (0.9, 0.999), 1e-8, 1e-5, step)
         ref = O.adam_step(ref, {"w": g}, st, 1e-3, weight_decay=1e-5)
     _close(p, ref["w"], rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ weight-stationary panel GEMM (bf16)
+def _bits(mask_bool):
+    """[M,N] bool -> the kernel's 1-bit mask layout (panel_gemm.hip header): 128-byte blocks per
+    (32-row tile, 32-column group); byte ((m&15)*4 + (c&3))*2 + ((m&31)>>4), c = n/8; bit e = column 8c+e."""
+    M, N = mask_bool.shape
+    w = (2 ** torch.arange(8, dtype=torch.int32)).view(1, 1, 8)
+    by = (mask_bool.view(M, N // 8, 8).int() * w).sum(-1).to(torch.uint8)          # [M, N/8]
+    m = torch.arange(M).view(M, 1)
+    c = torch.arange(N // 8).view(1, N // 8)
+    idx = ((m // 32) * (N // 32) + c // 4) * 128 + ((m & 15) * 4 + (c & 3)) * 2 + ((m & 31) >> 4)
+    out = torch.zeros(M * N // 8, dtype=torch.uint8)
+    out[idx.reshape(-1)] = by.reshape(-1)
+    return out.view(M, N // 8)
+
+
+@pytest.mark.parametrize("M", [32, 4096, 131072 + 64])
+def test_panel_gemm_forward_bias_relu_and_bitmask(M):
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(20, f"A{M}", (M, 512)).bfloat16()
+    W = _rand(20, "W", (512, 512), 1 / math.sqrt(512)).bfloat16()
+    bias = _rand(20, "b", (512,), 0.5)
+    assert ops.panel_supported(M, 512, 512, ops.PG_BIAS_RELU)
+    C, bm, _ = ops.panel_gemm(A.to(dev), W.to(dev), ops.PG_BIAS_RELU, bias=bias.to(dev), want_bitmask=True)
+    ref = torch.relu(A.double() @ W.double().t() + bias.double())
+    _close(C.float(), ref, rtol=1e-2, atol=1e-2, msg="C")
+    assert torch.equal(bm.cpu(), _bits(C.cpu().float() > 0)), "bit mask must describe the stored output exactly"
+    # agrees with the tile kernel bit for bit? (same products, different k order -> allow bf16 rounding flips)
+    C2 = ops.gemm_nt(A.to(dev), W.to(dev), epi=ops.EPI_BIAS_RELU, bias=bias.to(dev))
+    assert (C.float() - C2.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [64, 8192])
+def test_panel_gemm_dgrad_mask_and_colsum(M):
+    from murcl_amd import ops
+    dev = _dev()
+    dZ = _rand(21, f"dZ{M}", (M, 512)).bfloat16()
+    Wt = _rand(21, "Wt", (512, 512), 1 / math.sqrt(512)).bfloat16()
+    H = _rand(21, f"H{M}", (M, 512))
+    bm = _bits(H > 0)
+    C, _, cs = ops.panel_gemm(dZ.to(dev), Wt.to(dev), ops.PG_MASK, bitmask=bm.to(dev), colsum=True)
+    ref = (dZ.double() @ Wt.double().t()) * (H.double() > 0)
+    _close(C.float(), ref, rtol=1e-2, atol=1e-2, msg="C")
+    _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
+
+
+@pytest.mark.parametrize("bags,n", [(2, 64), (8, 1024)])
+def test_panel_gemm_rank1_mask(bags, n):
+    from murcl_amd import ops
+    dev = _dev()
+    M = bags * n
+    dT = _rand(22, f"dT{M}", (M, 128)).bfloat16()
+    WaT = _rand(22, "WaT", (512, 128), 0.1).bfloat16()
+    H = _rand(22, f"H{M}", (M, 512))
+    a = torch.from_numpy(detrand.uniform(22, f"a{M}", (M,)))
+    dM = _rand(22, f"dM{bags}", (bags, 512))
+    C, _, cs = ops.panel_gemm(dT.to(dev), WaT.to(dev), ops.PG_RANK1_MASK, bitmask=_bits(H > 0).to(dev),
+                              rowscale=a.to(dev), rank1=dM.to(dev), rows_per_bag=n, colsum=True)
+    ref = (dT.double() @ WaT.double().t() + a.double()[:, None] * dM.double().repeat_interleave(n, 0)) * (H.double() > 0)
+    _close(C.float(), ref, rtol=1e-2, atol=1e-2, msg="C")
+    _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
+
+
+def test_panel_gemm_unsupported_shapes_fall_back():
+    from murcl_amd import ops
+    assert not ops.panel_supported(100, 512, 512, ops.PG_BIAS_RELU)      # M % 32
+    assert not ops.panel_supported(64, 384, 512, ops.PG_BIAS_RELU)       # N % 256
+    assert not ops.panel_supported(64, 512, 128, ops.PG_RANK1_MASK, 48)  # bag not a whole number of tiles

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Isolated kernel timings at BASELINE configs[1] sizes (HIP events, median of reps).  Dev tool."""
+import argparse
+import math
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from murcl_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--bags", type=int, default=128)
+    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, N = a.bags, a.n
+    M = B * N
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    X = (torch.randn((M, 512), generator=g, device=dev).abs() * 0.5).bfloat16()
+    W = (torch.randn((512, 512), generator=g, device=dev) / math.sqrt(512)).bfloat16()
+    bias = torch.randn((512,), generator=g, device=dev) * 0.1
+    Wa = (torch.randn((128, 512), generator=g, device=dev) / math.sqrt(512)).bfloat16()
+    ba = torch.randn((128,), generator=g, device=dev) * 0.1
+    wb = torch.randn((1, 128), generator=g, device=dev) * 0.3
+    bb = torch.zeros((1,), device=dev)
+    dM = torch.randn((B, 512), generator=g, device=dev)
+    dT = (torch.randn((M, 128), generator=g, device=dev) * 0.01).bfloat16()
+    WaT = Wa.t().contiguous()
+    Asc = torch.rand((M,), generator=g, device=dev)
+    H, bm, _ = ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True)
+    sc, Aw, Mp, ml = ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb)
+    cases = {
+        "copy_bf16": (lambda: H.copy_(X), 2 * M * 512 * 2, 0),
+        "k2_fwd": (lambda: ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
+        "k2_bwd": (lambda: ops.abmil_pool_bwd(H.view(B, N, 512), Wa, ba, wb, sc, ml, Mp, dM), M * 640 * 2, 2.0 * M * 512 * 128),
+        "panel_fwd": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
+        "panel_fwd_nobm": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
+        "panel_mask": (lambda: ops.panel_gemm(X, W, ops.PG_MASK, bitmask=bm, colsum=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
+        "panel_rank1": (lambda: ops.panel_gemm(dT, WaT, ops.PG_RANK1_MASK, bitmask=bm, rowscale=Asc, rank1=dM, rows_per_bag=N, colsum=True),
+                        M * (128 + 512) * 2, 2.0 * M * 512 * 128),
+        "tile_nt": (lambda: ops.gemm_nt(X, W, epi=ops.EPI_BIAS_RELU, bias=bias), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
+        "tn_512": (lambda: ops.gemm_tn(X, H), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
+        "tn_128": (lambda: ops.gemm_tn(dT, H), M * 640 * 2, 2.0 * M * 512 * 128),
+    }
+    for name, (fn, nbytes, flops) in cases.items():
+        if a.only and not any(tok in name for tok in a.only.split(",")):
+            continue
+        med, mn = timeit(fn, a.reps)
+        print(f"{name:16s} median {med * 1e3:8.1f} us  min {mn * 1e3:8.1f} us   {nbytes / med / 1e6:8.1f} GB/s  {flops / med / 1e9:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
