@@ -322,7 +322,7 @@ static int pick_chunk(int B, int N, int tr, int n_wg) {
 }
 
 extern "C" int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_chunks) {
-    const int tr = K2_TR;
+    const int tr = 32;                       // multiple of both kernels' tile heights (fwd 16, bwd 32/16)
     const int c = pick_chunk(B, N, tr, dtype == MURCL_DTYPE_BF16 ? 512 : 256);
     *chunk_rows = c;
     *n_chunks = (N + c - 1) / c;

@@ -231,6 +231,90 @@ static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, i
     return MURCL_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------- skinny NT (f32, M <= 128)
+// Bag-level layers (decoder, GRU projections, heads): M = bags (<= 128 rows), so a 128x128-tile grid has only
+// N/128 workgroups.  Here a workgroup owns a 32-column slab and one K split; A and B fragments come straight
+// from global memory (the operands are a few hundred KiB and L2-resident), 16x16x4 f32 MFMA, partial results
+// are added atomically into C, which the launcher pre-sets (memset; split 0 adds the bias).
+__global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                 float* __restrict__ C, int M, int N, int K, int lda,
+                                                                 int ldb, int ldc, const float* __restrict__ bias,
+                                                                 int k_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int n0 = blockIdx.x * 32, m0 = wave * 32;
+    if (m0 >= M) return;
+    const int kb = blockIdx.y * k_per_split, ke = min(K, kb + k_per_split);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap[2];
+    const float* bp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ap[i] = A + (size_t)min(m0 + 16 * i + r16, M - 1) * lda + 4 * q4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bp[j] = B + (size_t)min(n0 + 16 * j + r16, N - 1) * ldb + 4 * q4;
+    for (int k = kb; k < ke; k += 16) {          // K % 16 == 0 (checked by the launcher)
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const f32x4*)(ap[i] + k);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *(const f32x4*)(bp[j] + k);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mma16<float>(b[j], a[i], acc[i][j]);   // rows <- n, cols <- m
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 16 * i + r16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * j + 4 * q4 + r;
+                if (n < N) {
+                    float v = acc[i][j][r];
+                    if (bias && blockIdx.y == 0) v += bias[n];
+                    atomicAdd(C + (size_t)m * ldc + n, v);
+                }
+            }
+    }
+}
+__global__ void relu_inplace_kernel(float* x, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+
+static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         int epi, const float* bias, int accumulate, hipStream_t s) {
+    if (!accumulate) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int slabs = (N + 31) / 32;
+    int splits = (384 + slabs - 1) / slabs;                 // ~1.5 workgroups per CU
+    const int kmax = K / 16;
+    if (splits > kmax) splits = kmax;
+    if (splits < 1) splits = 1;
+    int kps = ((K / 16 + splits - 1) / splits) * 16;
+    splits = (K + kps - 1) / kps;
+    hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(slabs, splits), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                       (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, kps);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    if (epi == EPI_BIAS_RELU) {
+        if (ldc != N) return -1;
+        const long n = (long)M * N;
+        hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, n);
+        rc = MURCL_CHECK_LAUNCH();
+    }
+    return rc;
+}
+
 // C-ABI: see include/murcl_amd.h
 extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                              int dtype_in, int dtype_out, int epilogue, const float* bias, const void* mask,
@@ -242,6 +326,10 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
     if ((lda * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16 || (ldb * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16)
         return -1;
     if (accumulate && dtype_out != MURCL_DTYPE_F32) return -1;
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && M <= 128 && K % 16 == 0 && !colsum_ws &&
+        (epilogue == EPI_NONE || epilogue == EPI_BIAS || (epilogue == EPI_BIAS_RELU && !accumulate && ldc == N)))
+        return launch_skinny((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, epilogue, bias,
+                             accumulate, stream);
     GemmEpi e{bias, mask, ldmask, rowscale, rank1, rows_per_bag > 0 ? rows_per_bag : 1, colsum_ws, accumulate};
     if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16)
         return launch_nt_epi<bf16_t, bf16_t>((const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, lda, ldb, ldc,
