@@ -381,14 +381,28 @@ __device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int la
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
-                                                      float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
-                                                      int ldc, int m_per_split) {
+__global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
+                                                         int ldc, int m_per_split, int nsplit) {
     typedef typename Frag<T>::type frag_t;
     typedef TnTraits<T> TT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB | B 16 KiB)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t1 = blockIdx.x, t2 = blockIdx.y, sp = blockIdx.z;
+    constexpr int NSLOT = 4;                      // slab ring: three slabs (96 KiB) in flight, counted vmcnt
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSLOT x (A 16 KiB | B 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware work map (speed only): workgroups b and b+8 share an XCD, so all T1*T2 output tiles of one
+    // M-split - which read the same A/B slabs - are placed on one XCD and share them through its L2.
+    const int T1 = (N1 + 127) >> 7, T2 = (N2 + 127) >> 7, tiles = T1 * T2;
+    int tile, sp;
+    if ((nsplit & 7) == 0) {
+        const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
+        sp = xcd + 8 * (w / tiles);
+        tile = w % tiles;
+    } else {
+        tile = blockIdx.x % tiles;
+        sp = blockIdx.x / tiles;
+    }
+    const int t1 = tile % T1, t2 = tile / T1;
     const int n10 = t1 << 7, n20 = t2 << 7;
     const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
     if (mbeg >= mend) return;
@@ -405,11 +419,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         acol[t] = min(n10 + c * EPC, N1 - EPC);   // clamp: columns past N1/N2 are never stored
         bcol[t] = min(n20 + c * EPC, N2 - EPC);
     }
-    auto stage = [&](int buf, int mrow0) {
-        const unsigned la = lds0 + buf * 32768, lb = la + 16384;
+    auto stage = [&](int s) {
+        const int mrow0 = mbeg + s * TT::ROWS;
+        const unsigned la = lds0 + (s & (NSLOT - 1)) * 32768, lb = la + 16384;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            // rows past mend are clamped to a valid row and zero-weighted below via kvalid
+            // rows past mend are clamped to a valid row; the ragged tail is zeroed in LDS before use
             int m = min(mrow0 + srow[t], M - 1);
             glds16(A + (size_t)m * lda + acol[t], la + (t * 256 + wave * 64) * 16);
             glds16(B + (size_t)m * ldb + bcol[t], lb + (t * 256 + wave * 64) * 16);
@@ -423,16 +438,45 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wr = wave >> 1, wc = wave & 1;
 
-    auto compute = [&](int buf) {
-        const char* la = smem + buf * 32768;
+    // bf16: the transposed-read offsets inside a slab are lane constants (the swizzle depends only on
+    // row&3 and (row>>3)&1, both fixed per lane); k-group kk adds 32 rows = 8 KiB.
+    unsigned aoff[4][2], boff[4][2];
+    if (sizeof(T) == 2) {
+        const int g = lane >> 4, u = lane & 15, rq = u >> 2, p4 = u & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 8 * g + rq + 4 * h;
+                const int ca = 2 * (wr * 4 + i) + (p4 >> 1), cb = 2 * (wc * 4 + i) + (p4 >> 1);
+                aoff[i][h] = row * 256 + ((ca ^ TnTraits<bf16_t>::swz(row)) << 4) + ((p4 & 1) << 3);
+                boff[i][h] = 16384 + row * 256 + ((cb ^ TnTraits<bf16_t>::swz(row)) << 4) + ((p4 & 1) << 3);
+            }
+    }
+    auto tr_frag = [&](const char* slab, unsigned o0, unsigned o1, int kk) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* lp;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(slab + o0 + kk * 8192));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(slab + o1 + kk * 8192));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    auto compute = [&](int s) {
+        const char* la = smem + (s & (NSLOT - 1)) * 32768;
         const char* lb = la + 16384;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             frag_t af[4], bfr[4];
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tn_frag(la, wr * 4 + i, kk, lane, T());
+                for (int i = 0; i < 4; ++i) af[i] = tr_frag(la, aoff[i][0], aoff[i][1], kk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(lb, wc * 4 + j, kk, lane, T());
+                for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(la, boff[j][0], boff[j][1], kk);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = tn_frag(la, wr * 4 + i, kk, lane, T());
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(lb, wc * 4 + j, kk, lane, T());
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -441,28 +485,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, c
     };
 
     const int nslab = (mend - mbeg + TT::ROWS - 1) / TT::ROWS;
-    stage(0, mbeg);
-    WAIT_VMCNT(0);
-    LDS_BARRIER();
+    for (int s = 0; s < 3 && s < nslab; ++s) stage(s);
     for (int s = 0; s < nslab; ++s) {
-        const bool more = s + 1 < nslab;
-        if (more) stage((s + 1) & 1, mbeg + (s + 1) * TT::ROWS);
+        // slab s landed when at most 8 * (slabs issued after it) LDS-DMA ops are outstanding
+        const int after = min(2, nslab - 1 - s);
+        if (after == 2) { WAIT_VMCNT(16); } else if (after == 1) { WAIT_VMCNT(8); } else { WAIT_VMCNT(0); }
+        LDS_BARRIER();                             // slab s visible to all waves; slot of slab s-1 is free
+        if (s + 3 < nslab) stage(s + 3);
         const int rows_here = min(TT::ROWS, mend - (mbeg + s * TT::ROWS));
-        if (rows_here < TT::ROWS) {
-            // ragged tail: zero the invalid rows of the A image (B may hold anything finite... but
-            // clamped duplicates could be inf/nan-free garbage times zero = 0 only if finite), so
-            // zero both images' tail rows.
-            char* la = smem + (s & 1) * 32768;
+        if (rows_here < TT::ROWS) {               // ragged tail: zero the invalid rows of both images
+            char* la = smem + (s & (NSLOT - 1)) * 32768;
             for (int idx = tid; idx < (TT::ROWS - rows_here) * (TT::ROWB / 16); idx += 256) {
                 int row = rows_here + idx / (TT::ROWB / 16), c = idx % (TT::ROWB / 16);
                 *(u32x4*)(la + row * TT::ROWB + c * 16) = u32x4{0, 0, 0, 0};
                 *(u32x4*)(la + 16384 + row * TT::ROWB + c * 16) = u32x4{0, 0, 0, 0};
             }
-            __syncthreads();
+            LDS_BARRIER();
         }
-        compute(s & 1);
-        WAIT_VMCNT(0);
-        LDS_BARRIER();
+        compute(s);
     }
     // lane holds C[n1 = n10+wr*64+i*16+4q+r][n2 = n20+wc*64+j*16+(lane&15)]
     const int q4 = lane >> 4, r16 = lane & 15;
@@ -486,23 +526,25 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
     const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
-    if (splits <= 0) {                       // fill the chip: ~2 workgroups per CU
-        splits = (512 + t1 * t2 - 1) / (t1 * t2);
+    if (splits <= 0) {                       // fill the chip: one 128 KiB-LDS workgroup per CU, splits % 8 == 0
+        splits = (256 + t1 * t2 - 1) / (t1 * t2);
+        splits = ((splits + 7) / 8) * 8;
+        while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
     }
     int mps = (M + splits - 1) / splits;
     mps = ((mps + rows - 1) / rows) * rows;
-    splits = (M + mps - 1) / mps;
-    dim3 grid(t1, t2, splits);
+    if ((long)mps * (splits - 1) >= M) splits = (M + mps - 1) / mps;           // tiny M: drop empty splits
+    dim3 grid(t1 * t2 * splits);
     if (dtype == MURCL_DTYPE_BF16) {
         auto k = gemm_tn_kernel<bf16_t>;
         static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps);
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 131072, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
     } else if (dtype == MURCL_DTYPE_F32) {
         auto k = gemm_tn_kernel<float>;
         static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps);
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 131072, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
     } else {
         return -1;
     }
