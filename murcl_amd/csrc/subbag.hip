@@ -1,0 +1,205 @@
+// K12 / K13: sub-bag construction (utils/datasets.py:274-308) and mix-up (utils/datasets.py:263-271).
+//
+// subbag_select_kernel: one workgroup per bag.  Bit-exact restatement of the reference's float32 arithmetic
+//     size_j = rint(float(n_j) * ratio)                (torch.round == round-half-even, datasets.py:286-287)
+//     l_j    = floor(a_j * float(n_j - size_j))        (datasets.py:290), r_j = l_j + size_j
+// followed by Python slice semantics c[l:r] (negative l / r wrap once, then clamp), concatenation over
+// clusters, ascending sort and truncation to feat_size.  Cluster id lists partition the bag (k-means labels,
+// wsi_processing/features_clustering.py:19-25), so the selected ids are distinct: they are marked in an LDS
+// bitmap and emitted in ascending order by a popcount prefix scan - no comparison sort, no host round trip
+// (the reference pays two .item() syncs per cluster per bag, datasets.py:294).
+//
+// subbag_gather_mix_kernel: out[b,r,:] = lam_b * X_b[idx_b[r]] + (1-lam_b) * X_p[idx_p[r]], p = perm[b]; rows past
+// the selection count are zero (the reference zero-pads, datasets.py:300-303).  One wave per output row, 16 B per
+// lane.  The f32 arithmetic keeps the reference's two products and one sum (no FMA contraction).
+#include "common.h"
+
+// The reference rounds every product before the following sum (datasets.py:268-270, 286-290): never fuse.
+#pragma clang fp contract(off)
+
+#define SB_MAX_WORDS 15360          // bitmap words in LDS (60 KiB): bags of up to 491,520 patches
+
+__device__ __forceinline__ void py_slice(int n, int l, int r, int& lo, int& hi) {
+    // Python: indices < 0 get len added once, then both are clamped to [0, len]
+    if (l < 0) { l += n; if (l < 0) l = 0; } else if (l > n) l = n;
+    if (r < 0) { r += n; if (r < 0) r = 0; } else if (r > n) r = n;
+    lo = l;
+    hi = r > l ? r : l;
+}
+
+__global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restrict__ cluster_ids,
+                                                            const int* __restrict__ cluster_off,   // [B][K+1] into cluster_ids
+                                                            const int* __restrict__ n_patches,     // [B]
+                                                            const float* __restrict__ ratio,       // [B] float32(feat_size / N_b)
+                                                            const float* __restrict__ actions,     // [B][K]
+                                                            int K, int feat_size, int* __restrict__ idx_out,
+                                                            int* __restrict__ count_out) {
+    __shared__ unsigned bitmap[SB_MAX_WORDS];
+    __shared__ int wsum[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = n_patches[b];
+    const int words = (N + 31) >> 5;
+    for (int w = tid; w < words; w += 256) bitmap[w] = 0u;
+    __syncthreads();
+    const int* off = cluster_off + (size_t)b * (K + 1);
+    const float rt = ratio[b];
+    for (int j = 0; j < K; ++j) {
+        const int beg = off[j], n = off[j + 1] - beg;
+        const int size = (int)rintf((float)n * rt);                                      // single f32 products:
+        const int l = (int)floorf(actions[(size_t)b * K + j] * (float)(n - size));       // nothing to contract
+        int lo, hi;
+        py_slice(n, l, l + size, lo, hi);
+        for (int t = lo + tid; t < hi; t += 256) {
+            const int id = cluster_ids[beg + t];
+            atomicOr(&bitmap[id >> 5], 1u << (id & 31));
+        }
+    }
+    __syncthreads();
+    // ascending emission: thread t owns a contiguous run of words; exclusive prefix of popcounts over threads
+    const int per = (words + 255) / 256;
+    const int w0 = tid * per, w1 = min(words, w0 + per);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) cnt += __popc(bitmap[w]);
+    wsum[tid] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {             // Hillis-Steele inclusive scan
+        int v = tid >= o ? wsum[tid - o] : 0;
+        __syncthreads();
+        wsum[tid] += v;
+        __syncthreads();
+    }
+    int pos = wsum[tid] - cnt;
+    const int total = wsum[255];
+    int* out = idx_out + (size_t)b * feat_size;
+    for (int w = w0; w < w1 && pos < feat_size; ++w) {
+        unsigned m = bitmap[w];
+        while (m && pos < feat_size) {
+            const int bit = __ffs(m) - 1;
+            out[pos++] = (w << 5) + bit;
+            m &= m - 1;
+        }
+    }
+    const int kept = min(total, feat_size);
+    for (int r = kept + tid; r < feat_size; r += 256) out[r] = -1;      // zero-padded rows
+    if (tid == 0) count_out[b] = kept;
+}
+
+extern "C" int murcl_subbag_select(const int* cluster_ids, const int* cluster_off, const int* n_patches,
+                                   const float* ratio, const float* actions, int B, int K, int feat_size,
+                                   int max_patches, int* idx_out, int* count_out, hipStream_t stream) {
+    if (B <= 0) return 0;
+    if (K <= 0 || feat_size <= 0 || max_patches > SB_MAX_WORDS * 32) return -1;
+    hipLaunchKernelGGL(subbag_select_kernel, dim3(B), dim3(256), 0, stream, cluster_ids, cluster_off, n_patches, ratio,
+                       actions, K, feat_size, idx_out, count_out);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------ gather (+ mix-up)
+template <typename TI> __device__ __forceinline__ void load8(const TI* p, float* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
+    const u32x4 u = *(const u32x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(u[e]); v[2 * e + 1] = bf_hi(u[e]); }
+}
+template <typename TO> __device__ __forceinline__ void store8(TO* p, const float* v);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+    *(u32x4*)p = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __restrict__ feats,
+                                                                const long* __restrict__ bag_row_off,
+                                                                const int* __restrict__ idx,
+                                                                const float* __restrict__ lam,
+                                                                const int* __restrict__ perm, TO* __restrict__ out,
+                                                                int B, int feat_size, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;                   // output row b*feat_size + r
+    if (row >= (long)B * feat_size) return;
+    const int b = (int)(row / feat_size), r = (int)(row - (long)b * feat_size);
+    const int i0 = idx[(size_t)b * feat_size + r];
+    const bool mix = lam != nullptr;
+    const int pb = mix ? perm[b] : b;
+    const int i1 = mix ? idx[(size_t)pb * feat_size + r] : -1;
+    const float l0 = mix ? lam[b] : 1.f, l1 = 1.f - l0;
+    const TI* s0 = feats + (bag_row_off[b] + (i0 < 0 ? 0 : i0)) * d;
+    const TI* s1 = feats + (bag_row_off[pb] + (i1 < 0 ? 0 : i1)) * d;
+    TO* o = out + row * d;
+    for (int c = lane * 8; c < d; c += 512) {
+        float x[8], y[8], v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = y[e] = 0.f;
+        if (i0 >= 0) load8<TI>(s0 + c, x);
+        if (mix) {
+            if (i1 >= 0) load8<TI>(s1 + c, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = l0 * x[e];
+                const float cc = l1 * y[e];
+                v[e] = a + cc;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = x[e];
+        }
+        store8<TO>(o + c, v);
+    }
+}
+
+extern "C" int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
+                                       const int* perm, void* out, int B, int feat_size, int d, int dtype_in,
+                                       int dtype_out, hipStream_t stream) {
+    if (B <= 0 || feat_size <= 0) return 0;
+    if (d % 8) return -1;
+    if ((lam == nullptr) != (perm == nullptr)) return -1;
+    const long rows = (long)B * feat_size;
+    dim3 grid((unsigned)((rows + 3) / 4));
+#define GM(TI, TO) hipLaunchKernelGGL((subbag_gather_mix_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)feats, \
+                                      bag_row_off, idx, lam, perm, (TO*)out, B, feat_size, d)
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32) GM(float, float);
+    else if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_BF16) GM(float, bf16_t);
+    else if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16) GM(bf16_t, bf16_t);
+    else if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_F32) GM(bf16_t, float);
+    else return -1;
+#undef GM
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------ stand-alone mix-up
+template <typename T>
+__global__ void mixup_kernel(const T* __restrict__ x, const float* __restrict__ lam, const int* __restrict__ perm,
+                             T* __restrict__ out, int B, long per_bag) {
+    const int b = blockIdx.y;
+    const float l0 = lam[b], l1 = 1.f - l0;
+    const T* x0 = x + (size_t)b * per_bag;
+    const T* x1 = x + (size_t)perm[b] * per_bag;
+    T* o = out + (size_t)b * per_bag;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_bag; i += (long)gridDim.x * blockDim.x) {
+        const float a = l0 * to_f<T>(x0[i]);
+        const float c = l1 * to_f<T>(x1[i]);
+        o[i] = from_f<T>(a + c);
+    }
+}
+extern "C" int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int B, long per_bag, int dtype,
+                           hipStream_t stream) {
+    if (B <= 0 || per_bag <= 0) return 0;
+    int gx = (int)((per_bag + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    dim3 grid(gx, B);
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(mixup_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, lam, perm, (float*)out, B, per_bag);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(mixup_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, lam, perm, (bf16_t*)out, B, per_bag);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}

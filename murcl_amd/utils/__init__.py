@@ -1,1 +1,1 @@
-from . import losses  # noqa: F401
+from . import datasets, losses  # noqa: F401

@@ -1,0 +1,93 @@
+"""K12/K13 on MI355X: patch selection bit-exact vs the reference goldens (G6) and the oracle; mix-up vs G7."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, params as P, select_oracle as S  # noqa: E402
+from tests.test_oracle_goldens import _g6_rebuild  # noqa: E402
+
+T = torch.from_numpy
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _marker_feats(N, d=8):
+    f = np.zeros((N, d), np.float32)
+    f[:, 0] = np.arange(N) + 1
+    f[:, 1] = 7.0
+    return f
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e"])
+def test_get_feats_indices_bit_exact_vs_reference_golden(golden, name):
+    from murcl_amd.utils.datasets import get_feats
+    g = golden("g6_get_feats")
+    N, fs, act = int(g[f"{name}.N"]), int(g[f"{name}.fs"]), g[f"{name}.act"]
+    cls = _g6_rebuild(name)
+    dev = _dev()
+    feats = [T(_marker_feats(N)).unsqueeze(0).to(dev) for _ in cls]
+    out = get_feats(feats, cls, T(act).to(dev), fs)
+    assert out.shape == (len(cls), fs, 8)
+    np.testing.assert_array_equal(out[:, :, 0].cpu().numpy().astype(np.int64), g[f"{name}.ids_plus1"])
+    pad = out[:, :, 0] == 0
+    assert (out[:, :, 1][pad] == 0).all() and (out[:, :, 1][~pad] == 7.0).all()
+
+
+@pytest.mark.parametrize("B,N,K,fs", [(8, 8192, 10, 1024), (3, 300, 4, 512), (5, 20000, 10, 1024), (2, 64, 3, 16)])
+def test_select_matches_oracle_random(B, N, K, fs):
+    """Random bags incl. ragged lengths and N < feat_size; ids must be identical (integers: no tolerance)."""
+    from murcl_amd.utils.datasets import BagPack, select_indices
+    dev = _dev()
+    Ns = [N - 37 * b for b in range(B)]
+    cls = [P.cluster_lists(31, f"c{b}", Ns[b], K) for b in range(B)]
+    feats = [T(_marker_feats(n)).to(dev) for n in Ns]
+    act = detrand.uniform(31, "act", (B, K))
+    act[0, 0], act[0, 1] = 0.0, 1.0
+    pack = BagPack.from_lists(feats, cls)
+    idx, cnt = select_indices(pack, T(act).to(dev), fs)
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(B):
+        want = S.select_indices(Ns[b], cls[b], act[b], fs)[:fs]
+        assert cnt[b] == len(want)
+        np.testing.assert_array_equal(idx[b, :len(want)], np.asarray(want, dtype=np.int64))
+        assert (idx[b, len(want):] == -1).all()
+
+
+def test_mixup_golden(golden):
+    from murcl_amd.utils.datasets import mixup_with, mixup
+    g = golden("g7_mixup")
+    dev = _dev()
+    x = T(detrand.normal(9, "g7.x", (5, 16, 8))).to(dev)
+    out = mixup_with(x, T(g["lam"]).to(dev), T(g["perm"]).to(dev))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["out"])            # same two products + one sum: bit-exact
+    o2, lam, perm = mixup(x, 0.9)
+    assert lam.shape == (5, 1) and (lam >= 0.9).all() and (lam <= 1).all()
+    assert sorted(perm.cpu().tolist()) == list(range(5))
+    np.testing.assert_array_equal(o2.cpu().numpy(), S.mixup(x.cpu().numpy(), lam.cpu().numpy(), perm.cpu().numpy()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_views_equal_get_feats_then_mixup(dtype):
+    from murcl_amd.utils.datasets import BagPack, subbag_views
+    dev = _dev()
+    B, N, K, fs, d = 6, 3000, 10, 256, 512
+    feats_np = [P.bags(41, f"f{b}", 1, N - 100 * b, d)[0] for b in range(B)]
+    cls = [P.cluster_lists(41, f"c{b}", N - 100 * b, K) for b in range(B)]
+    pack = BagPack.from_lists([T(f).to(dev) for f in feats_np], cls)
+    acts = [detrand.uniform(41, f"a{v}", (B, K)) for v in range(2)]
+    draws = [(T(detrand.uniform(41, f"l{v}", (B, 1), 0.9, 1.0)).to(dev), T(detrand.permutation(41, f"p{v}", B)).to(dev)) for v in range(2)]
+    views, used = subbag_views(pack, [T(a).to(dev) for a in acts], fs, draws=draws, out_dtype=dtype)
+    assert views[1].data_ptr() == views[0].data_ptr() + views[0].numel() * views[0].element_size()   # back to back
+    for v in range(2):
+        sub, _ = S.get_feats(feats_np, cls, acts[v], fs)
+        want = S.mixup(sub, draws[v][0].cpu().numpy(), draws[v][1].cpu().numpy())
+        got = views[v].float().cpu().numpy()
+        if dtype == torch.float32:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=8e-3, atol=1e-6)
