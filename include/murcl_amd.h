@@ -101,6 +101,24 @@ int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const in
 int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int B, long per_bag, int dtype,
                 murcl_stream_t stream);
 
+/* K6 -- DSMIL aggregator pieces (models/dsmil.py:64-81); the projections themselves are murcl_gemm_nt calls.
+ * argmax: m[b,c] = first index of max_n scores[b,n,c] (the reference takes row 0 of a descending sort, :71-73).
+ * gather_rows: out[b*C+c,:] = src[b, m[b,c], col0:col0+width].  attn: A[b,n,c] = softmax_n(Q[b,n].qmax[b,c]/sqrt(128))
+ * (:76-77).  weighted_rowsum: Z[b,c,:] = sum_n A[b,n,c] X[b,n,:] - with bag = Z Wv^T + bv this equals A^T V (:78)
+ * because every column of A sums to one.  rows_dot: out[b,n,c] = X[b,n,:].V[b,c,:].  attn_bwd: soft-max backward,
+ * dQ written into dY[:, qcol0:qcol0+128] and dqmax[b,c,:]. */
+int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_out, murcl_stream_t stream);
+int murcl_gather_rows(const void* src, const int* m, int B, int C, int N, int ld, int col0, int width, void* out,
+                      int dtype, murcl_stream_t stream);
+int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float* qmax, int B, int N, int C, float* A,
+                     murcl_stream_t stream);
+int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
+                          murcl_stream_t stream);
+int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
+                   murcl_stream_t stream);
+int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0, const float* qmax, int B,
+                         int N, int C, float* dY, int ldy, float* dqmax, murcl_stream_t stream);
+
 /* helpers */
 int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, murcl_stream_t stream);
 int murcl_transpose_cast(const float* x, void* y, int R, int C, int dtype_out, murcl_stream_t stream);

@@ -30,6 +30,12 @@ SIGNATURES = {
     "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_mixup": [_P, _P, _P, _P, _I, _L, _I, _P],
+    "murcl_dsmil_argmax": [_P, _I, _I, _I, _I, _P, _P],
+    "murcl_gather_rows": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "murcl_dsmil_attn": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
+    "murcl_weighted_rowsum": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_rows_dot": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_dsmil_attn_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "murcl_cast": [_P, _P, _L, _I, _I, _P],
     "murcl_transpose_cast": [_P, _P, _I, _I, _I, _P],
     "murcl_colsum": [_P, _P, _I, _I, _I, _I, _I, _P],

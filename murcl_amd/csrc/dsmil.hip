@@ -1,0 +1,255 @@
+// K6: DSMIL aggregator pieces (models/dsmil.py:64-81) around the shared GEMM kernels.
+//
+//   classes = X Wc^T + bc                       gemm_nt (together with Q: one pass over X)
+//   m[c]    = argmax_n classes[n,c]             dsmil_argmax_kernel      (lowest index wins ties)
+//   q_max   = Q[m]                              dsmil_gather_rows_kernel
+//   A       = softmax_n(Q q_max^T / sqrt(128))  dsmil_attn_kernel        (reads only Q: N x 128)
+//   Z       = A^T X                             weighted_rowsum_kernel   (one streaming pass over X)
+//   bag     = Z Wv^T + bv                       skinny gemm_nt           (= A^T (X Wv^T + bv): columns of A sum to 1,
+//                                                                          dropout_v = 0, dsmil.py:53,118)
+// Backward adds rows_dot_kernel (dA = X dZ^T) and dsmil_attn_bwd_kernel.
+#include "common.h"
+
+#define DS_Q 128
+
+// per (bag, class): first index of the maximum of scores[b, :, c]   (scores [B,N,ld] f32, classes in columns 0..C-1)
+__global__ __launch_bounds__(256) void dsmil_argmax_kernel(const float* __restrict__ scores, int N, int ld, int C,
+                                                           int* __restrict__ m_out) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const float* s = scores + (size_t)b * N * ld + c;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int n = tid; n < N; n += 256) {
+        const float v = s[(size_t)n * ld];
+        if (v > best || (v == best && n < idx)) { best = v; idx = n; }
+    }
+    bv[tid] = best; bi[tid] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v = bv[tid + o]; const int i = bi[tid + o];
+            if (v > bv[tid] || (v == bv[tid] && i < bi[tid])) { bv[tid] = v; bi[tid] = i; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) m_out[b * C + c] = bi[0];
+}
+extern "C" int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_out, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(dsmil_argmax_kernel, dim3(B, C), dim3(256), 0, s, scores, N, ld, C, m_out);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// out[b*C + c, :] = src[b, m[b,c], col0 : col0+width]   (src [B,N,ld])
+template <typename T>
+__global__ void dsmil_gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ m, int N, int ld, int col0,
+                                         int width, T* __restrict__ out, int C) {
+    const int r = blockIdx.x, b = r / C;
+    const T* s = src + ((size_t)b * N + m[r]) * ld + col0;
+    for (int k = threadIdx.x; k < width; k += blockDim.x) out[(size_t)r * width + k] = s[k];
+}
+extern "C" int murcl_gather_rows(const void* src, const int* m, int B, int C, int N, int ld, int col0, int width,
+                                 void* out, int dtype, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    if (dtype == MURCL_DTYPE_F32) {
+        hipLaunchKernelGGL(dsmil_gather_rows_kernel<float>, dim3(B * C, 1), dim3(256), 0, s, (const float*)src, m, N, ld, col0, width, (float*)out, C);
+    } else if (dtype == MURCL_DTYPE_BF16) {
+        hipLaunchKernelGGL(dsmil_gather_rows_kernel<bf16_t>, dim3(B * C, 1), dim3(256), 0, s, (const bf16_t*)src, m, N, ld, col0, width, (bf16_t*)out, C);
+    } else {
+        return -1;
+    }
+    return MURCL_CHECK_LAUNCH();
+}
+
+// A[b,n,c] = softmax_n( Q[b,n,:] . qmax[b,c,:] * scale ).  One workgroup per (bag, class); Q rows at stride ldq.
+__global__ __launch_bounds__(256) void dsmil_attn_kernel(const float* __restrict__ Q, int ldq, int qcol0,
+                                                         const float* __restrict__ qmax, int N, int C, float scale,
+                                                         float* __restrict__ A) {
+    __shared__ float red[256];
+    __shared__ float qm[DS_Q];
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (tid < DS_Q) qm[tid] = qmax[((size_t)b * C + c) * DS_Q + tid];
+    __syncthreads();
+    const float* q = Q + (size_t)b * N * ldq + qcol0;
+    float* a = A + (size_t)b * N * C + c;
+    float mx = -INFINITY;
+    for (int n = tid; n < N; n += 256) {
+        const float* qr = q + (size_t)n * ldq;
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < DS_Q; k += 4) {
+            const f32x4 v = *(const f32x4*)(qr + k);
+            s += v[0] * qm[k] + v[1] * qm[k + 1] + v[2] * qm[k + 2] + v[3] * qm[k + 3];
+        }
+        s *= scale;
+        a[(size_t)n * C] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        const float e = expf(a[(size_t)n * C] - mx);
+        a[(size_t)n * C] = e;
+        sum += e;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.f / red[0];
+    for (int n = tid; n < N; n += 256) a[(size_t)n * C] *= inv;
+}
+extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float* qmax, int B, int N, int C, float* A,
+                                hipStream_t s) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(dsmil_attn_kernel, dim3(B, C), dim3(256), 0, s, Q, ldq, qcol0, qmax, N, C, 1.0f / sqrtf((float)DS_Q), A);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]      (one streaming pass over X; C <= 4)
+// grid (B, row splits); each workgroup reduces its row range for all d columns and adds atomically.
+template <typename T>
+__global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restrict__ X, const float* __restrict__ A,
+                                                              int N, int d, int C, int rows_per_block,
+                                                              float* __restrict__ Z) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    const T* x = X + (size_t)b * N * d;
+    const float* a = A + (size_t)b * N * C;
+    for (int c0 = tid * 4; c0 < d; c0 += 1024) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = r0; n < r1; ++n) {
+            const f32x4 v = load4<T>(x + (size_t)n * d + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < C) acc[c] += a[(size_t)n * C + c] * v;
+        }
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(Z + ((size_t)b * C + c) * d + c0 + e, acc[c][e]);
+    }
+}
+extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
+                                     hipStream_t s) {
+    if (B <= 0) return 0;
+    if (C > 4 || d % 4) return -1;
+    hipError_t e = hipMemsetAsync(Z, 0, (size_t)B * C * d * 4, s);
+    if (e != hipSuccess) return (int)e;
+    int splits = (1024 + B - 1) / B;
+    if (splits > (N + 63) / 64) splits = (N + 63) / 64;
+    if (splits < 1) splits = 1;
+    const int rpb = (N + splits - 1) / splits;
+    dim3 grid(B, (N + rpb - 1) / rpb);
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(weighted_rowsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, A, N, d, C, rpb, Z);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(weighted_rowsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, A, N, d, C, rpb, Z);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
+// out[b,n,c] = X[b,n,:] . V[b,c,:]      (dA = X dZ^T; one wave per row, C <= 4)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, const float* __restrict__ V, int N, int d,
+                                                       int C, float* __restrict__ out, long rows_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows_total) return;
+    const int b = (int)(row / N);
+    const T* x = X + row * d;
+    const float* v = V + (size_t)b * C * d;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < d; k += 256) {
+        const f32x4 xv = load4<T>(x + k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                const f32x4 w = *(const f32x4*)(v + (size_t)c * d + k);
+                acc[c] += xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
+            }
+    }
+    for (int c = 0; c < C; ++c) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0) out[row * C + c] = s;
+    }
+}
+extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
+                              hipStream_t s) {
+    if (B <= 0) return 0;
+    if (C > 4 || d % 4) return -1;
+    const long rows = (long)B * N;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(rows_dot_kernel<float>, grid, dim3(256), 0, s, (const float*)X, V, N, d, C, out, rows);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(rows_dot_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, V, N, d, C, out, rows);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
+// Soft-max backward over N per (bag, class) + the two small products that follow it:
+//   dS = A * (dA - sum_n A dA);  dY[b,n, qcol0:qcol0+128] = sum_c dS[n,c] qmax[c,:] * scale;
+//   dqmax[b,c,:] = sum_n dS[n,c] Q[b,n,:] * scale
+__global__ __launch_bounds__(256) void dsmil_attn_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                             const float* __restrict__ Q, int ldq, int qcol0,
+                                                             const float* __restrict__ qmax, int N, int C, float scale,
+                                                             float* __restrict__ dY, int ldy, float* __restrict__ dqmax) {
+    __shared__ float red[256];
+    __shared__ float dots[4];
+    __shared__ float qm[4 * DS_Q];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < C * DS_Q; k += 256) qm[k] = qmax[(size_t)b * C * DS_Q + k];
+    const float* a = A + (size_t)b * N * C;
+    const float* da = dA + (size_t)b * N * C;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (int n = tid; n < N; n += 256) s += a[(size_t)n * C + c] * da[(size_t)n * C + c];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) dots[c] = red[0];
+        __syncthreads();
+    }
+    // dQ rows: thread handles (n, 4 columns)
+    const float* q = Q + (size_t)b * N * ldq + qcol0;
+    float* dy = dY + (size_t)b * N * ldy + qcol0;
+    const int kq = (tid & 31) * 4, nl = tid >> 5;               // 32 threads per row, 8 rows per pass
+    f32x4 dqm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dqm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = nl; n < N; n += 8) {
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 qv = *(const f32x4*)(q + (size_t)n * ldq + kq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+                const float ds = a[(size_t)n * C + c] * (da[(size_t)n * C + c] - dots[c]) * scale;
+                g += ds * *(const f32x4*)&qm[c * DS_Q + kq];
+                dqm[c] += ds * qv;
+            }
+        *(f32x4*)(dy + (size_t)n * ldy + kq) = g;
+    }
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dqmax + ((size_t)b * C + c) * DS_Q + kq + e, dqm[c][e]);
+}
+extern "C" int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0,
+                                    const float* qmax, int B, int N, int C, float* dY, int ldy, float* dqmax,
+                                    hipStream_t s) {
+    if (B <= 0) return 0;
+    if (C > 4) return -1;
+    hipError_t e = hipMemsetAsync(dqmax, 0, (size_t)B * C * DS_Q * 4, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dsmil_attn_bwd_kernel, dim3(B), dim3(256), 0, s, A, dA, Q, ldq, qcol0, qmax, N, C,
+                       1.0f / sqrtf((float)DS_Q), dY, ldy, dqmax);
+    return MURCL_CHECK_LAUNCH();
+}

@@ -166,3 +166,60 @@ class NTXentFn(torch.autograd.Function):
         (dz,) = ctx.saved_tensors
         g = dz * dloss
         return g[:ctx.B], g[ctx.B:], None, None, None
+
+
+class DSMILFn(torch.autograd.Function):
+    """MILNet.forward for a batch of equal-length bags (models/dsmil.py:9-16,64-81,104-113).
+
+    One GEMM over X produces the queries Q (columns 0..127) and the instance scores (columns 128..128+C-1);
+    the value projection is applied AFTER pooling: bag = (A^T X) Wv^T + bv, identical to A^T (X Wv^T + bv)
+    because every column of the soft-max sums to one (dropout_v = 0).  Returns (classes [B,N,C], bag [B,C,d]).
+    """
+    QD = 128
+
+    @staticmethod
+    def forward(ctx, x, wc, bc, wq, bq, wv, bv):
+        B, N, d = x.shape
+        T = x.dtype
+        C = wc.shape[0]
+        QD = DSMILFn.QD
+        LD = QD + ((C + 7) // 8) * 8
+        w = torch.zeros((LD, d), dtype=torch.float32, device=x.device)
+        bias = torch.zeros((LD,), dtype=torch.float32, device=x.device)
+        w[:QD], w[QD:QD + C], bias[:QD], bias[QD:QD + C] = wq, wc, bq, bc
+        x2 = x.reshape(B * N, d)
+        Y = ops.gemm_nt(x2, w if T == torch.float32 else ops.cast(w, T), epi=ops.EPI_BIAS, bias=bias,
+                        out_dtype=torch.float32)
+        m = ops.dsmil_argmax(Y[:, QD:], B, N, C)
+        qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
+        A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
+        Z = ops.weighted_rowsum(x, A)
+        bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
+        classes = Y[:, QD:QD + C].reshape(B, N, C)
+        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv)
+        ctx.meta = (B, N, d, C, LD)
+        ctx.mark_non_differentiable(m)
+        return classes, bag, m
+
+    @staticmethod
+    def backward(ctx, dclasses, dbag, _dm):
+        x, Y, m, qmax, A, Z, wv = ctx.saved_tensors
+        B, N, d, C, LD = ctx.meta
+        T, QD = x.dtype, DSMILFn.QD
+        dev = x.device
+        x2 = x.reshape(B * N, d)
+        dbag2 = (dbag if dbag is not None else torch.zeros((B, C, d), device=dev)).reshape(B * C, d).contiguous()
+        dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
+        dbv = ops.colsum(dbag2)
+        dZ = ops.gemm_nt(dbag2, ops.transpose_cast(wv, torch.float32)).view(B, C, d)
+        dA = ops.rows_dot(x, dZ)
+        dY = torch.zeros((B * N, LD), dtype=torch.float32, device=dev)
+        if dclasses is not None:
+            dY[:, QD:QD + C] = dclasses.reshape(B * N, C)
+        dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dY, B, N, C)
+        dW = ops.gemm_tn(dY if T == torch.float32 else ops.cast(dY, T), x2)                 # [LD, d]
+        db = ops.colsum(dY)
+        xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
+        dwq = ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dW[:QD].contiguous())
+        dbq = ops.colsum(dqmax, out=db[:QD].contiguous(), accumulate=True)
+        return None, dW[QD:QD + C].contiguous(), db[QD:QD + C].contiguous(), dwq, dbq, dwv, dbv

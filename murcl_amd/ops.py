@@ -285,3 +285,54 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step):
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
     check(_lib.lib().murcl_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]),
                                      float(betas[1]), float(eps), float(weight_decay), int(step), stream()), "adam_step")
+
+
+# ------------------------------------------------------------------------------------------ DSMIL (K6)
+def dsmil_argmax(scores_view, B, N, C):
+    """scores_view: [B*N, >=C] f32 view (row stride = its stride(0)); -> m [B,C] int32."""
+    m = torch.empty((B, C), dtype=torch.int32, device=scores_view.device)
+    check(_lib.lib().murcl_dsmil_argmax(ptr(scores_view), B, N, scores_view.stride(0), C, ptr(m), stream()), "dsmil_argmax")
+    return m
+
+
+def gather_rows(src, m, B, C, N, col0, width):
+    """out[b*C+c,:] = src[b*N + m[b,c], col0:col0+width]  (src [B*N, ld] contiguous)."""
+    out = torch.empty((B * C, width), dtype=src.dtype, device=src.device)
+    check(_lib.lib().murcl_gather_rows(ptr(src), ptr(m), B, C, N, src.stride(0), col0, width, ptr(out), dt(src), stream()),
+          "gather_rows")
+    return out
+
+
+def dsmil_attn(Y, qcol0, qmax, B, N, C):
+    A = torch.empty((B, N, C), dtype=torch.float32, device=Y.device)
+    check(_lib.lib().murcl_dsmil_attn(ptr(Y), Y.stride(0), qcol0, ptr(qmax), B, N, C, ptr(A), stream()), "dsmil_attn")
+    return A
+
+
+def weighted_rowsum(X, A):
+    """Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]   X [B,N,d] (f32/bf16), A [B,N,C] f32 -> Z [B,C,d] f32."""
+    X, A = _c(X), _c(A)
+    B, N, d = X.shape
+    C = A.shape[2]
+    Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
+    with _span(f"weighted_rowsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C)):
+        check(_lib.lib().murcl_weighted_rowsum(ptr(X), ptr(A), ptr(Z), B, N, d, C, dt(X), stream()), "weighted_rowsum")
+    return Z
+
+
+def rows_dot(X, V):
+    """out[b,n,c] = X[b,n,:] . V[b,c,:]."""
+    X, V = _c(X), _c(V)
+    B, N, d = X.shape
+    C = V.shape[1]
+    out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
+    with _span(f"rows_dot<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C)):
+        check(_lib.lib().murcl_rows_dot(ptr(X), ptr(V), ptr(out), B, N, d, C, dt(X), stream()), "rows_dot")
+    return out
+
+
+def dsmil_attn_bwd(A, dA, Y, qcol0, qmax, dY, B, N, C):
+    dqmax = torch.empty((B * C, qmax.shape[1]), dtype=torch.float32, device=Y.device)
+    check(_lib.lib().murcl_dsmil_attn_bwd(ptr(A), ptr(_c(dA)), ptr(Y), Y.stride(0), qcol0, ptr(qmax), B, N, C, ptr(dY),
+                                          dY.stride(0), ptr(dqmax), stream()), "dsmil_attn_bwd")
+    return dqmax

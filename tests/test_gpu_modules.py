@@ -185,3 +185,66 @@ def test_ntxent_module_golden(golden):
             np.testing.assert_allclose(loss.item(), g[f"loss.{B}.{tau}"], rtol=1e-4)
             np.testing.assert_allclose(zi.grad.cpu().numpy(), g[f"dzi.{B}.{tau}"], rtol=1e-3, atol=1e-7)
             np.testing.assert_allclose(zj.grad.cpu().numpy(), g[f"dzj.{B}.{tau}"], rtol=1e-3, atol=1e-7)
+
+
+# ------------------------------------------------------------------ DSMIL (K6)
+def _dsmil(seed, d=512, C=2, dtype=torch.float32):
+    from murcl_amd.models.dsmil import build_dsmil
+    m = build_dsmil(d, C)
+    m.load_state_dict(P.to_torch(P.dsmil(seed, d, C)))
+    m.compute_dtype = dtype
+    return m.to(_dev())
+
+
+def test_dsmil_vs_reference_golden(golden):
+    """G5: classes, arg-max patch ids (bit-exact), bag embedding and gradients vs the reference."""
+    g = golden("g5_dsmil")
+    m = _dsmil(5)
+    x = T(P.bags(5, "g5.x", 3, 200, 512)).to(_dev())
+    classes, bag, det = m(x)
+    assert isinstance(classes, list) and len(classes) == 3 and not det.requires_grad
+    np.testing.assert_allclose(torch.stack(classes).detach().cpu().numpy(), g["classes"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(m.last_critical.cpu().numpy(), g["m_ids"])
+    np.testing.assert_allclose(bag.detach().cpu().numpy(), g["bag"], rtol=1e-4, atol=1e-5)
+    (bag.sum() + sum(c.max(0)[0].sum() for c in classes)).backward()
+    for k, v in m.named_parameters():
+        key = "grad." + k
+        if key in g.files:
+            _check_summ(_summ(v.grad), g[key], 1e-3, key)
+    assert m.b_classifier.fcc.weight.grad is None
+    c1, b1, _ = m(x[:1])                                           # single-bag path returns a tensor
+    np.testing.assert_allclose(c1.detach().cpu().numpy(), g["classes_single"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b1.detach().cpu().numpy(), g["bag_single"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,d,C", [(2, 1000, 1024, 2), (4, 333, 512, 3)])
+def test_dsmil_vs_oracle_full_grads(B, N, d, C):
+    m = _dsmil(6, d, C)
+    p = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.dsmil(6, d, C)).items()}
+    x = T(P.bags(6, f"x{B}{N}", B, N, d))
+    wb_, wc_ = T(detrand.normal(6, "wb", (B, C, d))), T(detrand.normal(6, "wc", (B, N, C)))
+    c_ref, bag_ref, A_ref, m_ref = O.dsmil_forward(p, x)
+    ((bag_ref * wb_).sum() + (c_ref * wc_).sum()).backward()
+    classes, bag, _ = m(x.to(_dev()))
+    np.testing.assert_array_equal(m.last_critical.cpu().numpy(), m_ref.numpy())
+    ((bag * wb_.to(_dev())).sum() + (torch.stack(classes) * wc_.to(_dev())).sum()).backward()
+    np.testing.assert_allclose(bag.detach().cpu().numpy(), bag_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for k, v in m.named_parameters():
+        if p[k].grad is None:
+            continue
+        ref = p[k].grad
+        np.testing.assert_allclose(v.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * ref.abs().max().item(), err_msg=k)
+
+
+def test_dsmil_bf16_and_ragged_list():
+    dev = _dev()
+    m32, m16 = _dsmil(7), _dsmil(7, dtype=torch.bfloat16)
+    x = T(P.bags(7, "x", 4, 2048, 512)).to(dev)
+    c32, b32, _ = m32(x)
+    c16, b16, _ = m16(x)
+    assert (b16 - b32).abs().max().item() <= 3e-2 * b32.abs().max().item()
+    xs = [T(P.bags(7, f"r{i}", 1, n, 512)).to(dev) for i, n in enumerate((100, 257))]
+    cl, bag, _ = m32(xs)
+    assert [tuple(c.shape) for c in cl] == [(100, 2), (257, 2)] and bag.shape == (2, 2, 512)
+    with pytest.raises(TypeError):
+        m32(3)
