@@ -119,6 +119,26 @@ int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int 
 int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0, const float* qmax, int B,
                          int N, int C, float* dY, int ldy, float* dqmax, murcl_stream_t stream);
 
+/* K4/K5 -- CLAM-SB pieces (models/clam.py); the fc and gate projections are murcl_gemm_nt / murcl_panel_gemm calls.
+ * gated_score: s[n] = sum_d tanh(U[n,d])*sigmoid(U[n,D+d])*wc[d] + bc (clam.py:56-59), optional dropout keep
+ * multipliers (0 or 1/0.75) for the two branches (clam.py:47-48); _bwd gives dU, dwc, dbc.  softmax_rows: A =
+ * softmax_N(s) per bag (clam.py:144).  topk_ids: ids[b,0:k] top-k of A, ids[b,k:2k] bottom-k (clam.py:107,109,126;
+ * lowest index wins ties).  take_rows / scatter_add_rows_masked: gather instance features and add their gradient back
+ * under the ReLU mask.  cross_entropy: mean CE over R rows + gradient + arg-max predictions (clam.py:116-118). */
+int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a, const void* keep_b,
+                          float* s, long rows, int D, int dtype, murcl_stream_t stream);
+int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b, const float* ds,
+                          void* dU, float* dwc, float* dbc, long rows, int D, int dtype, murcl_stream_t stream);
+int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t stream);
+int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
+int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);
+int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d, int dtype, murcl_stream_t stream);
+int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, const float* g, int R, int d, int dtype,
+                                  murcl_stream_t stream);
+int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
+                        long* preds, murcl_stream_t stream);
+int murcl_mul(const void* x, const void* k, void* y, long n, int dtype, murcl_stream_t stream);
+
 /* helpers */
 int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, murcl_stream_t stream);
 int murcl_transpose_cast(const float* x, void* y, int R, int C, int dtype_out, murcl_stream_t stream);

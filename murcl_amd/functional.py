@@ -223,3 +223,110 @@ class DSMILFn(torch.autograd.Function):
         dwq = ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dW[:QD].contiguous())
         dbq = ops.colsum(dqmax, out=db[:QD].contiguous(), accumulate=True)
         return None, dW[QD:QD + C].contiguous(), db[QD:QD + C].contiguous(), dwq, dbq, dwv, dbv
+
+
+class CLAMFn(torch.autograd.Function):
+    """CLAM_SB.bag_forward for a batch of equal-length bags, optionally with the instance-level loss
+    (models/clam.py:134-181,103-132).
+
+    x [B,N,d] in the compute dtype; parameters f32.  ``keeps`` = None (eval) or the three dropout keep-multiplier
+    tensors (values 0 or 1/0.75) for h, the tanh branch and the sigmoid branch (clam.py:71-72,47-48).
+    ``inst`` = None or (W [n_cls,2,512], b [n_cls,2], labels: list[int], k_sample, subtyping).
+    Returns (M [B,512], A [B,N], raw scores [B,N], inst_loss [B], ids [B,2k]); only M and inst_loss carry grad.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wa, ba, wb, bb, wc, bc, inst_w, inst_b, keeps, inst_cfg):
+        B, N, d = x.shape
+        T = x.dtype
+        f32 = T == torch.float32
+        c = (lambda w: w) if f32 else (lambda w: ops.cast(w, T))
+        x2 = x.reshape(B * N, d)
+        L, D = w1.shape[0], wa.shape[0]
+        h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                    # clam.py:69
+        k1 = ka = kb = None
+        if keeps is not None:
+            k1, ka, kb = keeps
+            ops.mul(h, k1)                                                             # Dropout(0.25) after ReLU
+        wab = torch.cat([wa, wb], 0)
+        U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=torch.cat([ba, bb], 0))      # both gate branches, one pass
+        s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb).view(B, N)
+        A = ops.softmax_rows(s)                                                        # clam.py:144
+        M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
+        dev = x.device
+        inst_loss = torch.zeros((B,), dtype=torch.float32, device=dev)
+        saved_inst = []
+        ids = None
+        if inst_cfg is not None:
+            labels, k, subtyping = inst_cfg
+            n_cls = inst_w.shape[0]
+            ids = ops.topk_ids(A, k)                                                   # [B, 2k]
+            base = (torch.arange(B, device=dev, dtype=torch.int64) * N).unsqueeze(1)
+            rows_all = base + ids.to(torch.int64)                                      # [B, 2k] rows of h
+            for i in range(n_cls):
+                inb = [b for b in range(B) if int(labels[b]) == i]
+                outb = [b for b in range(B) if int(labels[b]) != i] if subtyping else []
+                for bags, width, tgt in ((inb, 2 * k, [1] * k + [0] * k), (outb, k, [0] * k)):
+                    if not bags:
+                        continue
+                    bi = torch.tensor(bags, device=dev)
+                    rows = rows_all[bi][:, :width].reshape(-1)
+                    feats = ops.take_rows(h, rows)                                     # [len*width, L] f32
+                    logits = ops.gemm_nt(feats, inst_w[i].contiguous(), epi=ops.EPI_BIAS, bias=inst_b[i].contiguous())
+                    targets = torch.tensor(tgt * len(bags), device=dev, dtype=torch.int64)
+                    loss, dl, preds = ops.cross_entropy(logits, targets, width)
+                    scale = 1.0 / n_cls if subtyping else 1.0                          # clam.py:167-168
+                    inst_loss.index_add_(0, bi, loss * scale)
+                    saved_inst.append((i, bi, rows, feats, dl, scale, width, preds, targets))
+        ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1))
+        ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
+        if ids is None:
+            ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
+        ctx.mark_non_differentiable(A, s, ids)
+        ctx.inst_out = [(sv[0], sv[1], sv[7], sv[8]) for sv in saved_inst]
+        return M, A, s, inst_loss, ids
+
+    @staticmethod
+    def backward(ctx, dM, _dA, _ds, dinst, _dids):
+        x2, h, U, A, M, w1, wa, wb, wc, inst_w = ctx.saved_tensors
+        B, N, d, L, D = ctx.dims
+        T = x2.dtype
+        f32 = T == torch.float32
+        c = (lambda t: t) if f32 else (lambda t: ops.cast(t, T))
+        k1 = ka = kb = None
+        if ctx.keeps is not None:
+            k1, ka, kb = ctx.keeps
+        dM = dM.contiguous() if dM is not None else torch.zeros_like(M)
+        # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
+        dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
+        ds = ops.softmax_rows_bwd(A, dA).view(-1)
+        dU, dwc, dbc = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb)
+        dwab = ops.gemm_tn(dU, h)                                                     # [2D, L]
+        dbab = ops.colsum(dU)
+        wab = torch.cat([wa, wb], 0)
+        # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
+        dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1), rank1=dM,
+                          rows_per_bag=N)
+        # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
+        dinst_w = dinst_b = None
+        if ctx.saved_inst:
+            dinst_w, dinst_b = torch.zeros_like(inst_w), inst_w.new_zeros(inst_w.shape[0], 2)
+            for (i, bi, rows, feats, dl, scale, width, _p, _t) in ctx.saved_inst:
+                up = (dinst[bi] * scale).repeat_interleave(width).unsqueeze(1)        # upstream weight per row
+                dlog = (dl * up).contiguous()
+                dlog4 = dlog.new_zeros((dlog.shape[0], 4))            # wgrad kernel wants N1 % 4 == 0
+                dlog4[:, :2] = dlog
+                dinst_w[i] += ops.gemm_tn(dlog4, feats)[:2]
+                dinst_b[i] += ops.colsum(dlog)
+                dlog32 = dlog.new_zeros((dlog.shape[0], 32))         # NT kernel wants K % 32 == 0: zero-pad K = 2
+                dlog32[:, :2] = dlog
+                wt32 = inst_w.new_zeros((inst_w.shape[2], 32))
+                wt32[:, :2] = inst_w[i].t()
+                g = ops.gemm_nt(dlog32, wt32)                                                       # [R, L]
+                ops.scatter_add_rows_masked(dz1, h, rows, g)
+        dw1 = ops.gemm_tn(dz1, x2)
+        db1 = ops.colsum(dz1)
+        if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
+            dw1, db1 = dw1 / 0.75, db1 / 0.75
+        return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),
+                dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)

@@ -1,1 +1,1 @@
-from . import abmil, cl, dsmil, rlmil  # noqa: F401
+from . import abmil, cl, clam, dsmil, rlmil  # noqa: F401

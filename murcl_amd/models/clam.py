@@ -1,0 +1,135 @@
+"""Drop-in ``CLAM_SB`` (reference: models/clam.py).
+
+Constructor, ``forward(h, label=None, instance_eval=False, return_features=False, attention_only=False)``,
+return tuples ``(M, M.detach()[, results])`` and state-dict keys (``attention_net.0.*``,
+``attention_net.3.attention_{a,b}.0.*``, ``attention_net.3.attention_c.*``, ``classifiers.*``,
+``instance_classifiers.{i}.*``; index 3 when ``dropout=True``, 2 otherwise) follow the reference, as do
+Xavier-normal weights / zero biases (clam.py:7-15).  The math runs in murcl_amd.functional.CLAMFn for
+all bags of a batch at once.  Only the gated attention (gate=True) of the training scripts is built.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from ..functional import CLAMFn
+
+
+class Attn_Net_Gated(nn.Module):
+    def __init__(self, L=1024, D=256, dropout=False, n_classes=1):
+        super().__init__()
+        a, b = [nn.Linear(L, D), nn.Tanh()], [nn.Linear(L, D), nn.Sigmoid()]
+        if dropout:
+            a.append(nn.Dropout(0.25))
+            b.append(nn.Dropout(0.25))
+        self.attention_a, self.attention_b = nn.Sequential(*a), nn.Sequential(*b)
+        self.attention_c = nn.Linear(D, n_classes)
+
+
+def initialize_weights(module):
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_normal_(m.weight)
+            m.bias.data.zero_()
+
+
+class CLAM_SB(nn.Module):
+    def __init__(self, gate=True, size_arg="small", dropout=False, k_sample=8, n_classes=2,
+                 instance_loss_fn=None, subtyping=False, in_dim=512):
+        super().__init__()
+        if not gate:
+            raise NotImplementedError("murcl_amd builds the gated attention only (the scripts use gate=True)")
+        size = {"small": [in_dim, 512, 256], "big": [in_dim, 512, 384]}[size_arg]
+        fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
+        if dropout:
+            fc.append(nn.Dropout(0.25))
+        fc.append(Attn_Net_Gated(L=size[1], D=size[2], dropout=dropout, n_classes=1))
+        self.attention_net = nn.Sequential(*fc)
+        self.classifiers = nn.Linear(size[1], n_classes)
+        self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
+        self.k_sample, self.n_classes, self.subtyping, self.dropout = k_sample, n_classes, subtyping, dropout
+        self.instance_loss_fn = instance_loss_fn          # kept for API compat; CE is evaluated by the HIP kernel
+        self.compute_dtype = torch.float32
+        self.last_attention = None
+        initialize_weights(self)
+
+    def relocate(self):
+        return self.to(torch.device("cuda" if torch.cuda.is_available() else "cpu"))
+
+    # ---------------------------------------------------------------------------------------
+    def _run(self, x, labels=None, instance_eval=False, keeps=None):
+        from .. import ops
+        if x.dtype != self.compute_dtype:
+            x = ops.cast(x.float().contiguous(), self.compute_dtype)
+        net = self.attention_net
+        g = net[-1]
+        if self.training and self.dropout and keeps is None:
+            BN, T = x.shape[0] * x.shape[1], x.dtype
+            L, D = net[0].out_features, g.attention_c.in_features
+            draw = lambda w: ((torch.rand((BN, w), device=x.device) >= 0.25).to(T) / 0.75)   # noqa: E731
+            keeps = (draw(L), draw(D), draw(D))
+        inst_w = inst_b = cfg = None
+        if instance_eval:
+            inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)
+            inst_b = torch.stack([c.bias for c in self.instance_classifiers], 0)
+            lab = [int(l) for l in (labels.reshape(-1).tolist() if isinstance(labels, torch.Tensor) else labels)]
+            cfg = (lab, self.k_sample, self.subtyping)
+        M, A, s, inst_loss, ids = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias,
+                                               g.attention_a[0].weight, g.attention_a[0].bias,
+                                               g.attention_b[0].weight, g.attention_b[0].bias,
+                                               g.attention_c.weight, g.attention_c.bias, inst_w, inst_b, keeps, cfg)
+        self.last_attention = A
+        inst_out = getattr(M.grad_fn, "inst_out", None) if M.grad_fn is not None else None
+        return M, A, s, inst_loss, ids, inst_out
+
+    def _results(self, b, M, inst_loss, inst_out, instance_eval, return_features):
+        res = {}
+        if instance_eval:
+            preds, targets = [], []
+            for (_cls, bi, p, t) in (inst_out or []):
+                sel = (bi == b).nonzero().flatten()
+                if sel.numel():
+                    w = p.numel() // bi.numel()
+                    j = int(sel[0])
+                    preds.extend(p[j * w:(j + 1) * w].cpu().numpy())
+                    targets.extend(t[j * w:(j + 1) * w].cpu().numpy())
+            res = {"instance_loss": inst_loss[b], "inst_labels": np.array(targets), "inst_preds": np.array(preds)}
+        if return_features:
+            res["features"] = M[b:b + 1]
+        return res
+
+    def bag_forward(self, bag, label=None, instance_eval=False, return_features=False, attention_only=False):
+        if bag.dim() == 3 and bag.shape[0] == 1:
+            bag = bag.squeeze(0)
+        assert bag.dim() == 2, f"h.shape: {bag.shape}"
+        M, A, s, il, ids, io = self._run(bag.unsqueeze(0), [int(label)] if instance_eval else None, instance_eval)
+        if attention_only:
+            return s                                               # raw scores [1,N] (clam.py:141-142)
+        return M, self._results(0, M, il, io, instance_eval, return_features)
+
+    def batch_forward(self, batch, label=None, instance_eval=False, return_features=False, attention_only=False):
+        bags = [b.squeeze(0) if b.dim() == 3 else b for b in batch] if not isinstance(batch, torch.Tensor) else None
+        if bags is not None and len({b.shape[0] for b in bags}) != 1:      # ragged: one launch set per bag
+            outs = [self.bag_forward(b, None if label is None else label[i], instance_eval, return_features, attention_only)
+                    for i, b in enumerate(bags)]
+            if attention_only:
+                return torch.cat(outs, 0), [{}] * len(outs)
+            return torch.cat([o[0] for o in outs], 0), [o[1] for o in outs]
+        x = batch if bags is None else torch.stack(bags, 0)
+        labels = None if not instance_eval else [int(l) for l in label]
+        M, A, s, il, ids, io = self._run(x, labels, instance_eval)
+        if attention_only:
+            return s, [{}] * x.shape[0]
+        return M, [self._results(b, M, il, io, instance_eval, return_features) for b in range(x.shape[0])]
+
+    def forward(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
+        if isinstance(h, list) or (isinstance(h, torch.Tensor) and h.dim() == 3 and h.shape[0] > 1):
+            outputs, results = self.batch_forward(h, label, instance_eval, return_features, attention_only)
+        elif isinstance(h, torch.Tensor):
+            outputs, results = self.bag_forward(h.squeeze(0) if h.dim() == 3 else h, label, instance_eval,
+                                                return_features, attention_only) if not attention_only else \
+                (self.bag_forward(h.squeeze(0) if h.dim() == 3 else h, label, instance_eval, return_features, True), {})
+        else:
+            raise TypeError
+        if instance_eval:
+            return outputs, outputs.detach(), results
+        return outputs, outputs.detach()

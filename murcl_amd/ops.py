@@ -336,3 +336,82 @@ def dsmil_attn_bwd(A, dA, Y, qcol0, qmax, dY, B, N, C):
     check(_lib.lib().murcl_dsmil_attn_bwd(ptr(A), ptr(_c(dA)), ptr(Y), Y.stride(0), qcol0, ptr(qmax), B, N, C, ptr(dY),
                                           dY.stride(0), ptr(dqmax), stream()), "dsmil_attn_bwd")
     return dqmax
+
+
+# ------------------------------------------------------------------------------------------ CLAM-SB (K4/K5)
+def gated_score_fwd(U, wc, bc, keep_a=None, keep_b=None):
+    """U [M,2D] -> s [M] f32: sum_d tanh(U[:, :D]) * sigmoid(U[:, D:]) * wc + bc."""
+    U = _c(U)
+    M, D2 = U.shape
+    s = torch.empty((M,), dtype=torch.float32, device=U.device)
+    check(_lib.lib().murcl_gated_score_fwd(ptr(U), ptr(wc), ptr(bc), ptr(keep_a), ptr(keep_b), ptr(s), M, D2 // 2, dt(U),
+                                           stream()), "gated_score_fwd")
+    return s
+
+
+def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None):
+    U, ds = _c(U), _c(ds)
+    M, D2 = U.shape
+    dU = torch.empty_like(U)
+    dwc = torch.empty((D2 // 2,), dtype=torch.float32, device=U.device)
+    dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
+    check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(keep_a), ptr(keep_b), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
+                                           M, D2 // 2, dt(U), stream()), "gated_score_bwd")
+    return dU, dwc, dbc
+
+
+def softmax_rows(s):
+    s = _c(s)
+    A = torch.empty_like(s)
+    check(_lib.lib().murcl_softmax_rows(ptr(s), ptr(A), s.shape[0], s.shape[1], stream()), "softmax_rows")
+    return A
+
+
+def softmax_rows_bwd(A, dA):
+    A, dA = _c(A), _c(dA)
+    ds = torch.empty_like(A)
+    check(_lib.lib().murcl_softmax_rows_bwd(ptr(A), ptr(dA), ptr(ds), A.shape[0], A.shape[1], stream()), "softmax_rows_bwd")
+    return ds
+
+
+def topk_ids(A, k):
+    """A [B,N] -> ids [B,2k] int32: top-k (descending) then bottom-k (ascending); lowest index wins ties."""
+    A = _c(A)
+    ids = torch.empty((A.shape[0], 2 * k), dtype=torch.int32, device=A.device)
+    check(_lib.lib().murcl_topk_ids(ptr(A), A.shape[0], A.shape[1], k, ptr(ids), stream()), "topk_ids")
+    return ids
+
+
+def take_rows(src, rows):
+    """src [R0,d] (f32/bf16), rows int64 [R] -> f32 [R,d]."""
+    src, rows = _c(src), _c(rows)
+    out = torch.empty((rows.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    check(_lib.lib().murcl_take_rows(ptr(src), ptr(rows), ptr(out), rows.numel(), src.shape[1], dt(src), stream()), "take_rows")
+    return out
+
+
+def scatter_add_rows_masked(dst, h, rows, g):
+    check(_lib.lib().murcl_scatter_add_rows_masked(ptr(dst), ptr(h), ptr(_c(rows)), ptr(_c(g)), rows.numel(), dst.shape[1],
+                                                   dt(dst), stream()), "scatter_add_rows_masked")
+
+
+def cross_entropy(logits, targets, group):
+    """Mean CE per group of `group` consecutive rows -> (loss [R/group], dlogits [R,C] (already / group), preds [R])."""
+    logits, targets = _c(logits), _c(targets)
+    R, C = logits.shape
+    G = R // group
+    loss = torch.empty((G,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits)
+    preds = torch.empty((R,), dtype=torch.int64, device=logits.device)
+    for gi in range(G):       # one launch per bag group (tens of rows each)
+        sl = slice(gi * group, (gi + 1) * group)
+        check(_lib.lib().murcl_cross_entropy(ptr(logits[sl]), ptr(targets[sl]), group, C, ptr(loss[gi:gi + 1]), ptr(dl[sl]),
+                                             ptr(preds[sl]), stream()), "cross_entropy")
+    return loss, dl, preds
+
+
+def mul(x, k, out=None):
+    x, k = _c(x), _c(k)
+    out = x if out is None else out
+    check(_lib.lib().murcl_mul(ptr(x), ptr(k), ptr(out), x.numel(), dt(x), stream()), "mul")
+    return out

@@ -248,3 +248,82 @@ def test_dsmil_bf16_and_ragged_list():
     assert [tuple(c.shape) for c in cl] == [(100, 2), (257, 2)] and bag.shape == (2, 2, 512)
     with pytest.raises(TypeError):
         m32(3)
+
+
+# ------------------------------------------------------------------ CLAM-SB (K4/K5)
+def _clam(seed, subtyping, dtype=torch.float32):
+    from murcl_amd.models.clam import CLAM_SB
+    m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=subtyping, in_dim=512)
+    m.load_state_dict(P.to_torch(P.clam_sb(seed)))               # reference keys (dropout=True layout) load as is
+    m.compute_dtype = dtype
+    return m.to(_dev()).eval()
+
+
+@pytest.mark.parametrize("subtyping", [False, True])
+def test_clam_vs_reference_golden(golden, subtyping):
+    """G4: pooled M, attention, raw scores, top-k ids (bit-exact), instance loss / preds / targets."""
+    g = golden("g4_clam")
+    tag = f"sub{int(subtyping)}"
+    m = _clam(11, subtyping)
+    x = T(P.bags(11, "g4.x", 3, 300, 512)).to(_dev())
+    M, det = m(x)
+    np.testing.assert_allclose(M.detach().cpu().numpy(), g[f"{tag}.M_batch"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), g[f"{tag}.A"], rtol=2e-4, atol=1e-9)
+    raw = torch.cat([m.bag_forward(x[b], attention_only=True) for b in range(3)])
+    np.testing.assert_allclose(raw.cpu().numpy(), g[f"{tag}.raw"], rtol=1e-4, atol=2e-5)
+    for label in (0, 1):
+        M2, _, res = m(x, label=[label] * 3, instance_eval=True)
+        np.testing.assert_allclose(M2.detach().cpu().numpy(), g[f"{tag}.l{label}.M"], rtol=1e-4, atol=1e-5)
+        for b in range(3):
+            np.testing.assert_allclose(float(res[b]["instance_loss"]), g[f"{tag}.l{label}.inst_loss"][b], rtol=2e-4)
+            np.testing.assert_array_equal(res[b]["inst_preds"], g[f"{tag}.l{label}.preds"][b])
+            np.testing.assert_array_equal(res[b]["inst_labels"], g[f"{tag}.l{label}.targets"][b])
+    from murcl_amd import ops
+    ids = ops.topk_ids(m.last_attention, 8).cpu().numpy()
+    np.testing.assert_array_equal(ids[:, :8], g[f"{tag}.top_p"])
+    np.testing.assert_array_equal(ids[:, 8:], g[f"{tag}.top_n"])
+
+
+def test_clam_grads_golden(golden):
+    g = golden("g4_clam")
+    m = _clam(11, True)
+    x = T(P.bags(11, "g4.x", 3, 300, 512)).to(_dev())
+    M, _, res = m(x, label=[1, 1, 1], instance_eval=True)
+    (M.sum() + sum(r["instance_loss"] for r in res)).backward()
+    for k, v in m.named_parameters():
+        key = "grad." + k
+        if key in g.files and not k.endswith("attention_c.bias"):
+            _check_summ(_summ(v.grad), g[key], 2e-3, key)
+
+
+def test_clam_train_mode_dropout_masks_vs_oracle():
+    """Training-mode Dropout(0.25) with injected keep masks vs the oracle's drop_mask path."""
+    from murcl_amd.functional import CLAMFn
+    dev = _dev()
+    B, N = 2, 256
+    p = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.clam_sb(12)).items()}
+    x = T(P.bags(12, "x", B, N, 512))
+    masks = [T((detrand.uniform(12, f"m{i}", (B, N, w)) >= 0.25).astype(np.float32)) for i, w in enumerate((512, 256, 256))]
+    M_ref, A_ref, _, _ = O.clam_sb_forward(p, x, drop_mask=masks)
+    w = T(detrand.normal(12, "w", (B, 512)))
+    (M_ref * w).sum().backward()
+    m = _clam(12, False)
+    keeps = tuple((mk.reshape(B * N, -1) / 0.75).to(dev).contiguous() for mk in masks)
+    M, A, s, il, ids, _ = m._run(x.to(dev), None, False, keeps)
+    (M * w.to(dev)).sum().backward()
+    np.testing.assert_allclose(M.detach().cpu().numpy(), M_ref.detach().numpy(), rtol=2e-4, atol=1e-5)
+    for k, v in m.named_parameters():
+        if p[k].grad is not None and not k.endswith("attention_c.bias"):
+            ref = p[k].grad
+            np.testing.assert_allclose(v.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=3e-4 * ref.abs().max().item(), err_msg=k)
+
+
+def test_clam_bf16_path_and_cl_wrapper():
+    from murcl_amd.models.cl import CL
+    dev = _dev()
+    m32, m16 = _clam(13, False), _clam(13, False, torch.bfloat16)
+    xs = [T(P.bags(13, f"v{v}", 4, 1024, 512)).to(dev) for v in range(2)]
+    h32, _ = CL(m32, 128, 512)(xs)
+    h16, _ = CL(m16, 128, 512)(xs)
+    for a, b in zip(h16, h32):
+        assert a.shape == (4, 512) and (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
