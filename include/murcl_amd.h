@@ -139,6 +139,18 @@ int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, 
                         long* preds, murcl_stream_t stream);
 int murcl_mul(const void* x, const void* k, void* y, long n, int dtype, murcl_stream_t stream);
 
+/* K10/K11 -- PPO head math (models/rlmil.py:66-127,152-184); MLP, GRU and heads are the GEMM / GRU-gate entries.
+ * policy_head_fwd: mu = sigmoid(z); with eps: action = clamp(mu + std*eps, 0, 1) (act), else evaluates act_in;
+ * logp of the diagonal Gaussian whose scale_tril is diag(std).  ppo_returns: discounted + normalised returns.
+ * ppo_loss: clipped surrogate + 0.5 MSE - 0.01 entropy, mean over n, with d/dlogp and d/dvalue. */
+int murcl_policy_head_fwd(const float* z, const float* eps, const float* act_in, float std_, int R, int K, float* mu,
+                          float* act_out, float* logp, murcl_stream_t stream);
+int murcl_policy_head_bwd(const float* mu, const float* act, const float* dlogp, float std_, int R, int K, float* dz,
+                          murcl_stream_t stream);
+int murcl_ppo_returns(const float* rewards, float gamma, int T, int B, float* ret, murcl_stream_t stream);
+int murcl_ppo_loss(const float* logp, const float* old_logp, const float* value, const float* ret, float eps_clip,
+                   float entropy, int n, float* loss, float* dlogp, float* dvalue, murcl_stream_t stream);
+
 /* helpers */
 int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, murcl_stream_t stream);
 int murcl_transpose_cast(const float* x, void* y, int R, int C, int dtype_out, murcl_stream_t stream);

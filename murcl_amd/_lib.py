@@ -45,6 +45,10 @@ SIGNATURES = {
     "murcl_scatter_add_rows_masked": [_P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_cross_entropy": [_P, _P, _I, _I, _P, _P, _P, _P],
     "murcl_mul": [_P, _P, _P, _L, _I, _P],
+    "murcl_policy_head_fwd": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
+    "murcl_policy_head_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "murcl_ppo_returns": [_P, _F, _I, _I, _P, _P],
+    "murcl_ppo_loss": [_P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P],
     "murcl_cast": [_P, _P, _L, _I, _I, _P],
     "murcl_transpose_cast": [_P, _P, _I, _I, _I, _P],
     "murcl_colsum": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -330,3 +330,34 @@ class CLAMFn(torch.autograd.Function):
             dw1, db1 = dw1 / 0.75, db1 / 0.75
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),
                 dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
+
+
+class PolicyHeadFn(torch.autograd.Function):
+    """log-prob of given actions under N(sigmoid(z), diag(std)) (ActorCritic.evaluate, rlmil.py:115-121)."""
+
+    @staticmethod
+    def forward(ctx, z, actions, std):
+        mu, act, logp = ops.policy_head_fwd(z, std, actions=actions)
+        ctx.save_for_backward(mu, act)
+        ctx.std = std
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        mu, act = ctx.saved_tensors
+        return ops.policy_head_bwd(mu, act, dlogp, ctx.std), None, None
+
+
+class PPOLossFn(torch.autograd.Function):
+    """mean(-min(surr1, surr2) + 0.5*MSE - 0.01*entropy) (PPO.update, rlmil.py:172-181)."""
+
+    @staticmethod
+    def forward(ctx, logp, old_logp, value, ret, eps_clip, entropy):
+        loss, dlogp, dvalue = ops.ppo_loss(logp, old_logp, value, ret, eps_clip, entropy)
+        ctx.save_for_backward(dlogp, dvalue)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dlogp, dvalue = ctx.saved_tensors
+        return dlogp * g, None, dvalue * g, None, None, None

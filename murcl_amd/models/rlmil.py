@@ -1,4 +1,10 @@
-"""Drop-in recurrent head ``Full_layer`` (reference: models/rlmil.py:187-239).
+"""Drop-in ``Memory``, ``ActorCritic``, ``PPO`` and recurrent head ``Full_layer`` (reference: models/rlmil.py).
+
+``ActorCritic`` (state MLP 512->2048->H, GRU(H,H), sigmoid actor, critic; keys ``state_encoder.{0,2}``, ``gru.*_l0``,
+``actor.0``, ``critic.0``) and ``PPO`` (``select_action`` / ``update`` with Adam, clipped surrogate, K_epochs) keep the
+reference API; ``policy_conv=True`` is never enabled by the scripts and is not built.
+
+``Full_layer`` (models/rlmil.py:187-239):
 
 ``fc_rnn=True`` (the only mode the training scripts use): one GRU time step per call with the
 hidden state carried in ``self.hidden`` across calls - including the reference's behaviour
@@ -8,7 +14,9 @@ State-dict keys: ``rnn.{weight,bias}_{ih,hh}_l0``, ``fc.{weight,bias}``.
 import torch
 from torch import nn
 
-from ..functional import GRUStepFn, LinearFn
+import math
+
+from ..functional import GRUStepFn, LinearFn, PolicyHeadFn, PPOLossFn
 
 
 class Memory:
@@ -54,3 +62,96 @@ class Full_layer(nn.Module):
             raise RuntimeError(f"Full_layer cascade: unexpected width {tuple(self.hidden.size())}")
         head = getattr(self, f"fc_{k}")
         return LinearFn.apply(self.hidden, head.weight, head.bias, False)
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, feature_dim, state_dim, hidden_state_dim=1024, policy_conv=False, action_std=0.1, action_size=2):
+        super().__init__()
+        if policy_conv:
+            raise NotImplementedError("policy_conv=True is never enabled by the training scripts (train_MuRCL.py:445)")
+        self.state_encoder = nn.Sequential(nn.Linear(state_dim, 2048), nn.ReLU(), nn.Linear(2048, hidden_state_dim), nn.ReLU())
+        self.gru = nn.GRU(hidden_state_dim, hidden_state_dim, batch_first=False)        # parameter holder
+        self.actor = nn.Sequential(nn.Linear(hidden_state_dim, action_size), nn.Sigmoid())
+        self.critic = nn.Sequential(nn.Linear(hidden_state_dim, 1))
+        self.action_std = float(action_std)       # used as the Cholesky factor: a std, not a variance (rlmil.py:84-85)
+        self.action_size = action_size
+        self.hidden_state_dim, self.policy_conv, self.feature_dim = hidden_state_dim, policy_conv, feature_dim
+        self.feature_ratio = int(math.sqrt(state_dim / feature_dim))
+
+    def forward(self):
+        raise NotImplementedError
+
+    def _trunk(self, state, hidden):
+        e = LinearFn.apply(state, self.state_encoder[0].weight, self.state_encoder[0].bias, True)
+        e = LinearFn.apply(e, self.state_encoder[2].weight, self.state_encoder[2].bias, True)
+        g = self.gru
+        return GRUStepFn.apply(e, hidden, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
+
+    def act(self, state_ini, memory, restart_batch=False, training=False, eps=None):
+        """One policy step (rlmil.py:66-97).  ``eps`` ~ N(0,1) [B,K] may be injected (parity tests)."""
+        from .. import ops
+        with torch.no_grad():
+            if restart_batch:
+                del memory.hidden[:]
+                memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
+            h = self._trunk(state_ini.flatten(1).float().contiguous(), memory.hidden[-1][0])
+            memory.hidden.append(h.unsqueeze(0))
+            z = ops.gemm_nt(h, self.actor[0].weight, epi=ops.EPI_BIAS, bias=self.actor[0].bias)
+            if eps is None:
+                eps = torch.randn((z.shape[0], self.action_size), device=z.device)
+            mu, action, logp = ops.policy_head_fwd(z, self.action_std, eps=eps)
+            if training:
+                memory.states.append(state_ini)
+                memory.actions.append(action)
+                memory.logprobs.append(logp)
+            else:
+                action = mu
+        return action.detach()
+
+    def evaluate(self, state, action):
+        """states [T,B,S], actions [T,B,K] -> (logp, value, entropy) each [T,B] (rlmil.py:99-127)."""
+        T_, B = state.shape[0], state.shape[1]
+        h, hs = None, []
+        for t in range(T_):                                     # GRU over the rollout from a zero hidden state
+            h = self._trunk(state[t].flatten(1).float().contiguous(), h)
+            hs.append(h)
+        hs = torch.cat(hs, 0)                                   # [T*B, H]
+        z = LinearFn.apply(hs, self.actor[0].weight, self.actor[0].bias, False)
+        logp = PolicyHeadFn.apply(z, action.reshape(T_ * B, -1).float().contiguous(), self.action_std)
+        value = LinearFn.apply(hs, self.critic[0].weight, self.critic[0].bias, False)
+        k = self.action_size
+        ent = 0.5 * k * (1.0 + math.log(2 * math.pi)) + k * math.log(self.action_std)
+        return logp.view(T_, B), value.view(T_, B), torch.full((T_, B), ent, device=state.device)
+
+
+class PPO:
+    def __init__(self, feature_dim, state_dim, hidden_state_dim, policy_conv, action_std=0.1, lr=0.0003,
+                 betas=(0.9, 0.999), gamma=0.7, K_epochs=1, eps_clip=0.2, action_size=2):
+        from ..optim import FlatAdam
+        self.lr, self.betas, self.gamma, self.eps_clip, self.K_epochs = lr, betas, gamma, eps_clip, K_epochs
+        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        self.policy = ActorCritic(feature_dim, state_dim, hidden_state_dim, policy_conv, action_std, action_size).to(dev)
+        self.policy_old = ActorCritic(feature_dim, state_dim, hidden_state_dim, policy_conv, action_std, action_size).to(dev)
+        self.policy_old.load_state_dict(self.policy.state_dict())
+        self.optimizer = FlatAdam([{"params": list(self.policy.parameters()), "lr": lr}], betas=betas) if dev.type == "cuda" else None
+
+    def select_action(self, state, memory, restart_batch=False, training=True, eps=None):
+        return self.policy_old.act(state, memory, restart_batch, training, eps)
+
+    def update(self, memory):
+        from .. import ops
+        rewards = torch.cat([r.reshape(1, -1) for r in memory.rewards], 0)             # [T,B] (rlmil.py:156-160)
+        returns = ops.ppo_returns(rewards, self.gamma)
+        old_states = torch.stack(memory.states, 0).detach()
+        old_actions = torch.stack(memory.actions, 0).detach()
+        old_logprobs = torch.stack(memory.logprobs, 0).detach()
+        for _ in range(self.K_epochs):
+            logp, value, ent = self.policy.evaluate(old_states, old_actions)
+            loss = PPOLossFn.apply(logp.reshape(-1), old_logprobs.reshape(-1), value.reshape(-1), returns.reshape(-1),
+                                   self.eps_clip, float(ent.flatten()[0]) if False else
+                                   0.5 * self.policy.action_size * (1.0 + math.log(2 * math.pi))
+                                   + self.policy.action_size * math.log(self.policy.action_std))
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+        self.policy_old.load_state_dict(self.policy.state_dict())

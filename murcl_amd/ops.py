@@ -88,6 +88,12 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     M, K = A.shape
     N = B.shape[0]
     assert B.shape[1] == K and A.dtype == B.dtype
+    kq = 32 if A.dtype == torch.float32 else 64
+    if K % kq:                      # head layers with a handful of outputs (dgrad K = 1, 2, 10): zero-pad K
+        Kp = ((K + kq - 1) // kq) * kq
+        Ap, Bp = A.new_zeros((M, Kp)), B.new_zeros((N, Kp))
+        Ap[:, :K], Bp[:, :K] = A, B
+        A, B, K = Ap, Bp, Kp
     odt = out_dtype or A.dtype
     C = out if out is not None else torch.empty((M, N), dtype=odt, device=A.device)
     ws = torch.empty(((M + 127) // 128, N), dtype=torch.float32, device=A.device) if colsum else None
@@ -137,6 +143,11 @@ def gemm_tn(A, B, *, splits=0, out=None):
     M, N1 = A.shape
     N2 = B.shape[1]
     assert B.shape[0] == M and A.dtype == B.dtype
+    epc = 4 if A.dtype == torch.float32 else 8
+    if N1 % epc and out is None:    # tiny head gradients (N1 = 1, 2, 10): zero-pad the columns of A, slice the result
+        Ap = A.new_zeros((M, ((N1 + epc - 1) // epc) * epc))
+        Ap[:, :N1] = A
+        return gemm_tn(Ap, B, splits=splits)[:N1].contiguous()
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     with _span(f"gemm_tn<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4)):
@@ -415,3 +426,42 @@ def mul(x, k, out=None):
     out = x if out is None else out
     check(_lib.lib().murcl_mul(ptr(x), ptr(k), ptr(out), x.numel(), dt(x), stream()), "mul")
     return out
+
+
+# ------------------------------------------------------------------------------------------ PPO (K10/K11)
+def policy_head_fwd(z, std, eps=None, actions=None):
+    """z [R,K] -> (mu [R,K], action [R,K], logp [R]); sample with eps or evaluate given actions."""
+    z = _c(z)
+    R, K = z.shape
+    mu = torch.empty_like(z)
+    logp = torch.empty((R,), dtype=torch.float32, device=z.device)
+    act = torch.empty_like(z) if eps is not None else _c(actions)
+    check(_lib.lib().murcl_policy_head_fwd(ptr(z), ptr(_c(eps)) if eps is not None else None,
+                                           None if eps is not None else ptr(act), float(std), R, K, ptr(mu),
+                                           ptr(act) if eps is not None else None, ptr(logp), stream()), "policy_head_fwd")
+    return mu, act, logp
+
+
+def policy_head_bwd(mu, act, dlogp, std):
+    dz = torch.empty_like(mu)
+    check(_lib.lib().murcl_policy_head_bwd(ptr(mu), ptr(_c(act)), ptr(_c(dlogp)), float(std), mu.shape[0], mu.shape[1],
+                                           ptr(dz), stream()), "policy_head_bwd")
+    return dz
+
+
+def ppo_returns(rewards, gamma):
+    """rewards [T,B] f32 -> normalised discounted returns [T,B]."""
+    rewards = _c(rewards.float())
+    ret = torch.empty_like(rewards)
+    check(_lib.lib().murcl_ppo_returns(ptr(rewards), float(gamma), rewards.shape[0], rewards.shape[1], ptr(ret), stream()),
+          "ppo_returns")
+    return ret
+
+
+def ppo_loss(logp, old_logp, value, ret, eps_clip, entropy):
+    n = logp.numel()
+    loss = torch.empty((1,), dtype=torch.float32, device=logp.device)
+    dlogp, dvalue = torch.empty_like(logp), torch.empty_like(value)
+    check(_lib.lib().murcl_ppo_loss(ptr(_c(logp)), ptr(_c(old_logp)), ptr(_c(value)), ptr(_c(ret)), float(eps_clip),
+                                    float(entropy), n, ptr(loss), ptr(dlogp), ptr(dvalue), stream()), "ppo_loss")
+    return loss, dlogp, dvalue

@@ -327,3 +327,57 @@ def test_clam_bf16_path_and_cl_wrapper():
     h16, _ = CL(m16, 128, 512)(xs)
     for a, b in zip(h16, h32):
         assert a.shape == (4, 512) and (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
+
+
+# ------------------------------------------------------------------ PPO (K10/K11)
+def test_ppo_act_evaluate_update_vs_reference_golden(golden):
+    """G8: act (injected eps) -> actions/logp/hidden; evaluate; one update (K_epochs=1, Adam lr 1e-3) -> parameters."""
+    from murcl_amd.models.rlmil import PPO, Memory
+    g = golden("g8_ppo")
+    dev = _dev()
+    seed, B, S_, H, K, Tm, std = 21, 6, 512, 512, 10, 3, 0.5
+    ppo = PPO(512, S_, H, False, action_std=std, lr=1e-3, gamma=0.1, K_epochs=1, action_size=K)
+    sd = P.to_torch(P.actor_critic(seed, S_, H, K))
+    ppo.policy.load_state_dict(sd)
+    ppo.policy_old.load_state_dict(sd)
+    mem = Memory()
+    for t in range(Tm):
+        st = T(detrand.normal(seed, f"g8.s{t}", (B, S_))).to(dev)
+        eps = T(detrand.normal(seed, f"g8.e{t}", (B, K))).to(dev)
+        a = ppo.select_action(st, mem, restart_batch=(t == 0), eps=eps)
+        np.testing.assert_allclose(a.cpu().numpy(), g[f"act.{t}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(mem.logprobs[-1].cpu().numpy(), g[f"logp.{t}"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(mem.hidden[-1][0].cpu().numpy(), g[f"hidden.{t}"], rtol=1e-3, atol=1e-5)
+        mem.rewards.append((T(detrand.normal(seed, f"g8.r{t}", (1, B))) * 0.1).to(dev))
+    with torch.no_grad():
+        lp, v, ent = ppo.policy.evaluate(torch.stack(mem.states, 0), torch.stack(mem.actions, 0))
+    np.testing.assert_allclose(lp.cpu().numpy(), g["eval.logp"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(v.cpu().numpy(), g["eval.value"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), g["eval.entropy"], rtol=1e-6)
+    ppo.update(mem)
+    for k, v in ppo.policy.state_dict().items():
+        np.testing.assert_allclose(_summ(v), g["post." + k], rtol=5e-4, atol=5e-6, err_msg=k)
+    for a, b in zip(ppo.policy.parameters(), ppo.policy_old.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_ppo_returns_and_loss_vs_oracle():
+    from murcl_amd import ops
+    dev = _dev()
+    Tn, B = 5, 64
+    rw = [T(detrand.normal(22, f"r{t}", (1, B)) * 0.1) for t in range(Tn)]
+    R_ref = O.ppo_returns(rw, 0.1)
+    R = ops.ppo_returns(torch.cat(rw, 0).to(dev), 0.1)
+    np.testing.assert_allclose(R.cpu().numpy(), R_ref.numpy(), rtol=1e-4, atol=1e-5)
+    lp = T(detrand.normal(22, "lp", (Tn * B,)) * 0.3).requires_grad_()
+    olp = T(detrand.normal(22, "olp", (Tn * B,)) * 0.3)
+    val = T(detrand.normal(22, "v", (Tn * B,))).requires_grad_()
+    ret = R_ref.reshape(-1)
+    ratio = torch.exp(lp - olp)
+    adv = ret - val.detach()
+    ref = (-torch.min(ratio * adv, ratio.clamp(0.8, 1.2) * adv) + 0.5 * torch.nn.functional.mse_loss(val, ret) - 0.01 * 3.0).mean()
+    ref.backward()
+    loss, dlp, dv = ops.ppo_loss(lp.detach().to(dev), olp.to(dev), val.detach().to(dev), ret.to(dev), 0.2, 3.0)
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    np.testing.assert_allclose(dlp.cpu().numpy(), lp.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(dv.cpu().numpy(), val.grad.numpy(), rtol=1e-4, atol=1e-8)
