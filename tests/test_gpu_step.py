@@ -1,0 +1,93 @@
+"""The full MuRCL hot step (train_MuRCL.py:233-304) on MI355X vs the oracle composition
+get_feats -> mixup -> CL(ABMIL) -> Full_layer -> NT-Xent over T patch-steps, with every random draw injected."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, mil_oracle as O, params as P, select_oracle as S  # noqa: E402
+
+T = torch.from_numpy
+
+
+def _args(**kw):
+    from murcl_amd.train_MuRCL import build_parser
+    a = build_parser().parse_args([])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_stage1_step_matches_oracle_and_updates_parameters():
+    from murcl_amd.train_MuRCL import create_model, get_optimizer, pretrain_step
+    from murcl_amd.utils.datasets import BagPack
+    from murcl_amd.utils.losses import NT_Xent
+    from murcl_amd.models import rlmil
+    dev = torch.device("cuda:0")
+    B, N, K, fs, Tn = 4, 700, 10, 256, 3
+    args = _args(T=Tn, feat_size=fs, batch_size=B, dtype="f32", train_stage=1, num_clusters=K, backbone_lr=1e-3, fc_lr=1e-3)
+    model, fc, ppo = create_model(args, 512, dev)
+    model.encoder.load_state_dict(P.to_torch(P.abmil(985)))
+    fc.load_state_dict(P.to_torch(P.full_layer(985)))
+    opt = get_optimizer(args, model, fc)
+    feats_np = [P.bags(51, f"f{b}", 1, N + 13 * b, 512)[0] for b in range(B)]
+    cls = [P.cluster_lists(51, f"c{b}", N + 13 * b, K) for b in range(B)]
+    pack = BagPack.from_lists([T(f).to(dev) for f in feats_np], cls)
+    inj = {"actions": [[T(detrand.uniform(51, f"a{t}{v}", (B, K))) for v in range(2)] for t in range(Tn)],
+           "draws": [[(T(detrand.uniform(51, f"l{t}{v}", (B, 1), 0.9, 1.0)).to(dev), T(detrand.permutation(51, f"p{t}{v}", B)).to(dev))
+                      for v in range(2)] for t in range(Tn)]}
+    w_before = model.encoder.encoder[0].weight.detach().clone()
+    loss, losses, rewards = pretrain_step(args, model, fc, ppo, NT_Xent(B, 1.0), opt, pack, [rlmil.Memory(), rlmil.Memory()], injected=inj)
+    # oracle
+    views = []
+    for t in range(Tn):
+        vt = []
+        for v in range(2):
+            sub, _ = S.get_feats(feats_np, cls, inj["actions"][t][v].numpy(), fs)
+            lam, perm = inj["draws"][t][v]
+            vt.append(T(S.mixup(sub, lam.cpu().numpy(), perm.cpu().numpy())))
+        views.append(vt)
+    mp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(985)).items()}
+    fp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.full_layer(985)).items()}
+    ref, ref_losses, ref_rewards, _ = O.pretrain_step(mp, fp, views, 1.0)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    np.testing.assert_allclose([l.item() for l in losses], [l.item() for l in ref_losses], rtol=1e-4)
+    np.testing.assert_allclose(torch.cat(rewards).cpu().numpy(), torch.stack(ref_rewards).numpy(), rtol=5e-3, atol=5e-6)
+    # one Adam step happened and matches the oracle's Adam on the oracle's gradient
+    ref.backward()
+    want = O.adam_step({"w": mp["encoder.0.weight"].detach()}, {"w": mp["encoder.0.weight"].grad}, {}, 1e-3, weight_decay=1e-5)["w"]
+    got = model.encoder.encoder[0].weight.detach().cpu()
+    assert not torch.equal(got, w_before.cpu())
+    assert ((got - want).norm() / (want - w_before.cpu()).norm()).item() < 5e-2
+
+
+def test_stage3_step_runs_with_ppo_sampler(tmp_path):
+    """Stage 2/3 wiring: PPO.select_action feeds the sub-bag sampler, rewards reach both memories, PPO.update runs."""
+    from murcl_amd.train_MuRCL import create_model, get_optimizer, pretrain_step
+    from murcl_amd.utils.datasets import BagPack
+    from murcl_amd.utils.losses import NT_Xent
+    from murcl_amd.models import rlmil
+    dev = torch.device("cuda:0")
+    B, N, K, fs = 4, 600, 10, 128
+    a1 = _args(T=3, feat_size=fs, batch_size=B, dtype="f32", train_stage=1, num_clusters=K, save_dir=str(tmp_path / "stage_1"))
+    model, fc, _ = create_model(a1, 512, dev)
+    (tmp_path / "stage_1").mkdir()
+    torch.save({"model_state_dict": model.state_dict(), "fc": fc.state_dict()}, tmp_path / "stage_1" / "model_best.pth.tar")
+    feats = [T(P.bags(52, f"f{b}", 1, N, 512)[0]).to(dev) for b in range(B)]
+    pack = BagPack.from_lists(feats, [P.cluster_lists(52, f"c{b}", N, K) for b in range(B)])
+    for stage in (2, 3):
+        a = _args(T=3, feat_size=fs, batch_size=B, dtype="f32", train_stage=stage, num_clusters=K, K_epochs=2,
+                  save_dir=str(tmp_path / f"stage_{stage}"), ppo_lr=1e-3)
+        if stage == 3:
+            (tmp_path / "stage_2").mkdir()
+            torch.save({"model_state_dict": model.state_dict(), "fc": fc.state_dict(), "policy": ppo.policy.state_dict()},
+                       tmp_path / "stage_2" / "model_best.pth.tar")
+        m, f, ppo = create_model(a, 512, dev)
+        opt = get_optimizer(a, m, f)
+        pol_before = ppo.policy.actor[0].weight.detach().clone()
+        loss, losses, rewards = pretrain_step(a, m, f, ppo, NT_Xent(B, 1.0), opt, pack, [rlmil.Memory(), rlmil.Memory()])
+        assert torch.isfinite(loss) and len(losses) == 3 and len(rewards) == 2 and rewards[0].shape == (1, B)
+        if stage == 2:
+            assert opt is None and not torch.equal(ppo.policy.actor[0].weight, pol_before)      # PPO.update moved the policy
+            assert all(torch.equal(x, y) for x, y in zip(ppo.policy.parameters(), ppo.policy_old.parameters()))
