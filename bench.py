@@ -127,8 +127,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("MURCL_FORCE_DIST") == "1"          # dev: run the RCCL code path with one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from murcl_amd import ops
@@ -136,10 +140,10 @@ def main():
     B, N, D = args.bags, args.patches, 512
     model, fc, opt, crit = build(dtype, device, B)
     views = synth_views(B, N, D, dtype, device, rank)
-    step = make_step(model, fc, opt, crit, views, world)
+    step = make_step(model, fc, opt, crit, views, 2 if force_dist else world)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,8 +176,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     ms_step = elapsed / args.steps * 1e3
@@ -211,7 +214,7 @@ def main():
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):
             print(f"{k:44s} calls/step {v['calls'] // 2:3d}  ms/step {v['ms_total'] / 2:8.4f}", file=sys.stderr)
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

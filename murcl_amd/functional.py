@@ -361,3 +361,18 @@ class PPOLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dlogp, dvalue = ctx.saved_tensors
         return dlogp * g, None, dvalue * g, None, None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) over [R,C] logits (train_RLMIL.py:316,502,709)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        loss, dl, preds = ops.cross_entropy(logits.float().contiguous(), targets.to(torch.int64).contiguous(), logits.shape[0])
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None

@@ -91,3 +91,49 @@ def test_stage3_step_runs_with_ppo_sampler(tmp_path):
         if stage == 2:
             assert opt is None and not torch.equal(ppo.policy.actor[0].weight, pol_before)      # PPO.update moved the policy
             assert all(torch.equal(x, y) for x, y in zip(ppo.policy.parameters(), ppo.policy_old.parameters()))
+
+
+@pytest.mark.parametrize("arch", ["ABMIL", "CLAM_SB", "DSMIL"])
+def test_supervised_rlmil_step_first_loss_matches_oracle_and_trains(arch):
+    """a21: the supervised step body for each aggregator; t=0 loss vs the oracle, then a few steps reduce the loss."""
+    from murcl_amd.train_RLMIL import create_model, supervised_step
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.models import rlmil
+    from murcl_amd.utils.datasets import BagPack
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    B, N, K, fs, C = 4, 500, 10, 128, 2
+    model, fc = create_model(arch, 512, C, dev)
+    model.eval() if arch == "CLAM_SB" else None                    # dropout off so the oracle comparison is exact
+    pk = P.abmil(61, dim_out=C) if arch == "ABMIL" else {"CLAM_SB": P.clam_sb, "DSMIL": P.dsmil}[arch](61)
+    model.load_state_dict(P.to_torch(pk))
+    fcp = P.full_layer(61, 512, 1024, C)
+    fc.load_state_dict(P.to_torch(fcp))
+    feats_np = [P.bags(61, f"f{b}", 1, N, 512)[0] for b in range(B)]
+    cls = [P.cluster_lists(61, f"c{b}", N, K) for b in range(B)]
+    pack = BagPack.from_lists([T(f).to(dev) for f in feats_np], cls)
+    labels = torch.tensor([0, 1, 1, 0], device=dev)
+    acts = [T(detrand.uniform(61, f"a{t}", (B, K))) for t in range(2)]
+    opt = FlatAdam([{"params": list(model.parameters()) + list(fc.parameters()), "lr": 1e-3}])
+    loss0, losses, rewards = supervised_step(arch, model, fc, None, opt, pack, labels, rlmil.Memory(), T=2, feat_size=fs, actions=acts)
+    # oracle for the t = 0 term
+    sub, _ = S.get_feats(feats_np, cls, acts[0].numpy(), fs)
+    p, fp, x, y = P.to_torch(pk), P.to_torch(fcp), T(sub), labels.cpu()
+    if arch == "ABMIL":
+        out = O.abmil_forward(p, x)[0]
+        ref = F.cross_entropy(O.full_layer_step(fp, out, None)[0], y)
+    elif arch == "CLAM_SB":
+        M, A, s, h = O.clam_sb_forward(p, x)
+        inst = torch.stack([O.clam_instance_eval(p, A[b], h[b], int(y[b]), C, 8, True)[0] for b in range(B)]).mean()
+        ref = 0.7 * F.cross_entropy(O.full_layer_step(fp, M, None)[0], y) + 0.3 * inst
+    else:
+        c, bag, _, _ = O.dsmil_forward(p, x)
+        ref = 0.5 * F.cross_entropy(O.full_layer_step(fp, bag.mean(1), None)[0], y) + 0.5 * F.cross_entropy(c.max(1)[0], y)
+    np.testing.assert_allclose(losses[0].item(), ref.item(), rtol=2e-4)
+    assert rewards[0].shape == (1, B)
+    w0 = fc.fc.weight.detach().clone()
+    for _ in range(4):
+        l, _, _ = supervised_step(arch, model, fc, None, opt, pack, labels, rlmil.Memory(), T=2, feat_size=fs, actions=acts)
+    assert torch.isfinite(l) and not torch.equal(fc.fc.weight, w0)
+    if arch != "ABMIL":          # (the ABMIL test weights carry a x60 decoder gain: Adam at 1e-3 overshoots there)
+        assert l.item() < loss0.item()
