@@ -145,7 +145,10 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
     for (int j = 0; j < C_::NJ; ++j) {
         const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
+        for (int kk = 0; kk < C_::NKK; ++kk) {
+            wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
+            asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ba_r[j][r] = ba[C_::DW * wave + 16 * j + 4 * q4 + r];

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256, 1) void abmil_pool_bwd_kernel(
     for (int j = 0; j < 2; ++j) {
         const T* wrow = Wa + (size_t)(32 * wave + 16 * j + r16) * K2_L;
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)((const char*)wrow + (4 * kk + q4) * 16);
+        for (int kk = 0; kk < C_::NKK; ++kk) {
+            wa[j][kk] = *(const frag_t*)((const char*)wrow + (4 * kk + q4) * 16);
+            asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ba_r[j][r] = ba[32 * wave + 16 * j + 4 * q4 + r];

@@ -108,7 +108,12 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
     for (int j = 0; j < NJ; ++j) {
         const bf16_t* wrow = W + (size_t)(n0 + 16 * j + r16) * K;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) wf[j][kk] = *(const bf16x8*)(wrow + 32 * kk + 8 * q4);
+        for (int kk = 0; kk < NKK; ++kk) {
+            wf[j][kk] = *(const bf16x8*)(wrow + 32 * kk + 8 * q4);
+            // opaque to the optimiser: otherwise hipcc rematerialises the fragments by re-loading them from global
+            // memory inside the tile loop (34 loads + vmcnt waits per tile that also drain the LDS-DMA ring)
+            asm volatile("" : "+v"(wf[j][kk]));
+        }
     }
     // bias for accumulator-layout columns n0 + 16j + 4q4 + r
     float bias_r[(EPI == PG_BIAS_RELU) ? NJ : 1][4];
