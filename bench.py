@@ -55,18 +55,21 @@ def synth_views(bags, n, d, dtype, device, rank):
 
 def make_step(model, fc, opt, crit, views, world):
     from murcl_amd import dist as mdist
+    reducer = mdist.OverlappedGradReduce(opt, early_groups=(1,)) if world > 1 else None
 
     def step():
         opt.zero_grad()
         outs, _ = model(views)
+        if reducer is not None:
+            reducer.arm(outs)              # head-gradient all-reduce starts when backward reaches the aggregator
         z = [fc(o, restart=True) for o in outs]
         if world > 1:
             loss, _ = mdist.gathered_nt_xent(z[0], z[1], 1.0)
         else:
             loss = crit(z[0], z[1])
         loss.backward()
-        if world > 1:
-            mdist.all_reduce_grads(opt.flat_grads())
+        if reducer is not None:
+            reducer.finish()
         opt.step()
         return loss
     return step

@@ -16,92 +16,7 @@
 // plain row-major (wave-uniform SGPR base + lane*16).
 #include "common.h"
 
-#define K2_L 512
-#define K2_D 128
-#define K2_TR 16                  // rows per tile (one MFMA row tile)
-#define K2_NSLOT 4                // ring slots per workgroup; three tiles in flight while one is consumed
-
-// NW waves per workgroup, each owning a DW = 128/NW column slice of Wa in registers:
-//   bf16: NW = 4 (DW = 32, 128 VGPRs of weights), TWO workgroups per CU - they desynchronise naturally, so
-//         one workgroup's barrier / LDS latencies are covered by the other's MFMA and VALU work;
-//   f32 : NW = 8 (DW = 16, 128 VGPRs of weights), one workgroup per CU (parity path).
-template <typename T> struct K2 {
-    static constexpr int NW = (sizeof(T) == 2) ? 4 : 8;
-    static constexpr int DW = K2_D / NW;                     // D columns per wave: 32 / 16
-    static constexpr int NJ = DW / 16;                       // MFMA column tiles per wave: 2 / 1
-    static constexpr int ROWB = K2_L * (int)sizeof(T);       // bytes per row in HBM: 1024 / 2048
-    static constexpr int PADB = ROWB + 16;                   // LDS row stride: +16 B rotates rows over the 16 bank slots
-    static constexpr int TR = K2_TR;
-    static constexpr int SLOT = TR * PADB;                   // 16.25 KiB / 32.25 KiB
-    static constexpr int GT = TR * ROWB / (NW * 1024);       // LDS-DMA instructions per wave per tile: 4 / 4
-    static constexpr int NKK = ROWB / 64;                    // MFMA k-steps: 16 / 32
-    static constexpr int PC = K2_L / NW;                     // pooled columns per wave: 128 / 64
-    static constexpr int NPJ = PC / 16;                      // pooling MFMA column tiles per wave: 8 / 4
-    static constexpr int WG_PER_CU = (sizeof(T) == 2) ? 2 : 1;
-};
-
-// LDS carve (bytes): ring | spart [NW waves][16 rows] f32 | pbuf [NW waves][16] u32 | sbuf [<= chunk rows] f32
-#define K2_MAX_CHUNK 1024
-template <typename T> struct K2Lds {
-    static constexpr int OFF_SPART = K2_NSLOT * K2<T>::SLOT;
-    static constexpr int OFF_PBUF = OFF_SPART + K2<T>::NW * 16 * 4;
-    static constexpr int OFF_SBUF = OFF_PBUF + K2<T>::NW * 16 * 4;
-    static constexpr int BYTES = OFF_SBUF + K2_MAX_CHUNK * 4;
-};
-
-template <typename T> struct WFrag;
-template <> struct WFrag<bf16_t> { typedef bf16x8 type; };
-template <> struct WFrag<float> { typedef f32x4 type; };
-
-template <typename T>
-__device__ __forceinline__ f32x4 k2_mma(typename WFrag<T>::type a, typename WFrag<T>::type b, f32x4 c);
-template <> __device__ __forceinline__ f32x4 k2_mma<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4 k2_mma<float>(f32x4 a, f32x4 b, f32x4 c) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
-    return c;
-}
-
-// Tile issue shared by forward and backward: LDS-DMA instruction ii = j*NW + wave copies 1 KiB =
-// one row (bf16) / half a row (f32); global base is wave-uniform (SGPRs), per-lane offset = lane*16.
-template <typename T>
-__device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N, unsigned slot_lds, int wave, int lane) {
-    typedef K2<T> C_;
-    const unsigned voff = lane * 16;
-    if (row0 + C_::TR <= N) {
-        // whole tile inside the bag (all but the last tile of a ragged bag): one scalar base, constant strides
-        const char* base = (const char*)bag_base + (size_t)row0 * C_::ROWB;
-#pragma unroll
-        for (int j = 0; j < C_::GT; ++j) {
-            const int ii = j * C_::NW + wave;
-            const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
-            const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
-            glds16_u(base + (size_t)(row * C_::ROWB + half * 1024), voff, slot_lds + row * C_::PADB + half * 1024);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < C_::GT; ++j) {
-            const int ii = j * C_::NW + wave;
-            const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
-            const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
-            const int grow = min(row0 + row, N - 1);              // rows past N: clamped, masked by the caller
-            glds16_u((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, voff,
-                     slot_lds + row * C_::PADB + half * 1024);
-        }
-    }
-}
-
-// Walks a workgroup's tile sequence without integer division in the loop: item = blockIdx + k*gridDim,
-// tile-in-item `tin`; (bag, chunk) are re-derived only when the item changes.
-struct K2Pos {
-    int tin, item, bag, ch;
-    __device__ __forceinline__ void init(int first_item, int S) { tin = 0; item = first_item; bag = item / S; ch = item - bag * S; }
-    __device__ __forceinline__ void next(int tiles_per_item, int stride, int S) {
-        if (++tin == tiles_per_item) { tin = 0; item += stride; bag = item / S; ch = item - bag * S; }
-    }
-};
+#include "k2_common.h"
 
 template <typename T, bool EXACT_TANH>
 __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(

@@ -6,57 +6,38 @@
 //   ds_n = p_n (g_n - c)
 //   dT[n,d] = ds_n * wb[d] * (1 - t[n,d]^2),   t = tanh(Wa H_n + ba)   (recomputed on the MFMAs)
 //   dba += sum_n dT[n,:]   dwb += sum_n ds_n t[n,:]   dbb += sum_n ds_n
-// dH = dT.Wa + A (x) dM and dWa = dT^T.H are then plain GEMMs (gemm.hip epilogue RANK1_MASK / TN).
+// dH = dT.Wa + A (x) dM and dWa = dT^T.H are then plain GEMMs (panel_gemm.hip RANK1_MASK / gemm.hip TN).
 //
-// Same streaming structure as the forward (attn_pool.hip): persistent workgroups, 4-slot LDS-DMA
-// ring of 32 KiB H tiles, Wa slice resident in registers.  The saved raw scores of a tile arrive by
-// a ninth (4-byte) LDS-DMA per wave so that the main loop contains no compiler-counted loads.
-#include "common.h"
+// Same streaming structure as the forward (k2_common.h): persistent workgroups (bf16: two 4-wave workgroups per
+// CU), 16-row H tiles through a 4-slot LDS-DMA ring with padded rows, Wa slice resident in registers.  The
+// per-row dots g_n = dM.H_n also run on the matrix cores: dM enters as rows 0/1 (bf16 hi + lo parts; f32: row 0)
+// of an MFMA A operand and every wave covers 1/NW of the k range, partial sums meet in LDS.  The saved raw scores
+// of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
+#include "k2_common.h"
 
-#define K2_L 512
-#define K2_D 128
-#define K2_SLOT 32768
-#define K2_NSLOT 4
-#define KB_OFF_SC (K2_NSLOT * K2_SLOT)                 // [4 slots][4 waves][64] f32
-#define KB_OFF_DS (KB_OFF_SC + 4 * 4 * 64 * 4)         // [32] f32
-#define KB_LDS_BYTES (KB_OFF_DS + 32 * 4)
-
-template <typename T> struct KB {
-    static constexpr int ROWB = K2_L * (int)sizeof(T);
-    static constexpr int TR = K2_SLOT / ROWB;            // 32 / 16
-    static constexpr int NI = TR / 16;
-    static constexpr int CPR = ROWB / 16;
-    static constexpr int NKK = K2_L * (int)sizeof(T) / 64;
-    static constexpr int RPW = TR / 4;                   // rows per wave for the g dot: 8 / 4
+template <typename T> struct KBLds {
+    static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32
+    static constexpr int OFF_SC = OFF_GPART + K2<T>::NW * 16 * 4;                   // [slot][NW][64] f32
+    static constexpr int BYTES = OFF_SC + K2_NSLOT * K2<T>::NW * 256;
 };
-template <typename T> struct BFrag;
-template <> struct BFrag<bf16_t> { typedef bf16x8 type; };
-template <> struct BFrag<float> { typedef f32x4 type; };
-template <typename T>
-__device__ __forceinline__ f32x4 kb_mma(typename BFrag<T>::type a, typename BFrag<T>::type b, f32x4 c);
-template <> __device__ __forceinline__ f32x4 kb_mma<bf16_t>(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4 kb_mma<float>(f32x4 a, f32x4 b, f32x4 c) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
-    return c;
-}
 
 template <typename T, bool EXACT_TANH>
-__global__ __launch_bounds__(256, 1) void abmil_pool_bwd_kernel(
+__global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ scores, const float* __restrict__ ml, const float* __restrict__ Mp,
     const float* __restrict__ dM, T* __restrict__ dT, float* __restrict__ dba, float* __restrict__ dwb,
     float* __restrict__ dbb, int B, int N, int chunk_rows, int S, float inv_sqrt_n) {
-    typedef KB<T> C_;
-    typedef typename BFrag<T>::type frag_t;
+    typedef K2<T> C_;
+    typedef KBLds<T> L_;
+    typedef typename WFrag<T>::type frag_t;
+    constexpr int KW = C_::NKK / C_::NW;                 // k-steps of the g dot owned by one wave: 4 / 4
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
     const unsigned lds0 = lds_off(smem);
-    float* scb = (float*)(smem + KB_OFF_SC);
-    float* dsbuf = (float*)(smem + KB_OFF_DS);
+    float* gpart = (float*)(smem + L_::OFF_GPART);
+    const float* scb = (const float*)(smem + L_::OFF_SC);
 
     const int n_items = B * S;
     const int tiles_per_item = chunk_rows / C_::TR;
@@ -64,159 +45,152 @@ __global__ __launch_bounds__(256, 1) void abmil_pool_bwd_kernel(
     const int my_tiles = my_items * tiles_per_item;
     if (my_tiles <= 0) return;
 
+    K2Pos ip, cp;
+    ip.init(blockIdx.x, S);
+    cp.init(blockIdx.x, S);
     auto issue = [&](int seq) {
-        const int item = blockIdx.x + (seq / tiles_per_item) * gridDim.x;
-        const int bag = item / S, ch = item - bag * S;
-        const int row0 = ch * chunk_rows + (seq % tiles_per_item) * C_::TR;
-        const char* base = (const char*)(H + (size_t)bag * N * K2_L);
-        const int sl = seq % K2_NSLOT;
-        const unsigned slot = lds0 + sl * K2_SLOT;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ci = (j * 4 + wave) * 64 + lane;
-            const int row = ci / C_::CPR, pos = ci % C_::CPR;
-            const int grow = min(row0 + row, N - 1);
-            glds16(base + (size_t)grow * C_::ROWB + ((pos ^ (row & 15)) << 4), slot + (j * 4 + wave) * 1024);
-        }
-        // ninth op: this wave's private copy of the tile's saved scores (lane r <-> row r)
-        glds4(scores + (size_t)bag * N + min(row0 + lane, N - 1), lds0 + KB_OFF_SC + (sl * 4 + wave) * 256);
+        const int row0 = ip.ch * chunk_rows + ip.tin * C_::TR;
+        const int sl = seq & (K2_NSLOT - 1);
+        k2_issue_tile<T>(H + (size_t)ip.bag * N * K2_L, row0, N, lds0 + sl * C_::SLOT, wave, lane);
+        // fifth op: this wave's private copy of the tile's saved scores (lane r <-> row r, clamped)
+        glds4_s(scores + (size_t)ip.bag * N, (unsigned)min(row0 + (lane & 15), N - 1) * 4u,
+                lds0 + L_::OFF_SC + (sl * C_::NW + wave) * 256);
+        ip.next(tiles_per_item, gridDim.x, S);
     };
-
     const int pre = min(3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
 
-    frag_t wa[2][C_::NKK];
-    float ba_r[2][4], wb_r[2][4], dba_r[2][4], dwb_r[2][4];
+    frag_t wa[C_::NJ][C_::NKK];
+    float ba_r[C_::NJ][4], wb_r[C_::NJ][4], dba_r[C_::NJ][4], dwb_r[C_::NJ][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const T* wrow = Wa + (size_t)(32 * wave + 16 * j + r16) * K2_L;
+    for (int j = 0; j < C_::NJ; ++j) {
+        const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
 #pragma unroll
         for (int kk = 0; kk < C_::NKK; ++kk) {
-            wa[j][kk] = *(const frag_t*)((const char*)wrow + (4 * kk + q4) * 16);
+            wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
             asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ba_r[j][r] = ba[32 * wave + 16 * j + 4 * q4 + r];
-            wb_r[j][r] = wb[32 * wave + 16 * j + 4 * q4 + r];
+            ba_r[j][r] = ba[C_::DW * wave + 16 * j + 4 * q4 + r];
+            wb_r[j][r] = wb[C_::DW * wave + 16 * j + 4 * q4 + r];
             dba_r[j][r] = 0.f;
             dwb_r[j][r] = 0.f;
         }
     }
     float dbb_acc = 0.f;
-    float dmr[8], bag_m = 0.f, bag_invl = 0.f, bag_c = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dmr[e] = 0.f;
+    frag_t dmf[KW];                                   // dM as MFMA A-operand rows for this wave's k-steps
+    float bag_m = 0.f, bag_invl = 0.f, bag_c = 0.f;
+    int cur_bag = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     for (int seq = 0; seq < my_tiles; ++seq) {
-        // Only the 9 LDS-DMA ops per tile are counted; the dT stores issued in between are also
-        // younger than tile `seq`'s loads, which only makes this wait more conservative.
+        // only the 5 LDS-DMA ops per tile are counted; the dT stores issued in between are also younger than
+        // tile seq's loads, which only makes this wait more conservative
         const int ahead = min(2, my_tiles - 1 - seq);
-        if (ahead == 2) { WAIT_VMCNT(18); } else if (ahead == 1) { WAIT_VMCNT(9); } else { WAIT_VMCNT(0); }
+        if (ahead == 2) { WAIT_VMCNT(10); } else if (ahead == 1) { WAIT_VMCNT(5); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();
         if (seq + 3 < my_tiles) issue(seq + 3);
 
-        const int tin = seq % tiles_per_item;
-        const int item = blockIdx.x + (seq / tiles_per_item) * gridDim.x;
-        const int bag = item / S, ch = item - bag * S;
-        const int row0 = ch * chunk_rows + tin * C_::TR;
-        const int sl = seq % K2_NSLOT;
-        const char* tile = smem + sl * K2_SLOT;
+        const int bag = cp.bag;
+        const int row0 = cp.ch * chunk_rows + cp.tin * C_::TR;
+        const int sl = seq & (K2_NSLOT - 1);
+        const char* tile = smem + sl * C_::SLOT;
 
-        if (tin == 0) {                         // new item: per-bag constants
+        if (bag != cur_bag) {                   // new bag: per-bag constants (compiler-visible loads, rare)
+            cur_bag = bag;
             const float* dmb = dM + (size_t)bag * K2_L;
             const float* mb = Mp + (size_t)bag * K2_L;
             float cpart = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int col = (sizeof(T) == 2) ? 8 * lane + e : (e < 4 ? 4 * lane + e : 256 + 4 * lane + (e - 4));
-                dmr[e] = dmb[col];
-                cpart += dmr[e] * mb[col];
-            }
+            for (int e = 0; e < 8; ++e) cpart += dmb[8 * lane + e] * mb[8 * lane + e];
             bag_c = wave_sum(cpart);
             bag_m = ml[2 * bag];
             bag_invl = 1.0f / ml[2 * bag + 1];
-        }
-
-        // ---- g_n and ds_n for this wave's rows
+            // A fragments: lane (q4, r16) holds A[row r16][k of chunk (kk + NKK*q4)], kk = KW*wave + i
 #pragma unroll
-        for (int rr = 0; rr < C_::RPW; ++rr) {
-            const int r = wave * C_::RPW + rr;
-            float part = 0.f;
-            if (sizeof(T) == 2) {
-                const u32x4 u = *(const u32x4*)(tile + r * C_::ROWB + ((lane ^ (r & 15)) << 4));
+            for (int i = 0; i < KW; ++i) {
+                const int chunk = (KW * wave + i) + C_::NKK * q4;
+                if (sizeof(T) == 2) {
+                    bf16x8 f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) part += dmr[2 * e] * bf_lo(u[e]) + dmr[2 * e + 1] * bf_hi(u[e]);
-            } else {
-                const f32x4 a = *(const f32x4*)(tile + r * C_::ROWB + ((lane ^ (r & 15)) << 4));
-                const f32x4 b = *(const f32x4*)(tile + r * C_::ROWB + (((64 + lane) ^ (r & 15)) << 4));
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = dmb[chunk * 8 + e];
+                        const bf16_t hi = f2bf(v);
+                        const bf16_t lo = f2bf(v - bf2f(hi));
+                        f[e] = (short)(r16 == 0 ? hi : (r16 == 1 ? lo : (bf16_t)0));
+                    }
+                    dmf[i] = __builtin_bit_cast(frag_t, f);
+                } else {
+                    f32x4 f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) part += dmr[e] * a[e] + dmr[4 + e] * b[e];
-            }
-            const float g = wave_sum(part) * inv_sqrt_n;
-            if (lane == 0) {
-                const float s = scb[(sl * 4 + wave) * 64 + r];
-                const float p = __expf(s - bag_m) * bag_invl;
-                dsbuf[r] = (row0 + r < N) ? p * (g - bag_c) : 0.f;
+                    for (int e = 0; e < 4; ++e) f[e] = (r16 == 0) ? dmb[chunk * 4 + e] : 0.f;
+                    dmf[i] = __builtin_bit_cast(frag_t, f);
+                }
             }
         }
 
-        // ---- recompute pre-activations for the tile (this wave's 32 columns of D)
-        f32x4 acc[C_::NI][2];
+        // ---- phase 1: pre-activations (this wave's DW columns) + this wave's k-quarter of g = H.dM
+        f32x4 acc[C_::NJ];
 #pragma unroll
-        for (int i = 0; i < C_::NI; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C_::NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hbase = tile + r16 * C_::PADB + C_::NKK * q4 * 16;
 #pragma unroll
         for (int kk = 0; kk < C_::NKK; ++kk) {
+            const frag_t h = *(const frag_t*)(hbase + kk * 16);
 #pragma unroll
-            for (int i = 0; i < C_::NI; ++i) {
-                const int row = 16 * i + r16, c = 4 * kk + q4;
-                frag_t h = *(const frag_t*)(tile + row * C_::ROWB + ((c ^ (row & 15)) << 4));
-                acc[i][0] = kb_mma<T>(wa[0][kk], h, acc[i][0]);
-                acc[i][1] = kb_mma<T>(wa[1][kk], h, acc[i][1]);
-            }
+            for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][kk], h, acc[j]);
         }
-        LDS_BARRIER();                          // dsbuf complete
+#pragma unroll
+        for (int i = 0; i < KW; ++i) {
+            const frag_t h = *(const frag_t*)(hbase + (KW * wave + i) * 16);
+            gacc = k2_mma<T>(dmf[i], h, gacc);
+        }
+        if (q4 == 0) gpart[wave * 16 + r16] = gacc[0] + gacc[1];     // rows 0 (+1): hi (+lo) parts
+        LDS_BARRIER();
 
-        if (wave == 0 && lane < C_::TR) dbb_acc += dsbuf[lane];
+        // ---- phase 2: ds for row r16 (every lane quarter redundantly), then dT
+        float g = 0.f;
 #pragma unroll
-        for (int i = 0; i < C_::NI; ++i) {
-            const int row = 16 * i + r16;
-            const float ds = dsbuf[row];
-            const int grow = row0 + row;
-            // rows past N are redirected to the 32 spare rows after the last bag (never read)
-            T* dst = dT + ((grow < N) ? ((size_t)bag * N + grow) : ((size_t)B * N + row)) * K2_D + 32 * wave + 4 * q4;
+        for (int w = 0; w < C_::NW; ++w) g += gpart[w * 16 + r16];
+        g *= inv_sqrt_n;
+        const float sc = scb[(sl * C_::NW + wave) * 64 + r16];
+        const float p = (EXACT_TANH ? __expf(sc - bag_m) : fast_exp(sc - bag_m)) * bag_invl;
+        const int grow = row0 + r16;
+        const float ds = (grow < N) ? p * (g - bag_c) : 0.f;
+        if (wave == 0 && q4 == 0) dbb_acc += ds;
+        // rows past N are redirected to the 32 spare rows after the last bag (never read)
+        T* dst = dT + ((grow < N) ? ((size_t)bag * N + grow) : ((size_t)B * N + r16)) * K2_D + C_::DW * wave + 4 * q4;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4 o;
+        for (int j = 0; j < C_::NJ; ++j) {
+            f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float x = acc[i][j][r] + ba_r[j][r];
-                    const float t = EXACT_TANH ? tanhf(x) : fast_tanh(x);
-                    o[r] = ds * wb_r[j][r] * (1.f - t * t);
-                    dba_r[j][r] += o[r];
-                    dwb_r[j][r] += ds * t;
-                }
-                store4<T>(dst + 16 * j, o);
+            for (int r = 0; r < 4; ++r) {
+                const float x = acc[j][r] + ba_r[j][r];
+                const float t = EXACT_TANH ? tanhf(x) : fast_tanh(x);
+                o[r] = ds * wb_r[j][r] * (1.f - t * t);
+                dba_r[j][r] += o[r];
+                dwb_r[j][r] += ds * t;
             }
+            store4<T>(dst + 16 * j, o);
         }
+        cp.next(tiles_per_item, gridDim.x, S);
     }
 
-    // ---- flush the parameter-gradient partials
+    // ---- flush the parameter-gradient partials (sum over the 16 rows = lanes of a quarter)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < C_::NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = dba_r[j][r], w = dwb_r[j][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); w += __shfl_xor(w, o, 64); }
+            const float a = row16_sum(dba_r[j][r]), w = row16_sum(dwb_r[j][r]);
             if (r16 == 0) {
-                atomicAdd(dba + 32 * wave + 16 * j + 4 * q4 + r, a);
-                atomicAdd(dwb + 32 * wave + 16 * j + 4 * q4 + r, w);
+                atomicAdd(dba + C_::DW * wave + 16 * j + 4 * q4 + r, a);
+                atomicAdd(dwb + C_::DW * wave + 16 * j + 4 * q4 + r, w);
             }
         }
     if (wave == 0) {
-        const float t = wave_sum(dbb_acc);
+        const float t = row16_sum(dbb_acc);
         if (lane == 0) atomicAdd(dbb, t);
     }
 }
@@ -233,18 +207,19 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     const int items = B * S;
-    const int grid = items < 256 ? items : 256;
+    const int max_grid = 256 * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
+    const int grid = items < max_grid ? items : max_grid;
     const float isn = 1.0f / sqrtf((float)N);
 #define KB_LAUNCH(T, EX)                                                                                       \
     {                                                                                                          \
         auto k = abmil_pool_bwd_kernel<T, EX>;                                                                 \
         static bool once = false;                                                                              \
         if (!once) {                                                                                           \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);     \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, KBLds<T>::BYTES);  \
             once = true;                                                                                       \
         }                                                                                                      \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), KB_LDS_BYTES, stream, (const T*)H, (const T*)Wa, ba, wb,  \
-                           scores, ml, M, dM, (T*)dT, dba, dwb, dbb, B, N, chunk, S, isn);                     \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), KBLds<T>::BYTES, stream, (const T*)H,         \
+                           (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, B, N, chunk, S, isn); \
     }
     if (dtype == MURCL_DTYPE_BF16) {
         if (exact_tanh) KB_LAUNCH(bf16_t, true) else KB_LAUNCH(bf16_t, false)

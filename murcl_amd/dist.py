@@ -52,3 +52,40 @@ def all_reduce_grads(flat_grads, group=None):
     """Sum the flat gradient buffers over ranks (one collective per optimizer group)."""
     for g in flat_grads:
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+
+
+class OverlappedGradReduce:
+    """All-reduce the optimizer's flat gradient buffers with the early groups overlapped with backward.
+
+    In the pre-train step the recurrent head's gradients (19.4 MB, group 1) are final as soon as the backward
+    pass reaches the aggregator outputs, long before the encoder gradients (4.7 MB, group 0) exist.  ``arm()``
+    registers hooks on those aggregator outputs; when the last one fires, the head group's all-reduce is
+    launched asynchronously (RCCL runs on its own stream, ordered after the kernels already queued) and overlaps
+    with the aggregator backward; ``finish()`` reduces the remaining groups and waits for everything.
+    """
+
+    def __init__(self, optimizer, early_groups=(1,), group=None):
+        self.opt, self.early, self.group = optimizer, tuple(early_groups), group
+        self._pending, self._works = 0, []
+
+    def arm(self, aggregator_outputs):
+        self._works, self._pending = [], len(aggregator_outputs)
+        for t in aggregator_outputs:
+            t.register_hook(self._fired)
+
+    def _fired(self, grad):
+        self._pending -= 1
+        if self._pending == 0:
+            flats = self.opt.flat_grads()
+            for gi in self.early:
+                self._works.append(dist.all_reduce(flats[gi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return grad
+
+    def finish(self):
+        flats = self.opt.flat_grads()
+        for gi in range(len(flats)):
+            if gi not in self.early or not self._works:
+                self._works.append(dist.all_reduce(flats[gi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works = []

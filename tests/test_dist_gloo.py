@@ -70,3 +70,60 @@ def test_sharded_ntxent_equals_global_single_process():
         assert l == pytest.approx(loss.item(), rel=1e-6)
         np.testing.assert_allclose(g, W.grad.reshape(-1).numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(s, sim[3 * r:3 * r + 3], rtol=1e-5)
+
+
+def _worker_overlap(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from murcl_amd import dist as mdist
+
+    class FakeOpt:                      # FlatAdam's flat-gradient interface without the HIP optimizer step
+        def __init__(self, groups):
+            self.flat = [torch.zeros(sum(p.numel() for p in g)) for g in groups]
+            for g, f in zip(groups, self.flat):
+                off = 0
+                for p in g:
+                    p.grad = f[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+
+        def flat_grads(self):
+            return self.flat
+
+    torch.manual_seed(rank)
+    enc = torch.nn.Linear(8, 8)
+    head = torch.nn.Linear(8, 4)
+    opt = FakeOpt([list(enc.parameters()), list(head.parameters())])
+    red = mdist.OverlappedGradReduce(opt, early_groups=(1,))
+    x = torch.randn(5, 8)
+    h = enc(x)
+    outs = list(h.split([2, 3], 0))
+    red.arm(outs)
+    loss = sum(head(o).pow(2).sum() for o in outs)
+    loss.backward()
+    red.finish()
+    out[rank] = [f.clone().numpy() for f in opt.flat]
+    dist.destroy_process_group()
+
+
+def test_overlapped_grad_reduce_sums_every_group_once():
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    # reference: sum over ranks of the single-process gradients
+    want = None
+    for rank in range(world):
+        torch.manual_seed(rank)
+        enc, head = torch.nn.Linear(8, 8), torch.nn.Linear(8, 4)
+        x = torch.randn(5, 8)
+        h = enc(x)
+        sum(head(o).pow(2).sum() for o in h.split([2, 3], 0)).backward()
+        g = [torch.cat([p.grad.reshape(-1) for p in enc.parameters()]).numpy(),
+             torch.cat([p.grad.reshape(-1) for p in head.parameters()]).numpy()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    for rank in range(world):
+        for got, w in zip(res[rank], want):
+            np.testing.assert_allclose(got, w, rtol=1e-5, atol=1e-6)
