@@ -381,13 +381,14 @@ __device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int la
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                          float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
                                                          int ldc, int m_per_split, int nsplit) {
     typedef typename Frag<T>::type frag_t;
     typedef TnTraits<T> TT;
-    constexpr int NSLOT = 4;                      // slab ring: three slabs (96 KiB) in flight, counted vmcnt
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSLOT x (A 16 KiB | B 16 KiB)
+    constexpr int NSLOT = 2;                      // double buffer per workgroup; TWO workgroups per CU desynchronise
+                                                  // and cover each other's barrier / DMA-issue stalls (218 -> 184 us)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB | B 16 KiB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work map (speed only): workgroups b and b+8 share an XCD, so all T1*T2 output tiles of one
@@ -485,13 +486,11 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_kernel(const T* __restrict__ A
     };
 
     const int nslab = (mend - mbeg + TT::ROWS - 1) / TT::ROWS;
-    for (int s = 0; s < 3 && s < nslab; ++s) stage(s);
+    stage(0);
     for (int s = 0; s < nslab; ++s) {
-        // slab s landed when at most 8 * (slabs issued after it) LDS-DMA ops are outstanding
-        const int after = min(2, nslab - 1 - s);
-        if (after == 2) { WAIT_VMCNT(16); } else if (after == 1) { WAIT_VMCNT(8); } else { WAIT_VMCNT(0); }
+        WAIT_VMCNT(0);                             // slab s landed (nothing else is in flight at this point)
         LDS_BARRIER();                             // slab s visible to all waves; slot of slab s-1 is free
-        if (s + 3 < nslab) stage(s + 3);
+        if (s + 1 < nslab) stage(s + 1);
         const int rows_here = min(TT::ROWS, mend - (mbeg + s * TT::ROWS));
         if (rows_here < TT::ROWS) {               // ragged tail: zero the invalid rows of both images
             char* la = smem + (s & (NSLOT - 1)) * 32768;
@@ -526,8 +525,8 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
     const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
-    if (splits <= 0) {                       // fill the chip: one 128 KiB-LDS workgroup per CU, splits % 8 == 0
-        splits = (256 + t1 * t2 - 1) / (t1 * t2);
+    if (splits <= 0) {                       // fill the chip: two 64 KiB-LDS workgroups per CU, splits % 8 == 0
+        splits = (512 + t1 * t2 - 1) / (t1 * t2);
         splits = ((splits + 7) / 8) * 8;
         while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
     }
@@ -538,13 +537,13 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     if (dtype == MURCL_DTYPE_BF16) {
         auto k = gemm_tn_kernel<bf16_t>;
         static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 131072, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
     } else if (dtype == MURCL_DTYPE_F32) {
         auto k = gemm_tn_kernel<float>;
         static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 131072, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
+        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
     } else {
         return -1;
     }

@@ -31,7 +31,7 @@ template <typename T> struct K2 {
 #define K2_MAX_CHUNK 1024
 template <typename T> struct K2Lds {
     static constexpr int OFF_SPART = K2_NSLOT * K2<T>::SLOT;
-    static constexpr int OFF_PBUF = OFF_SPART + K2<T>::NW * 16 * 4;
+    static constexpr int OFF_PBUF = OFF_SPART + 2 * K2<T>::NW * 16 * 4;    // spart is double-buffered
     static constexpr int OFF_SBUF = OFF_PBUF + K2<T>::NW * 16 * 4;
     static constexpr int BYTES = OFF_SBUF + K2_MAX_CHUNK * 4;
 };

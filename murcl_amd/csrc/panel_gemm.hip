@@ -45,7 +45,11 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
     const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
     float* __restrict__ colsum_out) {
     constexpr int ROWB = K * 2;                 // bytes per A row
-    constexpr int SLOT = PG_TR * ROWB;          // 32 KiB / 8 KiB
+    // K = 512: one LDS-DMA instruction writes exactly one row, so rows can be stored at a padded stride (conflict-free
+    // 16-row fragment reads with immediate offsets, no swizzle math).  K = 128: four rows per instruction -> XOR swizzle.
+    constexpr bool PAD = (K == 512);
+    constexpr int PADB = PAD ? ROWB + 16 : ROWB;
+    constexpr int SLOT = PG_TR * PADB;          // 32.5 KiB / 8 KiB
     constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
     constexpr int GT = SLOT / (PG_NW * 1024);   // tile LDS-DMA ops per wave: 4 / 1
     constexpr int NJ = WN / 16, NKK = K / 32;
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
     constexpr int OFF_RS = OFF_BM + (NB ? PG_NSLOT * PG_NW * 256 : 0);          // [slot][wave][64 f32]
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
     const unsigned lds0 = lds_off(smem);
     const int panels = N / NP;
@@ -83,10 +88,15 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
         const char* base = (const char*)(A + (size_t)row0 * K);
 #pragma unroll
         for (int j = 0; j < GT; ++j) {
-            const int ci = (j * PG_NW + wave) * 64 + lane;
-            const int row = ci / CPR, pos = ci % CPR;
-            glds16(base + (size_t)row * ROWB + ((pos ^ (row & 15)) << 4),
-                   lds0 + sl * SLOT + (j * PG_NW + wave) * 1024);
+            if (PAD) {
+                const int row = j * PG_NW + wave;                       // wave-uniform: scalar base, lane offset lane*16
+                glds16_u(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
+            } else {
+                const int ci = (j * PG_NW + wave) * 64 + lane;
+                const int row = ci / CPR, pos = ci % CPR;
+                glds16(base + (size_t)row * ROWB + ((pos ^ (row & 15)) << 4),
+                       lds0 + sl * SLOT + (j * PG_NW + wave) * 1024);
+            }
         }
         if (EPI != PG_BIAS_RELU) {
             // this wave's mask blocks of the tile (WN/32 blocks of 128 B, contiguous): one 4-byte piece per lane
@@ -109,7 +119,8 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
         const bf16_t* wrow = W + (size_t)(n0 + 16 * j + r16) * K;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
-            wf[j][kk] = *(const bf16x8*)(wrow + 32 * kk + 8 * q4);
+            // k assignment of lane quarter q4 in k-step kk: PAD -> 16-byte chunk (kk + NKK*q4); else chunk (4kk + q4)
+            wf[j][kk] = *(const bf16x8*)(wrow + (PAD ? (kk + NKK * q4) * 8 : 32 * kk + 8 * q4));
             // opaque to the optimiser: otherwise hipcc rematerialises the fragments by re-loading them from global
             // memory inside the tile loop (34 loads + vmcnt waits per tile that also drain the LDS-DMA ring)
             asm volatile("" : "+v"(wf[j][kk]));
@@ -153,12 +164,14 @@ __global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hb = tile + r16 * PADB + NKK * q4 * 16;               // PAD: base + immediates only
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 16 * i + r16, c = 4 * kk + q4;
-                const bf16x8 h = *(const bf16x8*)(tile + row * ROWB + ((c ^ (row & 15)) << 4));
+                const bf16x8 h = PAD ? *(const bf16x8*)(hb + i * 16 * PADB + kk * 16)
+                                     : *(const bf16x8*)(tile + row * ROWB + ((c ^ (row & 15)) << 4));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], h, acc[i][j], 0, 0, 0);
             }
@@ -250,7 +263,7 @@ template <int K, int WN, int EPI, bool BM_OUT>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
                      float* colsum_out, hipStream_t s) {
-    constexpr int SLOT = PG_TR * K * 2;
+    constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
     constexpr int STG_LD = WN * 2 + 16;
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD + (EPI != PG_BIAS_RELU ? PG_NSLOT * PG_NW * 256 : 0) +
                         (EPI == PG_RANK1_MASK ? PG_NSLOT * PG_NW * 256 : 0);
