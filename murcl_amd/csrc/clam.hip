@@ -216,35 +216,36 @@ extern "C" int murcl_scatter_add_rows_masked(void* dst, const void* h, const lon
     return MURCL_CHECK_LAUNCH();
 }
 
-// ---------------------------------------------------------------- mean cross-entropy over R rows of C logits (C <= 32)
-// loss = mean_r [ lse(logits_r) - logits_r[target_r] ];  dlogits = (softmax - onehot) / R ; pred = argmax (first max)
-__global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ targets, int R, int C,
-                                  float* __restrict__ loss, float* __restrict__ dlogits, long* __restrict__ preds) {
-    __shared__ float part[256];
-    const int tid = threadIdx.x;
+// ---------------------------------------------------------------- mean cross-entropy per group of G consecutive rows
+// (C <= 32 logits per row).  One workgroup per group:  loss[g] = mean_r [ lse(logits_r) - logits_r[target_r] ];
+// dlogits = (softmax - onehot) / G ; pred = argmax (first max)
+__global__ __launch_bounds__(64) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ targets,
+                                                        int G, int C, float* __restrict__ loss,
+                                                        float* __restrict__ dlogits, long* __restrict__ preds) {
+    const int grp = blockIdx.x, tid = threadIdx.x;
     float acc = 0.f;
-    for (int r = tid; r < R; r += 256) {
-        const float* x = logits + (size_t)r * C;
+    for (int r = tid; r < G; r += 64) {
+        const size_t row = (size_t)grp * G + r;
+        const float* x = logits + row * C;
         float mx = x[0];
         int am = 0;
         for (int c = 1; c < C; ++c) if (x[c] > mx) { mx = x[c]; am = c; }
         float sum = 0.f;
         for (int c = 0; c < C; ++c) sum += expf(x[c] - mx);
         const float lse = mx + logf(sum);
-        const int t = (int)targets[r];
+        const int t = (int)targets[row];
         acc += lse - x[t];
         if (dlogits)
-            for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) / (float)R;
-        if (preds) preds[r] = am;
+            for (int c = 0; c < C; ++c) dlogits[row * C + c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) / (float)G;
+        if (preds) preds[row] = am;
     }
-    part[tid] = acc; __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) part[tid] += part[tid + o]; __syncthreads(); }
-    if (tid == 0) loss[0] = part[0] / (float)R;
+    acc = wave_sum(acc);
+    if (tid == 0) loss[grp] = acc / (float)G;
 }
 extern "C" int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
-                                   long* preds, hipStream_t st) {
-    if (R <= 0 || C <= 0) return -1;
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(256), 0, st, logits, targets, R, C, loss, dlogits, preds);
+                                   long* preds, int group, hipStream_t st) {
+    if (R <= 0 || C <= 0 || group <= 0 || R % group) return -1;
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R / group), dim3(64), 0, st, logits, targets, group, C, loss, dlogits, preds);
     return MURCL_CHECK_LAUNCH();
 }
 

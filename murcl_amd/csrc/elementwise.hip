@@ -53,20 +53,29 @@ extern "C" int murcl_transpose_cast(const float* x, void* y, int R, int C, int d
 }
 
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
-// grid = (column groups of 64, row splits); each block reduces its row range and adds 64 values atomically.
+// grid = (column groups of 256, row splits); a thread owns 4 consecutive columns (8/16-byte loads) for one of 4 row
+// lanes; each block adds its 256 partial sums atomically.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld, int rows_per_block) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld,
+                                                     int rows_per_block) {
+    __shared__ f32x4 red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cl * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float s = 0.f;
-    if (c < N)
-        for (int r = r0 + rl; r < r1; r += 4) s += to_f<T>(x[(size_t)r * ld + c]);
-    red[rl][threadIdx.x & 63] = s;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c + 3 < N && (ld & 3) == 0) {                        // aligned rows: 8/16-byte loads
+        for (int r = r0 + rl; r < r1; r += 4) s += load4<T>(x + (size_t)r * ld + c);
+    } else if (c < N) {
+        for (int r = r0 + rl; r < r1; r += 4)
+            for (int e = 0; e < 4 && c + e < N; ++e) s[e] += to_f<T>(x[(size_t)r * ld + c + e]);
+    }
+    red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < N) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (gridDim.y == 1) out[c] += s; else atomicAdd(out + c, s);
+        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        for (int e = 0; e < 4 && c + e < N; ++e) {
+            if (gridDim.y == 1) out[c + e] += s[e]; else atomicAdd(out + c + e, s[e]);
+        }
     }
 }
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s) {
@@ -75,8 +84,8 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
         hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, s);
         if (e != hipSuccess) return (int)e;
     }
-    const int cg = (N + 63) / 64;
-    int splits = R > 64 ? (512 + cg - 1) / cg : 1;          // ~512 blocks, >= 32 rows each
+    const int cg = (N + 255) / 256;
+    int splits = R > 64 ? (1024 + cg - 1) / cg : 1;        // ~1024 blocks, >= 32 rows each
     if (splits > (R + 31) / 32) splits = (R + 31) / 32;
     if (splits < 1) splits = 1;
     const int rpb = (R + splits - 1) / splits;

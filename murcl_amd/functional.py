@@ -232,7 +232,8 @@ class CLAMFn(torch.autograd.Function):
     x [B,N,d] in the compute dtype; parameters f32.  ``keeps`` = None (eval) or the three dropout keep-multiplier
     tensors (values 0 or 1/0.75) for h, the tanh branch and the sigmoid branch (clam.py:71-72,47-48).
     ``inst`` = None or (W [n_cls,2,512], b [n_cls,2], labels: list[int], k_sample, subtyping).
-    Returns (M [B,512], A [B,N], raw scores [B,N], inst_loss [B], ids [B,2k]); only M and inst_loss carry grad.
+    Returns (M [B,512], A [B,N], raw scores [B,N], inst_loss [B], ids [B,2k], preds/targets [2,B,n_cls,2k]); only M and
+    inst_loss carry grad.
     """
 
     @staticmethod
@@ -257,9 +258,12 @@ class CLAMFn(torch.autograd.Function):
         inst_loss = torch.zeros((B,), dtype=torch.float32, device=dev)
         saved_inst = []
         ids = None
+        inst_pt = None
         if inst_cfg is not None:
             labels, k, subtyping = inst_cfg
             n_cls = inst_w.shape[0]
+            # predictions / targets of every bag: [B, n_cls, 2k] int64, -1 where a class contributes nothing
+            inst_pt = torch.full((2, B, n_cls, 2 * k), -1, dtype=torch.int64, device=dev)
             ids = ops.topk_ids(A, k)                                                   # [B, 2k]
             base = (torch.arange(B, device=dev, dtype=torch.int64) * N).unsqueeze(1)
             rows_all = base + ids.to(torch.int64)                                      # [B, 2k] rows of h
@@ -277,17 +281,20 @@ class CLAMFn(torch.autograd.Function):
                     loss, dl, preds = ops.cross_entropy(logits, targets, width)
                     scale = 1.0 / n_cls if subtyping else 1.0                          # clam.py:167-168
                     inst_loss.index_add_(0, bi, loss * scale)
+                    inst_pt[0, bi, i, :width] = preds.view(len(bags), width)
+                    inst_pt[1, bi, i, :width] = targets.view(len(bags), width)
                     saved_inst.append((i, bi, rows, feats, dl, scale, width, preds, targets))
         ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1))
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
             ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
-        ctx.mark_non_differentiable(A, s, ids)
-        ctx.inst_out = [(sv[0], sv[1], sv[7], sv[8]) for sv in saved_inst]
-        return M, A, s, inst_loss, ids
+        if inst_pt is None:
+            inst_pt = torch.zeros((2, B, 0, 0), dtype=torch.int64, device=dev)
+        ctx.mark_non_differentiable(A, s, ids, inst_pt)
+        return M, A, s, inst_loss, ids, inst_pt
 
     @staticmethod
-    def backward(ctx, dM, _dA, _ds, dinst, _dids):
+    def backward(ctx, dM, _dA, _ds, dinst, _dids, _dpt):
         x2, h, U, A, M, w1, wa, wb, wc, inst_w = ctx.saved_tensors
         B, N, d, L, D = ctx.dims
         T = x2.dtype

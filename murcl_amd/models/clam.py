@@ -73,26 +73,23 @@ class CLAM_SB(nn.Module):
             inst_b = torch.stack([c.bias for c in self.instance_classifiers], 0)
             lab = [int(l) for l in (labels.reshape(-1).tolist() if isinstance(labels, torch.Tensor) else labels)]
             cfg = (lab, self.k_sample, self.subtyping)
-        M, A, s, inst_loss, ids = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias,
+        M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias,
                                                g.attention_a[0].weight, g.attention_a[0].bias,
                                                g.attention_b[0].weight, g.attention_b[0].bias,
                                                g.attention_c.weight, g.attention_c.bias, inst_w, inst_b, keeps, cfg)
         self.last_attention = A
-        inst_out = getattr(M.grad_fn, "inst_out", None) if M.grad_fn is not None else None
         return M, A, s, inst_loss, ids, inst_out
 
-    def _results(self, b, M, inst_loss, inst_out, instance_eval, return_features):
+    @staticmethod
+    def _host_inst(inst_out):
+        """One device->host copy for the whole batch (the reference does .cpu() per bag and class, clam.py:156-161)."""
+        return None if inst_out is None else inst_out.cpu().numpy()
+
+    def _results(self, b, M, inst_loss, inst_host, instance_eval, return_features):
         res = {}
         if instance_eval:
-            preds, targets = [], []
-            for (_cls, bi, p, t) in (inst_out or []):
-                sel = (bi == b).nonzero().flatten()
-                if sel.numel():
-                    w = p.numel() // bi.numel()
-                    j = int(sel[0])
-                    preds.extend(p[j * w:(j + 1) * w].cpu().numpy())
-                    targets.extend(t[j * w:(j + 1) * w].cpu().numpy())
-            res = {"instance_loss": inst_loss[b], "inst_labels": np.array(targets), "inst_preds": np.array(preds)}
+            p, t = inst_host[0, b].reshape(-1), inst_host[1, b].reshape(-1)     # class-major order, like the reference
+            res = {"instance_loss": inst_loss[b], "inst_labels": t[t >= 0], "inst_preds": p[p >= 0]}
         if return_features:
             res["features"] = M[b:b + 1]
         return res
@@ -104,7 +101,7 @@ class CLAM_SB(nn.Module):
         M, A, s, il, ids, io = self._run(bag.unsqueeze(0), [int(label)] if instance_eval else None, instance_eval)
         if attention_only:
             return s                                               # raw scores [1,N] (clam.py:141-142)
-        return M, self._results(0, M, il, io, instance_eval, return_features)
+        return M, self._results(0, M, il, self._host_inst(io) if instance_eval else None, instance_eval, return_features)
 
     def batch_forward(self, batch, label=None, instance_eval=False, return_features=False, attention_only=False):
         bags = [b.squeeze(0) if b.dim() == 3 else b for b in batch] if not isinstance(batch, torch.Tensor) else None
@@ -119,7 +116,8 @@ class CLAM_SB(nn.Module):
         M, A, s, il, ids, io = self._run(x, labels, instance_eval)
         if attention_only:
             return s, [{}] * x.shape[0]
-        return M, [self._results(b, M, il, io, instance_eval, return_features) for b in range(x.shape[0])]
+        host = self._host_inst(io) if instance_eval else None
+        return M, [self._results(b, M, il, host, instance_eval, return_features) for b in range(x.shape[0])]
 
     def forward(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
         if isinstance(h, list) or (isinstance(h, torch.Tensor) and h.dim() == 3 and h.shape[0] > 1):

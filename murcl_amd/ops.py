@@ -414,10 +414,8 @@ def cross_entropy(logits, targets, group):
     loss = torch.empty((G,), dtype=torch.float32, device=logits.device)
     dl = torch.empty_like(logits)
     preds = torch.empty((R,), dtype=torch.int64, device=logits.device)
-    for gi in range(G):       # one launch per bag group (tens of rows each)
-        sl = slice(gi * group, (gi + 1) * group)
-        check(_lib.lib().murcl_cross_entropy(ptr(logits[sl]), ptr(targets[sl]), group, C, ptr(loss[gi:gi + 1]), ptr(dl[sl]),
-                                             ptr(preds[sl]), stream()), "cross_entropy")
+    check(_lib.lib().murcl_cross_entropy(ptr(logits), ptr(targets), R, C, ptr(loss), ptr(dl), ptr(preds), group, stream()),
+          "cross_entropy")
     return loss, dl, preds
 
 
