@@ -149,6 +149,52 @@ class GRUStepFn(torch.autograd.Function):
         return dx, dh_prev, dw_ih, dw_hh, db_ih, db_hh
 
 
+class GRUSeqFn(torch.autograd.Function):
+    """nn.GRU over a whole rollout from a zero hidden state (ActorCritic.evaluate, models/rlmil.py:99-112).
+
+    x [T,B,I] -> all hidden states [T,B,H].  The input projection and every weight/bias gradient are one GEMM /
+    one column sum over the T*B rows; only h W_hh^T and the gate kernels stay inside the time loop.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        T, B, _ = x.shape
+        H = w_hh.shape[1]
+        x2 = x.reshape(T * B, -1).contiguous()
+        gi = ops.gemm_nt(x2, w_ih, epi=ops.EPI_BIAS, bias=b_ih).view(T, B, 3 * H)
+        gh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=x.device)
+        gates = torch.empty_like(gh)
+        hs = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+        gh[0] = b_hh                                                     # W_hh . 0 + b_hh
+        for t in range(T):
+            if t:
+                ops.gemm_nt(hs[t - 1], w_hh, epi=ops.EPI_BIAS, bias=b_hh, out=gh[t])
+            ops.gru_gates_fwd(gi[t], gh[t], hs[t - 1] if t else None, hnew=hs[t], gates=gates[t])
+        ctx.save_for_backward(x2, w_ih, w_hh, gates, gh, hs)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x2, w_ih, w_hh, gates, gh, hs = ctx.saved_tensors
+        T, B, H = hs.shape
+        dhs = dhs.contiguous()
+        dgi, dgh = torch.empty_like(gh), torch.empty_like(gh)
+        w_hh_t = ops.transpose_cast(w_hh, torch.float32)
+        carry = None
+        for t in range(T - 1, -1, -1):
+            dh = dhs[t] if carry is None else dhs[t] + carry
+            _, _, dhp = ops.gru_gates_bwd(dh, gates[t], gh[t], hs[t - 1] if t else None, dgi=dgi[t], dgh=dgh[t])
+            if t:
+                carry = ops.gemm_nt(dgh[t], w_hh_t, out=dhp, accumulate=True)
+        dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dgi2, ops.transpose_cast(w_ih, torch.float32)).view(T, B, -1)
+        dw_ih = ops.gemm_tn(dgi2, x2)
+        dw_hh = ops.gemm_tn(dgh2[B:], hs.view(T * B, H)[:-B]) if T > 1 else torch.zeros_like(w_hh)
+        return dx, dw_ih, dw_hh, ops.colsum(dgi2), ops.colsum(dgh2)
+
+
 class NTXentFn(torch.autograd.Function):
     """NT_Xent.forward (utils/losses.py:24-41); gradient comes out of the same launch."""
 

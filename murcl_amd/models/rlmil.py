@@ -16,7 +16,7 @@ from torch import nn
 
 import math
 
-from ..functional import GRUStepFn, LinearFn, PolicyHeadFn, PPOLossFn
+from ..functional import GRUSeqFn, GRUStepFn, LinearFn, PolicyHeadFn, PPOLossFn
 
 
 class Memory:
@@ -111,11 +111,12 @@ class ActorCritic(nn.Module):
     def evaluate(self, state, action):
         """states [T,B,S], actions [T,B,K] -> (logp, value, entropy) each [T,B] (rlmil.py:99-127)."""
         T_, B = state.shape[0], state.shape[1]
-        h, hs = None, []
-        for t in range(T_):                                     # GRU over the rollout from a zero hidden state
-            h = self._trunk(state[t].flatten(1).float().contiguous(), h)
-            hs.append(h)
-        hs = torch.cat(hs, 0)                                   # [T*B, H]
+        enc = self.state_encoder                                # encoder over all T*B rows at once (rlmil.py:103-109)
+        e = LinearFn.apply(state.reshape(T_ * B, -1).float().contiguous(), enc[0].weight, enc[0].bias, True)
+        e = LinearFn.apply(e, enc[2].weight, enc[2].bias, True)
+        g = self.gru                                            # GRU over the rollout from a zero hidden state
+        hs = GRUSeqFn.apply(e.view(T_, B, -1), g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
+        hs = hs.reshape(T_ * B, -1)
         z = LinearFn.apply(hs, self.actor[0].weight, self.actor[0].bias, False)
         logp = PolicyHeadFn.apply(z, action.reshape(T_ * B, -1).float().contiguous(), self.action_std)
         value = LinearFn.apply(hs, self.critic[0].weight, self.critic[0].bias, False)

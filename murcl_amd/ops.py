@@ -268,23 +268,30 @@ def relu_bwd(dy, y):
     return dx
 
 
-def gru_gates_fwd(gi, gh, hprev):
+def gru_gates_fwd(gi, gh, hprev, hnew=None, gates=None):
     _need_cuda(gi, gh)
     B, H3 = gi.shape
     H = H3 // 3
-    hnew = torch.empty((B, H), dtype=torch.float32, device=gi.device)
-    gates = torch.empty((B, H3), dtype=torch.float32, device=gi.device)
+    assert gi.is_contiguous() and gh.is_contiguous()
+    if hnew is None:
+        hnew = torch.empty((B, H), dtype=torch.float32, device=gi.device)
+    if gates is None:
+        gates = torch.empty((B, H3), dtype=torch.float32, device=gi.device)
+    assert hnew.is_contiguous() and gates.is_contiguous()
     check(_lib.lib().murcl_gru_gates_fwd(ptr(gi), ptr(gh), ptr(hprev), ptr(hnew), ptr(gates), B, H, stream()),
           "gru_gates_fwd")
     return hnew, gates
 
 
-def gru_gates_bwd(dh, gates, gh, hprev):
+def gru_gates_bwd(dh, gates, gh, hprev, dgi=None, dgh=None):
     _need_cuda(dh, gates, gh)
     dh = _c(dh)
     B, H = dh.shape
-    dgi = torch.empty((B, 3 * H), dtype=torch.float32, device=dh.device)
-    dgh = torch.empty((B, 3 * H), dtype=torch.float32, device=dh.device)
+    if dgi is None:
+        dgi = torch.empty((B, 3 * H), dtype=torch.float32, device=dh.device)
+    if dgh is None:
+        dgh = torch.empty((B, 3 * H), dtype=torch.float32, device=dh.device)
+    assert dgi.is_contiguous() and dgh.is_contiguous() and gates.is_contiguous() and gh.is_contiguous()
     dhp = torch.empty((B, H), dtype=torch.float32, device=dh.device)
     check(_lib.lib().murcl_gru_gates_bwd(ptr(dh), ptr(gates), ptr(gh), ptr(hprev), ptr(dgi), ptr(dgh), ptr(dhp), B, H,
                                          stream()), "gru_gates_bwd")

@@ -277,17 +277,21 @@ def test_adam_matches_oracle():
 
 # ------------------------------------------------------------------ weight-stationary panel GEMM (bf16)
 def _bits(mask_bool):
-    """[M,N] bool -> the kernel's 1-bit mask layout (panel_gemm.hip header): 128-byte blocks per
-    (32-row tile, 32-column group); byte ((m&15)*4 + (c&3))*2 + ((m&31)>>4), c = n/8; bit e = column 8c+e."""
+    """[M,N] bool -> the kernel's 1-bit mask layout (panel_gemm.hip header): 128-byte blocks per (32-row tile,
+    32-column group); 16-bit word L = 16*((n&15)>>2) + (m&15); bit (7 - idx//2) + 8*(idx&1) with
+    idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3)."""
     M, N = mask_bool.shape
-    w = (2 ** torch.arange(8, dtype=torch.int32)).view(1, 1, 8)
-    by = (mask_bool.view(M, N // 8, 8).int() * w).sum(-1).to(torch.uint8)          # [M, N/8]
     m = torch.arange(M).view(M, 1)
-    c = torch.arange(N // 8).view(1, N // 8)
-    idx = ((m // 32) * (N // 32) + c // 4) * 128 + ((m & 15) * 4 + (c & 3)) * 2 + ((m & 31) >> 4)
-    out = torch.zeros(M * N // 8, dtype=torch.uint8)
-    out[idx.reshape(-1)] = by.reshape(-1)
-    return out.view(M, N // 8)
+    n = torch.arange(N).view(1, N)
+    blk = (m // 32) * (N // 32) + n // 32
+    L = 16 * ((n & 15) >> 2) + (m & 15)
+    idx = 8 * ((m >> 4) & 1) + 4 * ((n >> 4) & 1) + (n & 3)
+    bit = (7 - idx // 2) + 8 * (idx & 1)
+    byte = (blk * 128 + L * 2 + bit // 8).reshape(-1)
+    val = (mask_bool.reshape(-1).int() << (bit % 8).expand(M, N).reshape(-1)).to(torch.int32)
+    out = torch.zeros(M * N // 8, dtype=torch.int32)
+    out.index_add_(0, byte, val)
+    return out.to(torch.uint8).view(M, N // 8)
 
 
 @pytest.mark.parametrize("M", [32, 4096, 131072 + 64])

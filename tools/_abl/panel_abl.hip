@@ -23,18 +23,18 @@
 // accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
 // exactly what "shift left, OR in the packed pair's >0 flags" leaves behind (2 VALU ops per bf16 pair), and
 // the consumer applies it with one v_bfe_i32 + v_and per accumulator value.
-#include "common.h"
+#include "../../murcl_amd/csrc/common.h"
 
 #define PG_TR 32
 #define PG_NSLOT 4
 #ifndef PG_GK
-#define PG_GK 4           // k-steps per LDS prefetch group
+#define PG_GK 2           // k-steps per LDS prefetch group
 #endif
 #ifndef PG_PF
-#define PG_PF 1           // groups requested ahead of the MFMAs
+#define PG_PF 2           // groups requested ahead of the MFMAs
 #endif
 #ifndef PG_WIDE
-#define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
+#define PG_WIDE 1         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
 enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2 };

@@ -14,28 +14,18 @@
 //   K = 128: WN = 64 -> one 512-column panel (dgrad of the attention projection)
 //
 // Epilogue (per tile, per wave, no workgroup barrier): f32 math in accumulator layout (bias+ReLU, or
-// rank-1 term a[m]*v[bag(m)][n]), ReLU' applied / recorded as one bit per element while still in accumulator
-// layout, round to bf16, transpose through a wave-private LDS patch so that each lane owns 8 consecutive
-// columns of a row, accumulate column sums (bias gradients) and store 16 B per lane in whole 128/256-byte row
-// segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
-// Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major.  A block is 64
-// 16-bit words, one per MFMA lane L = 16*((n&15)>>2) + (m&15); element (m, n) of the block is the lane's
-// accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
-// exactly what "shift left, OR in the packed pair's >0 flags" leaves behind (2 VALU ops per bf16 pair), and
-// the consumer applies it with one v_bfe_i32 + v_and per accumulator value.
-#include "common.h"
+// rank-1 term a[m]*v[bag(m)][n]), round to bf16, transpose through a wave-private LDS patch so that each
+// lane owns 8 consecutive columns of a row, then ReLU'-mask from a 1-bit-per-element mask, accumulate
+// column sums (bias gradients) and store 16 B per lane in whole 128/256-byte row segments.
+// The forward variant emits that bit mask, so the backward reads 1/16 of the bytes of H to apply ReLU'.
+// Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major; inside a block
+// byte ((m&15)*4 + (n&31)/8)*2 + ((m&31)>>4) holds columns 8*(n/8)..+7 of row m (bit e = column 8*(n/8)+e),
+// i.e. exactly the two bytes a lane of the producing wave owns, stored as one 16-bit word.
+#include "../../murcl_amd/csrc/common.h"
 
 #define PG_TR 32
 #define PG_NSLOT 4
-#ifndef PG_GK
-#define PG_GK 4           // k-steps per LDS prefetch group
-#endif
-#ifndef PG_PF
-#define PG_PF 1           // groups requested ahead of the MFMAs
-#endif
-#ifndef PG_WIDE
-#define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
-#endif
+#define PG_NW 8
 
 enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2 };
 
@@ -48,16 +38,8 @@ __device__ __forceinline__ void pg_store2(void* p, unsigned v) {
     asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-// per bf16 half of w: 1 if > 0 (signed 16-bit compare: -0.0 and negatives give 0), else 0.  Inline asm because hipcc
-// turns the min/max pair into two compares, two selects and a permute.
-__device__ __forceinline__ unsigned pg_pos_flags(unsigned w, unsigned ones) {
-    unsigned t;
-    asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(t) : "v"(w), "v"(ones));
-    return t;
-}
-
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
-__global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
+template <int K, int WN, int EPI, bool BM_OUT>
+__global__ __launch_bounds__(64 * PG_NW, 2) void panel_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
     const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
     const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
@@ -69,7 +51,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr int PADB = PAD ? ROWB + 16 : ROWB;
     constexpr int SLOT = PG_TR * PADB;          // 32.5 KiB / 8 KiB
     constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
-    constexpr int GT = PAD ? PG_TR / PG_NW : SLOT / (PG_NW * 1024);   // tile LDS-DMA ops per wave
+    constexpr int GT = SLOT / (PG_NW * 1024);   // tile LDS-DMA ops per wave: 4 / 1
     constexpr int NJ = WN / 16, NKK = K / 32;
     constexpr int NP = PG_NW * WN;              // columns per workgroup: 256 / 512
     constexpr int CPW = WN / 8;                 // 16-byte chunks per output row per wave: 4 / 8
@@ -79,8 +61,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr int NB = (EPI != PG_BIAS_RELU) ? 1 : 0;               // mask LDS-DMA op (128 or 256 B per wave)
     constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
     constexpr int G = GT + NB + NR;             // counted loads per tile per wave
-    constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
-    constexpr int S = NS + NMS;                 // counted stores per tile per wave
+    constexpr int S = NS + (BM_OUT ? 1 : 0);    // counted stores per tile per wave
     // LDS carve
     constexpr int OFF_STG = PG_NSLOT * SLOT;
     constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
@@ -151,12 +132,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                bias_r[j][r] = bias[n0 + 16 * j + 4 * q4 + r];
-                // pinned here so that hipcc waits for these loads now: left alone it puts its s_waitcnt vmcnt(0) at
-                // the first use, inside the tile loop, where it drains the LDS-DMA ring on every tile
-                asm volatile("" : "+v"(bias_r[j][r]));
-            }
+            for (int r = 0; r < 4; ++r) bias_r[j][r] = bias[n0 + 16 * j + 4 * q4 + r];
     }
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
     int cur_bag = -1;
@@ -165,6 +141,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    static_assert(!BM_OUT || (WN == 32 && NS == 2), "mask producer layout assumes 32-column waves");
     char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
     const int crow = lane / CPW, cchunk = lane % CPW;            // row-wise phase: row RPI*g + crow, chunk cchunk
 
@@ -182,60 +159,21 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         const int sl = seq % PG_NSLOT;
         const char* tile = smem + sl * SLOT;
 
-        // this lane's mask words (one per 32-column block of the wave), requested ahead of the MFMA loop
-        unsigned mw[NJ / 2];
-        unsigned ones = 0x00010001u;
-        asm volatile("" : "+v"(ones));
-#pragma unroll
-        for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = 0u;
-        if (EPI != PG_BIAS_RELU) {
-            const uint16_t* bml = (const uint16_t*)(smem + OFF_BM + (sl * PG_NW + wave) * 256);
-#pragma unroll
-            for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = bml[bq * 64 + lane];
-        }
-
         f32x4 acc[2][NJ];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* hb = tile + r16 * PADB + NKK * q4 * 16;               // PAD: base + immediates only
-        if (PAD) {
-            // explicit software pipeline: the fragments of k-group g+PG_PF are requested before the MFMAs of group g
-            // are issued (left alone hipcc keeps only two ds_read_b128 in flight and the MFMAs wait on LDS latency)
-            constexpr int GK = PG_GK, NG = NKK / GK, D = PG_PF, NBUF = D + 1;
-            bf16x8 hq[NBUF][GK][2];
-            auto load_grp = [&](int g, int buf) {
 #pragma unroll
-                for (int k2 = 0; k2 < GK; ++k2)
+        for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) hq[buf][k2][i] = *(const bf16x8*)(hb + i * 16 * PADB + (g * GK + k2) * 16);
-            };
+            for (int i = 0; i < 2; ++i) {
+                const int row = 16 * i + r16, c = 4 * kk + q4;
+                const bf16x8 h = PAD ? *(const bf16x8*)(hb + i * 16 * PADB + kk * 16)
+                                     : *(const bf16x8*)(tile + row * ROWB + ((c ^ (row & 15)) << 4));
 #pragma unroll
-            for (int g = 0; g < D; ++g) load_grp(g, g);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + D < NG) load_grp(g + D, (g + D) % NBUF);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k2 = 0; k2 < GK; ++k2)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][g * GK + k2], hq[g % NBUF][k2][i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = 16 * i + r16, c = 4 * kk + q4;
-                    const bf16x8 h = *(const bf16x8*)(tile + row * ROWB + ((c ^ (row & 15)) << 4));
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], h, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], h, acc[i][j], 0, 0, 0);
             }
         }
 
@@ -267,39 +205,46 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += a_m * rk[j][r];
                 }
-                if (EPI != PG_BIAS_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int idx = 8 * i + 4 * (j & 1) + r;
-                        const int keep = __builtin_amdgcn_sbfe((int)mw[j >> 1], (7 - (idx >> 1)) + 8 * (idx & 1), 1);   // 0 / -1
-                        v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
-                    }
-                }
-                const unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
-                if (BM_OUT) {
-                    const unsigned f0 = pg_pos_flags(w0, ones), f1 = pg_pos_flags(w1, ones);
-                    mw[j >> 1] = (mw[j >> 1] << 1) | f0;
-                    mw[j >> 1] = (mw[j >> 1] << 1) | f1;
-                }
-                *(u32x2*)(stg + row * STG_LD + (16 * j + 4 * q4) * 2) = u32x2{w0, w1};
+                *(u32x2*)(stg + row * STG_LD + (16 * j + 4 * q4) * 2) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             }
         }
-        if (BM_OUT) {
-            uint8_t* blk = bm_out + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128;
-#pragma unroll
-            for (int bq = 0; bq < NJ / 2; ++bq) pg_store2(blk + bq * 128 + lane * 2, mw[bq] | (mw[bq] >> 8));
-        }
         // ---- row-wise phase: lane owns 8 consecutive columns (one 16-byte chunk) of RPI rows per pass
+        const uint8_t* bml = (const uint8_t*)(smem + OFF_BM + (sl * PG_NW + wave) * 256);
+        unsigned mword = 0;
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
             const int row = RPI * g + crow;
-            const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
+            u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
+            if (EPI != PG_BIAS_RELU) {
+                // block (cchunk>>2) of this wave; byte ((row&15)*4 + (cchunk&3))*2 + (row>>4)
+                const unsigned mb = bml[(cchunk >> 2) * 128 + (((row & 15) * 4 + (cchunk & 3)) << 1) + (row >> 4)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned w = u[e];
+                    if (!((mb >> (2 * e)) & 1)) w &= 0xffff0000u;
+                    if (!((mb >> (2 * e + 1)) & 1)) w &= 0x0000ffffu;
+                    u[e] = w;
+                }
+            }
             if (colsum_out) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { csum[2 * e] += bf_lo(u[e]); csum[2 * e + 1] += bf_hi(u[e]); }
             }
-            pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
+            bf16_t* dst = C + (size_t)(row0 + row) * N + n0 + cchunk * 8;
+            pg_store16(dst, u);
+            if (BM_OUT) {
+                unsigned mb = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // bf16 > 0  <=>  sign clear and not zero (post-ReLU values are never negative)
+                    mb |= ((u[e] & 0x7fffu) != 0 && !(u[e] & 0x8000u)) ? (1u << (2 * e)) : 0u;
+                    mb |= ((u[e] & 0x7fff0000u) != 0 && !(u[e] & 0x80000000u)) ? (1u << (2 * e + 1)) : 0u;
+                }
+                mword |= mb << (8 * g);          // BM_OUT variant: NS == 2, row = 16g + crow
+            }
         }
+        if (BM_OUT)      // lane (crow, cchunk) owns bytes ((crow*4 + cchunk)*2 + {0,1}) of this wave's block
+            pg_store2(bm_out + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128 + lane * 2, mword);
     }
 
     if (colsum_out) {
@@ -314,7 +259,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
 }
 
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
+template <int K, int WN, int EPI, bool BM_OUT>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
                      float* colsum_out, hipStream_t s) {
@@ -323,7 +268,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD + (EPI != PG_BIAS_RELU ? PG_NSLOT * PG_NW * 256 : 0) +
                         (EPI == PG_RANK1_MASK ? PG_NSLOT * PG_NW * 256 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
+    auto k = panel_nt_kernel<K, WN, EPI, BM_OUT>;
     static bool once = false;
     if (!once) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -361,16 +306,16 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     const uint8_t* bi = (const uint8_t*)bitmask_in;
     if (K == 512 && epilogue == PG_BIAS_RELU) {
         if (!bias) return -1;
-        return bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream)
-                  : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+        return bo ? pg_launch<512, 32, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream)
+                  : pg_launch<512, 32, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
     }
     if (K == 512 && epilogue == PG_MASK) {
         if (!bi) return -1;
-        return pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+        return pg_launch<512, 32, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
     }
     if (K == 128 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
-        return pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+        return pg_launch<128, 64, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
     }
     return -1;
 }
