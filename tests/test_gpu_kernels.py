@@ -90,7 +90,8 @@ def test_gemm_nt_accumulate():
 
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (1000, 128, 512), (130, 3072, 512), (77, 16, 1024), (20000, 512, 128)])
+@pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (1000, 128, 512), (130, 3072, 512), (77, 16, 1024), (20000, 512, 128),
+                                     (8192 + 37, 512, 512), (4100, 256, 128), (65536, 512, 512)])
 def test_gemm_tn(dtype, M, N1, N2):
     from murcl_amd import ops
     dev = _dev()

@@ -10,7 +10,8 @@
 // f32 inputs the exact-f32 v_mfma_f32_16x16x4_f32 (parity path).  LDS images are XOR-swizzled on
 // the 16-byte chunk index; the swizzle is applied to the per-lane *source* address (the LDS-DMA
 // destination is lane-linear) and again on the fragment reads.
-#include "common.h"
+#include <cstdlib>
+#include "../../murcl_amd/csrc/common.h"
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_RANK1_MASK = 4 };
 
@@ -695,7 +696,8 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
     const int es = dtype == MURCL_DTYPE_BF16 ? 2 : 4, epc = 16 / es;
     if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
-    if (dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 128 == 0 && M >= 4096) {
+    static const bool wide_ok = !(getenv("MURCL_TN_WIDE") && getenv("MURCL_TN_WIDE")[0] == '0');   // dev A/B switch
+    if (wide_ok && dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 128 == 0 && M >= 4096) {
         const int tiles = (N1 / 256) * (N2 / 128);
         int sp = splits;
         if (sp <= 0) {                           // one 144 KiB-LDS workgroup per CU, splits % 8 == 0
