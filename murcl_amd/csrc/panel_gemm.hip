@@ -348,9 +348,10 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
 
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
-                                const float* rank1, int rows_per_bag, float* colsum_out, hipStream_t stream) {
+                                const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
+                                hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
-    if (colsum_out) {
+    if (colsum_out && !colsum_accumulate) {
         hipError_t e = hipMemsetAsync(colsum_out, 0, (size_t)N * 4, stream);
         if (e != hipSuccess) return (int)e;
     }

@@ -13,6 +13,47 @@ def _flat2(x):
     return x.reshape(-1, x.shape[-1])
 
 
+# Direct gradient accumulation.  With FlatAdam every parameter's ``.grad`` is a zeroed view of one flat buffer before
+# the backward pass starts, so the weight-gradient GEMM / column-sum kernels can add into it themselves (their split-M
+# reduction accumulates into the output anyway) and hand autograd ``None``: no zero-filled temporary and no
+# AccumulateGrad add per parameter.  Opt-in because it bypasses per-parameter autograd hooks.
+_DIRECT = False
+
+
+def set_direct_grad(flag):
+    """Enable/disable accumulation of parameter gradients straight into pre-seated ``.grad`` buffers."""
+    global _DIRECT
+    _DIRECT = bool(flag)
+
+
+def _direct(p):
+    return _DIRECT and p is not None and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+
+
+def _wgrad(dy, x, w):
+    """dW = dy^T x [N1,N2]; returns it, or adds it to w.grad and returns None."""
+    if _direct(w):
+        ops.gemm_tn(dy, x, out=w.grad)
+        return None
+    return ops.gemm_tn(dy, x)
+
+
+def _bgrad(dy, b):
+    """db = column sums of dy."""
+    if _direct(b):
+        ops.colsum(dy, out=b.grad.view(-1), accumulate=True)
+        return None
+    return ops.colsum(dy)
+
+
+def _pgrad(g, p):
+    """A gradient that a kernel already produced as its own tensor."""
+    if _direct(p):
+        p.grad.add_(g.view_as(p.grad))
+        return None
+    return g
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) for small (bag-level) f32 matrices; act in {none, relu}."""
 
@@ -20,14 +61,14 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, relu):
         x2 = _flat2(x).contiguous()
         y = ops.gemm_nt(x2, w, epi=ops.EPI_BIAS_RELU if relu else ops.EPI_BIAS, bias=b)
-        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.save_for_backward(x2, w, y if relu else None, b)
         ctx.relu = relu
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
+        x2, w, y, b = ctx.saved_tensors
         dy2 = _flat2(dy).contiguous()
         if ctx.relu:
             dy2 = ops.relu_bwd(dy2, y)
@@ -35,9 +76,9 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy2, ops.transpose_cast(w, torch.float32)).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy2, x2)
+            dw = _wgrad(dy2, x2, w)
         if ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)
+            db = _bgrad(dy2, b)
         return dx, dw, db, None
 
 
@@ -71,48 +112,54 @@ class ABMILFn(torch.autograd.Function):
         wac = c(wa)
         scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
         out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
-        ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3)
+        ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
+                              b1, b2, b3, bb, bd)
         ctx.dims = (B, N, d)
         ctx.mark_non_differentiable(A)
         return out, A
 
     @staticmethod
     def backward(ctx, dout, _dA):
-        x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3 = ctx.saved_tensors
+        (x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
+         b1, b2, b3, bb, bd) = ctx.saved_tensors
         B, N, d = ctx.dims
         T = x2.dtype
         L = h3.shape[1]
         # decoder (bag level, f32)
         dpre = ops.relu_bwd(dout.contiguous(), out)
-        dwd = ops.gemm_tn(dpre, M)
-        dbd = ops.colsum(dpre)
+        dwd = _wgrad(dpre, M, wd)
+        dbd = _bgrad(dpre, bd)
         dM = ops.gemm_nt(dpre, ops.transpose_cast(wd, torch.float32))
         # attention pooling
         dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
-        dwa = ops.gemm_tn(dT, h3)
+        dwa = _wgrad(dT, h3, wa)
         # encoder layer 3: dZ3 = (dT Wa + A (x) dM) * relu'(H3)
         if m3 is not None:
+            into = lambda b: b.grad.view(-1) if _direct(b) else None      # bias gradients straight from the epilogue
             dz3, _, db3 = ops.panel_gemm(dT, ops.transpose_cast(wa, T), ops.PG_RANK1_MASK, bitmask=m3,
-                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
-            dw3 = ops.gemm_tn(dz3, h2)
-            dz2, _, db2 = ops.panel_gemm(dz3, ops.transpose_cast(w3, T), ops.PG_MASK, bitmask=m2, colsum=True)
-            dw2 = ops.gemm_tn(dz2, h1)
-            dz1, _, db1 = ops.panel_gemm(dz2, ops.transpose_cast(w2, T), ops.PG_MASK, bitmask=m1, colsum=True)
+                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_into=into(b3))
+            dw3 = _wgrad(dz3, h2, w3)
+            dz2, _, db2 = ops.panel_gemm(dz3, ops.transpose_cast(w3, T), ops.PG_MASK, bitmask=m2, colsum=True,
+                                         colsum_into=into(b2))
+            dw2 = _wgrad(dz2, h1, w2)
+            dz1, _, db1 = ops.panel_gemm(dz2, ops.transpose_cast(w2, T), ops.PG_MASK, bitmask=m1, colsum=True,
+                                         colsum_into=into(b1))
         else:
             dz3, ws = ops.gemm_nt(dT, ops.transpose_cast(wa, T), epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
                                   rank1=dM, rows_per_bag=N, colsum=True)
-            db3 = ops.colsum(ws)
-            dw3 = ops.gemm_tn(dz3, h2)
+            db3 = _bgrad(ws, b3)
+            dw3 = _wgrad(dz3, h2, w3)
             dz2, ws = ops.gemm_nt(dz3, ops.transpose_cast(w3, T), epi=ops.EPI_MASK, mask=h2, colsum=True)
-            db2 = ops.colsum(ws)
-            dw2 = ops.gemm_tn(dz2, h1)
+            db2 = _bgrad(ws, b2)
+            dw2 = _wgrad(dz2, h1, w2)
             dz1, ws = ops.gemm_nt(dz2, ops.transpose_cast(w2, T), epi=ops.EPI_MASK, mask=h1, colsum=True)
-            db1 = ops.colsum(ws)
-        dw1 = ops.gemm_tn(dz1, x2)
+            db1 = _bgrad(ws, b1)
+        dw1 = _wgrad(dz1, x2, w1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dz1, ops.transpose_cast(w1, T)).view(B, N, d)
-        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb.view(1, -1), dbb, dwd, dbd
+        return (dx, dw1, db1, dw2, db2, dw3, db3, dwa, _pgrad(dba, ba), _pgrad(dwb.view(1, -1), wb), _pgrad(dbb, bb),
+                dwd, dbd)
 
 
 class GRUStepFn(torch.autograd.Function):
@@ -128,21 +175,21 @@ class GRUStepFn(torch.autograd.Function):
             h_prev = h_prev.contiguous()
             gh = ops.gemm_nt(h_prev, w_hh, epi=ops.EPI_BIAS, bias=b_hh)
         h_new, gates = ops.gru_gates_fwd(gi, gh, h_prev)
-        ctx.save_for_backward(x, h_prev, w_ih, w_hh, gates, gh)
+        ctx.save_for_backward(x, h_prev, w_ih, w_hh, gates, gh, b_ih, b_hh)
         return h_new
 
     @staticmethod
     def backward(ctx, dh):
-        x, h_prev, w_ih, w_hh, gates, gh = ctx.saved_tensors
+        x, h_prev, w_ih, w_hh, gates, gh, b_ih, b_hh = ctx.saved_tensors
         dgi, dgh, dhp = ops.gru_gates_bwd(dh.contiguous(), gates, gh, h_prev)
         dx = ops.gemm_nt(dgi, ops.transpose_cast(w_ih, torch.float32)) if ctx.needs_input_grad[0] else None
-        dw_ih = ops.gemm_tn(dgi, x)
-        db_ih = ops.colsum(dgi)
-        db_hh = ops.colsum(dgh)
+        dw_ih = _wgrad(dgi, x, w_ih)
+        db_ih = _bgrad(dgi, b_ih)
+        db_hh = _bgrad(dgh, b_hh)
         if h_prev is None:
-            dh_prev, dw_hh = None, torch.zeros_like(w_hh)
+            dh_prev, dw_hh = None, (None if _direct(w_hh) else torch.zeros_like(w_hh))
         else:
-            dw_hh = ops.gemm_tn(dgh, h_prev)
+            dw_hh = _wgrad(dgh, h_prev, w_hh)
             dh_prev = None
             if ctx.needs_input_grad[1]:
                 dh_prev = ops.gemm_nt(dgh, ops.transpose_cast(w_hh, torch.float32), out=dhp, accumulate=True)
@@ -170,12 +217,12 @@ class GRUSeqFn(torch.autograd.Function):
             if t:
                 ops.gemm_nt(hs[t - 1], w_hh, epi=ops.EPI_BIAS, bias=b_hh, out=gh[t])
             ops.gru_gates_fwd(gi[t], gh[t], hs[t - 1] if t else None, hnew=hs[t], gates=gates[t])
-        ctx.save_for_backward(x2, w_ih, w_hh, gates, gh, hs)
+        ctx.save_for_backward(x2, w_ih, w_hh, gates, gh, hs, b_ih, b_hh)
         return hs
 
     @staticmethod
     def backward(ctx, dhs):
-        x2, w_ih, w_hh, gates, gh, hs = ctx.saved_tensors
+        x2, w_ih, w_hh, gates, gh, hs, b_ih, b_hh = ctx.saved_tensors
         T, B, H = hs.shape
         dhs = dhs.contiguous()
         dgi, dgh = torch.empty_like(gh), torch.empty_like(gh)
@@ -190,9 +237,12 @@ class GRUSeqFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dgi2, ops.transpose_cast(w_ih, torch.float32)).view(T, B, -1)
-        dw_ih = ops.gemm_tn(dgi2, x2)
-        dw_hh = ops.gemm_tn(dgh2[B:], hs.view(T * B, H)[:-B]) if T > 1 else torch.zeros_like(w_hh)
-        return dx, dw_ih, dw_hh, ops.colsum(dgi2), ops.colsum(dgh2)
+        dw_ih = _wgrad(dgi2, x2, w_ih)
+        if T > 1:
+            dw_hh = _wgrad(dgh2[B:], hs.view(T * B, H)[:-B], w_hh)
+        else:
+            dw_hh = None if _direct(w_hh) else torch.zeros_like(w_hh)
+        return dx, dw_ih, dw_hh, _bgrad(dgi2, b_ih), _bgrad(dgh2, b_hh)
 
 
 class NTXentFn(torch.autograd.Function):

@@ -119,8 +119,9 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False):
-    """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None)."""
+               colsum=False, colsum_into=None):
+    """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
+    ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None."""
     _need_cuda(A, W)
     A, W = _c(A), _c(W)
     M, K = A.shape
@@ -128,11 +129,15 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
     C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     bm = torch.empty((M, N // 8), dtype=torch.uint8, device=A.device) if want_bitmask else None
-    cs = torch.empty((N,), dtype=torch.float32, device=A.device) if colsum else None
+    cs = torch.empty((N,), dtype=torch.float32, device=A.device) if (colsum and colsum_into is None) else None
+    if colsum_into is not None:
+        assert colsum_into.is_contiguous() and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
     with _span(f"panel_gemm<K{K},{_PG_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0))):
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
-                                          ptr(rowscale), ptr(rank1), rows_per_bag, ptr(cs), stream()), "panel_gemm")
+                                          ptr(rowscale), ptr(rank1), rows_per_bag,
+                                          ptr(colsum_into if colsum_into is not None else cs),
+                                          int(colsum_into is not None), stream()), "panel_gemm")
     return C, bm, cs
 
 
@@ -144,10 +149,11 @@ def gemm_tn(A, B, *, splits=0, out=None):
     N2 = B.shape[1]
     assert B.shape[0] == M and A.dtype == B.dtype
     epc = 4 if A.dtype == torch.float32 else 8
-    if N1 % epc and out is None:    # tiny head gradients (N1 = 1, 2, 10): zero-pad the columns of A, slice the result
+    if N1 % epc:                    # tiny head gradients (N1 = 1, 2, 10): zero-pad the columns of A, slice the result
         Ap = A.new_zeros((M, ((N1 + epc - 1) // epc) * epc))
         Ap[:, :N1] = A
-        return gemm_tn(Ap, B, splits=splits)[:N1].contiguous()
+        res = gemm_tn(Ap, B, splits=splits)[:N1]
+        return out.add_(res) if out is not None else res.contiguous()
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     with _span(f"gemm_tn<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4)):

@@ -3,6 +3,10 @@
 Parameters of each group are re-seated as views of one contiguous f32 buffer, and so are their
 ``.grad``s: ``zero_grad`` is one memset, ``step`` one kernel launch per group, and a data-parallel
 gradient all-reduce is one collective over the flat gradient buffer (no per-tensor buckets).
+
+Because every ``.grad`` exists (zeroed) before backward starts, the backward kernels add weight and bias gradients
+straight into the flat buffer (``functional.set_direct_grad``; pass ``direct_grad=False`` to keep autograd's own
+AccumulateGrad path, e.g. when per-parameter hooks are registered).
 """
 import torch
 
@@ -10,7 +14,9 @@ from . import ops
 
 
 class FlatAdam:
-    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True):
+        from . import functional
+        functional.set_direct_grad(direct_grad)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.groups = []
         self.step_count = 0
