@@ -62,7 +62,7 @@ def make_step(model, fc, opt, crit, views, world):
         outs, _ = model(views)
         if reducer is not None:
             reducer.arm(outs)              # head-gradient all-reduce starts when backward reaches the aggregator
-        z = [fc(o, restart=True) for o in outs]
+        z = fc.forward_views(outs, restart=True)
         if world > 1:
             loss, _ = mdist.gathered_nt_xent(z[0], z[1], 1.0)
         else:

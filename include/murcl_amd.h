@@ -165,9 +165,10 @@ int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, fl
 int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
                         float* dgh, float* dhprev, int B, int H, murcl_stream_t stream);
 
-/* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182). */
-int murcl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int step, murcl_stream_t stream);
+/* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g
+ * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */
+int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, int zero_grad, murcl_stream_t stream);
 
 #ifdef __cplusplus
 }

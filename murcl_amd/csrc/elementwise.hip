@@ -169,13 +169,14 @@ extern "C" int murcl_gru_gates_bwd(const float* dh, const float* gates, const fl
 }
 
 // ---------------------------------------------------------------- Adam (torch.optim.Adam semantics, L2 weight decay)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                            float bc1, float bc2_sqrt) {
+                            float bc1, float bc2_sqrt, int zero_grad) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         float gi = g[i];
+        if (zero_grad) g[i] = 0.f;              // next step's zero_grad folded into this pass
         const float pi = p[i];
         if (wd != 0.f) gi += wd * pi;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -186,12 +187,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] = pi - (lr / bc1) * (mi / denom);
     }
 }
-extern "C" int murcl_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, int step, hipStream_t s) {
+extern "C" int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, int zero_grad, hipStream_t s) {
     if (n <= 0) return 0;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, zero_grad);
     return MURCL_CHECK_LAUNCH();
 }

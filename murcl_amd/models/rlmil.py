@@ -64,6 +64,22 @@ class Full_layer(nn.Module):
         return LinearFn.apply(self.hidden, head.weight, head.bias, False)
 
 
+    def forward_views(self, xs, restart=False):
+        """``[self(x, restart) for x in xs]`` - the per-view loop of the training scripts (train_MuRCL.py:243,272).
+
+        With ``restart=True`` every view starts from a zero hidden state, so the views are independent rows of one
+        batch: they run through ONE GRU step / classifier GEMM (row-wise identical math, half the launches) and
+        ``self.hidden`` ends as the last view's state, exactly as after the sequential loop."""
+        xs = list(xs)
+        if not (self.fc_rnn and restart and len(xs) > 1 and len({tuple(x.shape) for x in xs}) == 1):
+            return [self(x, restart) for x in xs]
+        n = xs[0].shape[0]
+        r = self.rnn
+        h = GRUStepFn.apply(torch.cat(xs, 0), None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        self.hidden = h[-n:].unsqueeze(0)
+        return list(LinearFn.apply(h, self.fc.weight, self.fc.bias, False).split(n, 0))
+
+
 class ActorCritic(nn.Module):
     def __init__(self, feature_dim, state_dim, hidden_state_dim=1024, policy_conv=False, action_std=0.1, action_size=2):
         super().__init__()

@@ -304,11 +304,12 @@ def gru_gates_bwd(dh, gates, gh, hprev, dgi=None, dgh=None):
     return dgi, dgh, dhp
 
 
-def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step):
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, zero_grad=False):
     _need_cuda(p, g, m, v)
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
     check(_lib.lib().murcl_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]),
-                                     float(betas[1]), float(eps), float(weight_decay), int(step), stream()), "adam_step")
+                                     float(betas[1]), float(eps), float(weight_decay), int(step), int(zero_grad),
+                                     stream()), "adam_step")
 
 
 # ------------------------------------------------------------------------------------------ DSMIL (K6)

@@ -6,7 +6,8 @@ gradient all-reduce is one collective over the flat gradient buffer (no per-tens
 
 Because every ``.grad`` exists (zeroed) before backward starts, the backward kernels add weight and bias gradients
 straight into the flat buffer (``functional.set_direct_grad``; pass ``direct_grad=False`` to keep autograd's own
-AccumulateGrad path, e.g. when per-parameter hooks are registered).
+AccumulateGrad path, e.g. when per-parameter hooks are registered).  ``step`` also clears the gradient buffer in its
+own pass (``fused_zero``), so the ``zero_grad`` that follows costs nothing; gradients are therefore zero AFTER ``step``.
 """
 import torch
 
@@ -14,10 +15,11 @@ from . import ops
 
 
 class FlatAdam:
-    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True):
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True, fused_zero=True):
         from . import functional
         functional.set_direct_grad(direct_grad)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.fused_zero, self._maybe_dirty = fused_zero, False      # the flat grads start as zeros
         self.groups = []
         self.step_count = 0
         for g in param_groups:
@@ -44,11 +46,15 @@ class FlatAdam:
         return [g["g"] for g in self.groups]
 
     def zero_grad(self):
-        for g in self.groups:
-            g["g"].zero_()
+        if self._maybe_dirty:                      # step() already cleared the buffers in its own pass
+            for g in self.groups:
+                g["g"].zero_()
+        self._maybe_dirty = True                   # a backward pass follows
 
     def step(self):
         self.step_count += 1
         for g in self.groups:
             ops.adam_step(g["p"], g["g"], g["m"], g["v"], g["lr"], self.betas, self.eps, self.weight_decay,
-                          self.step_count)
+                          self.step_count, zero_grad=self.fused_zero)
+        if self.fused_zero:
+            self._maybe_dirty = False

@@ -99,7 +99,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                                 draws=None if injected is None else injected["draws"][t])   # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
             outputs, states = model(views)                                                   # :242,271
-            outputs = [fc(o, restart=(t == 0)) for o in outputs]                             # :243,272
+            outputs = fc.forward_views(outputs, restart=(t == 0))                            # :243,272
             if world > 1:
                 loss, sim = mdist.gathered_nt_xent(outputs[0], outputs[1], args.temperature)
             else:

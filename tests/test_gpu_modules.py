@@ -135,6 +135,34 @@ def test_full_layer_interleaved_hidden_golden(golden):
                 np.testing.assert_allclose(fc.hidden[0].cpu().numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
 
 
+def test_full_layer_forward_views_equals_the_per_view_loop():
+    """forward_views(restart=True) batches the independent views: same outputs, hidden state and gradients as
+    the reference's `[fc(o, restart) for o in outputs]` loop (train_MuRCL.py:243); restart=False stays sequential."""
+    from murcl_amd.models.rlmil import Full_layer
+    dev = _dev()
+
+    def run(batched):
+        fc = Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        fc = fc.to(dev)
+        zs = []
+        for t in range(2):
+            xs = [T(detrand.normal(31, f"fv.x.{t}.{v}", (8, 512))).to(dev).requires_grad_() for v in range(2)]
+            out = fc.forward_views(xs, restart=(t == 0)) if batched else [fc(x, restart=(t == 0)) for x in xs]
+            zs += out
+        loss = sum((z * z).sum() * (i + 1) for i, z in enumerate(zs))
+        loss.backward()
+        return [z.detach().cpu() for z in zs], fc.hidden.detach().cpu(), {k: v.grad.cpu() for k, v in fc.named_parameters()}
+
+    za, ha, ga = run(True)
+    zb, hb, gb = run(False)
+    for a, b in zip(za, zb):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ha.numpy(), hb.numpy(), rtol=1e-5, atol=1e-6)
+    for k in ga:
+        np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=2e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-7, err_msg=k)
+
+
 @pytest.mark.parametrize("Tn", [1, 3])
 def test_pretrain_step_golden(golden, Tn):
     """G3: CL(ABMIL) + Full_layer + NT_Xent over T patch-steps: losses, rewards, gradients vs the reference."""
