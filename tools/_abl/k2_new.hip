@@ -14,9 +14,9 @@
 // 1 KiB inside one row, so the pad is free): 16 lanes reading the same 16-byte chunk of 16 consecutive
 // rows hit 16 different bank slots, every fragment address is base + immediate, and the DMA source is
 // plain row-major (wave-uniform SGPR base + lane*16).
-#include "common.h"
+#include "../../murcl_amd/csrc/common.h"
 
-#include "k2_common.h"
+#include "../../murcl_amd/csrc/k2_common.h"
 
 #ifndef K2_GK
 #define K2_GK 4                  // k-steps per LDS prefetch group in the score MFMA loop

@@ -14,13 +14,9 @@
 // 1 KiB inside one row, so the pad is free): 16 lanes reading the same 16-byte chunk of 16 consecutive
 // rows hit 16 different bank slots, every fragment address is base + immediate, and the DMA source is
 // plain row-major (wave-uniform SGPR base + lane*16).
-#include "common.h"
+#include "../../murcl_amd/csrc/common.h"
 
-#include "k2_common.h"
-
-#ifndef K2_GK
-#define K2_GK 4                  // k-steps per LDS prefetch group in the score MFMA loop
-#endif
+#include "../../murcl_amd/csrc/k2_common.h"
 
 template <typename T, bool EXACT_TANH>
 __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
@@ -110,26 +106,11 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < C_::NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* hbase = tile + r16 * C_::PADB + C_::NKK * q4 * 16;
-        {
-            // explicit software pipeline: the fragments of k-group g+1 are requested before the MFMAs of group g issue
-            // (left alone hipcc keeps two ds_read_b128 in flight and every MFMA pair waits out an LDS round trip)
-            constexpr int GK = K2_GK, NG = C_::NKK / GK;
-            frag_t hq[2][GK];
 #pragma unroll
-            for (int k2 = 0; k2 < GK; ++k2) hq[0][k2] = *(const frag_t*)(hbase + k2 * 16);
+        for (int kk = 0; kk < C_::NKK; ++kk) {
+            const frag_t h = *(const frag_t*)(hbase + kk * 16);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
-#pragma unroll
-                    for (int k2 = 0; k2 < GK; ++k2) hq[(g + 1) & 1][k2] = *(const frag_t*)(hbase + ((g + 1) * GK + k2) * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k2 = 0; k2 < GK; ++k2)
-#pragma unroll
-                    for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][g * GK + k2], hq[g & 1][k2], acc[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][kk], h, acc[j]);
         }
         float ps = 0.f;
 #pragma unroll

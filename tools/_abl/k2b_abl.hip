@@ -13,8 +13,11 @@
 // per-row dots g_n = dM.H_n also run on the matrix cores: dM enters as rows 0/1 (bf16 hi + lo parts; f32: row 0)
 // of an MFMA A operand and every wave covers 1/NW of the k range, partial sums meet in LDS.  The saved raw scores
 // of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
-#include "k2_common.h"
+#include "../../murcl_amd/csrc/k2_common.h"
 
+#ifndef KB_ABLATE
+#define KB_ABLATE 0
+#endif
 template <typename T> struct KBLds {
     static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32
     static constexpr int OFF_SC = OFF_GPART + K2<T>::NW * 16 * 4;                   // [slot][NW][64] f32
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         const int sl = seq & (K2_NSLOT - 1);
         k2_issue_tile<T>(H + (size_t)ip.bag * N * K2_L, row0, N, lds0 + sl * C_::SLOT, wave, lane);
         // fifth op: this wave's private copy of the tile's saved scores (lane r <-> row r, clamped)
-        glds4_s(scores + (size_t)ip.bag * N, (unsigned)min(row0 + (lane & 15), N - 1) * 4u,
+        if (KB_ABLATE != 4) glds4_s(scores + (size_t)ip.bag * N, (unsigned)min(row0 + (lane & 15), N - 1) * 4u,
                 lds0 + L_::OFF_SC + (sl * C_::NW + wave) * 256);
         ip.next(tiles_per_item, gridDim.x, S);
     };
@@ -88,10 +91,12 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         // only the 5 LDS-DMA ops per tile are counted; the dT stores issued in between are also younger than
         // tile seq's loads, which only makes this wait more conservative
         const int ahead = min(2, my_tiles - 1 - seq);
+        if (KB_ABLATE == 4) { if (ahead == 2) { WAIT_VMCNT(8); } else if (ahead == 1) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); } } else
         if (ahead == 2) { WAIT_VMCNT(10); } else if (ahead == 1) { WAIT_VMCNT(5); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();
         if (seq + 3 < my_tiles) issue(seq + 3);
 
+        if (KB_ABLATE >= 2) { cp.next(tiles_per_item, gridDim.x, S); continue; }
         const int bag = cp.bag;
         const int row0 = cp.ch * chunk_rows + cp.tin * C_::TR;
         const int sl = seq & (K2_NSLOT - 1);

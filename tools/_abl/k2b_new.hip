@@ -13,7 +13,7 @@
 // per-row dots g_n = dM.H_n also run on the matrix cores: dM enters as rows 0/1 (bf16 hi + lo parts; f32: row 0)
 // of an MFMA A operand and every wave covers 1/NW of the k range, partial sums meet in LDS.  The saved raw scores
 // of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
-#include "k2_common.h"
+#include "../../murcl_amd/csrc/k2_common.h"
 
 template <typename T> struct KBLds {
     static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32

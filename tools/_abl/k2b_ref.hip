@@ -13,7 +13,7 @@
 // per-row dots g_n = dM.H_n also run on the matrix cores: dM enters as rows 0/1 (bf16 hi + lo parts; f32: row 0)
 // of an MFMA A operand and every wave covers 1/NW of the k range, partial sums meet in LDS.  The saved raw scores
 // of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
-#include "k2_common.h"
+#include "../../murcl_amd/csrc/k2_common.h"
 
 template <typename T> struct KBLds {
     static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32
@@ -136,32 +136,16 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         for (int j = 0; j < C_::NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 gacc = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* hbase = tile + r16 * C_::PADB + C_::NKK * q4 * 16;
-        {
-            // explicit software pipeline (as in the forward): fragments of k-group g+1 are requested before the MFMAs
-            // of group g issue.  The g dot of this wave's k-quarter (k-steps KW*wave .. +KW-1) reuses the same
-            // fragments: a wave-uniform branch adds its MFMAs to the groups that hold them.
-            constexpr int GK = 2, NG = C_::NKK / GK;
-            static_assert(KW % GK == 0, "a wave's g-dot k-steps must be whole prefetch groups");
-            frag_t hq[2][GK];
 #pragma unroll
-            for (int k2 = 0; k2 < GK; ++k2) hq[0][k2] = *(const frag_t*)(hbase + k2 * 16);
+        for (int kk = 0; kk < C_::NKK; ++kk) {
+            const frag_t h = *(const frag_t*)(hbase + kk * 16);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) {
+            for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][kk], h, acc[j]);
+        }
 #pragma unroll
-                    for (int k2 = 0; k2 < GK; ++k2) hq[(g + 1) & 1][k2] = *(const frag_t*)(hbase + ((g + 1) * GK + k2) * 16);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k2 = 0; k2 < GK; ++k2)
-#pragma unroll
-                    for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][g * GK + k2], hq[g & 1][k2], acc[j]);
-                if ((g * GK) / KW == wave) {
-#pragma unroll
-                    for (int k2 = 0; k2 < GK; ++k2) gacc = k2_mma<T>(dmf[(g * GK) % KW + k2], hq[g & 1][k2], gacc);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int i = 0; i < KW; ++i) {
+            const frag_t h = *(const frag_t*)(hbase + (KW * wave + i) * 16);
+            gacc = k2_mma<T>(dmf[i], h, gacc);
         }
         if (q4 == 0) gpart[wave * 16 + r16] = gacc[0] + gacc[1];     // rows 0 (+1): hi (+lo) parts
         LDS_BARRIER();
@@ -178,30 +162,18 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         if (wave == 0 && q4 == 0) dbb_acc += ds;
         // rows past N are redirected to the 32 spare rows after the last bag (never read)
         T* dst = dT + ((grow < N) ? ((size_t)bag * N + grow) : ((size_t)B * N + r16)) * K2_D + C_::DW * wave + 4 * q4;
-        f32x4 o[C_::NJ];
 #pragma unroll
         for (int j = 0; j < C_::NJ; ++j) {
+            f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = acc[j][r] + ba_r[j][r];
                 const float t = EXACT_TANH ? tanhf(x) : fast_tanh(x);
-                o[j][r] = ds * wb_r[j][r] * (1.f - t * t);
-                dba_r[j][r] += o[j][r];
+                o[r] = ds * wb_r[j][r] * (1.f - t * t);
+                dba_r[j][r] += o[r];
                 dwb_r[j][r] += ds * t;
             }
-        }
-        if constexpr (sizeof(T) == 2) {
-            // a lane holds 4 columns of each of its two 16-column groups (8 + 8 bytes, 32-byte row segments).  Swapping
-            // the j = 1 words of the even lane quarters with the j = 0 words of the odd ones (one v_permlane16_swap per
-            // word) leaves every lane with 8 consecutive columns: ONE 16-byte store, 64 contiguous bytes per row.
-            static_assert(C_::NJ == 2, "bf16 path: two column groups per wave");
-            const auto s0 = __builtin_amdgcn_permlane16_swap(pack_bf2(o[0][0], o[0][1]), pack_bf2(o[1][0], o[1][1]), false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(pack_bf2(o[0][2], o[0][3]), pack_bf2(o[1][2], o[1][3]), false, false);
-            // (dst already points at column DW*wave + 4*q4) -> column DW*wave + 16*(q4&1) + 4*(q4&~1)
-            *(u32x4*)(dst + 16 * (q4 & 1) - 4 * (q4 & 1)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < C_::NJ; ++j) store4<T>(dst + 16 * j, o[j]);
+            store4<T>(dst + 16 * j, o);
         }
         cp.next(tiles_per_item, gridDim.x, S);
     }
