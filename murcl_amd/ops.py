@@ -155,7 +155,8 @@ def gemm_tn(A, B, *, splits=0, out=None):
         res = gemm_tn(Ap, B, splits=splits)[:N1]
         return out.add_(res) if out is not None else res.contiguous()
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
-    with _span(f"gemm_tn<{_DT_NAME[A.dtype]}>",
+    wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
+    with _span(f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4)):
         check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, stream()),
               "gemm_tn")

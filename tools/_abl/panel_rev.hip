@@ -1,0 +1,380 @@
+// Weight-stationary bf16 "panel" GEMM for the patch-level Linear layers (M = B*N rows >> N, K <= 512):
+//
+//     C[M,N] = epi( A[M,K] . W[N,K]^T )          A, W, C bf16; f32 accumulate
+//
+// Structure = the K2 streaming kernel: persistent workgroups (one per CU, 8 waves = two per SIMD so that one
+// wave's LDS-DMA issue / epilogue overlaps its SIMD partner's MFMAs), each wave keeps a WN-column slice of
+// W as MFMA operands in registers for the whole launch, A row tiles (32 rows) stream HBM -> LDS through a
+// 4-slot LDS-DMA ring with three tiles in flight.  Every VMEM operation in the main loop is inline asm
+// (LDS-DMA loads, output stores, mask stores) and is counted by hand with s_waitcnt vmcnt(N), so hipcc
+// never drains the ring.
+//
+//   K = 512: WN = 32 -> a workgroup owns a 256-column panel; N/256 panels walk the same row tiles on
+//                       workgroups b and b+8 (same XCD under round-robin dispatch -> A re-read from L2)
+//   K = 128: WN = 64 -> one 512-column panel (dgrad of the attention projection)
+//
+// Epilogue (per tile, per wave, no workgroup barrier): f32 math in accumulator layout (bias+ReLU, or
+// rank-1 term a[m]*v[bag(m)][n]), ReLU' applied / recorded as one bit per element while still in accumulator
+// layout, round to bf16, transpose through a wave-private LDS patch so that each lane owns 8 consecutive
+// columns of a row, accumulate column sums (bias gradients) and store 16 B per lane in whole 128/256-byte row
+// segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
+// Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major.  A block is 64
+// 16-bit words, one per MFMA lane L = 16*((n&15)>>2) + (m&15); element (m, n) of the block is the lane's
+// accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
+// exactly what "shift left, OR in the packed pair's >0 flags" leaves behind (2 VALU ops per bf16 pair), and
+// the consumer applies it with one v_bfe_i32 + v_and per accumulator value.
+#include <cstdlib>
+#include "../../murcl_amd/csrc/common.h"
+
+#define PG_TR 32
+#define PG_NSLOT 4
+#ifndef PG_GK
+#define PG_GK 4           // k-steps per LDS prefetch group
+#endif
+#ifndef PG_PF
+#define PG_PF 1           // groups requested ahead of the MFMAs
+#endif
+#ifndef PG_WIDE
+#define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
+#endif
+
+enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2 };
+
+#define PG_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+__device__ __forceinline__ void pg_store16(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void pg_store2(void* p, unsigned v) {
+    asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// per bf16 half of w: 1 if > 0 (signed 16-bit compare: -0.0 and negatives give 0), else 0.  Inline asm because hipcc
+// turns the min/max pair into two compares, two selects and a permute.
+__device__ __forceinline__ unsigned pg_pos_flags(unsigned w, unsigned ones) {
+    unsigned t;
+    asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(t) : "v"(w), "v"(ones));
+    return t;
+}
+
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
+__global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
+    const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
+    const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
+    float* __restrict__ colsum_out, int reverse) {
+    constexpr int ROWB = K * 2;                 // bytes per A row
+    // K = 512: one LDS-DMA instruction writes exactly one row, so rows can be stored at a padded stride (conflict-free
+    // 16-row fragment reads with immediate offsets, no swizzle math).  K = 128: four rows per instruction -> XOR swizzle.
+    constexpr bool PAD = (K == 512);
+    constexpr int PADB = PAD ? ROWB + 16 : ROWB;
+    constexpr int SLOT = PG_TR * PADB;          // 32.5 KiB / 8 KiB
+    constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+    constexpr int GT = PAD ? PG_TR / PG_NW : SLOT / (PG_NW * 1024);   // tile LDS-DMA ops per wave
+    constexpr int NJ = WN / 16, NKK = K / 32;
+    constexpr int NP = PG_NW * WN;              // columns per workgroup: 256 / 512
+    constexpr int CPW = WN / 8;                 // 16-byte chunks per output row per wave: 4 / 8
+    constexpr int RPI = 64 / CPW;               // rows per store instruction: 16 / 8
+    constexpr int NS = PG_TR / RPI;             // store instructions per tile: 2 / 4
+    constexpr int STG_LD = WN * 2 + 16;         // staging row stride (bytes), 16-B aligned, breaks the pow-2 stride
+    constexpr int NB = (EPI != PG_BIAS_RELU) ? 1 : 0;               // mask LDS-DMA op (128 or 256 B per wave)
+    constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
+    constexpr int G = GT + NB + NR;             // counted loads per tile per wave
+    constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
+    constexpr int S = NS + NMS;                 // counted stores per tile per wave
+    // LDS carve
+    constexpr int OFF_STG = PG_NSLOT * SLOT;
+    constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
+    constexpr int OFF_RS = OFF_BM + (NB ? PG_NSLOT * PG_NW * 256 : 0);          // [slot][wave][64 f32]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const unsigned lds0 = lds_off(smem);
+    const int panels = N / NP;
+    const int b = blockIdx.x;
+    const int panel = (b >> 3) % panels;
+    const int streams = gridDim.x / panels;
+    const int stream = (b & 7) + 8 * (b / (8 * panels));
+    const int n_tiles = M / PG_TR;
+    const int my_tiles = (n_tiles - stream + streams - 1) / streams;
+    if (stream >= streams || my_tiles <= 0) return;
+    const int n0 = panel * NP + wave * WN;          // first column of this wave
+
+    auto issue = [&](int seq) {
+        const int row0 = (reverse ? n_tiles - 1 - (stream + seq * streams) : (stream + seq * streams)) * PG_TR;
+        const int sl = seq % PG_NSLOT;
+        const char* base = (const char*)(A + (size_t)row0 * K);
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+            if (PAD) {
+                const int row = j * PG_NW + wave;                       // wave-uniform: scalar base, lane offset lane*16
+                glds16_u(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
+            } else {
+                const int ci = (j * PG_NW + wave) * 64 + lane;
+                const int row = ci / CPR, pos = ci % CPR;
+                glds16(base + (size_t)row * ROWB + ((pos ^ (row & 15)) << 4),
+                       lds0 + sl * SLOT + (j * PG_NW + wave) * 1024);
+            }
+        }
+        if (EPI != PG_BIAS_RELU) {
+            // this wave's mask blocks of the tile (WN/32 blocks of 128 B, contiguous): one 4-byte piece per lane
+            const int nbytes = (WN / 32) * 128;
+            const int off = min(lane * 4, nbytes - 4);
+            glds4(bm_in + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128 + off,
+                  lds0 + OFF_BM + (sl * PG_NW + wave) * 256);
+        }
+        if (EPI == PG_RANK1_MASK)
+            glds4(rowscale + row0 + (lane & 31), lds0 + OFF_RS + (sl * PG_NW + wave) * 256);
+    };
+
+    const int pre = min(3, my_tiles);
+    for (int s = 0; s < pre; ++s) issue(s);
+
+    // ---- W slice: MFMA "a" operands, rows n = n0 + 16j + r16
+    bf16x8 wf[NJ][NKK];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const bf16_t* wrow = W + (size_t)(n0 + 16 * j + r16) * K;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            // k assignment of lane quarter q4 in k-step kk: PAD -> 16-byte chunk (kk + NKK*q4); else chunk (4kk + q4)
+            wf[j][kk] = *(const bf16x8*)(wrow + (PAD ? (kk + NKK * q4) * 8 : 32 * kk + 8 * q4));
+            // opaque to the optimiser: otherwise hipcc rematerialises the fragments by re-loading them from global
+            // memory inside the tile loop (34 loads + vmcnt waits per tile that also drain the LDS-DMA ring)
+            asm volatile("" : "+v"(wf[j][kk]));
+        }
+    }
+    // bias for accumulator-layout columns n0 + 16j + 4q4 + r
+    float bias_r[(EPI == PG_BIAS_RELU) ? NJ : 1][4];
+    if (EPI == PG_BIAS_RELU) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bias_r[j][r] = bias[n0 + 16 * j + 4 * q4 + r];
+                // pinned here so that hipcc waits for these loads now: left alone it puts its s_waitcnt vmcnt(0) at
+                // the first use, inside the tile loop, where it drains the LDS-DMA ring on every tile
+                asm volatile("" : "+v"(bias_r[j][r]));
+            }
+    }
+    float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
+    int cur_bag = -1;
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
+    const int crow = lane / CPW, cchunk = lane % CPW;            // row-wise phase: row RPI*g + crow, chunk cchunk
+
+    for (int seq = 0; seq < my_tiles; ++seq) {
+        // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between
+        if (seq + 2 < my_tiles) {
+            if (seq == 0) { PG_WAIT(2 * G); } else if (seq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
+        } else {
+            PG_WAIT(0);
+        }
+        LDS_BARRIER();
+        if (seq + 3 < my_tiles) issue(seq + 3);
+
+        const int row0 = (reverse ? n_tiles - 1 - (stream + seq * streams) : (stream + seq * streams)) * PG_TR;
+        const int sl = seq % PG_NSLOT;
+        const char* tile = smem + sl * SLOT;
+
+        // this lane's mask words (one per 32-column block of the wave), requested ahead of the MFMA loop
+        unsigned mw[NJ / 2];
+        unsigned ones = 0x00010001u;
+        asm volatile("" : "+v"(ones));
+#pragma unroll
+        for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = 0u;
+        if (EPI != PG_BIAS_RELU) {
+            const uint16_t* bml = (const uint16_t*)(smem + OFF_BM + (sl * PG_NW + wave) * 256);
+#pragma unroll
+            for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = bml[bq * 64 + lane];
+        }
+
+        f32x4 acc[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* hb = tile + r16 * PADB + NKK * q4 * 16;               // PAD: base + immediates only
+        if (PAD) {
+            // explicit software pipeline: the fragments of k-group g+PG_PF are requested before the MFMAs of group g
+            // are issued (left alone hipcc keeps only two ds_read_b128 in flight and the MFMAs wait on LDS latency)
+            constexpr int GK = PG_GK, NG = NKK / GK, D = PG_PF, NBUF = D + 1;
+            bf16x8 hq[NBUF][GK][2];
+            auto load_grp = [&](int g, int buf) {
+#pragma unroll
+                for (int k2 = 0; k2 < GK; ++k2)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) hq[buf][k2][i] = *(const bf16x8*)(hb + i * 16 * PADB + (g * GK + k2) * 16);
+            };
+#pragma unroll
+            for (int g = 0; g < D; ++g) load_grp(g, g);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + D < NG) load_grp(g + D, (g + D) % NBUF);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k2 = 0; k2 < GK; ++k2)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][g * GK + k2], hq[g % NBUF][k2][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = 16 * i + r16, c = 4 * kk + q4;
+                    const bf16x8 h = *(const bf16x8*)(tile + row * ROWB + ((c ^ (row & 15)) << 4));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], h, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- accumulator-layout math: lane holds row 16i+r16, columns 16j+4q4+r
+        if (EPI == PG_RANK1_MASK) {
+            const int bag = row0 / rows_per_bag;
+            if (bag != cur_bag) {                                  // rare: compiler-visible loads, drains once per bag
+                cur_bag = bag;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rk[j][r] = rank1[(size_t)bag * N + n0 + 16 * j + 4 * q4 + r];
+            }
+        }
+        const float* rs = (const float*)(smem + OFF_RS + (sl * PG_NW + wave) * 256);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * i + r16;
+            float a_m = 0.f;
+            if (EPI == PG_RANK1_MASK) a_m = rs[row];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 v = acc[i][j];
+                if (EPI == PG_BIAS_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + bias_r[j][r], 0.f);
+                }
+                if (EPI == PG_RANK1_MASK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += a_m * rk[j][r];
+                }
+                if (EPI != PG_BIAS_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = 8 * i + 4 * (j & 1) + r;
+                        const int keep = __builtin_amdgcn_sbfe((int)mw[j >> 1], (7 - (idx >> 1)) + 8 * (idx & 1), 1);   // 0 / -1
+                        v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
+                    }
+                }
+                const unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
+                if (BM_OUT) {
+                    const unsigned f0 = pg_pos_flags(w0, ones), f1 = pg_pos_flags(w1, ones);
+                    mw[j >> 1] = (mw[j >> 1] << 1) | f0;
+                    mw[j >> 1] = (mw[j >> 1] << 1) | f1;
+                }
+                *(u32x2*)(stg + row * STG_LD + (16 * j + 4 * q4) * 2) = u32x2{w0, w1};
+            }
+        }
+        if (BM_OUT) {
+            uint8_t* blk = bm_out + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128;
+#pragma unroll
+            for (int bq = 0; bq < NJ / 2; ++bq) pg_store2(blk + bq * 128 + lane * 2, mw[bq] | (mw[bq] >> 8));
+        }
+        // ---- row-wise phase: lane owns 8 consecutive columns (one 16-byte chunk) of RPI rows per pass
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const int row = RPI * g + crow;
+            const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
+            if (colsum_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { csum[2 * e] += bf_lo(u[e]); csum[2 * e + 1] += bf_hi(u[e]); }
+            }
+            pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
+        }
+    }
+
+    if (colsum_out) {
+        // lanes with equal cchunk own the same 8 columns: reduce over crow, then one atomic per column per wave
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = csum[e];
+#pragma unroll
+            for (int o = CPW; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (crow == 0) atomicAdd(colsum_out + n0 + cchunk * 8 + e, s);
+        }
+    }
+}
+
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
+static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
+                     const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
+                     float* colsum_out, hipStream_t s) {
+    constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
+    constexpr int STG_LD = WN * 2 + 16;
+    constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD + (EPI != PG_BIAS_RELU ? PG_NSLOT * PG_NW * 256 : 0) +
+                        (EPI == PG_RANK1_MASK ? PG_NSLOT * PG_NW * 256 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once = true;
+    }
+    const int panels = N / (PG_NW * WN);
+    int grid = 256;
+    const int n_tiles = M / PG_TR;
+    if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
+    static int rev = getenv("PG_REVERSE") ? atoi(getenv("PG_REVERSE")) : 0;
+    static int calls = 0; ++calls;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * PG_NW), LDS, s, A, W, C, M, N, bias, bm_out, bm_in, rowscale, rank1,
+                       rows_per_bag, colsum_out, rev == 2 ? (calls & 1) : rev);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// C-ABI: see include/murcl_amd.h
+extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag) {
+    if (M <= 0 || M % PG_TR) return 0;
+    if (K == 512) return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK);
+    if (K == 128) return N == 512 && epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0;
+    return 0;
+}
+
+extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
+                                const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
+                                const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
+                                hipStream_t stream) {
+    if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
+    if (colsum_out && !colsum_accumulate) {
+        hipError_t e = hipMemsetAsync(colsum_out, 0, (size_t)N * 4, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* w = (const bf16_t*)W;
+    bf16_t* c = (bf16_t*)C;
+    uint8_t* bo = (uint8_t*)bitmask_out;
+    const uint8_t* bi = (const uint8_t*)bitmask_in;
+    if (K == 512 && epilogue == PG_BIAS_RELU) {
+        if (!bias) return -1;
+        return bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream)
+                  : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+    }
+    if (K == 512 && epilogue == PG_MASK) {
+        if (!bi) return -1;
+        return pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+    }
+    if (K == 128 && epilogue == PG_RANK1_MASK) {
+        if (!bi || !rowscale || !rank1) return -1;
+        return pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+    }
+    return -1;
+}
