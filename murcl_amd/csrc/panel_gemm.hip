@@ -15,9 +15,9 @@
 //
 // Epilogue (per tile, per wave, no workgroup barrier): f32 math in accumulator layout (bias+ReLU, or
 // rank-1 term a[m]*v[bag(m)][n]), ReLU' applied / recorded as one bit per element while still in accumulator
-// layout, round to bf16, transpose through a wave-private LDS patch so that each lane owns 8 consecutive
-// columns of a row, accumulate column sums (bias gradients) and store 16 B per lane in whole 128/256-byte row
-// segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
+// layout (column sums for the bias gradients are taken there too, from the f32 values), round to bf16, transpose
+// through a wave-private LDS patch so that each lane owns 8 consecutive columns of a row and store 16 B per lane in
+// whole 128/256-byte row segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
 // Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major.  A block is 64
 // 16-bit words, one per MFMA lane L = 16*((n&15)>>2) + (m&15); element (m, n) of the block is the lane's
 // accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
@@ -97,12 +97,18 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const int streams = gridDim.x / panels;
     const int stream = (b & 7) + 8 * (b / (8 * panels));
     const int n_tiles = M / PG_TR;
-    const int my_tiles = (n_tiles - stream + streams - 1) / streams;
+    // K = 512: tiles dealt round-robin (tile = stream + seq*streams), so the two panels of a row tile run side by side.
+    // RANK1: a workgroup takes a CONTIGUOUS run of tiles - dealt round-robin every tile would land in another bag and
+    // reload the per-bag rank-1 vector (compiler-visible loads that drain the LDS-DMA ring) once per tile.
+    constexpr bool CONTIG = (EPI == PG_RANK1_MASK);
+    const int per = (n_tiles + streams - 1) / streams;
+    const int tile0 = CONTIG ? stream * per : stream, tstep = CONTIG ? 1 : streams;
+    const int my_tiles = CONTIG ? min(per, n_tiles - tile0) : (n_tiles - stream + streams - 1) / streams;
     if (stream >= streams || my_tiles <= 0) return;
     const int n0 = panel * NP + wave * WN;          // first column of this wave
 
     auto issue = [&](int seq) {
-        const int row0 = (stream + seq * streams) * PG_TR;
+        const int row0 = (tile0 + seq * tstep) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* base = (const char*)(A + (size_t)row0 * K);
 #pragma unroll
@@ -160,9 +166,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
     int cur_bag = -1;
-    float csum[8];
+    float csum[NJ][4];                       // column sums in accumulator layout: column 16j + 4q4 + r, over this lane's rows
 #pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         LDS_BARRIER();
         if (seq + 3 < my_tiles) issue(seq + 3);
 
-        const int row0 = (stream + seq * streams) * PG_TR;
+        const int row0 = (tile0 + seq * tstep) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* tile = smem + sl * SLOT;
 
@@ -275,6 +283,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                         v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
                     }
                 }
+                if (colsum_out) {          // bias gradient from the f32 values, before they are rounded to bf16
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) csum[j][r] += v[r];
+                }
                 const unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
                 if (BM_OUT) {
                     const unsigned f0 = pg_pos_flags(w0, ones), f1 = pg_pos_flags(w1, ones);
@@ -294,23 +306,19 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         for (int g = 0; g < NS; ++g) {
             const int row = RPI * g + crow;
             const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
-            if (colsum_out) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { csum[2 * e] += bf_lo(u[e]); csum[2 * e + 1] += bf_hi(u[e]); }
-            }
             pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
         }
     }
 
     if (colsum_out) {
-        // lanes with equal cchunk own the same 8 columns: reduce over crow, then one atomic per column per wave
+        // the 16 lanes of a quarter hold the same columns for different rows: reduce over them, one atomic per column
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s = csum[e];
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int o = CPW; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-            if (crow == 0) atomicAdd(colsum_out + n0 + cchunk * 8 + e, s);
-        }
+            for (int r = 0; r < 4; ++r) {
+                const float t = row16_sum(csum[j][r]);
+                if (r16 == 0) atomicAdd(colsum_out + n0 + 16 * j + 4 * q4 + r, t);
+            }
     }
 }
 

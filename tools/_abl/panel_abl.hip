@@ -15,9 +15,9 @@
 //
 // Epilogue (per tile, per wave, no workgroup barrier): f32 math in accumulator layout (bias+ReLU, or
 // rank-1 term a[m]*v[bag(m)][n]), ReLU' applied / recorded as one bit per element while still in accumulator
-// layout, round to bf16, transpose through a wave-private LDS patch so that each lane owns 8 consecutive
-// columns of a row, accumulate column sums (bias gradients) and store 16 B per lane in whole 128/256-byte row
-// segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
+// layout (column sums for the bias gradients are taken there too, from the f32 values), round to bf16, transpose
+// through a wave-private LDS patch so that each lane owns 8 consecutive columns of a row and store 16 B per lane in
+// whole 128/256-byte row segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
 // Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major.  A block is 64
 // 16-bit words, one per MFMA lane L = 16*((n&15)>>2) + (m&15); element (m, n) of the block is the lane's
 // accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
@@ -28,13 +28,13 @@
 #define PG_TR 32
 #define PG_NSLOT 4
 #ifndef PG_GK
-#define PG_GK 2           // k-steps per LDS prefetch group
+#define PG_GK 4           // k-steps per LDS prefetch group
 #endif
 #ifndef PG_PF
-#define PG_PF 2           // groups requested ahead of the MFMAs
+#define PG_PF 1           // groups requested ahead of the MFMAs
 #endif
 #ifndef PG_WIDE
-#define PG_WIDE 1         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
+#define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
 enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2 };
@@ -160,9 +160,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
     int cur_bag = -1;
-    float csum[8];
+    float csum[NJ][4];                       // column sums in accumulator layout: column 16j + 4q4 + r, over this lane's rows
 #pragma unroll
-    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
@@ -275,6 +277,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                         v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
                     }
                 }
+                if (colsum_out) {          // bias gradient from the f32 values, before they are rounded to bf16
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) csum[j][r] += v[r];
+                }
                 const unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
                 if (BM_OUT) {
                     const unsigned f0 = pg_pos_flags(w0, ones), f1 = pg_pos_flags(w1, ones);
@@ -294,23 +300,19 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         for (int g = 0; g < NS; ++g) {
             const int row = RPI * g + crow;
             const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
-            if (colsum_out) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { csum[2 * e] += bf_lo(u[e]); csum[2 * e + 1] += bf_hi(u[e]); }
-            }
             pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
         }
     }
 
     if (colsum_out) {
-        // lanes with equal cchunk own the same 8 columns: reduce over crow, then one atomic per column per wave
+        // the 16 lanes of a quarter hold the same columns for different rows: reduce over them, one atomic per column
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s = csum[e];
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int o = CPW; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
-            if (crow == 0) atomicAdd(colsum_out + n0 + cchunk * 8 + e, s);
-        }
+            for (int r = 0; r < 4; ++r) {
+                const float t = row16_sum(csum[j][r]);
+                if (r16 == 0) atomicAdd(colsum_out + n0 + 16 * j + 4 * q4 + r, t);
+            }
     }
 }
 
@@ -348,9 +350,10 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
 
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
-                                const float* rank1, int rows_per_bag, float* colsum_out, hipStream_t stream) {
+                                const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
+                                hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
-    if (colsum_out) {
+    if (colsum_out && !colsum_accumulate) {
         hipError_t e = hipMemsetAsync(colsum_out, 0, (size_t)N * 4, stream);
         if (e != hipSuccess) return (int)e;
     }
