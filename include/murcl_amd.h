@@ -159,11 +159,18 @@ int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int
 int murcl_relu_bwd(const float* dy, const float* y, float* dx, long n, murcl_stream_t stream);
 
 /* K7/K10 -- one nn.GRU time step's gate math (rlmil.py:47,78,199,213-217); the two projections are
- * murcl_gemm_nt calls.  gates [B,3H] = (r,z,n) saved for backward. */
+ * murcl_gemm_nt calls.  gates [B,3H] = (r,z,n) saved for backward.  gh_bcast != 0: gh is a single row [3H]
+ * shared by all B rows (zero initial state: gh = b_hh, no [B,3H] copy of the bias). */
 int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, float* hnew, float* gates, int B, int H,
-                        murcl_stream_t stream);
+                        int gh_bcast, murcl_stream_t stream);
 int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
-                        float* dgh, float* dhprev, int B, int H, murcl_stream_t stream);
+                        float* dgh, float* dhprev, int B, int H, int gh_bcast, murcl_stream_t stream);
+
+/* Compute-dtype copies / transposes of several f32 weight matrices in one launch.  jobs_dev: n_jobs records of
+ * { const float* src; void* dst; int rows, cols, transpose, dtype_out; } (32 bytes each) in device memory; max_tiles =
+ * the largest ceil(rows/32)*ceil(cols/32) among them.  Replaces the per-tensor `.to(dtype)` / `.t()` copies that the
+ * reference's nn.Linear calls imply (abmil.py:12-21). */
+int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stream_t stream);
 
 /* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g
  * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */

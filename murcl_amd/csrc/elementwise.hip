@@ -52,6 +52,44 @@ extern "C" int murcl_transpose_cast(const float* x, void* y, int R, int C, int d
     return MURCL_CHECK_LAUNCH();
 }
 
+// Several weight matrices -> their compute-dtype copies and/or transposes in ONE launch (the encoder needs W1..W3, Wa
+// in bf16 for the forward and W2^T, W3^T, Wa^T for the dgrads: seven 4-5 us launches otherwise).  blockIdx.y = job.
+struct MurclCastJob {           // 32 bytes, mirrored by murcl_amd/ops.py
+    const float* src;           // [rows, cols] f32, contiguous
+    void* dst;                  // [rows, cols] or (transpose) [cols, rows] in dtype_out
+    int rows, cols, transpose, dtype_out;
+};
+template <typename T>
+__device__ __forceinline__ void cast_job_tile(const MurclCastJob& j, int tile, float (*t)[33]) {
+    const int tc = (j.cols + 31) / 32;
+    const int c0 = (tile % tc) * 32, r0 = (tile / tc) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* y = (T*)j.dst;
+    if (j.transpose) {
+        for (int k = ty; k < 32; k += 8)
+            if (r0 + k < j.rows && c0 + tx < j.cols) t[k][tx] = j.src[(size_t)(r0 + k) * j.cols + c0 + tx];
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8)
+            if (c0 + k < j.cols && r0 + tx < j.rows) y[(size_t)(c0 + k) * j.rows + r0 + tx] = from_f<T>(t[tx][k]);
+    } else {
+        for (int k = ty; k < 32; k += 8)
+            if (r0 + k < j.rows && c0 + tx < j.cols)
+                y[(size_t)(r0 + k) * j.cols + c0 + tx] = from_f<T>(j.src[(size_t)(r0 + k) * j.cols + c0 + tx]);
+    }
+}
+__global__ __launch_bounds__(256) void cast_batch_kernel(const MurclCastJob* __restrict__ jobs) {
+    __shared__ float t[32][33];
+    const MurclCastJob j = jobs[blockIdx.y];
+    const int tiles = ((j.rows + 31) / 32) * ((j.cols + 31) / 32);
+    if ((int)blockIdx.x >= tiles) return;
+    if (j.dtype_out == MURCL_DTYPE_BF16) cast_job_tile<bf16_t>(j, blockIdx.x, t);
+    else cast_job_tile<float>(j, blockIdx.x, t);
+}
+extern "C" int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, hipStream_t s) {
+    if (n_jobs <= 0 || max_tiles <= 0) return 0;
+    hipLaunchKernelGGL(cast_batch_kernel, dim3(max_tiles, n_jobs), dim3(256), 0, s, (const MurclCastJob*)jobs_dev);
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
 // grid = (column groups of 256, row splits); a thread owns 4 consecutive columns (8/16-byte loads) for one of 4 row
 // lanes; each block adds its 256 partial sums atomically.
@@ -115,14 +153,15 @@ extern "C" int murcl_relu_bwd(const float* dy, const float* y, float* dx, long n
 
 // ---------------------------------------------------------------- GRU gates (PyTorch order r, z, n)
 // gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both [B,3H].  gates out: [B,3H] = (r, z, n) for backward.
+// gh_bcast != 0: gh is a single row [3H] shared by every batch row (zero initial state: gh = b_hh).
 __global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
                                      const float* __restrict__ hprev, float* __restrict__ hnew,
-                                     float* __restrict__ gates, int B, int H) {
+                                     float* __restrict__ gates, int B, int H, int gh_bcast) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * H) return;
     const int b = (int)(idx / H), k = (int)(idx % H);
     const float* gib = gi + (size_t)b * 3 * H;
-    const float* ghb = gh + (size_t)b * 3 * H;
+    const float* ghb = gh + (gh_bcast ? 0 : (size_t)b * 3 * H);
     const float r = 1.f / (1.f + expf(-(gib[k] + ghb[k])));
     const float z = 1.f / (1.f + expf(-(gib[H + k] + ghb[H + k])));
     const float nn = tanhf(gib[2 * H + k] + r * ghb[2 * H + k]);
@@ -135,13 +174,13 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* 
 __global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ gates,
                                      const float* __restrict__ gh, const float* __restrict__ hprev,
                                      float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhprev,
-                                     int B, int H) {
+                                     int B, int H, int gh_bcast) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * H) return;
     const int b = (int)(idx / H), k = (int)(idx % H);
     const float* g = gates + (size_t)b * 3 * H;
     const float r = g[k], z = g[H + k], nn = g[2 * H + k];
-    const float ghn = gh[(size_t)b * 3 * H + 2 * H + k];
+    const float ghn = gh[(gh_bcast ? 0 : (size_t)b * 3 * H) + 2 * H + k];
     const float hp = hprev ? hprev[idx] : 0.f;
     const float d = dh[idx];
     const float dn = d * (1.f - z) * (1.f - nn * nn);
@@ -154,17 +193,17 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* 
     if (dhprev) dhprev[idx] = d * z;
 }
 extern "C" int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, float* hnew, float* gates,
-                                   int B, int H, hipStream_t s) {
+                                   int B, int H, int gh_bcast, hipStream_t s) {
     const long n = (long)B * H;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gi, gh, hprev, hnew, gates, B, H);
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gi, gh, hprev, hnew, gates, B, H, gh_bcast);
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
-                                   float* dgh, float* dhprev, int B, int H, hipStream_t s) {
+                                   float* dgh, float* dhprev, int B, int H, int gh_bcast, hipStream_t s) {
     const long n = (long)B * H;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H);
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H, gh_bcast);
     return MURCL_CHECK_LAUNCH();
 }
 

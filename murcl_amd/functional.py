@@ -64,7 +64,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w, y if relu else None, b)
         ctx.relu = relu
         ctx.xshape = x.shape
-        return y.view(*x.shape[:-1], w.shape[0])
+        return y if x.dim() == 2 else y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -95,25 +95,36 @@ class ABMILFn(torch.autograd.Function):
         B, N, d = x.shape
         T = x.dtype
         x2 = x.reshape(B * N, d)
-        c = (lambda w: w) if T == torch.float32 else (lambda w: ops.cast(w, T))
         L = w3.shape[0]
+        # compute-dtype copies of W1..W3, Wa for this pass and W2^T, W3^T, Wa^T for the dgrads of the backward pass: one
+        # launch, and only when a parameter changed since they were last built (ops.weight_views)
+        wmats = (w1, w2, w3, wa)
+        if all(w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() for w in wmats):
+            tr = [(wa, True, T), (w3, True, T), (w2, True, T)]
+            if T == torch.float32:
+                w1c, w2c, w3c, wac = wmats
+                wat, w3t, w2t = ops.weight_views(tr)
+            else:
+                w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views([(w, False, T) for w in wmats] + tr)
+        else:
+            w1c, w2c, w3c, wac = (ops.cast(w.contiguous(), T) for w in wmats)
+            wat, w3t, w2t = (ops.transpose_cast(w, T) for w in (wa, w3, w2))
         # bf16 + panel-friendly shapes: weight-stationary GEMMs that also emit 1-bit ReLU masks
         fast = (T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
                 and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
         if fast:
-            h1, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=True)
-            h2, m2, _ = ops.panel_gemm(h1, c(w2), ops.PG_BIAS_RELU, bias=b2, want_bitmask=True)
-            h3, m3, _ = ops.panel_gemm(h2, c(w3), ops.PG_BIAS_RELU, bias=b3, want_bitmask=True)
+            h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=True)
+            h2, m2, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=True)
+            h3, m3, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=True)
         else:
             m1 = m2 = m3 = None
-            h1 = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)
-            h2 = ops.gemm_nt(h1, c(w2), epi=ops.EPI_BIAS_RELU, bias=b2)
-            h3 = ops.gemm_nt(h2, c(w3), epi=ops.EPI_BIAS_RELU, bias=b3)
-        wac = c(wa)
+            h1 = ops.gemm_nt(x2, w1c, epi=ops.EPI_BIAS_RELU, bias=b1)
+            h2 = ops.gemm_nt(h1, w2c, epi=ops.EPI_BIAS_RELU, bias=b2)
+            h3 = ops.gemm_nt(h2, w3c, epi=ops.EPI_BIAS_RELU, bias=b3)
         scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
         out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
         ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
-                              b1, b2, b3, bb, bd)
+                              b1, b2, b3, bb, bd, wat, w3t, w2t)
         ctx.dims = (B, N, d)
         ctx.mark_non_differentiable(A)
         return out, A
@@ -121,7 +132,7 @@ class ABMILFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dA):
         (x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
-         b1, b2, b3, bb, bd) = ctx.saved_tensors
+         b1, b2, b3, bb, bd, wat, w3t, w2t) = ctx.saved_tensors
         B, N, d = ctx.dims
         T = x2.dtype
         L = h3.shape[1]
@@ -131,35 +142,40 @@ class ABMILFn(torch.autograd.Function):
         dbd = _bgrad(dpre, bd)
         dM = ops.gemm_nt(dpre, ops.transpose_cast(wd, torch.float32))
         # attention pooling
-        dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
+        direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
+        dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM,
+                                               into=(ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None)
         dwa = _wgrad(dT, h3, wa)
         # encoder layer 3: dZ3 = (dT Wa + A (x) dM) * relu'(H3)
         if m3 is not None:
             into = lambda b: b.grad.view(-1) if _direct(b) else None      # bias gradients straight from the epilogue
-            dz3, _, db3 = ops.panel_gemm(dT, ops.transpose_cast(wa, T), ops.PG_RANK1_MASK, bitmask=m3,
+            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3,
                                          rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_into=into(b3))
             dw3 = _wgrad(dz3, h2, w3)
-            dz2, _, db2 = ops.panel_gemm(dz3, ops.transpose_cast(w3, T), ops.PG_MASK, bitmask=m2, colsum=True,
+            dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True,
                                          colsum_into=into(b2))
             dw2 = _wgrad(dz2, h1, w2)
-            dz1, _, db1 = ops.panel_gemm(dz2, ops.transpose_cast(w2, T), ops.PG_MASK, bitmask=m1, colsum=True,
+            dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True,
                                          colsum_into=into(b1))
         else:
-            dz3, ws = ops.gemm_nt(dT, ops.transpose_cast(wa, T), epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
+            dz3, ws = ops.gemm_nt(dT, wat, epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
                                   rank1=dM, rows_per_bag=N, colsum=True)
             db3 = _bgrad(ws, b3)
             dw3 = _wgrad(dz3, h2, w3)
-            dz2, ws = ops.gemm_nt(dz3, ops.transpose_cast(w3, T), epi=ops.EPI_MASK, mask=h2, colsum=True)
+            dz2, ws = ops.gemm_nt(dz3, w3t, epi=ops.EPI_MASK, mask=h2, colsum=True)
             db2 = _bgrad(ws, b2)
             dw2 = _wgrad(dz2, h1, w2)
-            dz1, ws = ops.gemm_nt(dz2, ops.transpose_cast(w2, T), epi=ops.EPI_MASK, mask=h1, colsum=True)
+            dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
             db1 = _bgrad(ws, b1)
         dw1 = _wgrad(dz1, x2, w1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dz1, ops.transpose_cast(w1, T)).view(B, N, d)
-        return (dx, dw1, db1, dw2, db2, dw3, db3, dwa, _pgrad(dba, ba), _pgrad(dwb.view(1, -1), wb), _pgrad(dbb, bb),
-                dwd, dbd)
+        if direct_k2:
+            dba = dwb = dbb = None
+        else:
+            dba, dwb, dbb = _pgrad(dba, ba), _pgrad(dwb.reshape(1, -1), wb), _pgrad(dbb, bb)
+        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd
 
 
 class GRUStepFn(torch.autograd.Function):
@@ -170,7 +186,7 @@ class GRUStepFn(torch.autograd.Function):
         x = x.contiguous()
         gi = ops.gemm_nt(x, w_ih, epi=ops.EPI_BIAS, bias=b_ih)
         if h_prev is None:
-            gh = b_hh.unsqueeze(0).expand(x.shape[0], -1).contiguous()      # W_hh . 0 + b_hh
+            gh = b_hh.detach().view(1, -1)                                   # W_hh . 0 + b_hh: one row, read by every batch row
         else:
             h_prev = h_prev.contiguous()
             gh = ops.gemm_nt(h_prev, w_hh, epi=ops.EPI_BIAS, bias=b_hh)
@@ -250,10 +266,12 @@ class NTXentFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z_i, z_j, temperature, grad_lo, grad_hi):
-        z = torch.cat([z_i, z_j], 0)
+        # z_j None: z_i already is the stacked [2B,P] batch (both views came out of one GEMM: no concatenation)
+        z = z_i if z_j is None else torch.cat([z_i, z_j], 0)
         loss, dz, sim = ops.ntxent(z, temperature, want_grad=True, grad_lo=grad_lo, grad_hi=grad_hi)
         ctx.save_for_backward(dz)
-        ctx.B = z_i.shape[0]
+        ctx.B = z.shape[0] // 2
+        ctx.joint = z_j is None
         ctx.mark_non_differentiable(sim)
         return loss[0], sim
 
@@ -261,6 +279,8 @@ class NTXentFn(torch.autograd.Function):
     def backward(ctx, dloss, _dsim):
         (dz,) = ctx.saved_tensors
         g = dz * dloss
+        if ctx.joint:
+            return g, None, None, None, None
         return g[:ctx.B], g[ctx.B:], None, None, None
 
 

@@ -195,8 +195,9 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
     return scores, A, M, ml
 
 
-def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None):
-    """-> dT [B*N,128] (dtype of H; 32 spare rows allocated behind it), dba[128], dwb[128], dbb[1]."""
+def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None):
+    """-> dT [B*N,128] (dtype of H; 32 spare rows allocated behind it), dba[128], dwb[128], dbb[1].
+    ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros."""
     _need_cuda(H, Wa, dM)
     H, Wa, dM = _c(H), _c(Wa), _c(dM)
     B, N, L = H.shape
@@ -205,9 +206,12 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None):
         exact_tanh = H.dtype == torch.float32
     dev = H.device
     dT_full = torch.empty((B * N + 32, D), dtype=H.dtype, device=dev)
-    dba = torch.zeros((D,), dtype=torch.float32, device=dev)
-    dwb = torch.zeros((D,), dtype=torch.float32, device=dev)
-    dbb = torch.zeros((1,), dtype=torch.float32, device=dev)
+    if into is not None:
+        dba, dwb, dbb = into
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in into) and dba.numel() == D and dwb.numel() == D
+    else:
+        z = torch.zeros((2 * D + 1,), dtype=torch.float32, device=dev)          # one fill for the three accumulators
+        dba, dwb, dbb = z[:D], z[D:2 * D], z[2 * D:]
     es = H.element_size()
     with _span(f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es)):
@@ -244,6 +248,61 @@ def cast(x, dtype):
     y = torch.empty_like(x, dtype=dtype)
     check(_lib.lib().murcl_cast(ptr(x), ptr(y), x.numel(), dt(x), dt(y), stream()), "cast")
     return y
+
+
+# ---- weight views: compute-dtype copies / transposes of parameter matrices, rebuilt in ONE launch when a parameter
+# changed.  The views are reused across calls only for parameters a FlatAdam owns: its step() advances PARAM_EPOCH (the
+# kernel writes through raw pointers, which torch's version counters do not see) and in-place torch ops on such a
+# parameter (load_state_dict, copy_) bump its ``_version``.  Anything else (``p.data`` edits have their own version
+# counter) cannot be tracked, so unmanaged parameters are re-converted on every call - still one launch, not seven.
+PARAM_EPOCH = 0
+MANAGED_PARAMS = {}           # data_ptr() -> weakref of a parameter whose every raw update is announced through PARAM_EPOCH
+_VIEWS = {}
+
+
+def manage_param(p, on=True):
+    import weakref
+    if on:
+        MANAGED_PARAMS[p.data_ptr()] = weakref.ref(p)
+    else:
+        MANAGED_PARAMS.pop(p.data_ptr(), None)
+
+
+def is_managed(p):
+    r = MANAGED_PARAMS.get(p.data_ptr())
+    return r is not None and r() is p
+
+
+def weight_views(specs):
+    """specs: sequence of (param [R,C] f32 contiguous, transpose: bool, dtype).  Returns the prepared tensors (read
+    only; they persist and are refreshed lazily)."""
+    import numpy as np
+    key = tuple((p.data_ptr(), p.shape[0], p.shape[1], bool(tr), d) for p, tr, d in specs)
+    ver = (PARAM_EPOCH, tuple(p._version for p, _, _ in specs))
+    st = _VIEWS.get(key)
+    if st is None:
+        if len(_VIEWS) >= 32:
+            _VIEWS.clear()
+        dev = specs[0][0].device
+        outs, rec, max_tiles = [], [], 0
+        for p, tr, d in specs:
+            _need_cuda(p)
+            assert p.dtype == torch.float32 and p.dim() == 2 and p.is_contiguous()
+            R, C = p.shape
+            o = torch.empty((C, R) if tr else (R, C), dtype=d, device=dev)
+            outs.append(o)
+            rec.append((p.data_ptr(), o.data_ptr(), R, C, int(tr), _lib.BF16 if d == torch.bfloat16 else _lib.F32))
+            max_tiles = max(max_tiles, ((R + 31) // 32) * ((C + 31) // 32))
+        jobs = np.array(rec, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                             ("tr", "<i4"), ("dt", "<i4")]))
+        table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
+        st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None,
+                                keep=[p for p, _, _ in specs], managed=False)
+    st["managed"] = all(is_managed(p) for p, _, _ in specs)
+    if st["ver"] != ver or not st["managed"]:
+        check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
+        st["ver"] = ver
+    return st["outs"]
 
 
 def transpose_cast(w, dtype):
@@ -285,7 +344,8 @@ def gru_gates_fwd(gi, gh, hprev, hnew=None, gates=None):
     if gates is None:
         gates = torch.empty((B, H3), dtype=torch.float32, device=gi.device)
     assert hnew.is_contiguous() and gates.is_contiguous()
-    check(_lib.lib().murcl_gru_gates_fwd(ptr(gi), ptr(gh), ptr(hprev), ptr(hnew), ptr(gates), B, H, stream()),
+    check(_lib.lib().murcl_gru_gates_fwd(ptr(gi), ptr(gh), ptr(hprev), ptr(hnew), ptr(gates), B, H,
+                                         int(gh.shape[0] == 1 and B != 1), stream()),
           "gru_gates_fwd")
     return hnew, gates
 
@@ -301,7 +361,7 @@ def gru_gates_bwd(dh, gates, gh, hprev, dgi=None, dgh=None):
     assert dgi.is_contiguous() and dgh.is_contiguous() and gates.is_contiguous() and gh.is_contiguous()
     dhp = torch.empty((B, H), dtype=torch.float32, device=dh.device)
     check(_lib.lib().murcl_gru_gates_bwd(ptr(dh), ptr(gates), ptr(gh), ptr(hprev), ptr(dgi), ptr(dgh), ptr(dhp), B, H,
-                                         stream()), "gru_gates_bwd")
+                                         int(gh.shape[0] == 1 and B != 1), stream()), "gru_gates_bwd")
     return dgi, dgh, dhp
 
 

@@ -34,6 +34,7 @@ class FlatAdam:
                 flat_p[off:off + k].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + k].view_as(p.data)
                 p.grad = flat_g[off:off + k].view_as(p.data)
+                ops.manage_param(p)                           # every raw update of p goes through step() below
                 off += k
             self.groups.append(dict(params=params, lr=g["lr"], p=flat_p, g=flat_g,
                                     m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p)))
@@ -56,5 +57,6 @@ class FlatAdam:
         for g in self.groups:
             ops.adam_step(g["p"], g["g"], g["m"], g["v"], g["lr"], self.betas, self.eps, self.weight_decay,
                           self.step_count, zero_grad=self.fused_zero)
+        ops.PARAM_EPOCH += 1                       # cached compute-dtype weight views are stale now
         if self.fused_zero:
             self._maybe_dirty = False

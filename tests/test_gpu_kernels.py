@@ -348,3 +348,39 @@ def test_panel_gemm_unsupported_shapes_fall_back():
     assert not ops.panel_supported(100, 512, 512, ops.PG_BIAS_RELU)      # M % 32
     assert not ops.panel_supported(64, 384, 512, ops.PG_BIAS_RELU)       # N % 256
     assert not ops.panel_supported(64, 512, 128, ops.PG_RANK1_MASK, 48)  # bag not a whole number of tiles
+
+
+# ------------------------------------------------------------------ cached weight views (one batched cast/transpose launch)
+def test_weight_views_follow_parameter_updates():
+    from murcl_amd import ops
+    dev = _dev()
+    w1 = _rand(40, "w1", (512, 512)).to(dev)
+    w2 = _rand(40, "w2", (128, 512)).to(dev)
+    w3 = _rand(40, "w3", (70, 33)).to(dev)            # ragged tiles
+    specs = [(w1, False, torch.bfloat16), (w2, True, torch.bfloat16), (w3, True, torch.float32), (w3, False, torch.bfloat16)]
+
+    def check():
+        a, b, c, d = ops.weight_views(specs)
+        assert torch.equal(a, w1.bfloat16()) and torch.equal(b, w2.t().contiguous().bfloat16())
+        assert torch.equal(c, w3.t().contiguous()) and torch.equal(d, w3.bfloat16())
+        return a.data_ptr()
+
+    p0 = check()
+    with torch.no_grad():
+        w1.mul_(1.5)                                   # in-place torch op: version counter moves
+        w3.add_(0.25)
+    assert check() == p0                               # same persistent buffers, refreshed contents
+    w2.data.copy_(w2 * -2)                             # .data copy_: also bumps the version
+    check()
+    # parameters owned by a FlatAdam are cached: a raw-pointer update (the Adam kernel) is announced through PARAM_EPOCH
+    for w in (w1, w2, w3):
+        ops.manage_param(w)
+    check()
+    ops.adam_step(w1.view(-1), torch.ones_like(w1).view(-1), torch.zeros_like(w1).view(-1), torch.zeros_like(w1).view(-1),
+                  1e-1, (0.9, 0.999), 1e-8, 0.0, 1)
+    stale = ops.weight_views(specs)[0]
+    assert not torch.equal(stale, w1.bfloat16())       # cached on purpose until the epoch moves
+    ops.PARAM_EPOCH += 1
+    check()
+    for w in (w1, w2, w3):
+        ops.manage_param(w, False)
