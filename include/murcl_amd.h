@@ -70,11 +70,13 @@ int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* ba, const f
                          int dtype, int exact_tanh, murcl_stream_t stream);
 /* backward of the above w.r.t. the pre-tanh activations: dT[b,n,:] = ds_n * wb * (1 - t^2) with
  * ds_n = p_n (dM.H_n / sqrt(N) - dM.M), plus dba += sum dT, dwb += sum ds_n t_n, dbb += sum ds_n
- * (f32 accumulators, atomically added).  dH and dWa follow from dT through murcl_gemm_nt
+ * (f32, ADDED to the buffers: per-workgroup partial rows in part_ws [512*(2D+1) floats] are summed by a second small
+ * launch - 512 atomic adders per address cost a third of the kernel).  dH and dWa follow from dT through murcl_gemm_nt
  * (MURCL_EPI_RANK1_MASK with rowscale = A, rank1 = dM) and murcl_gemm_tn. */
 int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
                          const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
-                         float* dbb, int B, int N, int L, int D, int dtype, int exact_tanh, murcl_stream_t stream);
+                         float* dbb, float* part_ws, int B, int N, int L, int D, int dtype, int exact_tanh,
+                         murcl_stream_t stream);
 
 /* K8/K9 -- NT_Xent.forward + its gradient + torch.cosine_similarity of the positive pairs in one
  * launch (utils/losses.py:24-41; train_MuRCL.py:249,253,277,282).  z [n,P] f32 = cat(z_i,z_j),
@@ -129,7 +131,8 @@ int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ld
 int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a, const void* keep_b,
                           float* s, long rows, int D, int dtype, murcl_stream_t stream);
 int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b, const float* ds,
-                          void* dU, float* dwc, float* dbc, long rows, int D, int dtype, murcl_stream_t stream);
+                          void* dU, float* dwc, float* dbc, float* part_ws /* [1024*(D+1)] */, long rows, int D, int dtype,
+                          murcl_stream_t stream);
 int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t stream);
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);

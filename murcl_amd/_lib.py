@@ -24,7 +24,7 @@ SIGNATURES = {
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _P, _P],
     "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
@@ -37,7 +37,7 @@ SIGNATURES = {
     "murcl_rows_dot": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "murcl_gated_score_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "murcl_gated_score_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "murcl_gated_score_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "murcl_softmax_rows": [_P, _P, _I, _I, _P],
     "murcl_softmax_rows_bwd": [_P, _P, _P, _I, _I, _P],
     "murcl_topk_ids": [_P, _I, _I, _I, _P, _P],

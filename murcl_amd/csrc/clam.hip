@@ -6,94 +6,168 @@
 //   instance eval: top-k / bottom-k ids of A (lowest index wins ties), CE on 2-way instance logits
 #include "common.h"
 
-// ---------------------------------------------------------------- gated attention score (one wave per row)
+// ---------------------------------------------------------------- gated attention score
+// Streaming kernels over U [rows, 2D]: a thread owns 8 consecutive columns of both gate halves (16-byte loads for
+// bf16), G = D/8 column groups, 256/G rows in flight per workgroup pass, a workgroup walks `rows_per_block` rows.
 template <typename T>
 __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const float* __restrict__ bc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
-                                                              float* __restrict__ s, long rows, int D) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const T* u = U + row * 2 * D;
-    float acc = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
-        const f32x4 ua = load4<T>(u + d), ub = load4<T>(u + D + d);
-        f32x4 ka = f32x4{1.f, 1.f, 1.f, 1.f}, kb = ka;
-        if (keep_a) { ka = load4<T>(keep_a + row * D + d); kb = load4<T>(keep_b + row * D + d); }
+                                                              float* __restrict__ s, long rows, int D, int rows_per_block) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
+    const int cg = tid % G, rl = tid / G;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float w[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc += (tanhf(ua[e]) * ka[e]) * (sigmoidf_(ub[e]) * kb[e]) * wc[d + e];
+    for (int e = 0; e < 8; ++e) w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f;
+    const float b0 = bc[0];
+    const bool pow2 = G <= 64 && (G & (G - 1)) == 0;
+    for (long base = r0; base < r1; base += RL) {
+        const long n = base + rl;
+        float acc = 0.f;
+        if (rl < RL && n < r1) {
+            float ua[8], ub[8];
+            load8<T>(U + n * 2 * D + 8 * cg, ua);
+            load8<T>(U + n * 2 * D + D + 8 * cg, ub);
+            if (keep_a) {
+                float ka[8], kb[8];
+                load8<T>(keep_a + n * D + 8 * cg, ka);
+                load8<T>(keep_b + n * D + 8 * cg, kb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += (tanhf(ua[e]) * ka[e]) * (sigmoidf_(ub[e]) * kb[e]) * w[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += tanhf(ua[e]) * sigmoidf_(ub[e]) * w[e];
+            }
+        }
+        // sum over the G threads of a row: lanes of one wave when G is a power of two <= 64, else through LDS
+        if (pow2) {
+            for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        } else {
+            red[tid] = acc;
+            __syncthreads();
+            if (cg == 0 && rl < RL) { acc = 0.f; for (int k = 0; k < G; ++k) acc += red[rl * G + k]; }
+            __syncthreads();
+        }
+        if (cg == 0 && rl < RL && n < r1) s[n] = acc + b0;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) s[row] = acc + bc[0];
 }
 // dU[n,d] = ds_n wc_d g (1-a^2) ka kb ; dU[n,D+d] = ds_n wc_d a g (1-g) ka kb ; dwc_d += ds_n a g ka kb ; dbc += ds_n
 template <typename T>
 __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
                                                               const float* __restrict__ ds, T* __restrict__ dU,
-                                                              float* __restrict__ dwc, float* __restrict__ dbc,
+                                                              float* __restrict__ part,
                                                               long rows, int D, int rows_per_block) {
-    // block: 256 threads = 64 column groups of 4 (D <= 256) ... generic: thread owns columns d0 + 1024*k
-    const int tid = threadIdx.x;
+    __shared__ float red[256][9];
+    const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
+    const int cg = tid % G, rl = tid / G;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float dbc_acc = 0.f;
-    for (int d = tid * 4; d < D; d += 1024) {
-        f32x4 wacc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 w = *(const f32x4*)(wc + d);
-        for (long n = r0; n < r1; ++n) {
-            const T* u = U + n * 2 * D;
-            const f32x4 ua = load4<T>(u + d), ub = load4<T>(u + D + d);
-            f32x4 ka = f32x4{1.f, 1.f, 1.f, 1.f}, kb = ka;
-            if (keep_a) { ka = load4<T>(keep_a + n * D + d); kb = load4<T>(keep_b + n * D + d); }
-            const float dsn = ds[n];
-            f32x4 da, db;
+    float w[8], wacc[8], dbc_acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = tanhf(ua[e]), g = sigmoidf_(ub[e]);
-                const float k = ka[e] * kb[e];
-                da[e] = dsn * w[e] * g * (1.f - a * a) * k;
-                db[e] = dsn * w[e] * a * g * (1.f - g) * k;
-                wacc[e] += dsn * a * g * k;
+    for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = 0.f; }
+    if (rl < RL) {
+        for (long n = r0 + rl; n < r1; n += RL) {
+            float ua[8], ub[8], da[8], db[8], k[8];
+            load8<T>(U + n * 2 * D + 8 * cg, ua);
+            load8<T>(U + n * 2 * D + D + 8 * cg, ub);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k[e] = 1.f;
+            if (keep_a) {
+                float ka[8], kb[8];
+                load8<T>(keep_a + n * D + 8 * cg, ka);
+                load8<T>(keep_b + n * D + 8 * cg, kb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) k[e] = ka[e] * kb[e];
             }
-            store4<T>(dU + n * 2 * D + d, da);
-            store4<T>(dU + n * 2 * D + D + d, db);
-        }
+            const float dsn = ds[n];
+            if (cg == 0) dbc_acc += dsn;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dwc + d + e, wacc[e]);
+            for (int e = 0; e < 8; ++e) {
+                const float a = tanhf(ua[e]), g = sigmoidf_(ub[e]);
+                da[e] = dsn * w[e] * g * (1.f - a * a) * k[e];
+                db[e] = dsn * w[e] * a * g * (1.f - g) * k[e];
+                wacc[e] += dsn * a * g * k[e];
+            }
+            store8<T>(dU + n * 2 * D + 8 * cg, da);
+            store8<T>(dU + n * 2 * D + D + 8 * cg, db);
+        }
     }
-    if (tid == 0) {
-        for (long n = r0; n < r1; ++n) dbc_acc += ds[n];
-        atomicAdd(dbc, dbc_acc);
+    // reduce over the row lanes, then this workgroup's row of partial sums (part [grid][D+1]; summed by
+    // gated_score_reduce_kernel - thousands of atomic adders on D addresses would serialise at the memory side)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid][e] = wacc[e];
+    red[tid][8] = dbc_acc;
+    __syncthreads();
+    if (rl == 0) {
+        float t[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) t[e] = 0.f;
+        for (int r = 0; r < RL; ++r)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) t[e] += red[r * G + cg][e];
+        float* prow = part + (size_t)blockIdx.x * (D + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) prow[8 * cg + e] = t[e];
+        if (cg == 0) prow[D] = t[8];
     }
+}
+// dwc[c] = sum_w part[w][c], dbc = sum_w part[w][D]
+__global__ __launch_bounds__(256) void gated_score_reduce_kernel(const float* __restrict__ part, int n_wg, int D,
+                                                                 float* __restrict__ dwc, float* __restrict__ dbc) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c <= D)
+        for (int w = rl; w < n_wg; w += 4) s += part[(size_t)w * (D + 1) + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c <= D) {
+        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        if (c < D) dwc[c] = t; else dbc[0] = t;
+    }
+}
+static bool gs_shape_ok(int D) { return D >= 8 && D <= 2048 && D % 8 == 0; }
+static int gs_rows_per_block(long rows, int D) {
+    const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
+    long rpb = (rows + 4095) / 4096;                       // ~4096 workgroups
+    rpb = ((rpb + RL - 1) / RL) * RL;
+    if (rpb < 4 * RL) rpb = 4 * RL;
+    return (int)rpb;
 }
 extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a,
                                      const void* keep_b, float* s, long rows, int D, int dtype, hipStream_t st) {
     if (rows <= 0) return 0;
-    if (D % 4) return -1;
-    dim3 grid((unsigned)((rows + 3) / 4));
+    if (!gs_shape_ok(D)) return -1;
+    const int rpb = gs_rows_per_block(rows, D);
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(gated_score_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)U, wc, bc, (const float*)keep_a, (const float*)keep_b, s, rows, D);
+        hipLaunchKernelGGL(gated_score_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)U, wc, bc, (const float*)keep_a, (const float*)keep_b, s, rows, D, rpb);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(gated_score_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)U, wc, bc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, s, rows, D);
+        hipLaunchKernelGGL(gated_score_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)U, wc, bc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, s, rows, D, rpb);
     else return -1;
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
-                                     const float* ds, void* dU, float* dwc, float* dbc, long rows, int D, int dtype,
-                                     hipStream_t st) {
+                                     const float* ds, void* dU, float* dwc, float* dbc, float* part_ws, long rows, int D,
+                                     int dtype, hipStream_t st) {
     if (rows <= 0) return 0;
-    if (D % 4) return -1;
-    hipError_t e = hipMemsetAsync(dwc, 0, (size_t)D * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(dbc, 0, 4, st);
-    if (e != hipSuccess) return (int)e;
-    const int rpb = 64;
-    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (!gs_shape_ok(D) || !part_ws) return -1;
+    const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
+    long rpb = (rows + 1023) / 1024;                       // <= 1024 workgroups = rows of part_ws [1024][D+1]
+    rpb = ((rpb + RL - 1) / RL) * RL;
+    if (rpb < 4 * RL) rpb = 4 * RL;
+    const int grid = (int)((rows + rpb - 1) / rpb);
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(gated_score_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)U, wc, (const float*)keep_a, (const float*)keep_b, ds, (float*)dU, dwc, dbc, rows, D, rpb);
+        hipLaunchKernelGGL(gated_score_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)U, wc, (const float*)keep_a, (const float*)keep_b, ds, (float*)dU, part_ws, rows, D, (int)rpb);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(gated_score_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)U, wc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, ds, (bf16_t*)dU, dwc, dbc, rows, D, rpb);
+        hipLaunchKernelGGL(gated_score_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)U, wc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, ds, (bf16_t*)dU, part_ws, rows, D, (int)rpb);
     else return -1;
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((D + 1 + 63) / 64), dim3(256), 0, st, part_ws, grid, D, dwc, dbc);
     return MURCL_CHECK_LAUNCH();
 }
 
@@ -143,12 +217,68 @@ extern "C" int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds
 // ---------------------------------------------------------------- top-k / bottom-k patch ids per bag (clam.py:107-109,126)
 // ids[b, 0:k] = indices of the k largest A[b,:] in descending order, ids[b, k:2k] = the k smallest in ascending
 // order; ties go to the lowest index.  k <= 32.
+// Bags of up to 256*TK_PT patches: every thread keeps its TK_PT values in registers as 64-bit keys
+// (order-preserving value bits | ~index, so ties go to the lowest index) and each of the k rounds is one wave
+// arg-max by shuffles + a 4-entry exchange through LDS, for the descending and the ascending selection at once.
+// Larger bags fall back to rounds of a full arg-max scan.
+#define TK_PT 16
+__device__ __forceinline__ unsigned tk_ord(float v) {            // monotone float -> uint32
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long tk_wave_max(unsigned long long k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(k, o, 64);
+        k = other > k ? other : k;
+    }
+    return k;
+}
 __global__ __launch_bounds__(256) void topk_ids_kernel(const float* __restrict__ A, int N, int k, int* __restrict__ ids) {
+    __shared__ unsigned long long wk[2][2][4];          // [round parity][desc/asc][wave]
     __shared__ float bv[256];
     __shared__ int bi[256];
     __shared__ int taken[64];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* a = A + (size_t)b * N;
+    int* out = ids + (size_t)b * 2 * k;
+    if (N <= 256 * TK_PT) {
+        unsigned long long kd[TK_PT], ka[TK_PT];
+#pragma unroll
+        for (int t = 0; t < TK_PT; ++t) {
+            const int n = tid + 256 * t;
+            if (n < N) {
+                const unsigned o = tk_ord(a[n]);
+                kd[t] = ((unsigned long long)o << 32) | (unsigned)(~n);
+                ka[t] = ((unsigned long long)(~o) << 32) | (unsigned)(~n);
+            } else {
+                kd[t] = 0ull; ka[t] = 0ull;
+            }
+        }
+        for (int r = 0; r < k; ++r) {
+            unsigned long long md = 0ull, ma = 0ull;
+#pragma unroll
+            for (int t = 0; t < TK_PT; ++t) { md = kd[t] > md ? kd[t] : md; ma = ka[t] > ma ? ka[t] : ma; }
+            md = tk_wave_max(md);
+            ma = tk_wave_max(ma);
+            if (lane == 0) { wk[r & 1][0][wave] = md; wk[r & 1][1][wave] = ma; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned long long d = wk[r & 1][0][w], c = wk[r & 1][1][w];
+                md = d > md ? d : md; ma = c > ma ? c : ma;
+            }
+            const int id = (int)~(unsigned)md, ia = (int)~(unsigned)ma;
+            if (tid == 0) { out[r] = id; out[k + r] = ia; }
+            // the owners retire the winners (key 0 never wins again)
+#pragma unroll
+            for (int t = 0; t < TK_PT; ++t) {
+                if (tid + 256 * t == id) kd[t] = 0ull;
+                if (tid + 256 * t == ia) ka[t] = 0ull;
+            }
+        }
+        return;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const float sgn = pass == 0 ? 1.f : -1.f;
         for (int r = 0; r < k; ++r) {
@@ -170,7 +300,7 @@ __global__ __launch_bounds__(256) void topk_ids_kernel(const float* __restrict__
                 }
                 __syncthreads();
             }
-            if (tid == 0) { taken[r] = bi[0]; ids[(size_t)b * 2 * k + pass * k + r] = bi[0]; }
+            if (tid == 0) { taken[r] = bi[0]; out[pass * k + r] = bi[0]; }
             __syncthreads();
         }
     }

@@ -49,6 +49,27 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
     *(u32x2*)p = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
 
+// 8 consecutive elements <-> float[8] (16-byte accesses for bf16, two for f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
+    const u32x4 u = *(const u32x4*)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(u[e]); v[2 * e + 1] = bf_hi(u[e]); }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+    *(u32x4*)p = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+}
+
 // LDS byte offset of a __shared__ object (flat LDS address: low 32 bits are the offset).
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(uintptr_t)p; }
 

@@ -112,34 +112,59 @@ extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float*
 }
 
 // Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]      (one streaming pass over X; C <= 4)
-// grid (B, row splits); each workgroup reduces its row range for all d columns and adds atomically.
+// grid (B, row splits).  A thread owns 8 consecutive columns (16-byte loads for bf16), G = d/8 column groups and
+// 256/G row lanes per workgroup; the row lanes meet in LDS and the workgroup adds its partial sums atomically.
 template <typename T>
 __global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restrict__ X, const float* __restrict__ A,
                                                               int N, int d, int C, int rows_per_block,
                                                               float* __restrict__ Z) {
+    __shared__ float red[256][8 + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(N, r0 + rows_per_block);
     const T* x = X + (size_t)b * N * d;
     const float* a = A + (size_t)b * N * C;
-    for (int c0 = tid * 4; c0 < d; c0 += 1024) {
-        f32x4 acc[4];
+    const int G = min(d >> 3, 256), RL = 256 / G, cg = tid % G, rl = tid / G;
+    for (int c0 = 8 * cg; c0 < d; c0 += 8 * G) {                // one pass unless d > 2048
+        float acc[4][8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int n = r0; n < r1; ++n) {
-            const f32x4 v = load4<T>(x + (size_t)n * d + c0);
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < C) acc[c] += a[(size_t)n * C + c] * v;
+            for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+        if (rl < RL) {
+            for (int n = r0 + rl; n < r1; n += RL) {
+                float v[8];
+                load8<T>(x + (size_t)n * d + c0, v);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < C) {
+                        const float w = a[(size_t)n * C + c];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[c][e] += w * v[e];
+                    }
+            }
         }
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c) {
+            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(Z + ((size_t)b * C + c) * d + c0 + e, acc[c][e]);
+            for (int e = 0; e < 8; ++e) red[tid][e] = acc[c][e];
+            __syncthreads();
+            if (rl == 0) {
+                float t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = 0.f;
+                for (int r = 0; r < RL; ++r)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] += red[r * G + cg][e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(Z + ((size_t)b * C + c) * d + c0 + e, t[e]);
+            }
+        }
     }
 }
 extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
                                      hipStream_t s) {
     if (B <= 0) return 0;
-    if (C > 4 || d % 4) return -1;
+    if (C > 4 || d % 8) return -1;
     hipError_t e = hipMemsetAsync(Z, 0, (size_t)B * C * d * 4, s);
     if (e != hipSuccess) return (int)e;
     int splits = (1024 + B - 1) / B;
@@ -156,37 +181,45 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
     return MURCL_CHECK_LAUNCH();
 }
 
-// out[b,n,c] = X[b,n,:] . V[b,c,:]      (dA = X dZ^T; one wave per row, C <= 4)
+// out[b,n,c] = X[b,n,:] . V[b,c,:]      (dA = X dZ^T; C <= 4).  A wave walks `RPW` rows; a lane owns 8 consecutive
+// columns per 512-column step (16-byte loads for bf16) and keeps its slice of V in registers when d <= 512.
+#define RD_RPW 16
 template <typename T>
 __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, const float* __restrict__ V, int N, int d,
                                                        int C, float* __restrict__ out, long rows_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows_total) return;
-    const int b = (int)(row / N);
-    const T* x = X + row * d;
-    const float* v = V + (size_t)b * C * d;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane * 4; k < d; k += 256) {
-        const f32x4 xv = load4<T>(x + k);
+    const long row0 = ((long)blockIdx.x * 4 + wave) * RD_RPW;
+    if (row0 >= rows_total) return;
+    const long row1 = min(rows_total, row0 + RD_RPW);
+    for (long row = row0; row < row1; ++row) {
+        const int b = (int)(row / N);
+        const T* x = X + row * d;
+        const float* v = V + (size_t)b * C * d;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane * 8; k < d; k += 512) {
+            float xv[8];
+            load8<T>(x + k, xv);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < C) {
-                const f32x4 w = *(const f32x4*)(v + (size_t)c * d + k);
-                acc[c] += xv[0] * w[0] + xv[1] * w[1] + xv[2] * w[2] + xv[3] * w[3];
-            }
-    }
-    for (int c = 0; c < C; ++c) {
-        const float s = wave_sum(acc[c]);
-        if (lane == 0) out[row * C + c] = s;
+            for (int c = 0; c < 4; ++c)
+                if (c < C) {
+                    float w[8];
+                    load8<float>(v + (size_t)c * d + k, w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[c] += xv[e] * w[e];
+                }
+        }
+        for (int c = 0; c < C; ++c) {
+            const float s = wave_sum(acc[c]);
+            if (lane == 0) out[row * C + c] = s;
+        }
     }
 }
 extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
                               hipStream_t s) {
     if (B <= 0) return 0;
-    if (C > 4 || d % 4) return -1;
+    if (C > 4 || d % 8) return -1;
     const long rows = (long)B * N;
-    dim3 grid((unsigned)((rows + 3) / 4));
+    dim3 grid((unsigned)((rows + 4 * RD_RPW - 1) / (4 * RD_RPW)));
     if (dtype == MURCL_DTYPE_F32)
         hipLaunchKernelGGL(rows_dot_kernel<float>, grid, dim3(256), 0, s, (const float*)X, V, N, d, C, out, rows);
     else if (dtype == MURCL_DTYPE_BF16)

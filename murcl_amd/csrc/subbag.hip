@@ -95,26 +95,6 @@ extern "C" int murcl_subbag_select(const int* cluster_ids, const int* cluster_of
 }
 
 // ------------------------------------------------------------------------------------------ gather (+ mix-up)
-template <typename TI> __device__ __forceinline__ void load8(const TI* p, float* v);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
-    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
-}
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* v) {
-    const u32x4 u = *(const u32x4*)p;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(u[e]); v[2 * e + 1] = bf_hi(u[e]); }
-}
-template <typename TO> __device__ __forceinline__ void store8(TO* p, const float* v);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
-    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-}
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
-    *(u32x4*)p = u32x4{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-}
-
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __restrict__ feats,
                                                                 const long* __restrict__ bag_row_off,

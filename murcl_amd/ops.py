@@ -212,11 +212,12 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
     else:
         z = torch.zeros((2 * D + 1,), dtype=torch.float32, device=dev)          # one fill for the three accumulators
         dba, dwb, dbb = z[:D], z[D:2 * D], z[2 * D:]
+    part = torch.empty((512 * (2 * D + 1),), dtype=torch.float32, device=dev)      # per-workgroup parameter-gradient rows
     es = H.element_size()
     with _span(f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es)):
         check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
-                                              ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), B, N, L, D, dt(H),
+                                              ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(part), B, N, L, D, dt(H),
                                               int(exact_tanh), stream()), "abmil_pool_bwd")
     return dT_full[:B * N], dba, dwb, dbb
 
@@ -441,8 +442,9 @@ def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None):
     dU = torch.empty_like(U)
     dwc = torch.empty((D2 // 2,), dtype=torch.float32, device=U.device)
     dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
+    part = torch.empty((1024 * (D2 // 2 + 1),), dtype=torch.float32, device=U.device)     # per-workgroup partial rows
     check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(keep_a), ptr(keep_b), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
-                                           M, D2 // 2, dt(U), stream()), "gated_score_bwd")
+                                           ptr(part), M, D2 // 2, dt(U), stream()), "gated_score_bwd")
     return dU, dwc, dbc
 
 

@@ -13,8 +13,11 @@
 // per-row dots g_n = dM.H_n also run on the matrix cores: dM enters as rows 0/1 (bf16 hi + lo parts; f32: row 0)
 // of an MFMA A operand and every wave covers 1/NW of the k range, partial sums meet in LDS.  The saved raw scores
 // of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
-#include "k2_common.h"
+#include "../../murcl_amd/csrc/k2_common.h"
 
+#ifndef KB_NOFLUSH
+#define KB_NOFLUSH 0
+#endif
 template <typename T> struct KBLds {
     static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32
     static constexpr int OFF_SC = OFF_GPART + K2<T>::NW * 16 * 4;                   // [slot][NW][64] f32
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ scores, const float* __restrict__ ml, const float* __restrict__ Mp,
     const float* __restrict__ dM, T* __restrict__ dT, float* __restrict__ dba, float* __restrict__ dwb,
-    float* __restrict__ dbb, float* __restrict__ part_ws, int B, int N, int chunk_rows, int S, float inv_sqrt_n) {
+    float* __restrict__ dbb, int B, int N, int chunk_rows, int S, float inv_sqrt_n) {
     typedef K2<T> C_;
     typedef KBLds<T> L_;
     typedef typename WFrag<T>::type frag_t;
@@ -206,53 +209,32 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         cp.next(tiles_per_item, gridDim.x, S);
     }
 
-    // ---- publish this workgroup's parameter-gradient partials (sum over the 16 rows = lanes of a quarter) as one row of
-    // part_ws.  Adding them atomically to dba/dwb/dbb from all 512 workgroups cost 42 of 121 us: float atomics execute at
-    // the memory side and 512 adders per address serialise; abmil_pool_bwd_reduce_kernel sums the rows instead.
-    float* prow = part_ws + (size_t)blockIdx.x * (2 * K2_D + 1);
+    if (KB_NOFLUSH) return;
+    // ---- flush the parameter-gradient partials (sum over the 16 rows = lanes of a quarter)
 #pragma unroll
     for (int j = 0; j < C_::NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float a = row16_sum(dba_r[j][r]), w = row16_sum(dwb_r[j][r]);
             if (r16 == 0) {
-                prow[C_::DW * wave + 16 * j + 4 * q4 + r] = a;
-                prow[K2_D + C_::DW * wave + 16 * j + 4 * q4 + r] = w;
+                atomicAdd(dba + C_::DW * wave + 16 * j + 4 * q4 + r, a);
+                atomicAdd(dwb + C_::DW * wave + 16 * j + 4 * q4 + r, w);
             }
         }
     if (wave == 0) {
         const float t = row16_sum(dbb_acc);
-        if (lane == 0) prow[2 * K2_D] = t;
-    }
-}
-
-// dba[c] += sum_w part[w][c], dwb[c] += sum_w part[w][D + c], dbb += sum_w part[w][2D]   (one thread column, 4 row lanes)
-__global__ __launch_bounds__(256) void abmil_pool_bwd_reduce_kernel(const float* __restrict__ part, int n_wg,
-                                                                    float* __restrict__ dba, float* __restrict__ dwb,
-                                                                    float* __restrict__ dbb) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, W = 2 * K2_D + 1;
-    float s = 0.f;
-    if (c < W)
-        for (int w = rl; w < n_wg; w += 4) s += part[(size_t)w * W + c];
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < W) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-        float* dst = c < K2_D ? dba + c : (c < 2 * K2_D ? dwb + (c - K2_D) : dbb);
-        *dst += t;
+        if (lane == 0) atomicAdd(dbb, t);
     }
 }
 
 extern "C" int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_chunks);
 
-// C-ABI: see include/murcl_amd.h.  dT must hold (B*N + 32) rows of D elements, part_ws 512*(2D+1) floats.
+// C-ABI: see include/murcl_amd.h.  dT must hold (B*N + 32) rows of D elements.
 extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
                                     const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
-                                    float* dbb, float* part_ws, int B, int N, int L, int D, int dtype, int exact_tanh,
+                                    float* dbb, int B, int N, int L, int D, int dtype, int exact_tanh,
                                     hipStream_t stream) {
-    if (L != K2_L || D != K2_D || !part_ws) return -1;
+    if (L != K2_L || D != K2_D) return -1;
     if (B <= 0 || N <= 0) return 0;
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
@@ -269,7 +251,7 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
             once = true;                                                                                       \
         }                                                                                                      \
         hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), KBLds<T>::BYTES, stream, (const T*)H,         \
-                           (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, part_ws, B, N, chunk, S, isn); \
+                           (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, B, N, chunk, S, isn); \
     }
     if (dtype == MURCL_DTYPE_BF16) {
         if (exact_tanh) KB_LAUNCH(bf16_t, true) else KB_LAUNCH(bf16_t, false)
@@ -279,9 +261,5 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
         return -1;
     }
 #undef KB_LAUNCH
-    int rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    hipLaunchKernelGGL(abmil_pool_bwd_reduce_kernel, dim3((2 * K2_D + 1 + 63) / 64), dim3(256), 0, stream, part_ws, grid, dba,
-                       dwb, dbb);
     return MURCL_CHECK_LAUNCH();
 }
