@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
     const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
     const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
-    float* __restrict__ colsum_out) {
+    float* __restrict__ colsum_part) {
     constexpr int ROWB = K * 2;                 // bytes per A row
     // K = 512: one LDS-DMA instruction writes exactly one row, so rows can be stored at a padded stride (conflict-free
     // 16-row fragment reads with immediate offsets, no swizzle math).  K = 128: four rows per instruction -> XOR swizzle.
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const int per = (n_tiles + streams - 1) / streams;
     const int tile0 = CONTIG ? stream * per : stream, tstep = CONTIG ? 1 : streams;
     const int my_tiles = CONTIG ? min(per, n_tiles - tile0) : (n_tiles - stream + streams - 1) / streams;
-    if (stream >= streams || my_tiles <= 0) return;
+    if (stream >= streams || my_tiles <= 0) {
+        if (colsum_part && stream < streams)                 // no tiles: this workgroup's row of partial sums is zero
+            for (int c = threadIdx.x; c < NP; c += 64 * PG_NW) colsum_part[(size_t)stream * N + panel * NP + c] = 0.f;
+        return;
+    }
     const int n0 = panel * NP + wave * WN;          // first column of this wave
 
     auto issue = [&](int seq) {
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                         v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
                     }
                 }
-                if (colsum_out) {          // bias gradient from the f32 values, before they are rounded to bf16
+                if (colsum_part) {         // bias gradient from the f32 values, before they are rounded to bf16
 #pragma unroll
                     for (int r = 0; r < 4; ++r) csum[j][r] += v[r];
                 }
@@ -310,14 +314,17 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         }
     }
 
-    if (colsum_out) {
-        // the 16 lanes of a quarter hold the same columns for different rows: reduce over them, one atomic per column
+    if (colsum_part) {
+        // the 16 lanes of a quarter hold the same columns for different rows: reduce over them and publish this
+        // workgroup's partial sums as row `stream` of colsum_part [streams][N] (plain stores; murcl_colsum adds the rows
+        // up afterwards - 128 atomic adders per column from here cost 10-15 us per launch)
+        float* prow = colsum_part + (size_t)stream * N;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = row16_sum(csum[j][r]);
-                if (r16 == 0) atomicAdd(colsum_out + n0 + 16 * j + 4 * q4 + r, t);
+                if (r16 == 0) prow[n0 + 16 * j + 4 * q4 + r] = t;
             }
     }
 }
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
-                     float* colsum_out, hipStream_t s) {
+                     float* colsum_part, int* streams_out, hipStream_t s) {
     constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
     constexpr int STG_LD = WN * 2 + 16;
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD + (EPI != PG_BIAS_RELU ? PG_NSLOT * PG_NW * 256 : 0) +
@@ -342,9 +349,12 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     const int n_tiles = M / PG_TR;
     if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * PG_NW), LDS, s, A, W, C, M, N, bias, bm_out, bm_in, rowscale, rank1,
-                       rows_per_bag, colsum_out);
+                       rows_per_bag, colsum_part);
+    *streams_out = grid / panels;
     return MURCL_CHECK_LAUNCH();
 }
+
+extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s);
 
 // C-ABI: see include/murcl_amd.h
 extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag) {
@@ -357,12 +367,11 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
                                 const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
-                                hipStream_t stream) {
+                                float* colsum_ws, hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
-    if (colsum_out && !colsum_accumulate) {
-        hipError_t e = hipMemsetAsync(colsum_out, 0, (size_t)N * 4, stream);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (colsum_out && !colsum_ws) return -1;
+    float* part = colsum_out ? colsum_ws : nullptr;
+    int streams = 0, rc = -1;
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;
     bf16_t* c = (bf16_t*)C;
@@ -370,16 +379,16 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     const uint8_t* bi = (const uint8_t*)bitmask_in;
     if (K == 512 && epilogue == PG_BIAS_RELU) {
         if (!bias) return -1;
-        return bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream)
-                  : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
-    }
-    if (K == 512 && epilogue == PG_MASK) {
+        rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream)
+                : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+    } else if (K == 512 && epilogue == PG_MASK) {
         if (!bi) return -1;
-        return pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
-    }
-    if (K == 128 && epilogue == PG_RANK1_MASK) {
+        rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+    } else if (K == 128 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
-        return pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, colsum_out, stream);
+        rc = pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
     }
-    return -1;
+    if (rc == 0 && colsum_out)         // sum the per-workgroup rows [streams][N] into the (bias-gradient) output
+        rc = murcl_colsum(part, colsum_out, streams, N, N, MURCL_DTYPE_F32, colsum_accumulate, stream);
+    return rc;
 }

@@ -132,12 +132,13 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     cs = torch.empty((N,), dtype=torch.float32, device=A.device) if (colsum and colsum_into is None) else None
     if colsum_into is not None:
         assert colsum_into.is_contiguous() and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
+    ws = torch.empty((256 * N,), dtype=torch.float32, device=A.device) if (colsum or colsum_into is not None) else None
     with _span(f"panel_gemm<K{K},{_PG_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0))):
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                           ptr(rowscale), ptr(rank1), rows_per_bag,
                                           ptr(colsum_into if colsum_into is not None else cs),
-                                          int(colsum_into is not None), stream()), "panel_gemm")
+                                          int(colsum_into is not None), ptr(ws), stream()), "panel_gemm")
     return C, bm, cs
 
 
