@@ -226,20 +226,22 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     }
 }
 
-// dba[c] += sum_w part[w][c], dwb[c] += sum_w part[w][D + c], dbb += sum_w part[w][2D]   (one thread column, 4 row lanes)
+// dba[c] += sum_w part[w][c], dwb[c] += sum_w part[w][D + c], dbb += sum_w part[w][2D]   (16 columns x 16 row lanes)
 __global__ __launch_bounds__(256) void abmil_pool_bwd_reduce_kernel(const float* __restrict__ part, int n_wg,
                                                                     float* __restrict__ dba, float* __restrict__ dwb,
                                                                     float* __restrict__ dbb) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, W = 2 * K2_D + 1;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, W = 2 * K2_D + 1;
     float s = 0.f;
     if (c < W)
-        for (int w = rl; w < n_wg; w += 4) s += part[(size_t)w * W + c];
+        for (int w = rl; w < n_wg; w += 16) s += part[(size_t)w * W + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < W) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
         float* dst = c < K2_D ? dba + c : (c < 2 * K2_D ? dwb + (c - K2_D) : dbb);
         *dst += t;
     }
@@ -281,7 +283,7 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
 #undef KB_LAUNCH
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(abmil_pool_bwd_reduce_kernel, dim3((2 * K2_D + 1 + 63) / 64), dim3(256), 0, stream, part_ws, grid, dba,
+    hipLaunchKernelGGL(abmil_pool_bwd_reduce_kernel, dim3((2 * K2_D + 1 + 15) / 16), dim3(256), 0, stream, part_ws, grid, dba,
                        dwb, dbb);
     return MURCL_CHECK_LAUNCH();
 }

@@ -23,34 +23,51 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
     for (int e = 0; e < 8; ++e) w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f;
     const float b0 = bc[0];
     const bool pow2 = G <= 64 && (G & (G - 1)) == 0;
-    for (long base = r0; base < r1; base += RL) {
-        const long n = base + rl;
-        float acc = 0.f;
-        if (rl < RL && n < r1) {
-            float ua[8], ub[8];
-            load8<T>(U + n * 2 * D + 8 * cg, ua);
-            load8<T>(U + n * 2 * D + D + 8 * cg, ub);
-            if (keep_a) {
-                float ka[8], kb[8];
-                load8<T>(keep_a + n * D + 8 * cg, ka);
-                load8<T>(keep_b + n * D + 8 * cg, kb);
+    constexpr int UR = 4;                                 // rows in flight per thread
+    for (long base = r0; base < r1; base += UR * RL) {
+        float ua[UR][8], ub[UR][8], acc[UR];
+        bool live[UR];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += (tanhf(ua[e]) * ka[e]) * (sigmoidf_(ub[e]) * kb[e]) * w[e];
-            } else {
+        for (int u = 0; u < UR; ++u) {
+            const long n = base + u * RL + rl;
+            live[u] = rl < RL && n < r1;
+            acc[u] = 0.f;
+            if (live[u]) {
+                load8<T>(U + n * 2 * D + 8 * cg, ua[u]);
+                load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += tanhf(ua[e]) * sigmoidf_(ub[e]) * w[e];
+        for (int u = 0; u < UR; ++u) {
+            const long n = base + u * RL + rl;
+            if (live[u]) {
+                if (keep_a) {
+                    float ka[8], kb[8];
+                    load8<T>(keep_a + n * D + 8 * cg, ka);
+                    load8<T>(keep_b + n * D + 8 * cg, kb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[u] += (tanhf(ua[u][e]) * ka[e]) * (sigmoidf_(ub[u][e]) * kb[e]) * w[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[u] += tanhf(ua[u][e]) * sigmoidf_(ub[u][e]) * w[e];
+                }
             }
         }
         // sum over the G threads of a row: lanes of one wave when G is a power of two <= 64, else through LDS
-        if (pow2) {
-            for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o, 64);
-        } else {
-            red[tid] = acc;
-            __syncthreads();
-            if (cg == 0 && rl < RL) { acc = 0.f; for (int k = 0; k < G; ++k) acc += red[rl * G + k]; }
-            __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const long n = base + u * RL + rl;
+            float t = acc[u];
+            if (pow2) {
+                for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o, 64);
+            } else {
+                red[tid] = t;
+                __syncthreads();
+                if (cg == 0 && rl < RL) { t = 0.f; for (int k = 0; k < G; ++k) t += red[rl * G + k]; }
+                __syncthreads();
+            }
+            if (cg == 0 && live[u]) s[n] = t + b0;
         }
-        if (cg == 0 && rl < RL && n < r1) s[n] = acc + b0;
     }
 }
 // dU[n,d] = ds_n wc_d g (1-a^2) ka kb ; dU[n,D+d] = ds_n wc_d a g (1-g) ka kb ; dwc_d += ds_n a g ka kb ; dbc += ds_n
@@ -68,30 +85,44 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = 0.f; }
     if (rl < RL) {
-        for (long n = r0 + rl; n < r1; n += RL) {
-            float ua[8], ub[8], da[8], db[8], k[8];
-            load8<T>(U + n * 2 * D + 8 * cg, ua);
-            load8<T>(U + n * 2 * D + D + 8 * cg, ub);
+        constexpr int UR = 2;                             // rows in flight per thread
+        for (long n0 = r0 + rl; n0 < r1; n0 += UR * RL) {
+            float ua[UR][8], ub[UR][8], dsn[UR];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) k[e] = 1.f;
-            if (keep_a) {
-                float ka[8], kb[8];
-                load8<T>(keep_a + n * D + 8 * cg, ka);
-                load8<T>(keep_b + n * D + 8 * cg, kb);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) k[e] = ka[e] * kb[e];
+            for (int u = 0; u < UR; ++u) {
+                const long n = n0 + u * RL;
+                dsn[u] = 0.f;
+                if (n < r1) {
+                    load8<T>(U + n * 2 * D + 8 * cg, ua[u]);
+                    load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
+                    dsn[u] = ds[n];
+                }
             }
-            const float dsn = ds[n];
-            if (cg == 0) dbc_acc += dsn;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = tanhf(ua[e]), g = sigmoidf_(ub[e]);
-                da[e] = dsn * w[e] * g * (1.f - a * a) * k[e];
-                db[e] = dsn * w[e] * a * g * (1.f - g) * k[e];
-                wacc[e] += dsn * a * g * k[e];
+            for (int u = 0; u < UR; ++u) {
+                const long n = n0 + u * RL;
+                if (n >= r1) continue;
+                float da[8], db[8], k[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) k[e] = 1.f;
+                if (keep_a) {
+                    float ka[8], kb[8];
+                    load8<T>(keep_a + n * D + 8 * cg, ka);
+                    load8<T>(keep_b + n * D + 8 * cg, kb);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) k[e] = ka[e] * kb[e];
+                }
+                if (cg == 0) dbc_acc += dsn[u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = tanhf(ua[u][e]), g = sigmoidf_(ub[u][e]);
+                    da[e] = dsn[u] * w[e] * g * (1.f - a * a) * k[e];
+                    db[e] = dsn[u] * w[e] * a * g * (1.f - g) * k[e];
+                    wacc[e] += dsn[u] * a * g * k[e];
+                }
+                store8<T>(dU + n * 2 * D + 8 * cg, da);
+                store8<T>(dU + n * 2 * D + D + 8 * cg, db);
             }
-            store8<T>(dU + n * 2 * D + 8 * cg, da);
-            store8<T>(dU + n * 2 * D + D + 8 * cg, db);
         }
     }
     // reduce over the row lanes, then this workgroup's row of partial sums (part [grid][D+1]; summed by
@@ -113,19 +144,21 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
         if (cg == 0) prow[D] = t[8];
     }
 }
-// dwc[c] = sum_w part[w][c], dbc = sum_w part[w][D]
+// dwc[c] = sum_w part[w][c], dbc = sum_w part[w][D]   (16 columns x 16 row lanes per workgroup)
 __global__ __launch_bounds__(256) void gated_score_reduce_kernel(const float* __restrict__ part, int n_wg, int D,
                                                                  float* __restrict__ dwc, float* __restrict__ dbc) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (c <= D)
-        for (int w = rl; w < n_wg; w += 4) s += part[(size_t)w * (D + 1) + c];
+        for (int w = rl; w < n_wg; w += 16) s += part[(size_t)w * (D + 1) + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c <= D) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
         if (c < D) dwc[c] = t; else dbc[0] = t;
     }
 }
@@ -167,7 +200,7 @@ extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void*
     else return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((D + 1 + 63) / 64), dim3(256), 0, st, part_ws, grid, D, dwc, dbc);
+    hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((D + 1 + 15) / 16), dim3(256), 0, st, part_ws, grid, D, dwc, dbc);
     return MURCL_CHECK_LAUNCH();
 }
 

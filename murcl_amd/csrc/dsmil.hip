@@ -131,7 +131,22 @@ __global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
         if (rl < RL) {
-            for (int n = r0 + rl; n < r1; n += RL) {
+            int n = r0 + rl;
+            for (; n + 3 * RL < r1; n += 4 * RL) {               // four rows in flight per thread
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load8<T>(x + (size_t)(n + u * RL) * d + c0, v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < C) {
+                            const float w = a[(size_t)(n + u * RL) * C + c];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[c][e] += w * v[u][e];
+                        }
+            }
+            for (; n < r1; n += RL) {
                 float v[8];
                 load8<T>(x + (size_t)n * d + c0, v);
 #pragma unroll
@@ -191,26 +206,40 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
     const long row0 = ((long)blockIdx.x * 4 + wave) * RD_RPW;
     if (row0 >= rows_total) return;
     const long row1 = min(rows_total, row0 + RD_RPW);
-    for (long row = row0; row < row1; ++row) {
-        const int b = (int)(row / N);
-        const T* x = X + row * d;
-        const float* v = V + (size_t)b * C * d;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long rb = row0; rb < row1; rb += 4) {                  // four rows in flight per wave
+        float acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[u][c] = 0.f;
         for (int k = lane * 8; k < d; k += 512) {
-            float xv[8];
-            load8<T>(x + k, xv);
+            float xv[4][8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (c < C) {
-                    float w[8];
-                    load8<float>(v + (size_t)c * d + k, w);
+            for (int u = 0; u < 4; ++u) {
+                const long row = min(rb + u, row1 - 1);
+                load8<T>(X + row * d + k, xv[u]);
+            }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[c] += xv[e] * w[e];
-                }
+            for (int u = 0; u < 4; ++u) {
+                const long row = min(rb + u, row1 - 1);
+                const float* v = V + (size_t)(row / N) * C * d;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < C) {
+                        float w[8];
+                        load8<float>(v + (size_t)c * d + k, w);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][e] * w[e];
+                    }
+            }
         }
-        for (int c = 0; c < C; ++c) {
-            const float s = wave_sum(acc[c]);
-            if (lane == 0) out[row * C + c] = s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rb + u >= row1) break;
+            for (int c = 0; c < C; ++c) {
+                const float s = wave_sum(acc[u][c]);
+                if (lane == 0) out[(rb + u) * C + c] = s;
+            }
         }
     }
 }

@@ -106,7 +106,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 #pragma unroll
     for (int e = 0; e < CPT; ++e) s[e] = 0.f;
     if (c + CPT - 1 < N && (ld % CPT) == 0) {                   // aligned rows: 16-byte loads
-        for (int r = r0 + rl; r < r1; r += 16) {
+        int r = r0 + rl;
+        for (; r + 48 < r1; r += 64) {                          // four rows in flight per thread
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (CPT == 8) {
+                    load8<T>(x + (size_t)(r + 16 * u) * ld + c, v[u]);
+                } else {
+                    const f32x4 t = load4<T>(x + (size_t)(r + 16 * u) * ld + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[u][e] = t[e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < CPT; ++e) s[e] += v[u][e];
+        }
+        for (; r < r1; r += 16) {
             if constexpr (CPT == 8) {
                 float v[8];
                 load8<T>(x + (size_t)r * ld + c, v);

@@ -137,10 +137,17 @@ __global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z
         s_pos += __shfl_xor(s_pos, o, 64);
     }
     const float my_lse = m_run + __logf(l_run);
+    if (c16 == 0) lse_j[i_loc] = (i_glob < n) ? (my_lse - s_pos) / (float)n : 0.f;     // lse_j is free until phase 2
     if (c16 == 0 && i_glob < n) {
         lse[i_glob] = my_lse;
-        atomicAdd(&ctl->loss, (my_lse - s_pos) / (float)n);
         if (i_glob < Bh && sim) sim[i_glob] = s_pos / inv_tau;      // cosine of the positive pair (K9)
+    }
+    __syncthreads();
+    if (tid == 0) {                           // one adder per workgroup: same-address float atomics serialise
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < NX_ROWS; ++r) t += lse_j[r];
+        atomicAdd(&ctl->loss, t);
     }
     if (!nx_grid_barrier(&ctl->arrive[1], nblk, &ctl->timeout)) return;
     if (blockIdx.x == 0 && tid == 0) loss_out[0] = __hip_atomic_load(&ctl->loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
