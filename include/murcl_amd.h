@@ -122,7 +122,7 @@ int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N,
 int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
                    murcl_stream_t stream);
 int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0, const float* qmax, int B,
-                         int N, int C, float* dY, int ldy, float* dqmax, murcl_stream_t stream);
+                         int N, int C, float* dY, int ldy, float* dqmax, float* dots_ws /* [B*C] */, murcl_stream_t stream);
 
 /* K4/K5 -- CLAM-SB pieces (models/clam.py); the fc and gate projections are murcl_gemm_nt / murcl_panel_gemm calls.
  * gated_score: s[n] = sum_d tanh(U[n,d])*sigmoid(U[n,D+d])*wc[d] + bc (clam.py:56-59), optional dropout keep

@@ -63,30 +63,48 @@ extern "C" int murcl_gather_rows(const void* src, const int* m, int B, int C, in
     return MURCL_CHECK_LAUNCH();
 }
 
-// A[b,n,c] = softmax_n( Q[b,n,:] . qmax[b,c,:] * scale ).  One workgroup per (bag, class); Q rows at stride ldq.
-__global__ __launch_bounds__(256) void dsmil_attn_kernel(const float* __restrict__ Q, int ldq, int qcol0,
-                                                         const float* __restrict__ qmax, int N, int C, float scale,
-                                                         float* __restrict__ A) {
-    __shared__ float red[256];
-    __shared__ float qm[DS_Q];
-    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    if (tid < DS_Q) qm[tid] = qmax[((size_t)b * C + c) * DS_Q + tid];
+// A[b,n,c] = softmax_n( Q[b,n,:] . qmax[b,c,:] * scale ); Q rows at stride ldq, C <= 4.
+// Two launches: raw scores with the rows spread over the whole chip (32 threads per row, 16-byte loads), then the
+// soft-max over n per (bag, class) on the 4-byte scores (one workgroup per (bag, class) is plenty for N*4 bytes).
+#define DS_RPB 64                  // rows per workgroup of the row-parallel kernels
+__global__ __launch_bounds__(256) void dsmil_scores_kernel(const float* __restrict__ Q, int ldq, int qcol0,
+                                                           const float* __restrict__ qmax, int N, int C, float scale,
+                                                           float* __restrict__ A) {
+    __shared__ float qm[4 * DS_Q];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < C * DS_Q; k += 256) qm[k] = qmax[(size_t)b * C * DS_Q + k];
     __syncthreads();
+    const int kq = (tid & 31) * 4, nl = tid >> 5;               // 32 threads per row, 8 rows per pass
+    const int r0 = blockIdx.x * DS_RPB, r1 = min(N, r0 + DS_RPB);
     const float* q = Q + (size_t)b * N * ldq + qcol0;
+    float* a = A + (size_t)b * N * C;
+    for (int n = r0 + nl; n < r1; n += 8) {
+        const f32x4 v = *(const f32x4*)(q + (size_t)n * ldq + kq);
+        float s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s[c] = 0.f;
+            if (c < C) {
+                const f32x4 w = *(const f32x4*)&qm[c * DS_Q + kq];
+                s[c] = v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) {
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) s[c] += __shfl_xor(s[c], o, 64);
+                if ((tid & 31) == 0) a[(size_t)n * C + c] = s[c] * scale;
+            }
+    }
+}
+// in-place soft-max over n of A[b, :, c] (stride C)
+__global__ __launch_bounds__(256) void dsmil_softmax_kernel(float* __restrict__ A, int N, int C) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     float* a = A + (size_t)b * N * C + c;
     float mx = -INFINITY;
-    for (int n = tid; n < N; n += 256) {
-        const float* qr = q + (size_t)n * ldq;
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < DS_Q; k += 4) {
-            const f32x4 v = *(const f32x4*)(qr + k);
-            s += v[0] * qm[k] + v[1] * qm[k + 1] + v[2] * qm[k + 2] + v[3] * qm[k + 3];
-        }
-        s *= scale;
-        a[(size_t)n * C] = s;
-        mx = fmaxf(mx, s);
-    }
+    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, a[(size_t)n * C]);
     red[tid] = mx;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
@@ -107,7 +125,12 @@ __global__ __launch_bounds__(256) void dsmil_attn_kernel(const float* __restrict
 extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float* qmax, int B, int N, int C, float* A,
                                 hipStream_t s) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(dsmil_attn_kernel, dim3(B, C), dim3(256), 0, s, Q, ldq, qcol0, qmax, N, C, 1.0f / sqrtf((float)DS_Q), A);
+    if (C > 4) return -1;
+    hipLaunchKernelGGL(dsmil_scores_kernel, dim3((N + DS_RPB - 1) / DS_RPB, B), dim3(256), 0, s, Q, ldq, qcol0, qmax, N, C,
+                       1.0f / sqrtf((float)DS_Q), A);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_softmax_kernel, dim3(B, C), dim3(256), 0, s, A, N, C);
     return MURCL_CHECK_LAUNCH();
 }
 
@@ -261,34 +284,44 @@ extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, 
 // Soft-max backward over N per (bag, class) + the two small products that follow it:
 //   dS = A * (dA - sum_n A dA);  dY[b,n, qcol0:qcol0+128] = sum_c dS[n,c] qmax[c,:] * scale;
 //   dqmax[b,c,:] = sum_n dS[n,c] Q[b,n,:] * scale
+// dots[b,c] = sum_n A[b,n,c] dA[b,n,c]
+__global__ __launch_bounds__(256) void dsmil_attn_dots_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                              int N, int C, float* __restrict__ dots) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const float* a = A + (size_t)b * N * C + c;
+    const float* da = dA + (size_t)b * N * C + c;
+    float s = 0.f;
+    for (int n = tid; n < N; n += 256) s += a[(size_t)n * C] * da[(size_t)n * C];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) dots[b * C + c] = red[0];
+}
+// rows spread over the chip: dY rows and this workgroup's share of dqmax (N/DS_RPB atomic adders per address)
 __global__ __launch_bounds__(256) void dsmil_attn_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA,
                                                              const float* __restrict__ Q, int ldq, int qcol0,
-                                                             const float* __restrict__ qmax, int N, int C, float scale,
+                                                             const float* __restrict__ qmax, const float* __restrict__ dots_g,
+                                                             int N, int C, float scale,
                                                              float* __restrict__ dY, int ldy, float* __restrict__ dqmax) {
-    __shared__ float red[256];
-    __shared__ float dots[4];
     __shared__ float qm[4 * DS_Q];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ f32x4 red[8][32][4];
+    const int b = blockIdx.y, tid = threadIdx.x;
     for (int k = tid; k < C * DS_Q; k += 256) qm[k] = qmax[(size_t)b * C * DS_Q + k];
+    float dots[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dots[c] = c < C ? dots_g[b * C + c] : 0.f;
+    __syncthreads();
     const float* a = A + (size_t)b * N * C;
     const float* da = dA + (size_t)b * N * C;
-    for (int c = 0; c < C; ++c) {
-        float s = 0.f;
-        for (int n = tid; n < N; n += 256) s += a[(size_t)n * C + c] * da[(size_t)n * C + c];
-        red[tid] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        if (tid == 0) dots[c] = red[0];
-        __syncthreads();
-    }
-    // dQ rows: thread handles (n, 4 columns)
     const float* q = Q + (size_t)b * N * ldq + qcol0;
     float* dy = dY + (size_t)b * N * ldy + qcol0;
-    const int kq = (tid & 31) * 4, nl = tid >> 5;               // 32 threads per row, 8 rows per pass
+    const int kl = tid & 31, kq = kl * 4, nl = tid >> 5;        // 32 threads per row, 8 rows per pass
+    const int r0 = blockIdx.x * DS_RPB, r1 = min(N, r0 + DS_RPB);
     f32x4 dqm[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dqm[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int n = nl; n < N; n += 8) {
+    for (int n = r0 + nl; n < r1; n += 8) {
         f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 qv = *(const f32x4*)(q + (size_t)n * ldq + kq);
 #pragma unroll
@@ -300,18 +333,30 @@ __global__ __launch_bounds__(256) void dsmil_attn_bwd_kernel(const float* __rest
             }
         *(f32x4*)(dy + (size_t)n * ldy + kq) = g;
     }
-    for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dqmax + ((size_t)b * C + c) * DS_Q + kq + e, dqm[c][e]);
+    for (int c = 0; c < 4; ++c) red[nl][kl][c] = dqm[c];
+    __syncthreads();
+    if (nl == 0) {
+        for (int c = 0; c < C; ++c) {
+            f32x4 t = red[0][kl][c];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) t += red[r][kl][c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dqmax + ((size_t)b * C + c) * DS_Q + kq + e, t[e]);
+        }
+    }
 }
 extern "C" int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0,
                                     const float* qmax, int B, int N, int C, float* dY, int ldy, float* dqmax,
-                                    hipStream_t s) {
+                                    float* dots_ws, hipStream_t s) {
     if (B <= 0) return 0;
-    if (C > 4) return -1;
+    if (C > 4 || !dots_ws) return -1;
     hipError_t e = hipMemsetAsync(dqmax, 0, (size_t)B * C * DS_Q * 4, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dsmil_attn_bwd_kernel, dim3(B), dim3(256), 0, s, A, dA, Q, ldq, qcol0, qmax, N, C,
-                       1.0f / sqrtf((float)DS_Q), dY, ldy, dqmax);
+    hipLaunchKernelGGL(dsmil_attn_dots_kernel, dim3(B, C), dim3(256), 0, s, A, dA, N, C, dots_ws);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_attn_bwd_kernel, dim3((N + DS_RPB - 1) / DS_RPB, B), dim3(256), 0, s, A, dA, Q, ldq, qcol0, qmax,
+                       dots_ws, N, C, 1.0f / sqrtf((float)DS_Q), dY, ldy, dqmax);
     return MURCL_CHECK_LAUNCH();
 }

@@ -421,8 +421,9 @@ def rows_dot(X, V):
 
 def dsmil_attn_bwd(A, dA, Y, qcol0, qmax, dY, B, N, C):
     dqmax = torch.empty((B * C, qmax.shape[1]), dtype=torch.float32, device=Y.device)
+    dots = torch.empty((B * C,), dtype=torch.float32, device=Y.device)
     check(_lib.lib().murcl_dsmil_attn_bwd(ptr(A), ptr(_c(dA)), ptr(Y), Y.stride(0), qcol0, ptr(qmax), B, N, C, ptr(dY),
-                                          dY.stride(0), ptr(dqmax), stream()), "dsmil_attn_bwd")
+                                          dY.stride(0), ptr(dqmax), ptr(dots), stream()), "dsmil_attn_bwd")
     return dqmax
 
 
