@@ -52,7 +52,7 @@ int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2,
  * ReLU' taken from a 1-bit-per-element mask ([M,N/8] bytes; bit e of byte c <=> column 8c+e of the forward
  * output was > 0) that the forward epilogue (epilogue 0) can emit through bitmask_out.
  * epilogue: 0 = relu(.+bias) (K=512), 1 = . * mask (K=512), 2 = (. + rowscale[m]*rank1[m/rows_per_bag][n]) * mask
- * (K=128, N=512).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
+ * (K=128 with N=512, or K=512), 3 = . + bias (K=512).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
  * when colsum_accumulate != 0 (accumulation straight into a gradient buffer); the workgroups' partial sums pass through
  * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.
  * murcl_panel_gemm_supported tells whether a shape is covered (else use murcl_gemm_nt). */
@@ -170,6 +170,10 @@ int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, fl
                         int gh_bcast, murcl_stream_t stream);
 int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
                         float* dgh, float* dhprev, int B, int H, int gh_bcast, murcl_stream_t stream);
+
+/* 1-bit ReLU' mask (x > 0) of an activation tensor x [M,N] in murcl_panel_gemm's bit-mask layout (M*N/8 bytes;
+ * M % 32 == 0, N % 32 == 0), for layers whose forward did not emit it (clam.py:69 with a 1024-wide input). */
+int murcl_relu_bitmask(const void* x, void* bits, int M, int N, int ld, int dtype, murcl_stream_t stream);
 
 /* Compute-dtype copies / transposes of several f32 weight matrices in one launch.  jobs_dev: n_jobs records of
  * { const float* src; void* dst; int rows, cols, transpose, dtype_out; } (32 bytes each) in device memory; max_tiles =

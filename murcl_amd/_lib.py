@@ -56,6 +56,7 @@ SIGNATURES = {
     "murcl_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_cast_batch": [_P, _I, _I, _P],
+    "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
 }
 _RESTYPE = {"murcl_ntxent_workspace_bytes": _L}

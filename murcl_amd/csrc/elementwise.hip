@@ -175,6 +175,46 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
     return MURCL_CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------- 1-bit ReLU' mask of an existing activation tensor
+// bits = (x > 0) in the panel GEMM's mask layout (panel_gemm.hip header): 128-byte blocks per (32-row tile, 32-column
+// group); one wave per block, lane L = 16*q4 + r16 owns the 16-bit word of rows {r16, 16+r16} x columns
+// {4q4.., 16+4q4..}.  For layers whose forward did not run through the panel kernel (CLAM's 1024 -> 512 layer).
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bitmask_kernel(const T* __restrict__ x, uint8_t* __restrict__ bits, int M,
+                                                           int N, int ld) {
+    const int lane = threadIdx.x & 63, q4 = lane >> 4, r16 = lane & 15;
+    const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6), groups = N >> 5;
+    if (blk >= (long)(M >> 5) * groups) return;
+    const long tile = blk / groups;
+    const int cgp = (int)(blk - tile * groups);
+    unsigned word = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const f32x4 v = load4<T>(x + (size_t)(32 * tile + 16 * i + r16) * ld + 32 * cgp + 16 * jj + 4 * q4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = 8 * i + 4 * jj + r;
+                word |= (v[r] > 0.f ? 1u : 0u) << ((7 - (idx >> 1)) + 8 * (idx & 1));
+            }
+        }
+    *(uint16_t*)(bits + blk * 128 + lane * 2) = (uint16_t)word;
+}
+extern "C" int murcl_relu_bitmask(const void* x, void* bits, int M, int N, int ld, int dtype, hipStream_t s) {
+    if (M <= 0 || N <= 0) return 0;
+    if (M % 32 || N % 32 || ld % 4) return -1;
+    const long blocks = (long)(M / 32) * (N / 32);
+    dim3 grid((unsigned)((blocks + 3) / 4));
+    if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(relu_bitmask_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (uint8_t*)bits, M, N, ld);
+    else if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(relu_bitmask_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (uint8_t*)bits, M, N, ld);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- ReLU backward: dx = dy * (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

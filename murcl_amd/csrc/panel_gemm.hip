@@ -37,7 +37,7 @@
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
-enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2 };
+enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3 };
 
 #define PG_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -76,7 +76,9 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr int RPI = 64 / CPW;               // rows per store instruction: 16 / 8
     constexpr int NS = PG_TR / RPI;             // store instructions per tile: 2 / 4
     constexpr int STG_LD = WN * 2 + 16;         // staging row stride (bytes), 16-B aligned, breaks the pow-2 stride
-    constexpr int NB = (EPI != PG_BIAS_RELU) ? 1 : 0;               // mask LDS-DMA op (128 or 256 B per wave)
+    constexpr bool MASKED = (EPI == PG_MASK || EPI == PG_RANK1_MASK);
+    constexpr bool BIASED = (EPI == PG_BIAS_RELU || EPI == PG_BIAS);
+    constexpr int NB = MASKED ? 1 : 0;                              // mask LDS-DMA op (128 or 256 B per wave)
     constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
     constexpr int G = GT + NB + NR;             // counted loads per tile per wave
     constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // LDS carve
     constexpr int OFF_STG = PG_NSLOT * SLOT;
     constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
-    constexpr int OFF_RS = OFF_BM + (NB ? PG_NSLOT * PG_NW * 256 : 0);          // [slot][wave][64 f32]
+    constexpr int OFF_RS = OFF_BM + (NB ? PG_NSLOT * PG_NW * 256 : 0);          // [slot][64 f32]: every wave copies the same 32 row scales
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                        lds0 + sl * SLOT + (j * PG_NW + wave) * 1024);
             }
         }
-        if (EPI != PG_BIAS_RELU) {
+        if (MASKED) {
             // this wave's mask blocks of the tile (WN/32 blocks of 128 B, contiguous): one 4-byte piece per lane
             const int nbytes = (WN / 32) * 128;
             const int off = min(lane * 4, nbytes - 4);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                   lds0 + OFF_BM + (sl * PG_NW + wave) * 256);
         }
         if (EPI == PG_RANK1_MASK)
-            glds4(rowscale + row0 + (lane & 31), lds0 + OFF_RS + (sl * PG_NW + wave) * 256);
+            glds4(rowscale + row0 + (lane & 31), lds0 + OFF_RS + sl * 256);
     };
 
     const int pre = min(3, my_tiles);
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         }
     }
     // bias for accumulator-layout columns n0 + 16j + 4q4 + r
-    float bias_r[(EPI == PG_BIAS_RELU) ? NJ : 1][4];
-    if (EPI == PG_BIAS_RELU) {
+    float bias_r[BIASED ? NJ : 1][4];
+    if (BIASED) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         asm volatile("" : "+v"(ones));
 #pragma unroll
         for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = 0u;
-        if (EPI != PG_BIAS_RELU) {
+        if (MASKED) {
             const uint16_t* bml = (const uint16_t*)(smem + OFF_BM + (sl * PG_NW + wave) * 256);
 #pragma unroll
             for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = bml[bq * 64 + lane];
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                     for (int r = 0; r < 4; ++r) rk[j][r] = rank1[(size_t)bag * N + n0 + 16 * j + 4 * q4 + r];
             }
         }
-        const float* rs = (const float*)(smem + OFF_RS + (sl * PG_NW + wave) * 256);
+        const float* rs = (const float*)(smem + OFF_RS + sl * 256);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 16 * i + r16;
@@ -275,11 +277,15 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + bias_r[j][r], 0.f);
                 }
+                if (EPI == PG_BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bias_r[j][r];
+                }
                 if (EPI == PG_RANK1_MASK) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += a_m * rk[j][r];
                 }
-                if (EPI != PG_BIAS_RELU) {
+                if (MASKED) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int idx = 8 * i + 4 * (j & 1) + r;
@@ -335,8 +341,9 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
                      float* colsum_part, int* streams_out, hipStream_t s) {
     constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
     constexpr int STG_LD = WN * 2 + 16;
-    constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD + (EPI != PG_BIAS_RELU ? PG_NSLOT * PG_NW * 256 : 0) +
-                        (EPI == PG_RANK1_MASK ? PG_NSLOT * PG_NW * 256 : 0);
+    constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD +
+                        ((EPI == PG_MASK || EPI == PG_RANK1_MASK) ? PG_NSLOT * PG_NW * 256 : 0) +
+                        (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
     static bool once = false;
@@ -359,7 +366,9 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
 // C-ABI: see include/murcl_amd.h
 extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag) {
     if (M <= 0 || M % PG_TR) return 0;
-    if (K == 512) return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK);
+    if (K == 512)
+        return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK || epilogue == PG_BIAS ||
+                                  (epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0));
     if (K == 128) return N == 512 && epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0;
     return 0;
 }
@@ -384,6 +393,12 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     } else if (K == 512 && epilogue == PG_MASK) {
         if (!bi) return -1;
         rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+    } else if (K == 512 && epilogue == PG_BIAS) {
+        if (!bias) return -1;
+        rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+    } else if (K == 512 && epilogue == PG_RANK1_MASK) {
+        if (!bi || !rowscale || !rank1) return -1;
+        rc = pg_launch<512, 32, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
     } else if (K == 128 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
         rc = pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);

@@ -366,7 +366,13 @@ class CLAMFn(torch.autograd.Function):
             k1, ka, kb = keeps
             ops.mul(h, k1)                                                             # Dropout(0.25) after ReLU
         wab = torch.cat([wa, wb], 0)
-        U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=torch.cat([ba, bb], 0))      # both gate branches, one pass
+        bab = torch.cat([ba, bb], 0)
+        # bf16 with 512-wide h and gates: the weight-stationary panel kernel (same GEMM, half the time of the tile kernel)
+        panel = (T == torch.bfloat16 and L == 512 and ops.panel_supported(B * N, 2 * D, 512, ops.PG_BIAS))
+        if panel:
+            U, _, _ = ops.panel_gemm(h, c(wab), ops.PG_BIAS, bias=bab)                  # both gate branches, one pass
+        else:
+            U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
         s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb).view(B, N)
         A = ops.softmax_rows(s)                                                        # clam.py:144
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
@@ -428,8 +434,12 @@ class CLAMFn(torch.autograd.Function):
         dbab = ops.colsum(dU)
         wab = torch.cat([wa, wb], 0)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
-        dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1), rank1=dM,
-                          rows_per_bag=N)
+        if (T == torch.bfloat16 and 2 * D == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
+            dz1, _, _ = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK, bitmask=ops.relu_bitmask(h),
+                                       rowscale=A.view(-1), rank1=dM, rows_per_bag=N)
+        else:
+            dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1),
+                              rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
         dinst_w = dinst_b = None
         if ctx.saved_inst:

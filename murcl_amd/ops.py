@@ -110,8 +110,8 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     return (C, ws) if colsum else C
 
 
-PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK = 0, 1, 2
-_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK"}
+PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK, PG_BIAS = 0, 1, 2, 3
+_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK", 3: "BIAS"}
 
 
 def panel_supported(M, N, K, epi, rows_per_bag=0):
@@ -140,6 +140,16 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
                                           ptr(colsum_into if colsum_into is not None else cs),
                                           int(colsum_into is not None), ptr(ws), stream()), "panel_gemm")
     return C, bm, cs
+
+
+def relu_bitmask(x):
+    """x [M,N] (M % 32 == 0, N % 32 == 0) -> the panel GEMM's 1-bit mask of x > 0, [M, N/8] uint8."""
+    _need_cuda(x)
+    x = _c(x)
+    M, N = x.shape
+    bits = torch.empty((M, N // 8), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().murcl_relu_bitmask(ptr(x), ptr(bits), M, N, N, dt(x), stream()), "relu_bitmask")
+    return bits
 
 
 def gemm_tn(A, B, *, splits=0, out=None):

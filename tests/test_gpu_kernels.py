@@ -384,3 +384,42 @@ def test_weight_views_follow_parameter_updates():
     check()
     for w in (w1, w2, w3):
         ops.manage_param(w, False)
+
+
+def test_relu_bitmask_matches_the_panel_layout():
+    from murcl_amd import ops
+    dev = _dev()
+    for dtype in (torch.bfloat16, torch.float32):
+        H = _rand(41, f"H{dtype}", (96, 512)).to(dtype)
+        H[5, 7] = 0.0
+        assert torch.equal(ops.relu_bitmask(H.to(dev)).cpu(), _bits(H.float() > 0))
+
+
+@pytest.mark.parametrize("M", [64, 4096])
+def test_panel_gemm_bias_only(M):
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(42, f"A{M}", (M, 512)).bfloat16()
+    W = _rand(42, "W", (512, 512), 1 / math.sqrt(512)).bfloat16()
+    bias = _rand(42, "b", (512,), 0.5)
+    assert ops.panel_supported(M, 512, 512, ops.PG_BIAS)
+    C, _, _ = ops.panel_gemm(A.to(dev), W.to(dev), ops.PG_BIAS, bias=bias.to(dev))
+    _close(C.float(), A.double() @ W.double().t() + bias.double(), rtol=1e-2, atol=1e-2, msg="C")
+
+
+@pytest.mark.parametrize("bags,n", [(2, 64), (4, 2048)])
+def test_panel_gemm_rank1_mask_k512(bags, n):
+    from murcl_amd import ops
+    dev = _dev()
+    M = bags * n
+    dU = _rand(43, f"dU{M}", (M, 512)).bfloat16()
+    Wt = _rand(43, "Wt", (512, 512), 1 / math.sqrt(512)).bfloat16()
+    H = _rand(43, f"H{M}", (M, 512))
+    a = torch.from_numpy(detrand.uniform(43, f"a{M}", (M,)))
+    dM = _rand(43, f"dM{bags}", (bags, 512))
+    assert ops.panel_supported(M, 512, 512, ops.PG_RANK1_MASK, n)
+    C, _, cs = ops.panel_gemm(dU.to(dev), Wt.to(dev), ops.PG_RANK1_MASK, bitmask=ops.relu_bitmask(H.to(dev)),
+                              rowscale=a.to(dev), rank1=dM.to(dev), rows_per_bag=n, colsum=True)
+    ref = (dU.double() @ Wt.double().t() + a.double()[:, None] * dM.double().repeat_interleave(n, 0)) * (H.double() > 0)
+    _close(C.float(), ref, rtol=1e-2, atol=1e-2, msg="C")
+    _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
