@@ -360,7 +360,12 @@ class CLAMFn(torch.autograd.Function):
         c = (lambda w: w) if f32 else (lambda w: ops.cast(w, T))
         x2 = x.reshape(B * N, d)
         L, D = w1.shape[0], wa.shape[0]
-        h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                    # clam.py:69
+        m1 = None
+        if T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU):
+            # weight-stationary panel kernel; without dropout its 1-bit ReLU mask also serves the backward pass
+            h, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=keeps is None)
+        else:
+            h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                # clam.py:69
         k1 = ka = kb = None
         if keeps is not None:
             k1, ka, kb = keeps
@@ -406,7 +411,7 @@ class CLAMFn(torch.autograd.Function):
                     inst_pt[0, bi, i, :width] = preds.view(len(bags), width)
                     inst_pt[1, bi, i, :width] = targets.view(len(bags), width)
                     saved_inst.append((i, bi, rows, feats, dl, scale, width, preds, targets))
-        ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1))
+        ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1), m1)
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
             ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
@@ -417,7 +422,7 @@ class CLAMFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dM, _dA, _ds, dinst, _dids, _dpt):
-        x2, h, U, A, M, w1, wa, wb, wc, inst_w = ctx.saved_tensors
+        x2, h, U, A, M, w1, wa, wb, wc, inst_w, m1 = ctx.saved_tensors
         B, N, d, L, D = ctx.dims
         T = x2.dtype
         f32 = T == torch.float32
@@ -435,7 +440,8 @@ class CLAMFn(torch.autograd.Function):
         wab = torch.cat([wa, wb], 0)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
         if (T == torch.bfloat16 and 2 * D == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
-            dz1, _, _ = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK, bitmask=ops.relu_bitmask(h),
+            dz1, _, _ = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
+                                       bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
                                        rowscale=A.view(-1), rank1=dM, rows_per_bag=N)
         else:
             dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1),

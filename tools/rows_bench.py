@@ -49,6 +49,11 @@ if "clam" in only or not only:
     # passes over [B*N,512]-sized tensors: fwd: x r, h w, h r (gate), U w, U r (score), h r (pool) = 6; bwd adds ~9
     report("a4-a8 CLAM_SB (K4/K5) C3", "forward+instance eval (eval mode)", timed(fwd), 6 * B * N * 512 * es, B, "bags")
     report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward", timed(fb), 15 * B * N * 512 * es, B, "bags")
+    def fb_agg():                      # the aggregator alone, as the contrastive pre-training uses it (no labels)
+        for p in m.parameters(): p.grad = None
+        M, _, _ = m(x)
+        M.sum().backward()
+    report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward, aggregator only (no instance eval)", timed(fb_agg), 15 * B * N * 512 * es, B, "bags")
 # ---- C5 share of one GPU: DSMIL 16 bags x 8192 x 1024 f32
 if "dsmil" in only or not only:
     B, N, d = 16, 8192, 1024
