@@ -380,30 +380,41 @@ extern "C" int murcl_scatter_add_rows_masked(void* dst, const void* h, const lon
 }
 
 // ---------------------------------------------------------------- mean cross-entropy per group of G consecutive rows
-// (C <= 32 logits per row).  One workgroup per group:  loss[g] = mean_r [ lse(logits_r) - logits_r[target_r] ];
-// dlogits = (softmax - onehot) / G ; pred = argmax (first max)
+// (C <= 32 logits per row).  One workgroup per group:  loss[g] = mean over the rows with target >= 0 of
+// [ lse(logits_r) - logits_r[target_r] ] (0 for a group without such rows); dlogits = (softmax - onehot) / count for
+// those rows, 0 for ignored rows (target < 0); pred = argmax (first max), -1 for ignored rows.
 __global__ __launch_bounds__(64) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ targets,
                                                         int G, int C, float* __restrict__ loss,
                                                         float* __restrict__ dlogits, long* __restrict__ preds) {
     const int grp = blockIdx.x, tid = threadIdx.x;
+    float cnt = 0.f;
+    for (int r = tid; r < G; r += 64) cnt += targets[(size_t)grp * G + r] >= 0 ? 1.f : 0.f;
+    cnt = wave_sum(cnt);
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
     float acc = 0.f;
     for (int r = tid; r < G; r += 64) {
         const size_t row = (size_t)grp * G + r;
         const float* x = logits + row * C;
+        const int t = (int)targets[row];
+        if (t < 0) {
+            if (dlogits)
+                for (int c = 0; c < C; ++c) dlogits[row * C + c] = 0.f;
+            if (preds) preds[row] = -1;
+            continue;
+        }
         float mx = x[0];
         int am = 0;
         for (int c = 1; c < C; ++c) if (x[c] > mx) { mx = x[c]; am = c; }
         float sum = 0.f;
         for (int c = 0; c < C; ++c) sum += expf(x[c] - mx);
         const float lse = mx + logf(sum);
-        const int t = (int)targets[row];
         acc += lse - x[t];
         if (dlogits)
-            for (int c = 0; c < C; ++c) dlogits[row * C + c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) / (float)G;
+            for (int c = 0; c < C; ++c) dlogits[row * C + c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * inv;
         if (preds) preds[row] = am;
     }
     acc = wave_sum(acc);
-    if (tid == 0) loss[grp] = acc / (float)G;
+    if (tid == 0) loss[grp] = acc * inv;
 }
 extern "C" int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
                                    long* preds, int group, hipStream_t st) {

@@ -383,34 +383,34 @@ class CLAMFn(torch.autograd.Function):
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
         dev = x.device
         inst_loss = torch.zeros((B,), dtype=torch.float32, device=dev)
-        saved_inst = []
+        saved_inst = None
         ids = None
         inst_pt = None
         if inst_cfg is not None:
+            # instance-level evaluation for ALL (bag, class) pairs at once (clam.py:103-132,150-168): the k top and k
+            # bottom patches of a bag are the same rows for every class, so one gather, one stacked classifier GEMM and
+            # one grouped cross-entropy launch replace the per-class / per-bag loops; pairs differ only in their targets:
+            #   class == label      -> 2k rows, targets [1]*k + [0]*k            (inst_eval,     clam.py:105-119)
+            #   class != label      -> k top rows with target 0 if subtyping    (inst_eval_out, clam.py:122-132), else none
             labels, k, subtyping = inst_cfg
             n_cls = inst_w.shape[0]
-            # predictions / targets of every bag: [B, n_cls, 2k] int64, -1 where a class contributes nothing
-            inst_pt = torch.full((2, B, n_cls, 2 * k), -1, dtype=torch.int64, device=dev)
             ids = ops.topk_ids(A, k)                                                   # [B, 2k]
             base = (torch.arange(B, device=dev, dtype=torch.int64) * N).unsqueeze(1)
-            rows_all = base + ids.to(torch.int64)                                      # [B, 2k] rows of h
-            for i in range(n_cls):
-                inb = [b for b in range(B) if int(labels[b]) == i]
-                outb = [b for b in range(B) if int(labels[b]) != i] if subtyping else []
-                for bags, width, tgt in ((inb, 2 * k, [1] * k + [0] * k), (outb, k, [0] * k)):
-                    if not bags:
-                        continue
-                    bi = torch.tensor(bags, device=dev)
-                    rows = rows_all[bi][:, :width].reshape(-1)
-                    feats = ops.take_rows(h, rows)                                     # [len*width, L] f32
-                    logits = ops.gemm_nt(feats, inst_w[i].contiguous(), epi=ops.EPI_BIAS, bias=inst_b[i].contiguous())
-                    targets = torch.tensor(tgt * len(bags), device=dev, dtype=torch.int64)
-                    loss, dl, preds = ops.cross_entropy(logits, targets, width)
-                    scale = 1.0 / n_cls if subtyping else 1.0                          # clam.py:167-168
-                    inst_loss.index_add_(0, bi, loss * scale)
-                    inst_pt[0, bi, i, :width] = preds.view(len(bags), width)
-                    inst_pt[1, bi, i, :width] = targets.view(len(bags), width)
-                    saved_inst.append((i, bi, rows, feats, dl, scale, width, preds, targets))
+            rows_all = (base + ids.to(torch.int64)).reshape(-1)                        # [B*2k] rows of h
+            feats = ops.take_rows(h, rows_all)                                         # [B*2k, L] f32
+            w_st = inst_w.reshape(n_cls * 2, -1).contiguous()
+            logits = ops.gemm_nt(feats, w_st, epi=ops.EPI_BIAS, bias=inst_b.reshape(-1).contiguous())   # [B*2k, 2 n_cls]
+            logits_g = logits.view(B, 2 * k, n_cls, 2).permute(0, 2, 1, 3).contiguous()                 # [B, n_cls, 2k, 2]
+            lab = torch.as_tensor([int(v) for v in labels], dtype=torch.int64).to(dev)
+            same = lab.view(B, 1) == torch.arange(n_cls, device=dev).view(1, n_cls)                     # [B, n_cls]
+            t_in = torch.tensor([1] * k + [0] * k, dtype=torch.int64, device=dev)
+            t_out = torch.tensor(([0] * k if subtyping else [-1] * k) + [-1] * k, dtype=torch.int64, device=dev)
+            targets = torch.where(same.unsqueeze(2), t_in.view(1, 1, -1), t_out.view(1, 1, -1)).contiguous()   # [B, n_cls, 2k]
+            loss_g, dl_g, preds_g = ops.cross_entropy(logits_g.view(-1, 2), targets.view(-1), 2 * k)
+            scale = 1.0 / n_cls if subtyping else 1.0                                  # clam.py:167-168
+            inst_loss = loss_g.view(B, n_cls).sum(1) * scale
+            inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
+            saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
         ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1), m1)
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
@@ -448,21 +448,14 @@ class CLAMFn(torch.autograd.Function):
                               rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
         dinst_w = dinst_b = None
-        if ctx.saved_inst:
-            dinst_w, dinst_b = torch.zeros_like(inst_w), inst_w.new_zeros(inst_w.shape[0], 2)
-            for (i, bi, rows, feats, dl, scale, width, _p, _t) in ctx.saved_inst:
-                up = (dinst[bi] * scale).repeat_interleave(width).unsqueeze(1)        # upstream weight per row
-                dlog = (dl * up).contiguous()
-                dlog4 = dlog.new_zeros((dlog.shape[0], 4))            # wgrad kernel wants N1 % 4 == 0
-                dlog4[:, :2] = dlog
-                dinst_w[i] += ops.gemm_tn(dlog4, feats)[:2]
-                dinst_b[i] += ops.colsum(dlog)
-                dlog32 = dlog.new_zeros((dlog.shape[0], 32))         # NT kernel wants K % 32 == 0: zero-pad K = 2
-                dlog32[:, :2] = dlog
-                wt32 = inst_w.new_zeros((inst_w.shape[2], 32))
-                wt32[:, :2] = inst_w[i].t()
-                g = ops.gemm_nt(dlog32, wt32)                                                       # [R, L]
-                ops.scatter_add_rows_masked(dz1, h, rows, g)
+        if ctx.saved_inst is not None:
+            rows_all, feats, dl_g, scale, k, n_cls = ctx.saved_inst
+            up = (dinst * scale).view(B, 1, 1, 1)                                      # upstream weight per (bag, ...)
+            dlog = (dl_g.view(B, n_cls, 2 * k, 2) * up).permute(0, 2, 1, 3).reshape(B * 2 * k, 2 * n_cls).contiguous()
+            dinst_w = ops.gemm_tn(dlog, feats).view(n_cls, 2, -1)                      # (gemm_tn pads narrow N1 itself)
+            dinst_b = ops.colsum(dlog).view(n_cls, 2)
+            g = ops.gemm_nt(dlog, inst_w.reshape(n_cls * 2, -1).t().contiguous())      # [B*2k, L]; K = 2 n_cls is padded
+            ops.scatter_add_rows_masked(dz1, h, rows_all, g)
         dw1 = ops.gemm_tn(dz1, x2)
         db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75

@@ -51,8 +51,8 @@ if "clam" in only or not only:
     report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward", timed(fb), 15 * B * N * 512 * es, B, "bags")
     def fb_agg():                      # the aggregator alone, as the contrastive pre-training uses it (no labels)
         for p in m.parameters(): p.grad = None
-        M, _, _ = m(x)
-        M.sum().backward()
+        out = m(x)
+        out[0].sum().backward()
     report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward, aggregator only (no instance eval)", timed(fb_agg), 15 * B * N * 512 * es, B, "bags")
 # ---- C5 share of one GPU: DSMIL 16 bags x 8192 x 1024 f32
 if "dsmil" in only or not only:
