@@ -12,6 +12,7 @@ scores = torch.empty((B, N), device=dev); A = torch.empty((B, N), device=dev); M
 ml = torch.empty((B, 2), device=dev); ws = torch.empty((B * 64 * 514,), device=dev)
 dM = torch.randn((B, 512), generator=g, device=dev)
 dT = torch.empty((B * N + 32, 128), dtype=torch.bfloat16, device=dev)
+pws = torch.empty(512 * 257, device=dev)
 dba = torch.zeros(128, device=dev); dwb = torch.zeros(128, device=dev); dbb = torch.zeros(1, device=dev)
 P, I = ctypes.c_void_p, ctypes.c_int
 ref = None
@@ -22,10 +23,10 @@ for rep in range(2):
     st = torch.cuda.current_stream().cuda_stream
     f(H.data_ptr(), Wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), bb.data_ptr(), scores.data_ptr(), A.data_ptr(), M.data_ptr(),
       ml.data_ptr(), ws.data_ptr(), B, N, 512, 128, 1, 0, st)
-    fb = L.murcl_abmil_pool_bwd; fb.argtypes = [P] * 12 + [I] * 6 + [P]
+    fb = L.murcl_abmil_pool_bwd; fb.argtypes = [P] * 13 + [I] * 6 + [P]
     def run():
         rc = fb(H.data_ptr(), Wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), scores.data_ptr(), ml.data_ptr(), M.data_ptr(), dM.data_ptr(),
-                dT.data_ptr(), dba.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), B, N, 512, 128, 1, 0, st)
+                dT.data_ptr(), dba.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), pws.data_ptr(), B, N, 512, 128, 1, 0, st)
         assert rc == 0, rc
     for _ in range(3): run()
     torch.cuda.synchronize()
