@@ -239,7 +239,7 @@ static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, i
 __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                  float* __restrict__ C, int M, int N, int K, int lda,
                                                                  int ldb, int ldc, const float* __restrict__ bias,
-                                                                 int k_per_split) {
+                                                                 int k_per_split, int relu, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q4 = lane >> 4, r16 = lane & 15;
     const int n0 = blockIdx.x * 32, m0 = wave * 32;
@@ -292,7 +292,13 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __
                 if (m < M && n < N) {
                     float v = acc[i][j][r];
                     if (bias && blockIdx.y == 0) v += bias[n];
-                    atomicAdd(C + (size_t)m * ldc + n, v);
+                    float* cp = C + (size_t)m * ldc + n;
+                    if (gridDim.y == 1) {          // the only writer of this element: plain store, epilogue in place
+                        if (accumulate) v += *cp;
+                        *cp = relu ? fmaxf(v, 0.f) : v;
+                    } else {
+                        atomicAdd(cp, v);
+                    }
                 }
             }
         }
@@ -304,10 +310,6 @@ __global__ void relu_inplace_kernel(float* x, long n) {
 
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s) {
-    if (!accumulate) {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
-        if (e != hipSuccess) return (int)e;
-    }
     const int slabs = (N + 31) / 32;
     int splits = (384 + slabs - 1) / slabs;                 // ~1.5 workgroups per CU
     const int kmax = (K + 127) / 128;                       // at least one 128-k chunk per split
@@ -316,11 +318,18 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
     int kps = ((K / 16 + splits - 1) / splits) * 16;
     kps = ((kps + 127) / 128) * 128;
     splits = (K + kps - 1) / kps;
+    const bool direct = splits == 1;                        // single writer per element: no zero-fill, no atomics
+    if (!direct && !accumulate) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool relu = epi == EPI_BIAS_RELU;
     hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(slabs, splits), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                       (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, kps);
+                       (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, kps, (int)(relu && direct),
+                       (int)(accumulate && direct));
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    if (epi == EPI_BIAS_RELU) {
+    if (relu && !direct) {
         if (ldc != N) return -1;
         const long n = (long)M * N;
         hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, n);
