@@ -208,12 +208,187 @@ __global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z
     }
 }
 
+// ------------------------------------------------------------------------------------------ n <= 128: one workgroup
+// The single-GPU batch (64 bags -> n = 128) fits one CU: z-hat and the n x n logit / weight matrix live in LDS
+// (2 x 66 KiB, row stride 132 floats = conflict-free 4-byte MFMA operand reads), both n x n x 128 products run on the
+// f32 matrix cores (v_mfma_f32_16x16x4_f32), and there is no grid barrier, no atomic and no workspace traffic:
+// 33 us -> ~10 us at n = 128.
+#define NXS_LD 132
+__global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restrict__ z, int n, int Bh, float inv_tau,
+                                                            float* __restrict__ dz, float* __restrict__ sim,
+                                                            float* __restrict__ loss_out, int grad_lo, int grad_hi) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* zh = sm;                                   // [128][NXS_LD]
+    float* S = sm + 128 * NXS_LD;                     // [128][NXS_LD] logits, then gradient weights
+    float* lse = S + 128 * NXS_LD;                    // [128]
+    float* inorm = lse + 128;                         // [128]
+    float* dotp = inorm + 128;                        // [2][128]
+    float* red = dotp + 256;                          // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+
+    // ---- phase 0: normalised rows (8 threads per row, 16 columns each); rows >= n are zero
+    {
+        const int i = tid >> 3, c0 = (tid & 7) * 16;
+        float v[16], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const f32x4 t = (i < n) ? *(const f32x4*)(z + (size_t)i * NX_P + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[e + k] = t[k]; ss += t[k] * t[k]; }
+        }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-8f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zh[i * NXS_LD + c0 + e] = v[e] * inv;
+        if ((tid & 7) == 0) inorm[i] = inv;
+    }
+    __syncthreads();
+
+    // ---- phase 1: S = zh zh^T / tau, 64 tiles of 16 x 16, four per wave (row tile = wave & 7)
+    const int ti = wave & 7, tj0 = (wave >> 3) * 4;
+    {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ar = zh + (16 * ti + r16) * NXS_LD + q4;
+#pragma unroll 4
+        for (int kk = 0; kk < NX_P / 4; ++kk) {
+            const float a = ar[4 * kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = zh[(16 * (tj0 + t) + r16) * NXS_LD + 4 * kk + q4];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        // lane holds S[16ti + 4q4 + r][16tj + r16]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(16 * ti + 4 * q4 + r) * NXS_LD + 16 * (tj0 + t) + r16] = acc[t][r] * inv_tau;
+    }
+    __syncthreads();
+
+    // ---- row statistics: 8 threads per row, columns (tid & 7) + 8u
+    const int i = tid >> 3, cb = tid & 7;
+    const int pos = (i < Bh) ? i + Bh : i - Bh;
+    float my_lse = 0.f;
+    {
+        float m = -INFINITY, l = 0.f, sp = 0.f;
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+            const int j = cb + 8 * u;
+            const float sv = S[i * NXS_LD + j];
+            if (j < n && j != i) {
+                const float mn = fmaxf(m, sv);
+                l = l * __expf(m - mn) + __expf(sv - mn);
+                m = mn;
+            }
+            if (j == pos) sp = sv;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+            const float mn = fmaxf(m, m2);
+            const float a = (m == -INFINITY) ? 0.f : l * __expf(m - mn);
+            const float b = (m2 == -INFINITY) ? 0.f : l2 * __expf(m2 - mn);
+            l = a + b;
+            m = mn;
+            sp += __shfl_xor(sp, o, 64);
+        }
+        my_lse = m + __logf(l);
+        if (cb == 0) {
+            lse[i] = my_lse;
+            red[i] = (i < n) ? (my_lse - sp) / (float)n : 0.f;
+            if (i < Bh && i < n && sim) sim[i] = sp / inv_tau;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float t = red[tid] + red[tid + 64];
+        t = wave_sum(t);
+        if (tid == 0) loss_out[0] = t;
+    }
+    if (!dz) return;
+
+    // ---- gradient weights in place: W_ij = (P_ij + P_ji - 2 [j == pos(i)]) / (n tau), 0 on the diagonal / padding
+    {
+        const float scale = inv_tau / (float)n;
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+            const int j = cb + 8 * u;
+            const float sv = S[i * NXS_LD + j];
+            float w = 0.f;
+            if (i < n && j < n && j != i) {
+                w = __expf(sv - my_lse) + __expf(sv - lse[j]);
+                if (j == pos) w -= 2.f;
+            }
+            S[i * NXS_LD + j] = w * scale;
+        }
+    }
+    __syncthreads();
+
+    // ---- G = W zh (row tile ti, column tiles tj0..tj0+3), then dz = (g - (zh.g) zh) / |z|
+    {
+        f32x4 g[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ar = S + (16 * ti + r16) * NXS_LD + q4;
+#pragma unroll 4
+        for (int kk = 0; kk < 128 / 4; ++kk) {
+            const float a = ar[4 * kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b = zh[(4 * kk + q4) * NXS_LD + 16 * (tj0 + t) + r16];
+                g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, g[t], 0, 0, 0);
+            }
+        }
+        float pd[4] = {0.f, 0.f, 0.f, 0.f};
+        float zv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                zv[t][r] = zh[(16 * ti + 4 * q4 + r) * NXS_LD + 16 * (tj0 + t) + r16];
+                pd[r] += g[t][r] * zv[t][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = row16_sum(pd[r]);
+            if (r16 == 0) dotp[(wave >> 3) * 128 + 16 * ti + 4 * q4 + r] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * q4 + r;
+            if (row >= n) continue;
+            const int bag = row < Bh ? row : row - Bh;
+            const bool want = bag >= grad_lo && bag < grad_hi;
+            const float dot = dotp[row] + dotp[128 + row], inv = inorm[row];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                dz[(size_t)row * NX_P + 16 * (tj0 + t) + r16] = want ? (g[t][r] - dot * zv[t][r]) * inv : 0.f;
+        }
+    }
+}
+
 extern "C" long murcl_ntxent_workspace_bytes(int n) { return (long)sizeof(NxCtl) + (long)n * (NX_P + 2) * 4; }
 
 // C-ABI: see include/murcl_amd.h
 extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz,
                                     float* sim, int grad_lo, int grad_hi, void* workspace, hipStream_t stream) {
     if (P != NX_P || n <= 0 || (n & 1)) return -1;
+    if (n <= 128) {
+        constexpr int LDS = (2 * 128 * NXS_LD + 128 * 5) * 4;
+        static bool once = false;
+        if (!once) {
+            hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            once = true;
+        }
+        hipLaunchKernelGGL(ntxent_small_kernel, dim3(1), dim3(1024), LDS, stream, z, n, n / 2, 1.0f / temperature, dz, sim,
+                           loss, grad_lo, grad_hi);
+        return MURCL_CHECK_LAUNCH();
+    }
     const int nblk = (n + NX_ROWS - 1) / NX_ROWS;
     if (nblk > 256) return -1;                               // grid barrier needs co-residency
     NxCtl* ctl = (NxCtl*)workspace;
