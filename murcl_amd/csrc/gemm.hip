@@ -403,14 +403,15 @@ __device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int la
     return v;
 }
 
-template <typename T>
+template <typename T, int NSLOT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                          float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
                                                          int ldc, int m_per_split, int nsplit) {
     typedef typename Frag<T>::type frag_t;
     typedef TnTraits<T> TT;
-    constexpr int NSLOT = 2;                      // double buffer per workgroup; TWO workgroups per CU desynchronise
-                                                  // and cover each other's barrier / DMA-issue stalls (218 -> 184 us)
+    // NSLOT = 2: double buffer per workgroup; TWO workgroups per CU desynchronise and cover each other's barrier /
+    // DMA-issue stalls (218 -> 184 us).  NSLOT = 4 (small grids, <= 1 workgroup per CU anyway): three slabs in flight,
+    // so a short reduction (bag-level layers: M = 128 rows = 2-4 slabs) costs one memory round trip instead of one per slab.
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 16 KiB | B 16 KiB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,11 +510,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
     };
 
     const int nslab = (mend - mbeg + TT::ROWS - 1) / TT::ROWS;
-    stage(0);
+    constexpr int D = NSLOT - 1;                   // slabs in flight (8 LDS-DMA ops per wave each)
+    for (int s = 0; s < D && s < nslab; ++s) stage(s);
     for (int s = 0; s < nslab; ++s) {
-        WAIT_VMCNT(0);                             // slab s landed (nothing else is in flight at this point)
+        const int ahead = min(D - 1, nslab - 1 - s);   // younger slabs that may stay in flight while slab s is awaited
+        if (ahead >= 2) { WAIT_VMCNT(16); } else if (ahead == 1) { WAIT_VMCNT(8); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();                             // slab s visible to all waves; slot of slab s-1 is free
-        if (s + 1 < nslab) stage(s + 1);
+        if (s + D < nslab) stage(s + D);
         const int rows_here = min(TT::ROWS, mend - (mbeg + s * TT::ROWS));
         if (rows_here < TT::ROWS) {               // ragged tail: zero the invalid rows of both images
             char* la = smem + (s & (NSLOT - 1)) * 32768;
@@ -748,18 +751,22 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     mps = ((mps + rows - 1) / rows) * rows;
     if ((long)mps * (splits - 1) >= M) splits = (M + mps - 1) / mps;           // tiny M: drop empty splits
     dim3 grid(t1 * t2 * splits);
+    const bool deep = t1 * t2 * splits <= 256 && mps > rows;      // small grid, several slabs per workgroup
+#define TN_LAUNCH(T, NS)                                                                                            \
+    {                                                                                                               \
+        auto k = gemm_tn_kernel<T, NS>;                                                                             \
+        static bool once = false;                                                                                   \
+        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768); once = true; } \
+        hipLaunchKernelGGL(k, grid, dim3(256), NS * 32768, stream, (const T*)A, (const T*)B, C, M, N1, N2, lda, ldb, ldc, mps, \
+                           splits);                                                                                 \
+    }
     if (dtype == MURCL_DTYPE_BF16) {
-        auto k = gemm_tn_kernel<bf16_t>;
-        static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
+        if (deep) TN_LAUNCH(bf16_t, 4) else TN_LAUNCH(bf16_t, 2)
     } else if (dtype == MURCL_DTYPE_F32) {
-        auto k = gemm_tn_kernel<float>;
-        static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); once = true; }
-        hipLaunchKernelGGL(k, grid, dim3(256), 65536, stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, mps, splits);
+        if (deep) TN_LAUNCH(float, 4) else TN_LAUNCH(float, 2)
     } else {
         return -1;
     }
+#undef TN_LAUNCH
     return MURCL_CHECK_LAUNCH();
 }

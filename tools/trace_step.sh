@@ -14,7 +14,7 @@ for f in glob.glob("$OUT/trace/*/*kernel_trace.csv"):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 # one step = between consecutive adam_kernel pairs near the end
-idx = [i for i, r in enumerate(rows) if r[2].startswith("ntxent_kernel")]
+idx = [i for i, r in enumerate(rows) if r[2].startswith("ntxent")]
 a, b = idx[-2], idx[-1]
 seq = rows[a:b]
 t0 = seq[0][0]
