@@ -742,7 +742,11 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     }
     const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
-    if (splits <= 0) {                       // fill the chip: two 64 KiB-LDS workgroups per CU, splits % 8 == 0
+    if (splits <= 0 && M <= 8 * rows && (long)N1 * N2 >= (1L << 20)) {
+        // bag-level layers: the whole reduction fits the four-slot ring (one memory round trip per workgroup), and every
+        // extra M-split would add N1*N2*4 bytes of float atomics (dW_ih: 6.3 MB each, ~5 us at the memory side)
+        splits = 1;
+    } else if (splits <= 0) {                // fill the chip: two 64 KiB-LDS workgroups per CU, splits % 8 == 0
         splits = (512 + t1 * t2 - 1) / (t1 * t2);
         splits = ((splits + 7) / 8) * 8;
         while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
@@ -751,7 +755,7 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     mps = ((mps + rows - 1) / rows) * rows;
     if ((long)mps * (splits - 1) >= M) splits = (M + mps - 1) / mps;           // tiny M: drop empty splits
     dim3 grid(t1 * t2 * splits);
-    const bool deep = t1 * t2 * splits <= 256 && mps > rows;      // small grid, several slabs per workgroup
+    const bool deep = (t1 * t2 * splits <= 256 || splits == 1) && mps > rows;   // small grid, several slabs per workgroup
 #define TN_LAUNCH(T, NS)                                                                                            \
     {                                                                                                               \
         auto k = gemm_tn_kernel<T, NS>;                                                                             \
