@@ -208,11 +208,11 @@ __global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z
     }
 }
 
-// ------------------------------------------------------------------------------------------ n <= 128: one workgroup
-// The single-GPU batch (64 bags -> n = 128) fits one CU: z-hat and the n x n logit / weight matrix live in LDS
-// (2 x 66 KiB, row stride 132 floats = conflict-free 4-byte MFMA operand reads), both n x n x 128 products run on the
-// f32 matrix cores (v_mfma_f32_16x16x4_f32), and there is no grid barrier, no atomic and no workspace traffic:
-// 33 us -> ~10 us at n = 128.
+// ------------------------------------------------------------------------------------------ n <= 128: no grid barrier
+// The single-GPU batch (64 bags -> n = 128) fits one CU's LDS: z-hat and the n x n logit / weight matrix (2 x 66 KiB,
+// row stride 132 floats = conflict-free 4-byte MFMA operand reads).  n/16 workgroups each recompute the logits and the
+// row statistics in full (v_mfma_f32_16x16x4_f32; cheaper than exchanging lse through a grid barrier) and then produce
+// the gradient of their own 16 rows: no barrier across workgroups, no atomic, no workspace traffic.
 #define NXS_LD 132
 __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restrict__ z, int n, int Bh, float inv_tau,
                                                             float* __restrict__ dz, float* __restrict__ sim,
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
         if (cb == 0) {
             lse[i] = my_lse;
             red[i] = (i < n) ? (my_lse - sp) / (float)n : 0.f;
-            if (i < Bh && i < n && sim) sim[i] = sp / inv_tau;
+            if (i < Bh && i < n && sim && blockIdx.x == 0) sim[i] = sp / inv_tau;
         }
     }
     __syncthreads();
     if (tid < 64) {
         float t = red[tid] + red[tid + 64];
         t = wave_sum(t);
-        if (tid == 0) loss_out[0] = t;
+        if (tid == 0 && blockIdx.x == 0) loss_out[0] = t;
     }
     if (!dz) return;
 
@@ -328,46 +328,45 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
     }
     __syncthreads();
 
-    // ---- G = W zh (row tile ti, column tiles tj0..tj0+3), then dz = (g - (zh.g) zh) / |z|
+    // ---- G = W zh for THIS workgroup's 16 rows (row tile blockIdx.x; waves 0..7 take one 16-column tile each), then
+    // dz = (g - (zh.g) zh) / |z|.  Everything above is recomputed by every workgroup (the n x n logits are needed in
+    // full for the column term P_ji), so the workgroups never exchange anything: no grid barrier.
     {
-        f32x4 g[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* ar = S + (16 * ti + r16) * NXS_LD + q4;
-#pragma unroll 4
-        for (int kk = 0; kk < 128 / 4; ++kk) {
-            const float a = ar[4 * kk];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float b = zh[(4 * kk + q4) * NXS_LD + 16 * (tj0 + t) + r16];
-                g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, g[t], 0, 0, 0);
+        const int tr = blockIdx.x;
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+        float zv[4], pd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 8) {
+            const float* ar = S + (16 * tr + r16) * NXS_LD + q4;
+#pragma unroll 8
+            for (int kk = 0; kk < 128 / 4; ++kk) {
+                const float a = ar[4 * kk];
+                const float b = zh[(4 * kk + q4) * NXS_LD + 16 * wave + r16];
+                g = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, g, 0, 0, 0);
             }
-        }
-        float pd[4] = {0.f, 0.f, 0.f, 0.f};
-        float zv[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                zv[t][r] = zh[(16 * ti + 4 * q4 + r) * NXS_LD + 16 * (tj0 + t) + r16];
-                pd[r] += g[t][r] * zv[t][r];
+                zv[r] = zh[(16 * tr + 4 * q4 + r) * NXS_LD + 16 * wave + r16];
+                pd[r] = g[r] * zv[r];
             }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float t = row16_sum(pd[r]);
-            if (r16 == 0) dotp[(wave >> 3) * 128 + 16 * ti + 4 * q4 + r] = t;
+            for (int r = 0; r < 4; ++r) {
+                const float t = row16_sum(pd[r]);
+                if (r16 == 0) dotp[wave * 16 + 4 * q4 + r] = t;
+            }
         }
         __syncthreads();
+        if (wave < 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ti + 4 * q4 + r;
-            if (row >= n) continue;
-            const int bag = row < Bh ? row : row - Bh;
-            const bool want = bag >= grad_lo && bag < grad_hi;
-            const float dot = dotp[row] + dotp[128 + row], inv = inorm[row];
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * q4 + r, row = 16 * tr + rl;
+                if (row >= n) continue;
+                const int bag = row < Bh ? row : row - Bh;
+                const bool want = bag >= grad_lo && bag < grad_hi;
+                float dot = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                dz[(size_t)row * NX_P + 16 * (tj0 + t) + r16] = want ? (g[t][r] - dot * zv[t][r]) * inv : 0.f;
+                for (int w = 0; w < 8; ++w) dot += dotp[w * 16 + rl];
+                dz[(size_t)row * NX_P + 16 * wave + r16] = want ? (g[r] - dot * zv[r]) * inorm[row] : 0.f;
+            }
         }
     }
 }
@@ -385,7 +384,7 @@ extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperat
             hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             once = true;
         }
-        hipLaunchKernelGGL(ntxent_small_kernel, dim3(1), dim3(1024), LDS, stream, z, n, n / 2, 1.0f / temperature, dz, sim,
+        hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16), dim3(1024), LDS, stream, z, n, n / 2, 1.0f / temperature, dz, sim,
                            loss, grad_lo, grad_hi);
         return MURCL_CHECK_LAUNCH();
     }
