@@ -18,6 +18,9 @@
 
 #include "k2_common.h"
 
+#ifndef K2_REVERSE
+#define K2_REVERSE 1
+#endif
 #ifndef K2_GK
 #define K2_GK 4                  // k-steps per LDS prefetch group in the score MFMA loop
 #endif
@@ -46,8 +49,10 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
     if (my_tiles <= 0) return;
 
     K2Pos ip, cp;                                                    // issue / compute positions
-    ip.init(blockIdx.x, S);
-    cp.init(blockIdx.x, S);
+    // items are walked from the LAST bag to the first: the encoder kernel that has just written H finished with the high
+    // rows, so the start of this pass finds them in the Infinity Cache / L2 while the write-back of H is still draining
+    ip.init(blockIdx.x, S, K2_REVERSE ? n_items - 1 : -1);
+    cp.init(blockIdx.x, S, K2_REVERSE ? n_items - 1 : -1);
     auto issue = [&](int seq) {
         k2_issue_tile<T>(H + (size_t)ip.bag * N * K2_L, ip.ch * chunk_rows + ip.tin * C_::TR, N,
                          lds0 + (seq & (K2_NSLOT - 1)) * C_::SLOT, wave, lane);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
         }
 
         if (tin == tiles_per_item - 1) {        // ---- end of item: publish partial + raw scores
-            float* pp = part + (size_t)cp.item * (K2_L + 2);
+            float* pp = part + ((size_t)cp.bag * S + cp.ch) * (K2_L + 2);
             if (q4 == 0) {                      // rows 0 (+1) of the accumulator tiles live in lane quarter 0
 #pragma unroll
                 for (int j = 0; j < C_::NPJ; ++j) pp[2 + C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];

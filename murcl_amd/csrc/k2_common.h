@@ -83,10 +83,10 @@ __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N
 // Walks a workgroup's tile sequence without integer division in the loop: item = blockIdx + k*gridDim,
 // tile-in-item `tin`; (bag, chunk) are re-derived only when the item changes.
 struct K2Pos {
-    int tin, item, bag, ch;
-    __device__ __forceinline__ void init(int first_item, int S) { tin = 0; item = first_item; bag = item / S; ch = item - bag * S; }
+    int tin, item, bag, ch, last;      // last >= 0: walk the items from the end (item' = last - item)
+    __device__ __forceinline__ void locate(int S) { const int it = last >= 0 ? last - item : item; bag = it / S; ch = it - bag * S; }
+    __device__ __forceinline__ void init(int first_item, int S, int last_item = -1) { tin = 0; item = first_item; last = last_item; locate(S); }
     __device__ __forceinline__ void next(int tiles_per_item, int stride, int S) {
-        if (++tin == tiles_per_item) { tin = 0; item += stride; bag = item / S; ch = item - bag * S; }
+        if (++tin == tiles_per_item) { tin = 0; item += stride; locate(S); }
     }
 };
-
