@@ -431,6 +431,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
     const int n10 = t1 << 7, n20 = t2 << 7;
     const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
     if (mbeg >= mend) return;
+    // The reduction runs from the last slab to the first: the producer of A (the dgrad / attention-backward kernel that
+    // has just finished) wrote the high rows last, so they are still in the Infinity Cache; walking up would evict
+    // them with the misses on the low rows before reaching them.
+    const int nslab_total = (mend - mbeg + TT::ROWS - 1) / TT::ROWS;
     const unsigned lds0 = lds_off(smem);
     constexpr int CPR = TT::ROWB / 16;            // 16-byte chunks per slab row (16 or 32)
     constexpr int EPC = 16 / (int)sizeof(T);      // elements per chunk
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
         bcol[t] = min(n20 + c * EPC, N2 - EPC);
     }
     auto stage = [&](int s) {
-        const int mrow0 = mbeg + s * TT::ROWS;
+        const int mrow0 = mbeg + (nslab_total - 1 - s) * TT::ROWS;       // slabs are walked from the high rows down
         const unsigned la = lds0 + (s & (NSLOT - 1)) * 32768, lb = la + 16384;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
         if (ahead >= 2) { WAIT_VMCNT(16); } else if (ahead == 1) { WAIT_VMCNT(8); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();                             // slab s visible to all waves; slot of slab s-1 is free
         if (s + D < nslab) stage(s + D);
-        const int rows_here = min(TT::ROWS, mend - (mbeg + s * TT::ROWS));
+        const int rows_here = min(TT::ROWS, mend - (mbeg + (nslab - 1 - s) * TT::ROWS));
         if (rows_here < TT::ROWS) {               // ragged tail: zero the invalid rows of both images
             char* la = smem + (s & (NSLOT - 1)) * 32768;
             for (int idx = tid; idx < (TT::ROWS - rows_here) * (TT::ROWB / 16); idx += 256) {
@@ -578,6 +582,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     const int n10 = t1 << 8, n20 = t2 << 7;
     const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
     if (mbeg >= mend) return;
+    const int nslab_total = (mend - mbeg + ROWS - 1) / ROWS;
     const unsigned lds0 = lds_off(smem);
     auto swz = [](int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); };
 
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     }
     auto stage = [&](int s) {
         if (TNW_ABLATE == 3) return;
-        const int mrow0 = mbeg + s * ROWS;
+        const int mrow0 = mbeg + (nslab_total - 1 - s) * ROWS;           // slabs are walked from the high rows down (see above)
         const unsigned la = lds0 + (s % NSLOT) * SLOT, lb = la + A_BYTES;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
         LDS_BARRIER();
         if (t + 2 < nslab) stage(t + 2);
         char* slab = smem + (t % NSLOT) * SLOT;
-        const int rows_here = min(ROWS, mend - (mbeg + t * ROWS));
+        const int rows_here = min(ROWS, mend - (mbeg + (nslab - 1 - t) * ROWS));
         if (rows_here < ROWS) {
             for (int idx = tid; idx < (ROWS - rows_here) * 32; idx += 512)
                 *(u32x4*)(slab + (rows_here + (idx >> 5)) * A_PITCH + (idx & 31) * 16) = u32x4{0, 0, 0, 0};
