@@ -21,7 +21,7 @@ SIGNATURES = {
     "murcl_gemm_nt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
-    "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
+    "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

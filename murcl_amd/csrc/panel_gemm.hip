@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
     const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
     const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
-    float* __restrict__ colsum_part) {
+    float* __restrict__ colsum_part, int walk_reverse) {
     constexpr int ROWB = K * 2;                 // bytes per A row
     // K = 512: one LDS-DMA instruction writes exactly one row, so rows can be stored at a padded stride (conflict-free
     // 16-row fragment reads with immediate offsets, no swizzle math).  K = 128: four rows per instruction -> XOR swizzle.
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const int n0 = panel * NP + wave * WN;          // first column of this wave
 
     auto issue = [&](int seq) {
-        const int row0 = (tile0 + seq * tstep) * PG_TR;
+        const int tix = tile0 + seq * tstep;
+        const int row0 = (walk_reverse ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* base = (const char*)(A + (size_t)row0 * K);
 #pragma unroll
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         LDS_BARRIER();
         if (seq + 3 < my_tiles) issue(seq + 3);
 
-        const int row0 = (tile0 + seq * tstep) * PG_TR;
+        const int tix = tile0 + seq * tstep;
+        const int row0 = (walk_reverse ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* tile = smem + sl * SLOT;
 
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
-                     float* colsum_part, int* streams_out, hipStream_t s) {
+                     float* colsum_part, int* streams_out, int walk_reverse, hipStream_t s) {
     constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
     constexpr int STG_LD = WN * 2 + 16;
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD +
@@ -356,7 +358,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     const int n_tiles = M / PG_TR;
     if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * PG_NW), LDS, s, A, W, C, M, N, bias, bm_out, bm_in, rowscale, rank1,
-                       rows_per_bag, colsum_part);
+                       rows_per_bag, colsum_part, walk_reverse);
     *streams_out = grid / panels;
     return MURCL_CHECK_LAUNCH();
 }
@@ -376,7 +378,7 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
                                 const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
-                                float* colsum_ws, hipStream_t stream) {
+                                float* colsum_ws, int walk_reverse, hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
     if (colsum_out && !colsum_ws) return -1;
     float* part = colsum_out ? colsum_ws : nullptr;
@@ -388,20 +390,20 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     const uint8_t* bi = (const uint8_t*)bitmask_in;
     if (K == 512 && epilogue == PG_BIAS_RELU) {
         if (!bias) return -1;
-        rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream)
-                : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+        rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream)
+                : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_MASK) {
         if (!bi) return -1;
-        rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+        rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_BIAS) {
         if (!bias) return -1;
-        rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+        rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
-        rc = pg_launch<512, 32, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+        rc = pg_launch<512, 32, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 128 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
-        rc = pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, stream);
+        rc = pg_launch<128, 64, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     }
     if (rc == 0 && colsum_out)         // sum the per-workgroup rows [streams][N] into the (bias-gradient) output
         rc = murcl_colsum(part, colsum_out, streams, N, N, MURCL_DTYPE_F32, colsum_accumulate, stream);

@@ -119,9 +119,10 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False, colsum_into=None):
+               colsum=False, colsum_into=None, reverse=False):
     """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
-    ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None."""
+    ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None.
+    ``reverse``: visit the row tiles last-to-first (cache reuse after a producer that walked forward; same result)."""
     _need_cuda(A, W)
     A, W = _c(A), _c(W)
     M, K = A.shape
@@ -138,7 +139,7 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                           ptr(rowscale), ptr(rank1), rows_per_bag,
                                           ptr(colsum_into if colsum_into is not None else cs),
-                                          int(colsum_into is not None), ptr(ws), stream()), "panel_gemm")
+                                          int(colsum_into is not None), ptr(ws), int(reverse), stream()), "panel_gemm")
     return C, bm, cs
 
 

@@ -16,11 +16,11 @@ names = sys.argv[1:] or [f"libabl_{k}.so" for k in range(6)]
 for nm in names:
     L = ctypes.CDLL(os.path.join(here, nm))
     f = L.murcl_panel_gemm
-    f.argtypes = [P, P, P, I, I, I, I, P, P, P, P, P, I, P, I, P, P]
+    f.argtypes = [P, P, P, I, I, I, I, P, P, P, P, P, I, P, I, P, I, P]
     st = torch.cuda.current_stream().cuda_stream
     def run(epi=0, bm_in=None):
         rc = f(X.data_ptr(), W.data_ptr(), C.data_ptr(), M, 512, 512, epi, bias.data_ptr(), bm.data_ptr() if epi == 0 else None,
-               bm.data_ptr() if epi == 1 else None, None, None, 0, cs.data_ptr() if (WITH_CS and epi == 1) else None, 0, csws.data_ptr(), st)
+               bm.data_ptr() if epi == 1 else None, None, None, 0, cs.data_ptr() if (WITH_CS and epi == 1) else None, 0, csws.data_ptr(), 0, st)
         assert rc == 0, rc
     for epi in (0, 1):
         for _ in range(3): run(epi)
