@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (loads libamdhip64.so.7 before our library resolves it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmurcl_amd.so")
+LIB_PATH = os.environ.get("MURCL_AMD_LIB") or os.path.join(_HERE, "libmurcl_amd.so")      # override: A/B builds (tools/)
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_RANK1_MASK = 0, 1, 2, 3, 4
