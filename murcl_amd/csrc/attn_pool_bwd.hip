@@ -15,6 +15,10 @@
 // of a tile arrive by a fifth (4-byte) LDS-DMA per wave, so the loop contains no compiler-counted loads.
 #include "k2_common.h"
 
+#ifndef K2B_REVERSE
+#define K2B_REVERSE 0          // 1: walk the items from the last bag down (A/B: tools/ab_build.sh)
+#endif
+
 template <typename T> struct KBLds {
     static constexpr int OFF_GPART = K2_NSLOT * K2<T>::SLOT;                        // [NW][16] f32
     static constexpr int OFF_SC = OFF_GPART + K2<T>::NW * 16 * 4;                   // [slot][NW][64] f32
@@ -46,8 +50,8 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     if (my_tiles <= 0) return;
 
     K2Pos ip, cp;
-    ip.init(blockIdx.x, S);
-    cp.init(blockIdx.x, S);
+    ip.init(blockIdx.x, S, K2B_REVERSE ? n_items - 1 : -1);
+    cp.init(blockIdx.x, S, K2B_REVERSE ? n_items - 1 : -1);
     auto issue = [&](int seq) {
         const int row0 = ip.ch * chunk_rows + ip.tin * C_::TR;
         const int sl = seq & (K2_NSLOT - 1);

@@ -33,6 +33,9 @@
 #ifndef PG_PF
 #define PG_PF 1           // groups requested ahead of the MFMAs
 #endif
+#ifndef PG_FLIP
+#define PG_FLIP 0
+#endif
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 
     auto issue = [&](int seq) {
         const int tix = tile0 + seq * tstep;
-        const int row0 = (walk_reverse ? n_tiles - 1 - tix : tix) * PG_TR;
+        const bool rev = (walk_reverse != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
+        const int row0 = (rev ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* base = (const char*)(A + (size_t)row0 * K);
 #pragma unroll
@@ -194,7 +198,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         if (seq + 3 < my_tiles) issue(seq + 3);
 
         const int tix = tile0 + seq * tstep;
-        const int row0 = (walk_reverse ? n_tiles - 1 - tix : tix) * PG_TR;
+        const bool rev = (walk_reverse != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
+        const int row0 = (rev ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* tile = smem + sl * SLOT;
 
