@@ -90,7 +90,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter: ~1 us instead of ~10 us per launch
+    for torch.cuda.current_stream(), which matters with ~50 launches per 1.7 ms step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -28,10 +28,13 @@
 #define PG_TR 32
 #define PG_NSLOT 4
 #ifndef PG_GK
-#define PG_GK 4           // k-steps per LDS prefetch group
+#define PG_GK 2           // k-steps per LDS prefetch group
 #endif
 #ifndef PG_PF
 #define PG_PF 1           // groups requested ahead of the MFMAs
+#endif
+#ifndef PG_ROTATE
+#define PG_ROTATE 0       // 1: phase rotation of the upper half of the workgroup (see the tile loop); measured 4 % slower
 #endif
 #ifndef PG_FLIP
 #define PG_FLIP 0
@@ -187,35 +190,32 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
     const int crow = lane / CPW, cchunk = lane % CPW;            // row-wise phase: row RPI*g + crow, chunk cchunk
 
-    for (int seq = 0; seq < my_tiles; ++seq) {
-        // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between
-        if (seq + 2 < my_tiles) {
-            if (seq == 0) { PG_WAIT(2 * G); } else if (seq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
-        } else {
-            PG_WAIT(0);
-        }
-        LDS_BARRIER();
-        if (seq + 3 < my_tiles) issue(seq + 3);
-
+    // ---- the two phases of a tile, as lambdas so that the two halves of the workgroup can run them in opposite order
+    auto row0_of = [&](int seq) {
         const int tix = tile0 + seq * tstep;
         const bool rev = (walk_reverse != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
-        const int row0 = (rev ? n_tiles - 1 - tix : tix) * PG_TR;
+        return (rev ? n_tiles - 1 - tix : tix) * PG_TR;
+    };
+    // side inputs of the epilogue that live in the tile's LDS slot: this lane's mask words (one per 32-column block
+    // of the wave) and the two row scales it needs
+    auto load_side = [&](int seq, unsigned (&mw)[NJ / 2], float (&am)[2]) {
         const int sl = seq % PG_NSLOT;
-        const char* tile = smem + sl * SLOT;
-
-        // this lane's mask words (one per 32-column block of the wave), requested ahead of the MFMA loop
-        unsigned mw[NJ / 2];
-        unsigned ones = 0x00010001u;
-        asm volatile("" : "+v"(ones));
 #pragma unroll
         for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = 0u;
+        am[0] = am[1] = 0.f;
         if (MASKED) {
             const uint16_t* bml = (const uint16_t*)(smem + OFF_BM + (sl * PG_NW + wave) * 256);
 #pragma unroll
             for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = bml[bq * 64 + lane];
         }
-
-        f32x4 acc[2][NJ];
+        if (EPI == PG_RANK1_MASK) {
+            const float* rs = (const float*)(smem + OFF_RS + sl * 256);
+            am[0] = rs[r16];
+            am[1] = rs[16 + r16];
+        }
+    };
+    auto mfma_phase = [&](int seq, f32x4 (&acc)[2][NJ]) {
+        const char* tile = smem + (seq % PG_NSLOT) * SLOT;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -259,7 +259,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                 }
             }
         }
-
+    };
+    auto epilogue = [&](int seq, f32x4 (&acc)[2][NJ], unsigned (&mw)[NJ / 2], float (&am)[2]) {
+        const int row0 = row0_of(seq);
+        unsigned ones = 0x00010001u;
+        asm volatile("" : "+v"(ones));
         // ---- accumulator-layout math: lane holds row 16i+r16, columns 16j+4q4+r
         if (EPI == PG_RANK1_MASK) {
             const int bag = row0 / rows_per_bag;
@@ -271,12 +275,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                     for (int r = 0; r < 4; ++r) rk[j][r] = rank1[(size_t)bag * N + n0 + 16 * j + 4 * q4 + r];
             }
         }
-        const float* rs = (const float*)(smem + OFF_RS + sl * 256);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = 16 * i + r16;
-            float a_m = 0.f;
-            if (EPI == PG_RANK1_MASK) a_m = rs[row];
+            const float a_m = am[i];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 f32x4 v = acc[i][j];
@@ -325,7 +327,40 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
             pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
         }
+    };
+
+    // Phase rotation (PG_ROTATE, off: the step got 4 % SLOWER with it, 1.70 -> 1.77 ms): the two waves of a SIMD (waves w and w + NW/2) meet at every tile barrier, so left alone they
+    // fight over the matrix pipe during the MFMA phase and over the VALU / LDS during the epilogue.  The upper half of
+    // the workgroup therefore runs "epilogue of the previous tile, then MFMAs of this tile" between two barriers while
+    // the lower half runs "MFMAs, then epilogue" of this tile: at any time one wave of a SIMD feeds the matrix cores
+    // and its partner rounds, transposes and stores.
+    constexpr bool ROT = PG_ROTATE != 0;
+    const bool late = ROT && wave >= PG_NW / 2;
+    f32x4 acc[2][NJ];
+    unsigned mw[NJ / 2];
+    float am[2];
+    for (int seq = 0; seq < my_tiles; ++seq) {
+        // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between (the late
+        // half issues the stores of a tile one iteration later: its counts lag by one)
+        if (seq + 2 < my_tiles) {
+            const int sq = late ? seq - 1 : seq;
+            if (sq <= 0) { PG_WAIT(2 * G); } else if (sq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
+        } else {
+            PG_WAIT(0);
+        }
+        LDS_BARRIER();
+        if (seq + 3 < my_tiles) issue(seq + 3);
+        if (!late) {
+            load_side(seq, mw, am);          // requested ahead of the MFMA loop
+            mfma_phase(seq, acc);
+            epilogue(seq, acc, mw, am);
+        } else {
+            if (seq > 0) epilogue(seq - 1, acc, mw, am);
+            load_side(seq, mw, am);
+            mfma_phase(seq, acc);
+        }
     }
+    if (late) epilogue(my_tiles - 1, acc, mw, am);
 
     if (colsum_part) {
         // the 16 lanes of a quarter hold the same columns for different rows: reduce over them and publish this

@@ -66,8 +66,9 @@ _NULL = _Null()
 TIMERS = None            # set to a KernelTimers to record
 
 
-def _span(key, work=None):
-    return TIMERS.span(key, work) if TIMERS is not None else _NULL
+def _span(meta):
+    """meta() -> (timer key, dict(flops=..., bytes=...)); only evaluated while a KernelTimers is installed."""
+    return TIMERS.span(*meta()) if TIMERS is not None else _NULL
 
 
 def _need_cuda(*ts):
@@ -101,9 +102,9 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
         mask = _c(mask)
         assert mask.dtype == A.dtype and mask.shape == (M, N)
     es = A.element_size()
-    with _span(f"gemm_nt<{_DT_NAME[A.dtype]},{_DT_NAME[C.dtype]},{_EPI_NAME[epi]}>",
+    with _span(lambda: (f"gemm_nt<{_DT_NAME[A.dtype]},{_DT_NAME[C.dtype]},{_EPI_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=(M * K + N * K) * es + M * N * C.element_size()
-                    + (M * N * es if mask is not None else 0))):
+                    + (M * N * es if mask is not None else 0)))):
         check(_lib.lib().murcl_gemm_nt(ptr(A), ptr(B), ptr(C), M, N, K, K, K, N, dt(A), dt(C), epi, ptr(bias),
                                        ptr(mask), N, ptr(rowscale), ptr(rank1), rows_per_bag, ptr(ws), int(accumulate),
                                        stream()), "gemm_nt")
@@ -134,8 +135,8 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     if colsum_into is not None:
         assert colsum_into.is_contiguous() and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
     ws = torch.empty((256 * N,), dtype=torch.float32, device=A.device) if (colsum or colsum_into is not None) else None
-    with _span(f"panel_gemm<K{K},{_PG_NAME[epi]}>",
-               dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0))):
+    with _span(lambda: (f"panel_gemm<K{K},{_PG_NAME[epi]}>",
+               dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0)))):
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                           ptr(rowscale), ptr(rank1), rows_per_bag,
                                           ptr(colsum_into if colsum_into is not None else cs),
@@ -168,8 +169,8 @@ def gemm_tn(A, B, *, splits=0, out=None):
         return out.add_(res) if out is not None else res.contiguous()
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
-    with _span(f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
-               dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4)):
+    with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
+               dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
         check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, stream()),
               "gemm_tn")
     return C
@@ -198,9 +199,9 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
     part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
     es = H.element_size()
     # algorithmic bytes per bag: H once + scores out + pooled M out; Wa amortised over the launch
-    with _span(f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>",
+    with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L),
-                    bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es)):
+                    bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es))):
         check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), ptr(A), ptr(M),
                                               ptr(ml), ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
               "abmil_pool_fwd")
@@ -226,8 +227,8 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
         dba, dwb, dbb = z[:D], z[D:2 * D], z[2 * D:]
     part = torch.empty((512 * (2 * D + 1),), dtype=torch.float32, device=dev)      # per-workgroup parameter-gradient rows
     es = H.element_size()
-    with _span(f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
-               dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es)):
+    with _span(lambda: (f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
+               dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
         check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
                                               ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(part), B, N, L, D, dt(H),
                                               int(exact_tanh), stream()), "abmil_pool_bwd")
@@ -247,7 +248,7 @@ def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None):
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dz = torch.empty_like(z) if want_grad else None
     sim = torch.empty((Bh,), dtype=torch.float32, device=dev)
-    with _span("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4)):
+    with _span(lambda: ("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4))):
         check(_lib.lib().murcl_ntxent_fwd_bwd(ptr(z), n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo,
                                               grad_hi, ptr(ws), stream()), "ntxent_fwd_bwd")
     return loss, dz, sim
@@ -414,7 +415,7 @@ def weighted_rowsum(X, A):
     B, N, d = X.shape
     C = A.shape[2]
     Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
-    with _span(f"weighted_rowsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C)):
+    with _span(lambda: (f"weighted_rowsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
         check(_lib.lib().murcl_weighted_rowsum(ptr(X), ptr(A), ptr(Z), B, N, d, C, dt(X), stream()), "weighted_rowsum")
     return Z
 
@@ -425,7 +426,7 @@ def rows_dot(X, V):
     B, N, d = X.shape
     C = V.shape[1]
     out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
-    with _span(f"rows_dot<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C)):
+    with _span(lambda: (f"rows_dot<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
         check(_lib.lib().murcl_rows_dot(ptr(X), ptr(V), ptr(out), B, N, d, C, dt(X), stream()), "rows_dot")
     return out
 
