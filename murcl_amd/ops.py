@@ -20,14 +20,19 @@ _DT_NAME = {torch.float32: "f32", torch.bfloat16: "bf16"}
 class KernelTimers:
     """Optional HIP-event timing of individual launches on the launch stream (bench.py).
 
-    ``only`` restricts recording to some kernel keys so that the timed region carries a handful of
-    event records per step instead of one pair per launch."""
+    ``only`` restricts recording to some kernel keys and ``every`` to every k-th launch of a key, so that the timed
+    region carries a few event records per step instead of one pair per launch (each pair costs ~2-3 us of stream
+    time)."""
 
-    def __init__(self, only=None):
-        self.only, self.records = only, {}
+    def __init__(self, only=None, every=1):
+        self.only, self.every, self.records, self._seen = only, max(1, int(every)), {}, {}
 
     def span(self, key, work=None):
-        return _Span(self, key, work) if (self.only is None or key in self.only) else _NULL
+        if self.only is not None and key not in self.only:
+            return _NULL
+        n = self._seen.get(key, 0)
+        self._seen[key] = n + 1
+        return _Span(self, key, work) if n % self.every == 0 else _NULL
 
     def summary(self):
         """key -> dict(calls, ms_total, ms_avg, flops, bytes)   (call after a device synchronize)"""
