@@ -89,7 +89,7 @@ class CLAM_SB(nn.Module):
         res = {}
         if instance_eval:
             p, t = inst_host[0, b].reshape(-1), inst_host[1, b].reshape(-1)     # class-major order, like the reference
-            res = {"instance_loss": inst_loss[b], "inst_labels": t[t >= 0], "inst_preds": p[p >= 0]}
+            res = {"instance_loss": inst_loss[b], "inst_labels": t[t >= 0], "inst_preds": p[p >= 0]}      # inst_loss: unbound list
         if return_features:
             res["features"] = M[b:b + 1]
         return res
@@ -117,7 +117,8 @@ class CLAM_SB(nn.Module):
         if attention_only:
             return s, [{}] * x.shape[0]
         host = self._host_inst(io) if instance_eval else None
-        return M, [self._results(b, M, il, host, instance_eval, return_features) for b in range(x.shape[0])]
+        ils = il.unbind(0) if instance_eval else il          # one autograd node for all bags (its backward is one stack)
+        return M, [self._results(b, M, ils, host, instance_eval, return_features) for b in range(x.shape[0])]
 
     def forward(self, h, label=None, instance_eval=False, return_features=False, attention_only=False):
         if isinstance(h, list) or (isinstance(h, torch.Tensor) and h.dim() == 3 and h.shape[0] > 1):
