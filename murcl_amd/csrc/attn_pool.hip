@@ -18,6 +18,11 @@
 
 #include "k2_common.h"
 
+#ifndef K2_FWD_NW
+#define K2_FWD_NW 0            // waves per workgroup of the bf16 forward (0 = 4; 8 = four waves per SIMD, A/B)
+#endif
+#define K2_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define K2F_NWO(T) (sizeof(T) == 2 ? K2_FWD_NW : 0)
 #ifndef K2_REVERSE
 #define K2_REVERSE 1
 #endif
@@ -26,12 +31,12 @@
 #endif
 
 template <typename T, bool EXACT_TANH>
-__global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
+__global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::MIN_WAVES)) void abmil_pool_fwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ bb_p, float* __restrict__ scores, float* __restrict__ part, int B, int N,
     int chunk_rows, int S) {
-    typedef K2<T> C_;
-    typedef K2Lds<T> L_;
+    typedef K2<T, K2F_NWO(T)> C_;
+    typedef K2Lds<T, K2F_NWO(T)> L_;
     typedef typename WFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
     ip.init(blockIdx.x, S, K2_REVERSE ? n_items - 1 : -1);
     cp.init(blockIdx.x, S, K2_REVERSE ? n_items - 1 : -1);
     auto issue = [&](int seq) {
-        k2_issue_tile<T>(H + (size_t)ip.bag * N * K2_L, ip.ch * chunk_rows + ip.tin * C_::TR, N,
+        k2_issue_tile<T, K2F_NWO(T)>(H + (size_t)ip.bag * N * K2_L, ip.ch * chunk_rows + ip.tin * C_::TR, N,
                          lds0 + (seq & (K2_NSLOT - 1)) * C_::SLOT, wave, lane);
         ip.next(tiles_per_item, gridDim.x, S);
     };
@@ -101,8 +106,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_fwd_kernel(
 
     for (int seq = 0; seq < my_tiles; ++seq) {
         const int ahead = min(2, my_tiles - 1 - seq);
-        static_assert(C_::GT == 4, "vmcnt literals below assume 4 LDS-DMA ops per wave per tile");
-        if (ahead == 2) { WAIT_VMCNT(8); } else if (ahead == 1) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
+        if (ahead == 2) { K2_WAIT(2 * C_::GT); } else if (ahead == 1) { K2_WAIT(C_::GT); } else { K2_WAIT(0); }
         LDS_BARRIER();                         // all waves' pieces landed; slot (seq+3)%4 is free
         if (seq + 3 < my_tiles) issue(seq + 3);
 
@@ -284,13 +288,15 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
     const int grid = items < max_grid ? items : max_grid;
 #define K2_LAUNCH(T, EX)                                                                                        \
     {                                                                                                           \
+        typedef K2<T, K2F_NWO(T)> CL_;                                                                          \
+        typedef K2Lds<T, K2F_NWO(T)> LL_;                                                                       \
         auto k = abmil_pool_fwd_kernel<T, EX>;                                                                  \
         static bool once = false;                                                                               \
         if (!once) {                                                                                            \
-            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, K2Lds<T>::BYTES);   \
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LL_::BYTES);        \
             once = true;                                                                                        \
         }                                                                                                       \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), K2Lds<T>::BYTES, stream, (const T*)H, (const T*)Wa, \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64 * CL_::NW), LL_::BYTES, stream, (const T*)H, (const T*)Wa,    \
                            ba, wb, bb, scores, part_ws, B, N, chunk, S);                                        \
     }
     if (dtype == MURCL_DTYPE_BF16) {

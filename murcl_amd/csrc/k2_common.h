@@ -12,8 +12,8 @@
 //   bf16: NW = 4 (DW = 32, 128 VGPRs of weights), TWO workgroups per CU - they desynchronise naturally, so
 //         one workgroup's barrier / LDS latencies are covered by the other's MFMA and VALU work;
 //   f32 : NW = 8 (DW = 16, 128 VGPRs of weights), one workgroup per CU (parity path).
-template <typename T> struct K2 {
-    static constexpr int NW = (sizeof(T) == 2) ? 4 : 8;
+template <typename T, int NWO = 0> struct K2 {      // NWO: waves per workgroup override (0 = the per-dtype default)
+    static constexpr int NW = NWO ? NWO : ((sizeof(T) == 2) ? 4 : 8);
     static constexpr int DW = K2_D / NW;                     // D columns per wave: 32 / 16
     static constexpr int NJ = DW / 16;                       // MFMA column tiles per wave: 2 / 1
     static constexpr int ROWB = K2_L * (int)sizeof(T);       // bytes per row in HBM: 1024 / 2048
@@ -25,14 +25,15 @@ template <typename T> struct K2 {
     static constexpr int PC = K2_L / NW;                     // pooled columns per wave: 128 / 64
     static constexpr int NPJ = PC / 16;                      // pooling MFMA column tiles per wave: 8 / 4
     static constexpr int WG_PER_CU = (sizeof(T) == 2) ? 2 : 1;
+    static constexpr int MIN_WAVES = WG_PER_CU * NW / 4;    // waves per SIMD the launch bound must leave room for
 };
 
 // LDS carve (bytes): ring | spart [NW waves][16 rows] f32 | pbuf [NW waves][16] u32 | sbuf [<= chunk rows] f32
 #define K2_MAX_CHUNK 1024
-template <typename T> struct K2Lds {
-    static constexpr int OFF_SPART = K2_NSLOT * K2<T>::SLOT;
-    static constexpr int OFF_PBUF = OFF_SPART + 2 * K2<T>::NW * 16 * 4;    // spart is double-buffered
-    static constexpr int OFF_SBUF = OFF_PBUF + K2<T>::NW * 16 * 4;
+template <typename T, int NWO = 0> struct K2Lds {
+    static constexpr int OFF_SPART = K2_NSLOT * K2<T, NWO>::SLOT;
+    static constexpr int OFF_PBUF = OFF_SPART + 2 * K2<T, NWO>::NW * 16 * 4;    // spart is double-buffered
+    static constexpr int OFF_SBUF = OFF_PBUF + K2<T, NWO>::NW * 16 * 4;
     static constexpr int BYTES = OFF_SBUF + K2_MAX_CHUNK * 4;
 };
 
@@ -53,9 +54,9 @@ template <> __device__ __forceinline__ f32x4 k2_mma<float>(f32x4 a, f32x4 b, f32
 
 // Tile issue shared by forward and backward: LDS-DMA instruction ii = j*NW + wave copies 1 KiB =
 // one row (bf16) / half a row (f32); global base is wave-uniform (SGPRs), per-lane offset = lane*16.
-template <typename T>
+template <typename T, int NWO = 0>
 __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N, unsigned slot_lds, int wave, int lane) {
-    typedef K2<T> C_;
+    typedef K2<T, NWO> C_;
     const unsigned voff = lane * 16;
     if (row0 + C_::TR <= N) {
         // whole tile inside the bag (all but the last tile of a ragged bag): one scalar base, constant strides
