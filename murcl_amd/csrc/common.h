@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/murcl_amd.h"      // every extern "C" definition is checked against its public declaration
 
 typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
