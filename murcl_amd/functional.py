@@ -302,18 +302,19 @@ class DSMILFn(torch.autograd.Function):
         C = wc.shape[0]
         QD = DSMILFn.QD
         LD = QD + ((C + 7) // 8) * 8
-        w = torch.zeros((LD, d), dtype=torch.float32, device=x.device)
-        bias = torch.zeros((LD,), dtype=torch.float32, device=x.device)
-        w[:QD], w[QD:QD + C], bias[:QD], bias[QD:QD + C] = wq, wc, bq, bc
         x2 = x.reshape(B * N, d)
-        Y = ops.gemm_nt(x2, w if T == torch.float32 else ops.cast(w, T), epi=ops.EPI_BIAS, bias=bias,
-                        out_dtype=torch.float32)
-        m = ops.dsmil_argmax(Y[:, QD:], B, N, C)
+        # queries: one 128-column GEMM.  The C (<= 4) instance-score columns are a streaming row dot product: as columns
+        # 128..128+C-1 of the same GEMM they would cost a second, almost empty 128-column tile pass over X.
+        Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
+                        out_dtype=torch.float32)                                        # Q [B*N, 128]
+        cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d)).view(B * N, C)
+        cls += bc
+        m = ops.dsmil_argmax(cls, B, N, C)
         qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
         A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
         Z = ops.weighted_rowsum(x, A)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
-        classes = Y[:, QD:QD + C].reshape(B, N, C)
+        classes = cls.view(B, N, C)
         ctx.save_for_backward(x, Y, m, qmax, A, Z, wv)
         ctx.meta = (B, N, d, C, LD)
         ctx.mark_non_differentiable(m)
@@ -331,16 +332,21 @@ class DSMILFn(torch.autograd.Function):
         dbv = ops.colsum(dbag2)
         dZ = ops.gemm_nt(dbag2, ops.transpose_cast(wv, torch.float32)).view(B, C, d)
         dA = ops.rows_dot(x, dZ)
-        dY = torch.zeros((B * N, LD), dtype=torch.float32, device=dev)
-        if dclasses is not None:
-            dY[:, QD:QD + C] = dclasses.reshape(B * N, C)
-        dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dY, B, N, C)
-        dW = ops.gemm_tn(dY if T == torch.float32 else ops.cast(dY, T), x2)                 # [LD, d]
-        db = ops.colsum(dY)
+        dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                      # written in full below
+        dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
+        dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2)                # [128, d]: one tile row
+        dbq = ops.colsum(dQ)
         xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
-        dwq = ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dW[:QD].contiguous())
-        dbq = ops.colsum(dqmax, out=db[:QD].contiguous(), accumulate=True)
-        return None, dW[QD:QD + C].contiguous(), db[QD:QD + C].contiguous(), dwq, dbq, dwv, dbv
+        ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
+        ops.colsum(dqmax, out=dbq, accumulate=True)
+        dwc = dbc = None
+        if dclasses is not None:
+            # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile
+            # for 2 columns would read X a second time through the GEMM path)
+            dcls = dclasses.reshape(1, B * N, C).float().contiguous()
+            dwc = ops.weighted_rowsum(x2.view(1, B * N, d), dcls).view(C, d)
+            dbc = dcls.view(B * N, C).sum(0)
+        return None, dwc, dbc, dwq, dbq, dwv, dbv
 
 
 class CLAMFn(torch.autograd.Function):
