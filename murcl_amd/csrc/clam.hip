@@ -151,8 +151,15 @@ __global__ __launch_bounds__(256) void gated_score_reduce_kernel(const float* __
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c <= D)
-        for (int w = rl; w < n_wg; w += 16) s += part[(size_t)w * (D + 1) + c];
+    if (c <= D) {
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};             // four independent chains: the loads of a pass are all in flight
+        int w = rl;
+        for (; w + 48 < n_wg; w += 64)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] += part[(size_t)(w + 16 * u) * (D + 1) + c];
+        for (; w < n_wg; w += 16) t4[0] += part[(size_t)w * (D + 1) + c];
+        s = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c <= D) {
