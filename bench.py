@@ -11,6 +11,7 @@ all-gathered for the global contrastive denominator and gradients all-reduced (R
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -153,6 +154,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # Everything alive now (modules, torch, the extension) is long-lived: move it out of the cyclic collector's young
+    # generations so that a full collection (30-40 ms of host stall once every few dozen steps, measured with
+    # tools/host_vs_gpu.py) does not land inside the timed steps.  The collector stays enabled.
+    gc.collect()
+    gc.freeze()
 
     # -- breakdown pass (untimed): find the kernel that dominates the step
     ops.TIMERS = ops.KernelTimers()

@@ -69,8 +69,15 @@ class OverlappedGradReduce:
         self._pending, self._works = 0, []
 
     def arm(self, aggregator_outputs):
-        self._works, self._pending = [], len(aggregator_outputs)
+        # outputs handed out as row blocks of one tensor (CL.forward) may be consumed through that tensor directly
+        # (Full_layer.forward_views), so the hook goes on the common base when there is one
+        targets = {}
         for t in aggregator_outputs:
+            b = getattr(t, "_base", None)
+            b = b if b is not None and b.requires_grad and b.grad_fn is not None else t
+            targets[id(b)] = b
+        self._works, self._pending = [], len(targets)
+        for t in targets.values():
             t.register_hook(self._fired)
 
     def _fired(self, grad):

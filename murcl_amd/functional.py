@@ -74,7 +74,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = ops.relu_bwd(dy2, y)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dy2, ops.transpose_cast(w, torch.float32)).view(ctx.xshape)
+            dx = ops.gemm_nt(dy2, ops.transposed(w)).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dy2, x2, w)
         if ctx.needs_input_grad[2]:
@@ -142,7 +142,7 @@ class ABMILFn(torch.autograd.Function):
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd = _wgrad(dpre, M, wd)
         dbd = _bgrad(dpre, bd)
-        dM = ops.gemm_nt(dpre, ops.transpose_cast(wd, torch.float32))
+        dM = ops.gemm_nt(dpre, ops.transposed(wd))
         # attention pooling
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
         dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM,
@@ -200,7 +200,7 @@ class GRUStepFn(torch.autograd.Function):
     def backward(ctx, dh):
         x, h_prev, w_ih, w_hh, gates, gh, b_ih, b_hh = ctx.saved_tensors
         dgi, dgh, dhp = ops.gru_gates_bwd(dh.contiguous(), gates, gh, h_prev)
-        dx = ops.gemm_nt(dgi, ops.transpose_cast(w_ih, torch.float32)) if ctx.needs_input_grad[0] else None
+        dx = ops.gemm_nt(dgi, ops.transposed(w_ih)) if ctx.needs_input_grad[0] else None
         dw_ih = _wgrad(dgi, x, w_ih)
         db_ih = _bgrad(dgi, b_ih)
         db_hh = _bgrad(dgh, b_hh)
@@ -210,7 +210,7 @@ class GRUStepFn(torch.autograd.Function):
             dw_hh = _wgrad(dgh, h_prev, w_hh)
             dh_prev = None
             if ctx.needs_input_grad[1]:
-                dh_prev = ops.gemm_nt(dgh, ops.transpose_cast(w_hh, torch.float32), out=dhp, accumulate=True)
+                dh_prev = ops.gemm_nt(dgh, ops.transposed(w_hh), out=dhp, accumulate=True)
         return dx, dh_prev, dw_ih, dw_hh, db_ih, db_hh
 
 
@@ -244,7 +244,7 @@ class GRUSeqFn(torch.autograd.Function):
         T, B, H = hs.shape
         dhs = dhs.contiguous()
         dgi, dgh = torch.empty_like(gh), torch.empty_like(gh)
-        w_hh_t = ops.transpose_cast(w_hh, torch.float32)
+        w_hh_t = ops.transposed(w_hh)
         carry = None
         for t in range(T - 1, -1, -1):
             dh = dhs[t] if carry is None else dhs[t] + carry
@@ -254,7 +254,7 @@ class GRUSeqFn(torch.autograd.Function):
         dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dgi2, ops.transpose_cast(w_ih, torch.float32)).view(T, B, -1)
+            dx = ops.gemm_nt(dgi2, ops.transposed(w_ih)).view(T, B, -1)
         dw_ih = _wgrad(dgi2, x2, w_ih)
         if T > 1:
             dw_hh = _wgrad(dgh2[B:], hs.view(T * B, H)[:-B], w_hh)
@@ -330,7 +330,7 @@ class DSMILFn(torch.autograd.Function):
         dbag2 = (dbag if dbag is not None else torch.zeros((B, C, d), device=dev)).reshape(B * C, d).contiguous()
         dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
         dbv = ops.colsum(dbag2)
-        dZ = ops.gemm_nt(dbag2, ops.transpose_cast(wv, torch.float32)).view(B, C, d)
+        dZ = ops.gemm_nt(dbag2, ops.transposed(wv)).view(B, C, d)
         dA = ops.rows_dot(x, dZ)
         dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                      # written in full below
         dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)

@@ -33,6 +33,23 @@ class Memory:
             del getattr(self, f)[:]
 
 
+def _whole(xs):
+    """The tensor whose consecutive row blocks ``xs`` are (``CL.forward`` hands out ``h.split(B)``), or None: lets the
+    batched head skip the concatenation and its backward."""
+    base = getattr(xs[0], "_base", None)
+    if base is None or base.dim() != 2 or not base.is_contiguous() or base.shape[0] != sum(x.shape[0] for x in xs):
+        return None
+    if base.requires_grad and base.grad_fn is None:
+        return None                                   # a leaf the caller may still want .grad on through its views
+    ptr, es = base.data_ptr(), base.element_size()
+    for x in xs:
+        if (getattr(x, "_base", None) is not base or x.requires_grad != base.requires_grad or x.dtype != base.dtype
+                or not x.is_contiguous() or x.data_ptr() != ptr):
+            return None
+        ptr += x.numel() * es
+    return base
+
+
 class Full_layer(nn.Module):
     def __init__(self, feature_num, hidden_state_dim=1024, fc_rnn=True, class_num=1000):
         super().__init__()
@@ -75,7 +92,8 @@ class Full_layer(nn.Module):
             return [self(x, restart) for x in xs]
         n = xs[0].shape[0]
         r = self.rnn
-        h = GRUStepFn.apply(torch.cat(xs, 0), None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        x = _whole(xs)
+        h = GRUStepFn.apply(torch.cat(xs, 0) if x is None else x, None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         self.hidden = h[-n:].unsqueeze(0)
         return list(LinearFn.apply(h, self.fc.weight, self.fc.bias, False).split(n, 0))
 

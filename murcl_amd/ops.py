@@ -300,8 +300,9 @@ def weight_views(specs):
     ver = (PARAM_EPOCH, tuple(p._version for p, _, _ in specs))
     st = _VIEWS.get(key)
     if st is None:
-        if len(_VIEWS) >= 32:
+        if len(_VIEWS) >= 64:
             _VIEWS.clear()
+            _MERGED.clear()
         dev = specs[0][0].device
         outs, rec, max_tiles = [], [], 0
         for p, tr, d in specs:
@@ -322,6 +323,47 @@ def weight_views(specs):
         check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
         st["ver"] = ver
     return st["outs"]
+
+
+def refresh_views(owned):
+    """Called by an optimizer right after it rewrote the parameters whose ``data_ptr()`` are in ``owned``: advance
+    PARAM_EPOCH and rebuild, in ONE launch, every cached view built from those parameters; views of other optimizers'
+    parameters stay valid."""
+    global PARAM_EPOCH
+    old = PARAM_EPOCH
+    PARAM_EPOCH += 1
+    todo = []
+    for key, st in _VIEWS.items():
+        if not st["managed"] or st["ver"] is None:
+            continue
+        if any(k[0] in owned for k in key):
+            if all(is_managed(p) for p in st["keep"]):
+                todo.append((key, st))
+        elif st["ver"][0] == old:
+            st["ver"] = (PARAM_EPOCH, st["ver"][1])
+    if not todo:
+        return
+    mkey = tuple(k for k, _ in todo)
+    merged = _MERGED.get(mkey)
+    if merged is None:
+        if len(_MERGED) >= 8:
+            _MERGED.clear()
+        merged = _MERGED[mkey] = (torch.cat([st["table"] for _, st in todo]) if len(todo) > 1 else todo[0][1]["table"],
+                                  sum(st["n"] for _, st in todo), max(st["max_tiles"] for _, st in todo))
+    check(_lib.lib().murcl_cast_batch(ptr(merged[0]), merged[1], merged[2], stream()), "cast_batch")
+    for _, st in todo:
+        st["ver"] = (PARAM_EPOCH, tuple(p._version for p in st["keep"]))
+
+
+_MERGED = {}
+
+
+def transposed(w, dtype=torch.float32):
+    """w [R,C] f32 parameter -> [C,R] in ``dtype``: a cached view for optimizer-managed parameters (rebuilt with all other
+    views in the optimizer's one launch per step), a fresh transpose otherwise."""
+    if w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and is_managed(w):
+        return weight_views(((w, True, dtype),))[0]
+    return transpose_cast(w, dtype)
 
 
 def transpose_cast(w, dtype):

@@ -22,6 +22,7 @@ class FlatAdam:
         self.fused_zero, self._maybe_dirty = fused_zero, False      # the flat grads start as zeros
         self.groups = []
         self.step_count = 0
+        self._owned = set()
         for g in param_groups:
             params = [p for p in g["params"] if p.requires_grad]
             n = sum(p.numel() for p in params)
@@ -35,6 +36,7 @@ class FlatAdam:
                 p.data = flat_p[off:off + k].view_as(p.data)
                 p.grad = flat_g[off:off + k].view_as(p.data)
                 ops.manage_param(p)                           # every raw update of p goes through step() below
+                self._owned.add(p.data_ptr())
                 off += k
             self.groups.append(dict(params=params, lr=g["lr"], p=flat_p, g=flat_g,
                                     m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p)))
@@ -57,6 +59,6 @@ class FlatAdam:
         for g in self.groups:
             ops.adam_step(g["p"], g["g"], g["m"], g["v"], g["lr"], self.betas, self.eps, self.weight_decay,
                           self.step_count, zero_grad=self.fused_zero)
-        ops.PARAM_EPOCH += 1                       # cached compute-dtype weight views are stale now
+        ops.refresh_views(self._owned)             # cached compute-dtype / transposed weight views: one launch
         if self.fused_zero:
             self._maybe_dirty = False

@@ -11,6 +11,7 @@ head, single-launch NT-Xent, PPO act/update.  One process per GPU: launch with
 Data: ``--data_csv`` in the reference's WSIWithCluster format (csv + npz ``img_features`` + json cluster lists),
 or ``--synthetic B,N`` for random bags.
 """
+import gc
 import argparse
 import json
 import math
@@ -185,6 +186,8 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, device, rank, w
     memory_list = [rlmil.Memory(), rlmil.Memory()]
     best = float("inf")
     base_lrs = [g["lr"] for g in optimizer.param_groups] if optimizer else []
+    gc.collect()
+    gc.freeze()          # models/optimizer state are long-lived: keep full collections (tens of ms) out of the step loop
     for epoch in range(args.epochs):
         train_set.shuffle()
         feats, clusters, last = [], [], float("nan")

@@ -163,6 +163,62 @@ def test_full_layer_forward_views_equals_the_per_view_loop():
         np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=2e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-7, err_msg=k)
 
 
+def test_full_layer_forward_views_on_row_blocks_of_one_tensor():
+    """CL.forward hands out `h.split(B)`: the batched head then consumes h itself (no concatenation) - same outputs,
+    and the same gradient reaches h as through the per-view loop."""
+    from murcl_amd.models.rlmil import Full_layer, _whole
+    dev = _dev()
+    h0 = T(detrand.normal(32, "fvb.h", (16, 512))).to(dev)
+
+    def run(batched):
+        fc = Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        fc = fc.to(dev)
+        leaf = h0.clone().requires_grad_()
+        h = leaf * 1.0                                  # non-leaf, like an aggregator output
+        xs = list(h.split(8, 0))
+        assert (_whole(xs) is h) and _whole(xs[::-1]) is None and _whole(list(leaf.split(8, 0))) is None
+        zs = fc.forward_views(xs, restart=True) if batched else [fc(x, restart=True) for x in xs]
+        (sum((z * z).sum() * (i + 1) for i, z in enumerate(zs))).backward()
+        return [z.detach().cpu() for z in zs], leaf.grad.cpu(), {k: v.grad.cpu() for k, v in fc.named_parameters()}
+
+    za, da, ga = run(True)
+    zb, db, gb = run(False)
+    for a, b in zip(za, zb):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(da.numpy(), db.numpy(), rtol=2e-4, atol=1e-6)
+    for k in ga:
+        np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=2e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-7, err_msg=k)
+
+
+def test_flat_adam_refreshes_cached_weight_views_in_its_step():
+    """Transposed f32 / compute-dtype views of optimizer-owned weights are rebuilt by FlatAdam.step (one launch for all
+    of them); views of another optimizer's weights stay valid and untouched."""
+    from murcl_amd import ops
+    from murcl_amd.optim import FlatAdam
+    dev = _dev()
+    a, b = torch.nn.Linear(96, 40).to(dev), torch.nn.Linear(33, 70).to(dev)
+    oa, ob = FlatAdam([{"params": list(a.parameters()), "lr": 1e-1}]), FlatAdam([{"params": list(b.parameters()), "lr": 1e-1}])
+    ta, tb = ops.transposed(a.weight), ops.transposed(b.weight)
+    ca = ops.weight_views([(a.weight, False, torch.bfloat16)])[0]
+    assert torch.equal(ta, a.weight.t()) and torch.equal(tb, b.weight.t())
+    for step in range(2):
+        a.weight.grad.fill_(1.0)
+        b_before = b.weight.detach().clone()
+        oa.step()
+        assert torch.equal(ta, a.weight.detach().t()) and torch.equal(ca, a.weight.detach().bfloat16())   # refreshed in place
+        assert ops.transposed(a.weight).data_ptr() == ta.data_ptr()
+        assert ops.transposed(b.weight).data_ptr() == tb.data_ptr() and torch.equal(tb, b_before.t())
+    b.weight.grad.fill_(-1.0)
+    ob.step()
+    assert torch.equal(ops.transposed(b.weight), b.weight.detach().t()) and not torch.equal(tb, b_before.t())
+    with torch.no_grad():
+        a.weight.mul_(2.0)                                # an in-place torch update is picked up at the next use
+    assert torch.equal(ops.transposed(a.weight), a.weight.detach().t())
+    w = torch.randn(5, 7, device=dev)                     # unmanaged: a fresh transpose every time
+    assert torch.equal(ops.transposed(w), w.t())
+
+
 @pytest.mark.parametrize("Tn", [1, 3])
 def test_pretrain_step_golden(golden, Tn):
     """G3: CL(ABMIL) + Full_layer + NT_Xent over T patch-steps: losses, rewards, gradients vs the reference."""
