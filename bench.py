@@ -55,7 +55,7 @@ def synth_views(bags, n, d, dtype, device, rank):
 
 
 def make_step(model, fc, opt, crit, views, world):
-    from murcl_amd import dist as mdist
+    from murcl_amd import dist as mdist, ops
     reducer = mdist.OverlappedGradReduce(opt, early_groups=(1,)) if world > 1 else None
 
     def step():
@@ -68,7 +68,7 @@ def make_step(model, fc, opt, crit, views, world):
             loss, _ = mdist.gathered_nt_xent(z[0], z[1], 1.0)
         else:
             loss = crit(z[0], z[1])
-        loss.backward()
+        loss.backward(ops.unit_grad(loss))
         if reducer is not None:
             reducer.finish()
         opt.step()

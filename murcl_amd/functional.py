@@ -129,6 +129,7 @@ class ABMILFn(torch.autograd.Function):
                               b1, b2, b3, bb, bd, wat, w3t, w2t)
         ctx.dims = (B, N, d)
         ctx.mark_non_differentiable(A)
+        ctx.set_materialize_grads(False)         # no zero-filled dA (a launch) for the attention output nobody differentiates
         return out, A
 
     @staticmethod
@@ -138,6 +139,8 @@ class ABMILFn(torch.autograd.Function):
         B, N, d = ctx.dims
         T = x2.dtype
         L = h3.shape[1]
+        if dout is None:
+            return (None,) * 13
         # decoder (bag level, f32)
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd = _wgrad(dpre, M, wd)
@@ -275,12 +278,15 @@ class NTXentFn(torch.autograd.Function):
         ctx.B = z.shape[0] // 2
         ctx.joint = z_j is None
         ctx.mark_non_differentiable(sim)
+        ctx.set_materialize_grads(False)
         return loss[0], sim
 
     @staticmethod
     def backward(ctx, dloss, _dsim):
         (dz,) = ctx.saved_tensors
-        g = dz * dloss
+        if dloss is None:
+            return None, None, None, None, None
+        g = dz if ops.is_unit_grad(dloss) else dz * dloss
         if ctx.joint:
             return g, None, None, None, None
         return g[:ctx.B], g[ctx.B:], None, None, None
@@ -318,6 +324,7 @@ class DSMILFn(torch.autograd.Function):
         ctx.save_for_backward(x, Y, m, qmax, A, Z, wv)
         ctx.meta = (B, N, d, C, LD)
         ctx.mark_non_differentiable(m)
+        ctx.set_materialize_grads(False)
         return classes, bag, m
 
     @staticmethod
@@ -426,6 +433,7 @@ class CLAMFn(torch.autograd.Function):
         if inst_pt is None:
             inst_pt = torch.zeros((2, B, 0, 0), dtype=torch.int64, device=dev)
         ctx.mark_non_differentiable(A, s, ids, inst_pt)
+        ctx.set_materialize_grads(False)
         return M, A, s, inst_loss, ids, inst_pt
 
     @staticmethod
@@ -456,7 +464,7 @@ class CLAMFn(torch.autograd.Function):
                               rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
         dinst_w = dinst_b = None
-        if ctx.saved_inst is not None:
+        if ctx.saved_inst is not None and dinst is not None:
             rows_all, feats, dl_g, scale, k, n_cls = ctx.saved_inst
             up = (dinst * scale).view(B, 1, 1, 1)                                      # upstream weight per (bag, ...)
             dlog = (dl_g.view(B, n_cls, 2 * k, 2) * up).permute(0, 2, 1, 3).reshape(B * 2 * k, 2 * n_cls).contiguous()

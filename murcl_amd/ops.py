@@ -325,6 +325,25 @@ def weight_views(specs):
     return st["outs"]
 
 
+_UNIT = {}
+
+
+def unit_grad(loss):
+    """A persistent ones tensor shaped like the scalar ``loss``: ``loss.backward(unit_grad(loss))`` spares autograd the
+    fill launch that seeds every backward pass."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return t
+
+
+def is_unit_grad(g):
+    """True when ``g`` is (storage-identical to) a tensor handed out by ``unit_grad``: a multiplication by it is a no-op."""
+    t = _UNIT.get((g.device, g.dtype, tuple(g.shape)))
+    return t is not None and t.data_ptr() == g.data_ptr()
+
+
 def refresh_views(owned):
     """Called by an optimizer right after it rewrote the parameters whose ``data_ptr()`` are in ``owned``: advance
     PARAM_EPOCH and rebuild, in ONE launch, every cached view built from those parameters; views of other optimizers'

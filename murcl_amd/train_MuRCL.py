@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from murcl_amd import dist as mdist
+from murcl_amd import dist as mdist, ops
 from murcl_amd.models import abmil, cl, clam, rlmil
 from murcl_amd.optim import FlatAdam
 from murcl_amd.utils.datasets import BagPack, subbag_views
@@ -116,7 +116,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     loss = sum(losses) / args.T                                                              # :291
     if train_enc:
         optimizer.zero_grad()
-        loss.backward()
+        loss.backward(ops.unit_grad(loss))
         if world > 1:
             mdist.all_reduce_grads(optimizer.flat_grads())
         optimizer.step()                                                                     # :293-295
