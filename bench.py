@@ -56,7 +56,11 @@ def synth_views(bags, n, d, dtype, device, rank):
 
 def make_step(model, fc, opt, crit, views, world):
     from murcl_amd import dist as mdist, ops
-    reducer = mdist.OverlappedGradReduce(opt, early_groups=(1,)) if world > 1 else None
+    # milestones (encoder gradients reduced layer by layer under the remaining backward): opt-in - three more collectives
+    # cost 85 us per step on one rank (1.83 vs 1.75 ms under MURCL_FORCE_DIST=1), more than the ~60 us of exposed
+    # all-reduce they can hide; to be re-measured on a real multi-GPU node
+    reducer = mdist.OverlappedGradReduce(opt, early_groups=(1,), milestones=os.environ.get("MURCL_MILESTONES") == "1") \
+        if world > 1 else None
 
     def step():
         opt.zero_grad()
@@ -227,9 +231,11 @@ def main():
     if args.breakdown:
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):
             print(f"{k:44s} calls/step {v['calls'] // 2:3d}  ms/step {v['ms_total'] / 2:8.4f}", file=sys.stderr)
-    print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: push it out BEFORE the result line
+    print(json.dumps(out), flush=True)
 
 
 def _pmc_traffic(key):

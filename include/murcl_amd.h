@@ -83,12 +83,15 @@ int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const f
                          murcl_stream_t stream);
 
 /* K8/K9 -- NT_Xent.forward + its gradient + torch.cosine_similarity of the positive pairs in one
- * launch (utils/losses.py:24-41; train_MuRCL.py:249,253,277,282).  z [n,P] f32 = cat(z_i,z_j),
- * n = 2B, P = 128.  dz (may be NULL) receives d loss / d z for bags in [grad_lo,grad_hi) of both
- * views, zero elsewhere.  sim (may be NULL) [B]. */
+ * call (one launch for n <= 128, two for the larger global batch of a multi-GPU step; utils/losses.py:24-41;
+ * train_MuRCL.py:249,253,277,282).  z [n,P] f32, n = 2B, P = 128.  Row layout: blocks of pair_stride rows alternate
+ * between the views - pair_stride = B (or 0) is cat(z_i, z_j) as the reference builds it; pair_stride = bags per rank is
+ * an all-gathered [rank][view][bag] buffer used as it arrives; bag ids are global (rank * pair_stride + b).
+ * dz (may be NULL) receives d loss / d z for bags in [grad_lo,grad_hi) of both views, zero elsewhere.  sim (may be
+ * NULL) [B] by bag id.  workspace: murcl_ntxent_workspace_bytes(n) bytes, contents don't matter. */
 long murcl_ntxent_workspace_bytes(int n);
 int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz, float* sim,
-                         int grad_lo, int grad_hi, void* workspace, murcl_stream_t stream);
+                         int grad_lo, int grad_hi, int pair_stride, void* workspace, murcl_stream_t stream);
 
 /* K12 -- get_feats (utils/datasets.py:274-308): per bag b and cluster j (ascending id list of length n_j):
  * size_j = rint(float(n_j)*ratio[b]), l_j = floor(actions[b][j]*float(n_j-size_j)), ids cluster_j[l_j : l_j+size_j]

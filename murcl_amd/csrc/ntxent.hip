@@ -4,207 +4,290 @@
 //   zh_i = z_i / max(|z_i|, 1e-8);  S = zh zh^T / tau;  loss = mean_i [ lse_{j!=i} S_ij - S_{i,pos(i)} ]
 //   d loss / d zh_i = (1/(n tau)) sum_{j!=i} [ P_ij + P_ji - 2 [j == pos(i)] ] zh_j,   P_ij = exp(S_ij - lse_i)
 //
-// S is symmetric, so the column term P_ji needs only lse_j: phase 1 computes lse for every row,
-// phase 2 the gradient, separated by an agent-scope grid barrier (<= 64 workgroups of 16 rows, always
-// co-resident).  Nothing of size n x n is ever materialised (the reference builds an n x n x 128
-// broadcast temp, losses.py:29).  Rows [grad_lo, grad_hi) of each view receive a gradient (bag
-// sharding across ranks: loss rows are global, gradients local).
+// S is symmetric, so the column term P_ji needs only lse_j: the lse of every row comes first, the gradient second.
+// n <= 128 (one GPU's batch): ONE launch, every workgroup recomputes all logits in LDS.  Larger n (the global batch of a
+// multi-GPU step): two launches, see below.  Nothing of size n x n is ever materialised in memory (the reference builds
+// an n x n x 128 broadcast temp, losses.py:29).  Rows [grad_lo, grad_hi) of each view receive a gradient (bag sharding
+// across ranks: loss rows are global, gradients local).
 #include "common.h"
 
 #define NX_P 128          // projection dim
-#define NX_ROWS 16        // rows per workgroup
-#define NX_JT 64          // columns (other embeddings) per LDS tile
-#define NX_SPIN_LIMIT (1u << 24)
 
-struct NxCtl {            // zeroed by a memset node before every launch
-    unsigned arrive[2];
-    unsigned timeout;
-    unsigned pad;
-    float loss;
-    float pad2[3];
-};
+// Row layout: blocks of `ps` rows alternate between the two views - [view 0 | view 1] with ps = B for one process,
+// [rank 0: view 0 | view 1][rank 1: view 0 | view 1]... with ps = bags per rank for an all-gathered global batch (the
+// gathered buffer is used as it arrives, no re-ordering copies).  Bag ids are global: rank * ps + b.
+__device__ __forceinline__ int nx_pos(int i, int ps) { return ((i / ps) & 1) ? i - ps : i + ps; }
+__device__ __forceinline__ int nx_bag(int i, int ps) { return (i / (2 * ps)) * ps + i % ps; }
+__device__ __forceinline__ bool nx_view0(int i, int ps) { return ((i / ps) & 1) == 0; }
 
-__device__ __forceinline__ bool nx_grid_barrier(unsigned* counter, unsigned target, unsigned* timeout) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
-    __syncthreads();
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > NX_SPIN_LIMIT) { ok = 0; __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ok_s = ok;
-    }
-    __syncthreads();
-    return ok_s != 0;
+// ------------------------------------------------------------------------------------------ n > 128: two launches
+// (the global batch of a multi-GPU step: n = 2 x 64 x ranks).  The lse of EVERY row must be known before any gradient
+// weight P_ji can be formed; the kernel boundary is that dependency (an agent-scope grid barrier inside one kernel cost
+// more than a launch here: release/acquire fences write back / invalidate whole L2s on a multi-XCD part, and 64
+// workgroups of 16 rows left three quarters of the chip idle: 206 us at n = 1024).
+//   launch 1 (ntxent_stats_kernel): workgroup (row block of 16, column tile of 256) - n/16 x n/256 workgroups, 16 waves
+//     each.  The tile is loaded raw and normalised on the way into LDS (row block 0 also publishes z-hat and 1/|z| for
+//     launch 2), every wave forms one 16 x 16 block of logits on the f32 matrix cores and the workgroup leaves
+//     (max, sum-exp, positive logit) per row for its tile.
+//   launch 2 (ntxent_grad_kernel): one workgroup per row block that owns rows in [grad_lo, grad_hi) walks all column
+//     tiles: lse_j from the tile statistics, the logit block again, W_ij = (P_ij + P_ji - 2[j == pos(i)]) / (n tau)
+//     into LDS, G += W . zh on the matrix cores (8 column blocks x 2 k-halves over the 16 waves), then the projection
+//     through the normalisation.  Workgroup 0 also reduces the loss in a fixed order.
+#define NXT_LD 132        // LDS row stride of z-hat rows (floats): conflict-free 4-byte MFMA operand reads
+#define NXT_WLD 260       // row stride of the weight block
+#define NXT_TC 256        // rows of a column tile
+#define NXT_LDS ((NXT_TC * NXT_LD + 16 * NXT_LD + 16 * NXT_WLD + 16 + NXT_TC + 128) * 4)
+
+__device__ __forceinline__ float nx_inv_norm(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, 1e-16f)); }   // 1/max(|z|,1e-8)
+__device__ __forceinline__ float nx_sum32(float v) {       // sum over the aligned group of 32 lanes
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+// merge two (max, sum-exp) pairs
+__device__ __forceinline__ void nx_merge(float& m, float& l, float m2, float l2) {
+    const float mn = fmaxf(m, m2);
+    const float x = (m == -INFINITY) ? 0.f : l * __expf(m - mn);
+    const float y = (m2 == -INFINITY) ? 0.f : l2 * __expf(m2 - mn);
+    l = x + y;
+    m = mn;
 }
 
-__global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z, int n, int Bh, float inv_tau,
-                                                     float* __restrict__ zh, float* __restrict__ inorm,
-                                                     float* __restrict__ lse, NxCtl* ctl, float* __restrict__ dz,
-                                                     float* __restrict__ sim, float* __restrict__ loss_out,
-                                                     int grad_lo, int grad_hi) {
-    __shared__ __attribute__((aligned(16))) float zi[NX_ROWS][NX_P + 4];    // own rows (normalised)
-    __shared__ __attribute__((aligned(16))) float zj[NX_JT][NX_P + 4];      // streamed tile
-    __shared__ float st[NX_ROWS][NX_JT + 1];                                // S tile / weights
-    __shared__ float lse_j[NX_JT];
-    const int tid = threadIdx.x, i_loc = tid >> 4, c16 = tid & 15;
-    const int row0 = blockIdx.x * NX_ROWS;
-    const int nblk = gridDim.x;
-
-    // ---------------- phase 0: normalise own rows
-    {
-        const int i = row0 + i_loc;
-        float v[8], ss = 0.f;
+__global__ __launch_bounds__(1024) void ntxent_stats_kernel(const float* __restrict__ z, int n, int ps, float inv_tau,
+                                                            float* __restrict__ zh_ws, float* __restrict__ inv_ws,
+                                                            float* __restrict__ stats_ws, float* __restrict__ sim) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* zj = sm;                              // [256][NXT_LD]
+    float* zi = zj + NXT_TC * NXT_LD;            // [16][NXT_LD]
+    float* st = zi + 16 * NXT_LD;                // [16 waves][16 rows][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int row0 = blockIdx.x * 16, j0 = blockIdx.y * NXT_TC;
+    // column tile: 256 rows x 32 float4, 32 lanes per row
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = (i < n) ? z[(size_t)i * NX_P + 8 * c16 + e] : 0.f;
-            ss += v[e] * v[e];
-        }
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
-        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-8f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            zi[i_loc][8 * c16 + e] = v[e] * inv;
-            if (i < n) zh[(size_t)i * NX_P + 8 * c16 + e] = v[e] * inv;
-        }
-        if (c16 == 0 && i < n) inorm[i] = inv;
-    }
-    if (!nx_grid_barrier(&ctl->arrive[0], nblk, &ctl->timeout)) return;
-
-    auto load_tile = [&](int j0) {            // zj <- zh[j0 .. j0+63]
-        for (int idx = tid; idx < NX_JT * (NX_P / 4); idx += 256) {
-            const int r = idx / (NX_P / 4), c4 = idx % (NX_P / 4);
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j0 + r < n) v = *(const f32x4*)(zh + (size_t)(j0 + r) * NX_P + 4 * c4);
-            *(f32x4*)&zj[r][4 * c4] = v;
-        }
-    };
-    // S_ij for this thread's row i_loc and columns j = c16 + 16*u (u = 0..3) of the tile
-    auto dots = [&](float* s4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < NX_P; k += 4) {
-            const f32x4 a = *(const f32x4*)&zi[i_loc][k];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 b = *(const f32x4*)&zj[c16 + 16 * u][k];
-                s4[u] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] *= inv_tau;
-    };
-
-    // ---------------- phase 1: row log-sum-exp (j != i) and the positive logit
-    const int i_glob = row0 + i_loc;
-    const int pos = (i_glob < Bh) ? i_glob + Bh : i_glob - Bh;
-    float m_run = -INFINITY, l_run = 0.f, s_pos = 0.f;
-    for (int j0 = 0; j0 < n; j0 += NX_JT) {
-        __syncthreads();
-        load_tile(j0);
-        __syncthreads();
-        float s4[4];
-        dots(s4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + c16 + 16 * u;
-            if (j < n && j != i_glob) {
-                const float mn = fmaxf(m_run, s4[u]);
-                l_run = l_run * __expf(m_run - mn) + __expf(s4[u] - mn);
-                m_run = mn;
-            }
-            if (j == pos) s_pos = s4[u];
+    for (int u = 0; u < 8; ++u) {
+        const int idx = tid + 1024 * u, r = idx >> 5, c4 = idx & 31, j = j0 + r;
+        const f32x4 v = (j < n) ? *(const f32x4*)(z + (size_t)j * NX_P + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float inv = nx_inv_norm(nx_sum32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+        const f32x4 h = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+        *(f32x4*)(zj + r * NXT_LD + 4 * c4) = h;
+        if (blockIdx.x == 0 && j < n) {
+            *(f32x4*)(zh_ws + (size_t)j * NX_P + 4 * c4) = h;
+            if (c4 == 0) inv_ws[j] = inv;
         }
     }
-    // combine the 16 threads of a row
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const float m2 = __shfl_xor(m_run, o, 64), l2 = __shfl_xor(l_run, o, 64);
-        const float mn = fmaxf(m_run, m2);
-        const float a = (m_run == -INFINITY) ? 0.f : l_run * __expf(m_run - mn);
-        const float b = (m2 == -INFINITY) ? 0.f : l2 * __expf(m2 - mn);
-        l_run = a + b;
-        m_run = mn;
-        s_pos += __shfl_xor(s_pos, o, 64);
-    }
-    const float my_lse = m_run + __logf(l_run);
-    if (c16 == 0) lse_j[i_loc] = (i_glob < n) ? (my_lse - s_pos) / (float)n : 0.f;     // lse_j is free until phase 2
-    if (c16 == 0 && i_glob < n) {
-        lse[i_glob] = my_lse;
-        if (i_glob < Bh && sim) sim[i_glob] = s_pos / inv_tau;      // cosine of the positive pair (K9)
+    if (tid < 512) {                             // own rows
+        const int i = tid >> 5, c4 = tid & 31, ig = row0 + i;
+        const f32x4 v = (ig < n) ? *(const f32x4*)(z + (size_t)ig * NX_P + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float inv = nx_inv_norm(nx_sum32(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+        *(f32x4*)(zi + i * NXT_LD + 4 * c4) = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
     }
     __syncthreads();
-    if (tid == 0) {                           // one adder per workgroup: same-address float atomics serialise
-        float t = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* ap = zi + r16 * NXT_LD + q4;
+        const float* bp = zj + (16 * wave + r16) * NXT_LD + q4;
 #pragma unroll
-        for (int r = 0; r < NX_ROWS; ++r) t += lse_j[r];
-        atomicAdd(&ctl->loss, t);
+        for (int kk = 0; kk < NX_P / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[4 * kk], acc, 0, 0, 0);
     }
-    if (!nx_grid_barrier(&ctl->arrive[1], nblk, &ctl->timeout)) return;
-    if (blockIdx.x == 0 && tid == 0) loss_out[0] = __hip_atomic_load(&ctl->loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!dz) return;
-
-    // ---------------- phase 2: gradient for rows whose bag index is in [grad_lo, grad_hi)
-    const int bag_i = (i_glob < Bh) ? i_glob : i_glob - Bh;
-    const bool want = i_glob < n && bag_i >= grad_lo && bag_i < grad_hi;
-    bool any = false;
-    for (int r = 0; r < NX_ROWS; ++r) {
-        const int ig = row0 + r, bg = ig < Bh ? ig : ig - Bh;
-        any |= (ig < n && bg >= grad_lo && bg < grad_hi);
-    }
-    float g[8];
+    // lane holds S[4q4 + r][16 wave + r16] of the tile: reduce over the 16 lanes that share a row
+    const int j = j0 + 16 * wave + r16;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = 0.f;
-    if (any) {
-        const float scale = inv_tau / (float)n;
-        for (int j0 = 0; j0 < n; j0 += NX_JT) {
-            __syncthreads();
-            load_tile(j0);
-            if (tid < NX_JT) lse_j[tid] = (j0 + tid < n) ? lse[j0 + tid] : 0.f;
-            __syncthreads();
-            float s4[4];
-            dots(s4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jl = c16 + 16 * u, j = j0 + jl;
-                float w = 0.f;
-                if (j < n && j != i_glob) {
-                    w = __expf(s4[u] - my_lse) + __expf(s4[u] - lse_j[jl]);
-                    if (j == pos) w -= 2.f;
-                }
-                st[i_loc][jl] = w * scale;
-            }
-            __syncthreads();
-            // thread (i_loc, c16) accumulates columns 8*c16 .. +7
-#pragma unroll 8
-            for (int jl = 0; jl < NX_JT; ++jl) {
-                const float w = st[i_loc][jl];
-                const f32x4 b0 = *(const f32x4*)&zj[jl][8 * c16];
-                const f32x4 b1 = *(const f32x4*)&zj[jl][8 * c16 + 4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { g[e] += w * b0[e]; g[4 + e] += w * b1[e]; }
-            }
+    for (int r = 0; r < 4; ++r) {
+        const int ig = row0 + 4 * q4 + r;
+        const int pos = nx_pos(ig, ps);
+        const float sv = acc[r] * inv_tau;
+        const bool valid = j < n && j != ig;
+        const float m = row16_max(valid ? sv : -INFINITY);
+        const float l = row16_sum(valid ? __expf(sv - m) : 0.f);
+        if (j == pos && ig < n) {
+            st[(wave * 16 + 4 * q4 + r) * 3 + 2] = sv;                   // exactly one lane of one wave per row, if any
+            if (sim && nx_view0(ig, ps)) sim[nx_bag(ig, ps)] = sv / inv_tau;   // cosine of the positive pair (K9)
+        }
+        if (r16 == 0) {
+            st[(wave * 16 + 4 * q4 + r) * 3 + 0] = m;
+            st[(wave * 16 + 4 * q4 + r) * 3 + 1] = l;
         }
     }
-    // project through the normalisation: dz = (g - (zh.g) zh) / |z|
-    float dot = 0.f;
+    __syncthreads();
+    if (tid < 16) {
+        const int ig = row0 + tid;
+        const int pos = nx_pos(ig, ps);
+        float m = -INFINITY, l = 0.f, sp = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            nx_merge(m, l, st[(w * 16 + tid) * 3], st[(w * 16 + tid) * 3 + 1]);
+            if (pos >= j0 + 16 * w && pos < j0 + 16 * w + 16) sp = st[(w * 16 + tid) * 3 + 2];
+        }
+        if (ig < n) {
+            float* o = stats_ws + ((size_t)blockIdx.y * n + ig) * 3;
+            o[0] = m; o[1] = l; o[2] = sp;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void ntxent_grad_kernel(int n, int ps, float inv_tau, const float* __restrict__ zh_ws,
+                                                           const float* __restrict__ inv_ws,
+                                                           const float* __restrict__ stats_ws, int ntile,
+                                                           float* __restrict__ dz, float* __restrict__ loss_out,
+                                                           int grad_lo, int grad_hi) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* zj = sm;                              // [256][NXT_LD]
+    float* zi = zj + NXT_TC * NXT_LD;            // [16][NXT_LD]
+    float* wt = zi + 16 * NXT_LD;                // [16][NXT_WLD]
+    float* lse_i_s = wt + 16 * NXT_WLD;          // [16]
+    float* lsej = lse_i_s + 16;                  // [256]
+    float* dotp = lsej + NXT_TC;                 // [8][16]
+    float* red = zj;                             // [1024] loss reduction scratch (before the tile walk)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int row0 = blockIdx.x * 16;
+    // lse and positive logit of row i from the per-tile statistics
+    auto row_stats = [&](int i, float& lse, float& sp) {
+        float m = -INFINITY, l = 0.f;
+        sp = 0.f;
+        for (int t = 0; t < ntile; ++t) {
+            const float* o = stats_ws + ((size_t)t * n + i) * 3;
+            nx_merge(m, l, o[0], o[1]);
+            sp += o[2];
+        }
+        lse = m + __logf(l);
+    };
+    if (blockIdx.x == 0) {                       // loss = mean_i (lse_i - s_i,pos(i)), summed in a fixed order
+        float t = 0.f;
+        for (int i = tid; i < n; i += 1024) {
+            float lse, sp;
+            row_stats(i, lse, sp);
+            t += (lse - sp) / (float)n;
+        }
+        red[tid] = t;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) loss_out[0] = red[0];
+        __syncthreads();
+    }
+    if (!dz) return;
+    bool any = false;
+    for (int r = 0; r < 16; ++r) {
+        const int ig = row0 + r, bg = nx_bag(ig, ps);
+        any |= (ig < n && bg >= grad_lo && bg < grad_hi);
+    }
+    if (!any) {                                  // rows of other ranks: their gradient slice is zero here
+        for (int idx = tid; idx < 16 * NX_P; idx += 1024) {
+            const int row = row0 + idx / NX_P;
+            if (row < n) dz[(size_t)row * NX_P + idx % NX_P] = 0.f;
+        }
+        return;
+    }
+    if (tid < 512) {
+        const int i = tid >> 5, c4 = tid & 31, ig = row0 + i;
+        *(f32x4*)(zi + i * NXT_LD + 4 * c4) = (ig < n) ? *(const f32x4*)(zh_ws + (size_t)ig * NX_P + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (tid < 528) {
+        const int ig = row0 + tid - 512;
+        float lse = 0.f, sp;
+        if (ig < n) row_stats(ig, lse, sp);
+        lse_i_s[tid - 512] = lse;
+    }
+    __syncthreads();
+    float a[NX_P / 4];                           // MFMA a-operands of the own rows: row r16, k = 4kk + q4
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dot += g[e] * zi[i_loc][8 * c16 + e];
-    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
-    if (i_glob < n) {
-        const float inv = inorm[i_glob];
+    for (int kk = 0; kk < NX_P / 4; ++kk) a[kk] = zi[r16 * NXT_LD + 4 * kk + q4];
+    int posr[4];
+    float lse_i[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            dz[(size_t)i_glob * NX_P + 8 * c16 + e] = want ? (g[e] - dot * zi[i_loc][8 * c16 + e]) * inv : 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int ig = row0 + 4 * q4 + r;
+        posr[r] = nx_pos(ig, ps);
+        lse_i[r] = lse_i_s[4 * q4 + r];
+    }
+    const float scale = inv_tau / (float)n;
+    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gc = wave & 7, gh = wave >> 3;     // output column block, k-half of the tile
+
+    f32x4 nxt[8];
+    float nlse = 0.f;
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 1024 * u, j = j0 + (idx >> 5);
+            nxt[u] = (j < n) ? *(const f32x4*)(zh_ws + (size_t)j * NX_P + 4 * (idx & 31)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < NXT_TC) {
+            float sp;
+            nlse = 0.f;
+            if (j0 + tid < n) row_stats(j0 + tid, nlse, sp);
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < n; j0 += NXT_TC) {
+        LDS_BARRIER();                           // the previous tile has no readers left
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 1024 * u;
+            *(f32x4*)(zj + (idx >> 5) * NXT_LD + 4 * (idx & 31)) = nxt[u];
+        }
+        if (tid < NXT_TC) lsej[tid] = nlse;
+        LDS_BARRIER();
+        if (j0 + NXT_TC < n) fetch(j0 + NXT_TC); // in flight under the MFMAs below
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* bp = zj + (16 * wave + r16) * NXT_LD + q4;
+#pragma unroll
+            for (int kk = 0; kk < NX_P / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], bp[4 * kk], acc, 0, 0, 0);
+        }
+        const int jl = 16 * wave + r16, j = j0 + jl;
+        const int jp = (jl & ~15) | ((jl & 3) << 2) | ((jl >> 2) & 3);       // storage column of W (see the G loop)
+        const float lj = lsej[jl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ig = row0 + 4 * q4 + r;
+            const float sv = acc[r] * inv_tau;
+            float w = 0.f;
+            if (ig < n && j < n && j != ig) {
+                w = __expf(sv - lse_i[r]) + __expf(sv - lj);
+                if (j == posr[r]) w -= 2.f;
+            }
+            wt[(4 * q4 + r) * NXT_WLD + jp] = w * scale;
+        }
+        LDS_BARRIER();
+        // G += W . zh over this wave's 128 tile rows.  k-step kk, lane quarter q4 takes tile row 16(kk>>2) + 4q4 + (kk&3):
+        // with a row stride of 132 floats the four quarters then read banks 16 apart (a natural k = 4kk + q4 order is a
+        // 4-way conflict), and W was stored with those two 2-bit column fields swapped so that its reads stay linear.
+        const float* ap = wt + r16 * NXT_WLD + 128 * gh + q4;
+        const float* bp = zj + (128 * gh + 4 * q4) * NXT_LD + 16 * gc + r16;
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk)
+            g = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * kk], bp[(16 * (kk >> 2) + (kk & 3)) * NXT_LD], g, 0, 0, 0);
+    }
+    // ---- add the two k-halves, project through the normalisation: dz = (g - (zh.g) zh) / |z|
+    __syncthreads();
+    if (gh == 1) *(f32x4*)(wt + (gc * 64 + lane) * 4) = g;
+    __syncthreads();
+    float zv[4];
+    if (gh == 0) {
+        const f32x4 o = *(const f32x4*)(wt + (gc * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            g[r] += o[r];
+            zv[r] = zi[(4 * q4 + r) * NXT_LD + 16 * gc + r16];
+            const float t = row16_sum(g[r] * zv[r]);
+            if (r16 == 0) dotp[gc * 16 + 4 * q4 + r] = t;
+        }
+    }
+    __syncthreads();
+    if (gh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rl = 4 * q4 + r, row = row0 + rl;
+            if (row >= n) continue;
+            const int bag = nx_bag(row, ps);
+            const bool want = bag >= grad_lo && bag < grad_hi;
+            float dot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dot += dotp[w * 16 + rl];
+            dz[(size_t)row * NX_P + 16 * gc + r16] = want ? (g[r] - dot * zv[r]) * inv_ws[row] : 0.f;
+        }
     }
 }
 
@@ -214,7 +297,7 @@ __global__ __launch_bounds__(256) void ntxent_kernel(const float* __restrict__ z
 // row statistics in full (v_mfma_f32_16x16x4_f32; cheaper than exchanging lse through a grid barrier) and then produce
 // the gradient of their own 16 rows: no barrier across workgroups, no atomic, no workspace traffic.
 #define NXS_LD 132
-__global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restrict__ z, int n, int Bh, float inv_tau,
+__global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restrict__ z, int n, int ps, float inv_tau,
                                                             float* __restrict__ dz, float* __restrict__ sim,
                                                             float* __restrict__ loss_out, int grad_lo, int grad_hi) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -271,7 +354,7 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
 
     // ---- row statistics: 8 threads per row, columns (tid & 7) + 8u
     const int i = tid >> 3, cb = tid & 7;
-    const int pos = (i < Bh) ? i + Bh : i - Bh;
+    const int pos = nx_pos(i, ps);
     float my_lse = 0.f;
     {
         float m = -INFINITY, l = 0.f, sp = 0.f;
@@ -300,7 +383,7 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
         if (cb == 0) {
             lse[i] = my_lse;
             red[i] = (i < n) ? (my_lse - sp) / (float)n : 0.f;
-            if (i < Bh && i < n && sim && blockIdx.x == 0) sim[i] = sp / inv_tau;
+            if (i < n && sim && blockIdx.x == 0 && nx_view0(i, ps)) sim[nx_bag(i, ps)] = sp / inv_tau;
         }
     }
     __syncthreads();
@@ -360,7 +443,7 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
             for (int r = 0; r < 4; ++r) {
                 const int rl = 4 * q4 + r, row = 16 * tr + rl;
                 if (row >= n) continue;
-                const int bag = row < Bh ? row : row - Bh;
+                const int bag = nx_bag(row, ps);
                 const bool want = bag >= grad_lo && bag < grad_hi;
                 float dot = 0.f;
 #pragma unroll
@@ -371,12 +454,18 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
     }
 }
 
-extern "C" long murcl_ntxent_workspace_bytes(int n) { return (long)sizeof(NxCtl) + (long)n * (NX_P + 2) * 4; }
+extern "C" long murcl_ntxent_workspace_bytes(int n) {
+    const long ntile = (n + NXT_TC - 1) / NXT_TC;
+    return ((long)n * NX_P + n + ntile * n * 3 + 16) * 4;          // z-hat, 1/|z|, per-tile row statistics
+}
 
 // C-ABI: see include/murcl_amd.h
 extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz,
-                                    float* sim, int grad_lo, int grad_hi, void* workspace, hipStream_t stream) {
+                                    float* sim, int grad_lo, int grad_hi, int pair_stride, void* workspace,
+                                    hipStream_t stream) {
     if (P != NX_P || n <= 0 || (n & 1)) return -1;
+    const int ps = pair_stride > 0 ? pair_stride : n / 2;
+    if (n % (2 * ps)) return -1;
     if (n <= 128) {
         constexpr int LDS = (2 * 128 * NXS_LD + 128 * 5) * 4;
         static bool once = false;
@@ -384,19 +473,27 @@ extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperat
             hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             once = true;
         }
-        hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16), dim3(1024), LDS, stream, z, n, n / 2, 1.0f / temperature, dz, sim,
+        hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz, sim,
                            loss, grad_lo, grad_hi);
         return MURCL_CHECK_LAUNCH();
     }
-    const int nblk = (n + NX_ROWS - 1) / NX_ROWS;
-    if (nblk > 256) return -1;                               // grid barrier needs co-residency
-    NxCtl* ctl = (NxCtl*)workspace;
-    float* zh = (float*)((char*)workspace + sizeof(NxCtl));
-    float* inorm = zh + (size_t)n * NX_P;
-    float* lse = inorm + n;
-    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(NxCtl), stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ntxent_kernel, dim3(nblk), dim3(256), 0, stream, z, n, n / 2, 1.0f / temperature, zh, inorm, lse,
-                       ctl, dz, sim, loss, grad_lo, grad_hi);
+    static_assert(NXT_LDS <= 160 * 1024, "LDS budget");
+    static bool once_t = false;
+    if (!once_t) {
+        (void)hipFuncSetAttribute((const void*)ntxent_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NXT_LDS);
+        (void)hipFuncSetAttribute((const void*)ntxent_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NXT_LDS);
+        once_t = true;
+    }
+    const int nblk = (n + 15) / 16, ntile = (n + NXT_TC - 1) / NXT_TC;
+    if (ntile > 65535) return -1;
+    float* zh = (float*)workspace;
+    float* inv = zh + (size_t)n * NX_P;
+    float* stats = inv + n;
+    hipLaunchKernelGGL(ntxent_stats_kernel, dim3(nblk, ntile), dim3(1024), NXT_LDS, stream, z, n, ps, 1.0f / temperature,
+                       zh, inv, stats, sim);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(ntxent_grad_kernel, dim3(dz ? nblk : 1), dim3(1024), NXT_LDS, stream, n, ps, 1.0f / temperature,
+                       (const float*)zh, (const float*)inv, (const float*)stats, ntile, dz, loss, grad_lo, grad_hi);
     return MURCL_CHECK_LAUNCH();
 }

@@ -17,34 +17,50 @@ def shard_range(rank, world, b_local):
     return rank * b_local, (rank + 1) * b_local
 
 
+def _stacked(z_i, z_j):
+    """[z_i; z_j] - without a copy when the two are the halves of one tensor (Full_layer.forward_views)."""
+    base = getattr(z_i, "_base", None)
+    if (base is not None and base is getattr(z_j, "_base", None) and base.dim() == 2 and base.is_contiguous()
+            and z_i.shape == z_j.shape and base.shape[0] == 2 * z_i.shape[0] and z_i.data_ptr() == base.data_ptr()
+            and z_j.data_ptr() == base.data_ptr() + z_i.numel() * z_i.element_size()):
+        return base.detach()
+    return torch.cat([z_i, z_j], 0)
+
+
 class _GatheredNTXent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z_i, z_j, temperature, group, kernel):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         bl = z_i.shape[0]
-        local = torch.cat([z_i, z_j], 0).contiguous()                  # [2*bl, P]
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local, group=group)
-        # global layout expected by NT_Xent: all view-0 rows (rank-major), then all view-1 rows
-        zg = torch.cat([p[:bl] for p in parts] + [p[bl:] for p in parts], 0)
+        local = _stacked(z_i, z_j).contiguous()                        # [2*bl, P]: view 0 rows, view 1 rows
+        # one collective into one buffer, used as it arrives: [rank][view][bag] (the kernel's pair_stride layout)
+        zg = torch.empty((world * 2 * bl, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(zg, local, group=group)
         lo, hi = shard_range(rank, world, bl)
-        loss, dz, sim = kernel(zg, temperature, grad_lo=lo, grad_hi=hi)
-        Bg = bl * world
-        ctx.save_for_backward(dz[lo:hi], dz[Bg + lo:Bg + hi])
+        loss, dz, sim = kernel(zg, temperature, grad_lo=lo, grad_hi=hi, pair_stride=bl)
+        r0 = rank * 2 * bl
+        ctx.save_for_backward(dz[r0:r0 + 2 * bl])
+        ctx.bl = bl
         ctx.mark_non_differentiable(sim)
+        ctx.set_materialize_grads(False)
         return loss.reshape(()), sim[lo:hi]
 
     @staticmethod
     def backward(ctx, dloss, _dsim):
-        dzi, dzj = ctx.saved_tensors
-        return dzi * dloss, dzj * dloss, None, None, None
+        (dz,) = ctx.saved_tensors
+        if dloss is None:
+            return None, None, None, None, None
+        from . import ops
+        if not ops.is_unit_grad(dloss):
+            dz = dz * dloss
+        return dz[:ctx.bl], dz[ctx.bl:], None, None, None
 
 
 def gathered_nt_xent(z_i, z_j, temperature, group=None, kernel=None):
     """Global NT-Xent over all ranks' bags; returns (loss identical on every rank, local cosines)."""
     if kernel is None:
         from . import ops
-        kernel = lambda z, t, grad_lo, grad_hi: ops.ntxent(z, t, True, grad_lo, grad_hi)  # noqa: E731
+        kernel = lambda z, t, grad_lo, grad_hi, pair_stride: ops.ntxent(z, t, True, grad_lo, grad_hi, pair_stride)  # noqa: E731
     return _GatheredNTXent.apply(z_i, z_j, float(temperature), group, kernel)
 
 
@@ -55,18 +71,35 @@ def all_reduce_grads(flat_grads, group=None):
 
 
 class OverlappedGradReduce:
-    """All-reduce the optimizer's flat gradient buffers with the early groups overlapped with backward.
+    """All-reduce the optimizer's flat gradient buffers in pieces, each as soon as it is final, overlapped with backward.
 
     In the pre-train step the recurrent head's gradients (19.4 MB, group 1) are final as soon as the backward
     pass reaches the aggregator outputs, long before the encoder gradients (4.7 MB, group 0) exist.  ``arm()``
     registers hooks on those aggregator outputs; when the last one fires, the head group's all-reduce is
     launched asynchronously (RCCL runs on its own stream, ordered after the kernels already queued) and overlaps
-    with the aggregator backward; ``finish()`` reduces the remaining groups and waits for everything.
+    with the aggregator backward.  With ``milestones=True`` the aggregator's backward additionally announces the
+    parameters whose gradients its kernels have just completed (``functional.set_grad_milestone``: attention + decoder,
+    then encoder layer 3, then layer 2), so only the first encoder layer (1 MB) is left for ``finish()``, which reduces
+    whatever has not been submitted yet and waits for everything.  Milestones assume the aggregator runs once per step.
     """
 
-    def __init__(self, optimizer, early_groups=(1,), group=None):
+    def __init__(self, optimizer, early_groups=(1,), group=None, milestones=False):
         self.opt, self.early, self.group = optimizer, tuple(early_groups), group
-        self._pending, self._works = 0, []
+        self._pending, self._works, self._covered = 0, [], {}
+        self._where = {}
+        if milestones and hasattr(optimizer, "groups"):
+            for gi, g in enumerate(optimizer.groups):
+                off = 0
+                for p in g["params"]:
+                    self._where[id(p)] = (gi, off, off + p.numel())
+                    off += p.numel()
+            from . import functional
+            functional.set_grad_milestone(self.milestone)
+
+    def _submit(self, gi, lo, hi):
+        flat = self.opt.flat_grads()[gi]
+        self._works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._covered.setdefault(gi, []).append((lo, hi))
 
     def arm(self, aggregator_outputs):
         # outputs handed out as row blocks of one tensor (CL.forward) may be consumed through that tensor directly
@@ -76,23 +109,39 @@ class OverlappedGradReduce:
             b = getattr(t, "_base", None)
             b = b if b is not None and b.requires_grad and b.grad_fn is not None else t
             targets[id(b)] = b
-        self._works, self._pending = [], len(targets)
+        self._works, self._covered, self._pending = [], {}, len(targets)
         for t in targets.values():
             t.register_hook(self._fired)
 
     def _fired(self, grad):
         self._pending -= 1
         if self._pending == 0:
-            flats = self.opt.flat_grads()
             for gi in self.early:
-                self._works.append(dist.all_reduce(flats[gi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._submit(gi, 0, self.opt.flat_grads()[gi].numel())
         return grad
 
+    def milestone(self, params):
+        spans = sorted(self._where[id(p)] for p in params if id(p) in self._where)
+        merged = []
+        for gi, lo, hi in spans:
+            if gi in self.early:
+                continue                              # the whole group is (or will be) reduced by the hook
+            if merged and merged[-1][0] == gi and merged[-1][2] == lo:
+                merged[-1][2] = hi
+            else:
+                merged.append([gi, lo, hi])
+        for gi, lo, hi in merged:
+            self._submit(gi, lo, hi)
+
     def finish(self):
-        flats = self.opt.flat_grads()
-        for gi in range(len(flats)):
-            if gi not in self.early or not self._works:
-                self._works.append(dist.all_reduce(flats[gi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for gi, flat in enumerate(self.opt.flat_grads()):
+            pos = 0
+            for lo, hi in sorted(self._covered.get(gi, [])):
+                if lo > pos:
+                    self._submit(gi, pos, lo)
+                pos = max(pos, hi)
+            if pos < flat.numel():
+                self._submit(gi, pos, flat.numel())
         for w in self._works:
             w.wait()
-        self._works = []
+        self._works, self._covered = [], {}

@@ -26,6 +26,22 @@ def set_direct_grad(flag):
     _DIRECT = bool(flag)
 
 
+_MILESTONE = None
+
+
+def set_grad_milestone(callback):
+    """``callback(params)`` is called from inside the aggregator's backward as soon as the kernels that complete the
+    gradients of ``params`` are enqueued (direct-gradient mode only).  A data-parallel reducer uses it to start their
+    all-reduce under the remaining backward kernels; only meaningful when the aggregator runs once per optimizer step."""
+    global _MILESTONE
+    _MILESTONE = callback
+
+
+def _final(*params):
+    if _MILESTONE is not None and all(_direct(p) for p in params):
+        _MILESTONE(params)
+
+
 def _direct(p):
     return _DIRECT and p is not None and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
 
@@ -151,15 +167,19 @@ class ABMILFn(torch.autograd.Function):
         dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM,
                                                into=(ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None)
         dwa = _wgrad(dT, h3, wa)
+        if direct_k2:
+            _final(wa, ba, wb, bb, wd, bd)
         # encoder layer 3: dZ3 = (dT Wa + A (x) dM) * relu'(H3)
         if m3 is not None:
             into = lambda b: b.grad.view(-1) if _direct(b) else None      # bias gradients straight from the epilogue
             dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3,
                                          rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_into=into(b3))
             dw3 = _wgrad(dz3, h2, w3)
+            _final(w3, b3)
             dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True,
                                          colsum_into=into(b2))
             dw2 = _wgrad(dz2, h1, w2)
+            _final(w2, b2)
             dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True,
                                          colsum_into=into(b1))
         else:
@@ -167,9 +187,11 @@ class ABMILFn(torch.autograd.Function):
                                   rank1=dM, rows_per_bag=N, colsum=True)
             db3 = _bgrad(ws, b3)
             dw3 = _wgrad(dz3, h2, w3)
+            _final(w3, b3)
             dz2, ws = ops.gemm_nt(dz3, w3t, epi=ops.EPI_MASK, mask=h2, colsum=True)
             db2 = _bgrad(ws, b2)
             dw2 = _wgrad(dz2, h1, w2)
+            _final(w2, b2)
             dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
             db1 = _bgrad(ws, b1)
         dw1 = _wgrad(dz1, x2, w1)

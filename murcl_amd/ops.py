@@ -240,14 +240,16 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
     return dT_full[:B * N], dba, dwb, dbb
 
 
-def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None):
-    """z [2B,128] f32 -> (loss [1], dz [2B,128] or None, sim [B])."""
+def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None, pair_stride=None):
+    """z [2B,128] f32 -> (loss [1], dz [2B,128] or None, sim [B]).  Rows: cat(view 0, view 1) by default; with
+    ``pair_stride`` = bags per rank, an all-gathered [rank][view][bag] batch (global bag id = rank * pair_stride + b)."""
     _need_cuda(z)
     z = _c(z.float())
     n, P = z.shape
     Bh = n // 2
     if grad_hi is None:
         grad_hi = Bh
+    ps = Bh if pair_stride is None else int(pair_stride)
     dev = z.device
     ws = torch.empty((_lib.lib().murcl_ntxent_workspace_bytes(n) + 3) // 4, dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
@@ -255,7 +257,7 @@ def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None):
     sim = torch.empty((Bh,), dtype=torch.float32, device=dev)
     with _span(lambda: ("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4))):
         check(_lib.lib().murcl_ntxent_fwd_bwd(ptr(z), n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo,
-                                              grad_hi, ptr(ws), stream()), "ntxent_fwd_bwd")
+                                              grad_hi, ps, ptr(ws), stream()), "ntxent_fwd_bwd")
     return loss, dz, sim
 
 

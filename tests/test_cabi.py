@@ -51,4 +51,5 @@ def test_unsupported_arguments_are_rejected_without_launching():
                            None, 0, None) == -1
     assert L.murcl_abmil_pool_fwd(None, None, None, None, None, None, None, None, None, None, 1, 8, 256, 128,
                                   _lib.F32, 1, None) == -1          # L != 512
-    assert L.murcl_ntxent_fwd_bwd(None, 7, 128, 1.0, None, None, None, 0, 1, None, None) == -1   # odd n
+    assert L.murcl_ntxent_fwd_bwd(None, 7, 128, 1.0, None, None, None, 0, 1, 0, None, None) == -1   # odd n
+    assert L.murcl_ntxent_fwd_bwd(None, 24, 128, 1.0, None, None, None, 0, 1, 5, None, None) == -1  # n not a multiple of 2*pair_stride

@@ -1,7 +1,7 @@
 """world_size-2 gloo test of the sharded contrastive step.
 
 The HIP NT-Xent kernel is GPU-only, so the CPU test injects the oracle with the same
-(z, tau, grad_lo, grad_hi) -> (loss, dz, sim) contract; what is under test is the distributed
+(z, tau, grad_lo, grad_hi, pair_stride) -> (loss, dz, sim) contract; what is under test is the distributed
 glue: all-gather layout, shard windows, local gradient slices, flat gradient all-reduce.
 """
 import os
@@ -16,18 +16,22 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _oracle_kernel(z, tau, grad_lo, grad_hi):
+def _oracle_kernel(z, tau, grad_lo, grad_hi, pair_stride):
+    """Oracle with the HIP kernel's contract: rows are [rank][view][bag] blocks of ``pair_stride``, bag ids global."""
     from oracle import mil_oracle as O
     n = z.shape[0]
-    Bh = n // 2
+    Bh, ps = n // 2, pair_stride
+    rows = torch.arange(n)
+    bag = (rows // (2 * ps)) * ps + rows % ps
+    to_view_major = torch.argsort(((rows // ps) % 2) * Bh + bag)          # view-major position -> gathered row
     with torch.enable_grad():                    # Function.forward runs with grad mode off
-        zz = z.detach().clone().requires_grad_()
+        zz = z.detach()[to_view_major].clone().requires_grad_()
         loss = O.nt_xent(zz[:Bh], zz[Bh:], tau)
         loss.backward()
     dz = torch.zeros_like(z)
-    dz[grad_lo:grad_hi] = zz.grad[grad_lo:grad_hi]
-    dz[Bh + grad_lo:Bh + grad_hi] = zz.grad[Bh + grad_lo:Bh + grad_hi]
-    return loss.detach().reshape(1), dz, O.row_cosine(z[:Bh], z[Bh:])
+    dz[to_view_major] = zz.grad
+    dz[(bag < grad_lo) | (bag >= grad_hi)] = 0
+    return loss.detach().reshape(1), dz, O.row_cosine(zz[:Bh].detach(), zz[Bh:].detach())
 
 
 def _worker(rank, world, port, out):
@@ -94,14 +98,20 @@ def _worker_overlap(rank, world, port, out):
     enc = torch.nn.Linear(8, 8)
     head = torch.nn.Linear(8, 4)
     opt = FakeOpt([list(enc.parameters()), list(head.parameters())])
-    red = mdist.OverlappedGradReduce(opt, early_groups=(1,))
+    opt.groups = [{"params": list(enc.parameters())}, {"params": list(head.parameters())}]
+    red = mdist.OverlappedGradReduce(opt, early_groups=(1,), milestones=True)
     x = torch.randn(5, 8)
     h = enc(x)
     outs = list(h.split([2, 3], 0))
     red.arm(outs)
     loss = sum(head(o).pow(2).sum() for o in outs)
     loss.backward()
+    # what the aggregator's backward announces while it runs: here the bias is "final" first; finish() covers the weight
+    red.milestone((enc.bias, head.weight))
+    assert red._covered == {1: [(0, 36)], 0: [(64, 72)]}
     red.finish()
+    from murcl_amd import functional
+    functional.set_grad_milestone(None)
     out[rank] = [f.clone().numpy() for f in opt.flat]
     dist.destroy_process_group()
 

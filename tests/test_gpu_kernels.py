@@ -189,7 +189,7 @@ def test_abmil_pool_bwd(dtype, B, N):
 
 
 # ------------------------------------------------------------------ NT-Xent
-@pytest.mark.parametrize("Bh", [2, 4, 9, 64, 512])
+@pytest.mark.parametrize("Bh", [2, 4, 9, 64, 65, 100, 128, 512, 777])
 @pytest.mark.parametrize("tau", [1.0, 0.5, 0.07])
 def test_ntxent(Bh, tau):
     from murcl_amd import ops
@@ -209,19 +209,47 @@ def test_ntxent(Bh, tau):
     _close(sim, O.row_cosine(zi.detach(), zj.detach()), rtol=1e-4, atol=1e-6, msg="sim")
 
 
-def test_ntxent_sharded_rows_match_global():
-    """Rank-local gradient slices assemble to the global gradient."""
+@pytest.mark.parametrize("Bh,step", [(32, 8), (256, 64), (200, 40)])
+def test_ntxent_sharded_rows_match_global(Bh, step):
+    """Rank-local gradient slices assemble to the global gradient; 256 = the global batch of 4 ranks."""
     from murcl_amd import ops
     dev = _dev()
-    Bh = 32
-    z = torch.cat([_rand(12, "a", (Bh, 128)), _rand(12, "b", (Bh, 128))]).to(dev)
+    z = torch.cat([_rand(12, f"a{Bh}", (Bh, 128)), _rand(12, f"b{Bh}", (Bh, 128))]).to(dev)
     loss, dz, _ = ops.ntxent(z, 0.5)
     parts = torch.zeros_like(dz)
-    for lo in range(0, Bh, 8):
-        l2, d2, _ = ops.ntxent(z, 0.5, grad_lo=lo, grad_hi=lo + 8)
+    for lo in range(0, Bh, step):
+        l2, d2, _ = ops.ntxent(z, 0.5, grad_lo=lo, grad_hi=lo + step)
+        rows = torch.zeros(2 * Bh, dtype=torch.bool)
+        rows[lo:lo + step] = rows[Bh + lo:Bh + lo + step] = True
+        assert not d2[~rows.to(dev)].any()               # other ranks' rows: exactly zero
         assert l2.item() == pytest.approx(loss.item(), rel=1e-6)
         parts += d2
     _close(parts, dz, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("world,bl", [(2, 8), (4, 64), (8, 64), (3, 40)])
+def test_ntxent_gathered_layout_equals_view_major(world, bl):
+    """pair_stride = bags per rank: the all-gathered [rank][view][bag] buffer gives the same loss, cosines and (row for
+    row) the same gradient as the reference's cat(z_i, z_j) order, and a rank's window touches only its own rows."""
+    from murcl_amd import ops
+    dev = _dev()
+    Bh = world * bl
+    zv = torch.cat([_rand(14, f"gi{world}.{bl}", (Bh, 128)), _rand(14, f"gj{world}.{bl}", (Bh, 128))])   # view-major
+    rows = torch.arange(2 * Bh)
+    bag = (rows // (2 * bl)) * bl + rows % bl
+    src = ((rows // bl) % 2) * Bh + bag                     # gathered row r holds view-major row src[r]
+    zg = zv[src].to(dev)
+    loss0, dz0, sim0 = ops.ntxent(zv.to(dev), 0.5)
+    loss1, dz1, sim1 = ops.ntxent(zg, 0.5, pair_stride=bl)
+    assert loss1.item() == pytest.approx(loss0.item(), rel=1e-6)
+    _close(sim1, sim0.cpu(), rtol=1e-6, atol=1e-7, msg="sim")
+    _close(dz1, dz0.cpu()[src], rtol=1e-5, atol=1e-9, msg="dz")
+    r = world - 1
+    _, dzr, _ = ops.ntxent(zg, 0.5, grad_lo=r * bl, grad_hi=(r + 1) * bl, pair_stride=bl)
+    mine = slice(r * 2 * bl, (r + 1) * 2 * bl)
+    _close(dzr[mine], dz1.cpu()[mine], rtol=1e-6, atol=1e-10, msg="own rows")
+    dzr[mine] = 0
+    assert not dzr.any()
 
 
 # ------------------------------------------------------------------ small helpers
