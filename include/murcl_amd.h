@@ -72,6 +72,10 @@ int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_
 int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* bb,
                          float* scores, float* A, float* M, float* ml, float* part_ws, int B, int N, int L, int D,
                          int dtype, int exact_tanh, murcl_stream_t stream);
+/* The second launch of murcl_abmil_pool_fwd on its own (chunk partials -> A, M, ml): pass A = M = ml = NULL to
+ * murcl_abmil_pool_fwd to get the partials only, e.g. to time the streaming kernel by itself. */
+int murcl_abmil_pool_combine(const float* scores, const float* part_ws, float* A, float* M, float* ml, int B, int N,
+                             int dtype, murcl_stream_t stream);
 /* backward of the above w.r.t. the pre-tanh activations: dT[b,n,:] = ds_n * wb * (1 - t^2) with
  * ds_n = p_n (dM.H_n / sqrt(N) - dM.M), plus dba += sum dT, dwb += sum ds_n t_n, dbb += sum ds_n
  * (f32, ADDED to the buffers: per-workgroup partial rows in part_ws [512*(2D+1) floats] are summed by a second small

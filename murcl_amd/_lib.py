@@ -24,6 +24,7 @@ SIGNATURES = {
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_combine": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],

@@ -308,7 +308,18 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
     }
 #undef K2_LAUNCH
     int rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
+    if (rc || (!A && !M && !ml)) return rc;          // partials only: the caller runs murcl_abmil_pool_combine itself
+    hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B), dim3(256), 0, stream, scores, part_ws, A, M, ml, N, S,
+                       1.0f / sqrtf((float)N));
+    return MURCL_CHECK_LAUNCH();
+}
+
+// C-ABI: see include/murcl_amd.h
+extern "C" int murcl_abmil_pool_combine(const float* scores, const float* part_ws, float* A, float* M, float* ml, int B,
+                                        int N, int dtype, hipStream_t stream) {
+    if (B <= 0 || N <= 0) return 0;
+    int chunk, S;
+    murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B), dim3(256), 0, stream, scores, part_ws, A, M, ml, N, S,
                        1.0f / sqrtf((float)N));
     return MURCL_CHECK_LAUNCH();

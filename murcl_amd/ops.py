@@ -207,9 +207,14 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
     with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L),
                     bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es))):
-        check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), ptr(A), ptr(M),
-                                              ptr(ml), ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
+        # the streaming kernel alone (chunk partials); the per-bag merge is its own launch and its own span below, so
+        # that the HIP-event time of this key is the kernel rocprofv3 lists as abmil_pool_fwd_kernel
+        check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
+                                              None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
               "abmil_pool_fwd")
+    with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
+        check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, dt(H), stream()),
+              "abmil_pool_combine")
     return scores, A, M, ml
 
 
