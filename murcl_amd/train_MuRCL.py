@@ -25,7 +25,7 @@ import torch.distributed as dist
 from murcl_amd import dist as mdist, ops
 from murcl_amd.models import abmil, cl, clam, rlmil
 from murcl_amd.optim import FlatAdam
-from murcl_amd.utils.datasets import BagPack, subbag_views
+from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, subbag_views
 from murcl_amd.utils.losses import NT_Xent
 
 
@@ -186,20 +186,36 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, device, rank, w
     memory_list = [rlmil.Memory(), rlmil.Memory()]
     best = float("inf")
     base_lrs = [g["lr"] for g in optimizer.param_groups] if optimizer else []
+    store = None
+    if not args.no_resident:
+        # this rank's slides, uploaded once and kept in HBM for the whole run (SURVEY 8(e),(f)): a batch is an index list
+        store = DeviceSlideStore.from_dataset(train_set, device, dtype=model.encoder.compute_dtype,
+                                              indices=range(rank, len(train_set), world))
+        if rank == 0:
+            print(f"resident slide store: {len(store)} slides, {store.bytes() / 2 ** 30:.2f} GiB on {device}", flush=True)
     gc.collect()
     gc.freeze()          # models/optimizer state are long-lived: keep full collections (tens of ms) out of the step loop
     for epoch in range(args.epochs):
-        train_set.shuffle()
-        feats, clusters, last = [], [], float("nan")
-        for data_idx in range(rank, len(train_set) * args.data_repeat, world):       # bags shard by WSI across ranks
-            feat, cluster, *_ = train_set[data_idx % len(train_set)]
-            feats.append(feat.to(device, non_blocking=True))
-            clusters.append(cluster)
-            if len(feats) == args.batch_size:
-                pack = BagPack.from_lists(feats, clusters)
+        last = float("nan")
+        if store is not None:
+            order = np.random.permutation(len(store))
+            draws = len(store) * args.data_repeat
+            for s in range(0, draws - args.batch_size + 1, args.batch_size):
+                pack = store.pack(order[np.arange(s, s + args.batch_size) % len(store)])
                 loss, _, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
                 last = loss.item()
-                feats, clusters = [], []
+        else:
+            train_set.shuffle()
+            feats, clusters = [], []
+            for data_idx in range(rank, len(train_set) * args.data_repeat, world):       # bags shard by WSI across ranks
+                feat, cluster, *_ = train_set[data_idx % len(train_set)]
+                feats.append(feat.to(device, non_blocking=True))
+                clusters.append(cluster)
+                if len(feats) == args.batch_size:
+                    pack = BagPack.from_lists(feats, clusters)
+                    loss, _, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
+                    last = loss.item()
+                    feats, clusters = [], []
         if optimizer is not None and epoch >= args.warmup:
             for g, b in zip(optimizer.param_groups, base_lrs):
                 g["lr"] = cosine_lr(b, epoch, args.epochs, args.warmup)
@@ -222,6 +238,8 @@ def build_parser():
     p.add_argument("--synthetic", type=str, default=None, help="n_slides,n_patches (random bags instead of --data_csv)")
     p.add_argument("--feat_size", default=1024, type=int)
     p.add_argument("--T", default=6, type=int)
+    p.add_argument("--no_resident", action="store_true",
+                   help="re-read and upload every slide on every step like the reference, instead of keeping the split in HBM")
     p.add_argument("--train_stage", default=1, type=int)
     p.add_argument("--checkpoint", default=None, type=str)
     p.add_argument("--optimizer", default="Adam", type=str)

@@ -137,3 +137,21 @@ def test_supervised_rlmil_step_first_loss_matches_oracle_and_trains(arch):
     assert torch.isfinite(l) and not torch.equal(fc.fc.weight, w0)
     if arch != "ABMIL":          # (the ABMIL test weights carry a x60 decoder gain: Adam at 1e-3 overshoots there)
         assert l.item() < loss0.item()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_train_script_runs_from_the_resident_store_and_from_per_step_uploads(tmp_path, resident, capsys):
+    """train_MuRCL.main on synthetic slides: the HBM-resident split (default) and the reference-style per-step upload
+    both train, write the reference's checkpoint keys, and the resident run reports its store."""
+    from murcl_amd import train_MuRCL
+    save = tmp_path / ("res" if resident else "stream") / "stage_1"
+    argv = ["--synthetic", "6,300", "--batch_size", "3", "--feat_size", "64", "--T", "2", "--epochs", "2", "--data_repeat", "2",
+            "--num_clusters", "4", "--dtype", "f32", "--save_dir", str(save)] + ([] if resident else ["--no_resident"])
+    train_MuRCL.main(argv)
+    out = capsys.readouterr().out
+    assert ("resident slide store: 6 slides" in out) == resident
+    assert "epoch 2: loss" in out
+    ck = torch.load(save / "model_best.pth.tar", map_location="cpu")
+    assert {"epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"} <= set(ck)
+    assert "encoder.encoder.0.weight" in ck["model_state_dict"] and "rnn.weight_ih_l0" in ck["fc"]
+    assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values())

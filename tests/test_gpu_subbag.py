@@ -91,3 +91,57 @@ def test_fused_views_equal_get_feats_then_mixup(dtype):
             np.testing.assert_array_equal(got, want)
         else:
             np.testing.assert_allclose(got, want, rtol=8e-3, atol=1e-6)
+
+
+class _ListSet:
+    """dataset[i] -> (feat, clusters, label, case_id), the WSIWithCluster item format."""
+
+    def __init__(self, feats, cls):
+        self.feats, self.cls = feats, cls
+
+    def __len__(self):
+        return len(self.feats)
+
+    def __getitem__(self, i):
+        return T(self.feats[i]).unsqueeze(0), self.cls[i], i % 2, f"case{i}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_device_slide_store_packs_equal_per_step_packs(dtype):
+    """a batch drawn from the HBM-resident split selects the same patch ids (bit-exact) and gathers
+    the same rows as a BagPack built from those slides' host tensors - any order, repeats, ragged slide lengths, N < feat_size."""
+    from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, select_indices, subbag_views
+    dev = _dev()
+    S_, K, fs, d = 9, 10, 256, 64
+    Ns = [3000 - 311 * b for b in range(S_ - 1)] + [100]                   # last slide shorter than feat_size
+    feats_np = [P.bags(51, f"f{b}", 1, Ns[b], d)[0] for b in range(S_)]
+    cls = [P.cluster_lists(51, f"c{b}", Ns[b], K) for b in range(S_)]
+    store = DeviceSlideStore.from_dataset(_ListSet(feats_np, cls), dev, dtype=dtype, chunk_rows=1000)
+    assert len(store) == S_ and store.K == K and store.patch_dim == d and store.feats.shape[0] == sum(Ns)
+    assert store.labels.tolist() == [i % 2 for i in range(S_)] and store.case_ids[3] == "case3"
+    assert store.bytes() == sum(Ns) * d * (2 if dtype == torch.bfloat16 else 4) + sum(Ns) * 4
+    for pick in ([8, 0, 3, 3, 7], list(range(S_)), [5]):
+        ref = BagPack.from_lists([T(feats_np[i]).to(dev) for i in pick], [cls[i] for i in pick], dtype=dtype)
+        got = store.pack(pick)
+        assert got.feats.data_ptr() == store.feats.data_ptr()               # the arena itself: nothing was copied
+        B = len(pick)
+        acts = [T(detrand.uniform(51, f"a{v}{B}", (B, K))).to(dev) for v in range(2)]
+        for a in acts:
+            i0, c0 = select_indices(ref, a, fs)
+            i1, c1 = select_indices(got, a, fs)
+            assert torch.equal(i0, i1) and torch.equal(c0, c1)
+            for b, s in enumerate(pick):                                    # and against the oracle
+                want = S.select_indices(Ns[s], cls[s], a[b].cpu().numpy(), fs)[:fs]
+                assert c1[b].item() == len(want) and i1[b, :len(want)].cpu().tolist() == list(want)
+        draws = [(T(detrand.uniform(51, f"l{v}{B}", (B, 1), 0.9, 1.0)).to(dev), T(detrand.permutation(51, f"p{v}{B}", B)).to(dev))
+                 for v in range(2)]
+        v0, _ = subbag_views(ref, acts, fs, draws=draws)
+        v1, _ = subbag_views(got, acts, fs, draws=draws)
+        for x, y in zip(v0, v1):
+            assert torch.equal(x, y)
+
+
+def test_device_slide_store_refuses_cpu():
+    from murcl_amd.utils.datasets import DeviceSlideStore
+    with pytest.raises(RuntimeError):
+        DeviceSlideStore.from_dataset(_ListSet([np.zeros((4, 8), np.float32)], [[[0, 1], [2, 3]]]), "cpu")

@@ -111,3 +111,28 @@ if "gru" in only or not only:
     def f():
         with torch.no_grad(): fc(x, restart=True); fc(x, restart=False)
     print(json.dumps({"row": "a14 Full_layer (K7)", "what": "2 GRU steps + projection, 128 rows", "ms": round(timed(f), 4)}), flush=True)
+# ---- f1: forming a C4 batch (64 raw slides x 8192 x 512): per-step upload as the reference does vs the HBM-resident store
+if "store" in only or not only:
+    from murcl_amd.utils.datasets import DeviceSlideStore
+    S_, B, N, K = 128, 64, 8192, 10
+    rng = np.random.default_rng(985)
+    host = [torch.from_numpy((np.abs(rng.standard_normal((N, 512), dtype=np.float32)) * 0.5)) for _ in range(S_)]
+    cls = []
+    for _ in range(S_):
+        lab = rng.integers(0, K, N)
+        cls.append([np.nonzero(lab == k)[0].tolist() for k in range(K)])
+    class _DS:
+        def __len__(self): return S_
+        def __getitem__(self, i): return host[i], cls[i], 0, str(i)
+    t0 = time.perf_counter(); store = DeviceSlideStore.from_dataset(_DS(), dev, dtype=torch.bfloat16); torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    def wall(fn, reps=5):
+        fn(); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+    pick = rng.permutation(S_)[:B]
+    ms_ref = wall(lambda: BagPack.from_lists([host[i].to(dev, non_blocking=True) for i in pick], [cls[i] for i in pick], dtype=torch.bfloat16))
+    ms_store = wall(lambda: store.pack(pick), reps=50)
+    print(json.dumps({"row": "f1 device-resident split (8(f) rank 1)", "what": f"form one batch of {B} slides x {N} x 512",
+                      "per_step_upload_ms": round(ms_ref, 2), "resident_store_pack_ms": round(ms_store, 4),
+                      "store_GiB": round(store.bytes() / 2 ** 30, 2), "one_time_upload_s": round(build_s, 2)}), flush=True)
