@@ -37,36 +37,46 @@ def _confidence(logits, labels):
     return torch.softmax(logits.detach(), 1).gather(1, labels.view(-1, 1)).view(1, -1)
 
 
+def _forward_loss(arch, model, fc, feats, labels, t, bag_weight):
+    """Aggregator + recurrent head + the arch's loss for one patch step -> (loss, logits, states)."""
+    if arch == "ABMIL":
+        out, states = model(feats)
+        logits = fc(out, restart=(t == 0))
+        loss = CrossEntropyFn.apply(logits, labels)                                    # :727
+    elif arch == "CLAM_SB":
+        out, states, res = model(feats, label=labels, instance_eval=True)
+        logits = fc(out, restart=(t == 0))
+        inst = torch.stack([r["instance_loss"] for r in res]).mean()
+        loss = bag_weight * CrossEntropyFn.apply(logits, labels) + (1 - bag_weight) * inst   # :336
+    else:
+        classes, bag, bag_det = model(feats)
+        states = bag_det.mean(1)                                                       # :515
+        cls = torch.stack(classes) if isinstance(classes, list) else classes.unsqueeze(0)
+        logits = fc(bag.mean(1), restart=(t == 0))                                     # :517-518
+        loss = 0.5 * CrossEntropyFn.apply(logits, labels) + 0.5 * CrossEntropyFn.apply(cls.max(1)[0], labels)   # :527-529
+    return loss, logits, states
+
+
+def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
+    if actions is not None:
+        return actions[t].to(dev)
+    if t == 0 or train_stage == 1:
+        return torch.rand((B, K), device=dev)
+    return ppo.select_action(states, memory, restart_batch=(t == 1))
+
+
 def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, feat_size=1024, train_stage=1,
-                    bag_weight=0.7, actions=None):
-    """One step on a BagPack with int64 labels [B].  Returns (loss, losses[T], rewards[T-1])."""
+                    bag_weight=0.7, actions=None, return_logits=False):
+    """One step on a BagPack with int64 labels [B].  Returns (loss, losses[T], rewards[T-1]) (+ the last patch step's
+    logits with ``return_logits``)."""
     B, K, dev = pack.B, pack.K, pack.feats.device
     train_enc = train_stage != 2
     losses, rewards, conf_last, states = [], [], None, None
     for t in range(T):
-        if actions is not None:
-            act = actions[t].to(dev)
-        elif t == 0 or train_stage == 1:
-            act = torch.rand((B, K), device=dev)
-        else:
-            act = ppo.select_action(states, memory, restart_batch=(t == 1))
+        act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions)
         (feats,), _ = subbag_views(pack, [act], feat_size, out_dtype=model.compute_dtype)
         with torch.set_grad_enabled(train_enc):
-            if arch == "ABMIL":
-                out, states = model(feats)
-                logits = fc(out, restart=(t == 0))
-                loss = CrossEntropyFn.apply(logits, labels)                                    # :727
-            elif arch == "CLAM_SB":
-                out, states, res = model(feats, label=labels, instance_eval=True)
-                logits = fc(out, restart=(t == 0))
-                inst = torch.stack([r["instance_loss"] for r in res]).mean()
-                loss = bag_weight * CrossEntropyFn.apply(logits, labels) + (1 - bag_weight) * inst   # :336
-            else:
-                classes, bag, bag_det = model(feats)
-                states = bag_det.mean(1)                                                       # :515
-                cls = torch.stack(classes) if isinstance(classes, list) else classes.unsqueeze(0)
-                logits = fc(bag.mean(1), restart=(t == 0))                                     # :517-518
-                loss = 0.5 * CrossEntropyFn.apply(logits, labels) + 0.5 * CrossEntropyFn.apply(cls.max(1)[0], labels)   # :527-529
+            loss, logits, states = _forward_loss(arch, model, fc, feats, labels, t, bag_weight)
         losses.append(loss)
         conf = _confidence(logits, labels)
         if t > 0:
@@ -81,4 +91,114 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     else:
         ppo.update(memory)
     memory.clear_memory()
-    return loss.detach(), [l.detach() for l in losses], rewards
+    out = (loss.detach(), [l.detach() for l in losses], rewards)
+    return out + (logits.detach(),) if return_logits else out
+
+
+# ------------------------------------------------------------------------------------ validation / test (8(f) rank 2)
+def get_metrics(outputs, targets):
+    """(acc, auc, precision, recall, f1) exactly as utils/general.py:174-200: arg-max accuracy, soft-max AUC (one-vs-rest
+    for more than two classes), binary / macro precision-recall-F1 from scikit-learn."""
+    from sklearn.metrics import precision_recall_fscore_support, roc_auc_score
+    with torch.no_grad():
+        assert outputs.shape[0] == targets.shape[0]
+        multi = outputs.shape[1] > 2
+        preds = outputs.argmax(1)
+        acc = (preds.eq(targets).sum() / targets.shape[0]).item()
+        t = targets.cpu().numpy().astype(int).reshape(-1)
+        probs = torch.softmax(outputs.float(), 1).cpu().numpy()
+        auc = roc_auc_score(t, probs, multi_class="ovr") if multi else roc_auc_score(t, probs[:, 1])
+        precision, recall, f1, _ = precision_recall_fscore_support(t, preds.cpu().numpy(), average="macro" if multi else "binary")
+    return acc, auc, precision, recall, f1
+
+
+def get_score(acc, auc, precision, recall, f1_score):
+    """Model-selection score (utils/general.py:203-204)."""
+    return 0.3 * acc + 0.3 * auc + 0.1 * precision + 0.1 * recall + 0.2 * f1_score
+
+
+def evaluate_split(arch, model, fc, ppo, memory, pack, labels, T=6, feat_size=1024, train_stage=1, bag_weight=0.7,
+                   actions=None):
+    """The reference's test_ABMIL / test_CLAM / test_DSMIL (train_RLMIL.py:410-472,607-679,799-854): the WHOLE split as
+    one batch, T forward-only patch steps in eval mode, metrics on the last step's logits.
+    Returns (loss of the last patch step, acc, auc, precision, recall, f1, logits [S,C], labels)."""
+    B, K, dev = pack.B, pack.K, pack.feats.device
+    was = (model.training, fc.training)
+    model.eval(), fc.eval()
+    conf_last = states = None
+    with torch.no_grad():
+        for t in range(T):
+            act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions)
+            (feats,), _ = subbag_views(pack, [act], feat_size, out_dtype=model.compute_dtype)
+            loss, logits, states = _forward_loss(arch, model, fc, feats, labels, t, bag_weight)
+            conf = _confidence(logits, labels)
+            if t > 0:
+                memory.rewards.append(conf - conf_last)
+            conf_last = conf
+        memory.clear_memory()
+    model.train(was[0]), fc.train(was[1])
+    return (loss.item(), *get_metrics(logits, labels), logits, labels)
+
+
+def predictions_frame(logits, labels, case_ids):
+    """pred.csv of the reference's ``test`` (train_RLMIL.py:984-1002): label, pred, correct, prob0.. indexed by case_id."""
+    import pandas as pd
+    prob = torch.softmax(logits.float(), 1).cpu()
+    pred = prob.argmax(1)
+    lab = labels.cpu()
+    df = pd.DataFrame({"label": lab.tolist(), "pred": pred.tolist(), "correct": (lab == pred).tolist(),
+                       **{f"prob{j}": prob[:, j].tolist() for j in range(prob.shape[1])}}, index=list(case_ids))
+    df.index.rename("case_id", inplace=True)
+    return df
+
+
+class BestPick:
+    """Best-epoch selection on the validation split (train_RLMIL.py:900-915): 'acc' | 'auc' | 'score' maximise, 'loss' minimises."""
+
+    def __init__(self, method="score"):
+        if method not in ("acc", "loss", "auc", "score"):
+            raise ValueError("picked_method error. ")
+        self.method, self.best, self.epoch = method, None, 0
+
+    def update(self, epoch, loss, acc, auc, precision, recall, f1):
+        v = {"acc": acc, "loss": -loss, "auc": auc, "score": get_score(acc, auc, precision, recall, f1)}[self.method]
+        if self.best is None or v > self.best:
+            self.best, self.epoch = v, epoch
+            return True
+        return False
+
+
+def fit(arch, model, fc, ppo, optimizer, stores, epochs, batch_size, T=6, feat_size=1024, train_stage=1, bag_weight=0.7,
+        picked_method="score", rng=None, log=print):
+    """Epoch loop of the reference's ``train`` (train_RLMIL.py:856-975) on HBM-resident splits.
+    ``stores`` = (train, valid, test) DeviceSlideStore with labels.  Returns (best state dict, final test tuple, pred frame)."""
+    import copy
+    import numpy as np
+    from murcl_amd.models import rlmil as _rl
+    rng = rng or np.random.default_rng(985)
+    train, valid, test = stores
+    dev = train.feats.device
+    lab = [torch.from_numpy(s.labels).to(dev) for s in stores]
+    memory, pick, best, final, frame = _rl.Memory(), BestPick(picked_method), None, None, None
+    for epoch in range(epochs):
+        order, tl, outs, ys = rng.permutation(len(train)), [], [], []
+        for s in range(0, len(order) - batch_size + 1, batch_size):
+            sel = order[s:s + batch_size]
+            loss, _, _, logits = supervised_step(arch, model, fc, ppo, optimizer, train.pack(sel), lab[0][torch.from_numpy(sel).to(dev)],
+                                                 memory, T, feat_size, train_stage, bag_weight, return_logits=True)
+            tl.append(loss)
+            outs.append(logits)
+            ys.append(lab[0][torch.from_numpy(sel).to(dev)])
+        tr_loss = torch.stack(tl).mean().item()
+        tr_acc = (torch.cat(outs).argmax(1) == torch.cat(ys)).float().mean().item()
+        v = evaluate_split(arch, model, fc, ppo, memory, valid.pack(range(len(valid))), lab[1], T, feat_size, train_stage, bag_weight)
+        te = evaluate_split(arch, model, fc, ppo, memory, test.pack(range(len(test))), lab[2], T, feat_size, train_stage, bag_weight)
+        if pick.update(epoch + 1, *v[:6]):
+            final = (epoch + 1, *te[:6])
+            frame = predictions_frame(te[6], te[7], test.case_ids)
+            best = {"epoch": epoch + 1, "model_state_dict": copy.deepcopy(model.state_dict()), "fc": copy.deepcopy(fc.state_dict()),
+                    "optimizer": None, "ppo_optimizer": None,
+                    "policy": copy.deepcopy(ppo.policy.state_dict()) if ppo else None}       # keys of :930-937
+        log(f"epoch {epoch + 1}: train loss {tr_loss:.4f} acc {tr_acc:.4f} | valid loss {v[0]:.4f} acc {v[1]:.4f} auc {v[2]:.4f} | "
+            f"test loss {te[0]:.4f} acc {te[1]:.4f} auc {te[2]:.4f} | final epoch {final[0]}")
+    return best, final, frame

@@ -294,8 +294,82 @@ def g9_full_layer():
     np.savez(os.path.join(OUT, "g9_full_layer.npz"), **res)
 
 
+def _ref_train_rlmil():
+    """The reference's train_RLMIL module (needs a stand-in for the absent tensorboard import, SURVEY 8(c) shim 2)."""
+    import types
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.modules.setdefault("tensorboard", types.ModuleType("tensorboard"))
+    sys.path.insert(0, REF)
+    try:
+        import train_RLMIL as r_train
+        from utils import general as r_general
+    finally:
+        sys.path.pop(0)
+    return r_train, r_general
+
+
+G10_SPLIT = dict(S=7, K=4, fs=64, T=3, d=512, C=2)
+
+
+def g10_inputs(seed=71):
+    """The small validation split of G10 (shared with tests/test_gpu_eval.py through this function's recipe)."""
+    c = G10_SPLIT
+    Ns = [260 - 23 * b for b in range(c["S"])]
+    feats = [P.bags(seed, f"g10.f{b}", 1, Ns[b], c["d"])[0] for b in range(c["S"])]
+    cls = [P.cluster_lists(seed, f"g10.c{b}", Ns[b], c["K"]) for b in range(c["S"])]
+    labels = np.array([0, 1, 1, 0, 1, 0, 0], dtype=np.int64)
+    acts = [detrand.uniform(seed, f"g10.a{t}", (c["S"], c["K"])).astype(np.float32) for t in range(c["T"])]
+    return Ns, feats, cls, labels, acts
+
+
+def g10_eval():
+    """8(f) rank 2: the reference's own validation bodies (train_RLMIL.py test_ABMIL / test_CLAM / test_DSMIL) and
+    utils/general.get_metrics / get_score, with the random sub-bag actions injected."""
+    r_train, r_general = _ref_train_rlmil()
+    res = {}
+    # ---- metrics alone: binary and 3-class
+    for name, n, C in (("bin", 14, 2), ("tri", 18, 3)):
+        out = T(detrand.normal(72, f"g10.m.{name}", (n, C)).astype(np.float32))
+        tgt = torch.from_numpy(np.arange(n) % C)
+        m = r_general.get_metrics(out, tgt)
+        res[f"metrics.{name}"] = np.array(m, dtype=np.float64)
+        res[f"score.{name}"] = np.float64(r_general.get_score(*m))
+    # ---- whole-split evaluation
+    c = G10_SPLIT
+    Ns, feats, cls, labels, acts = g10_inputs()
+    test_set = [(T(f), cl, torch.tensor(int(y)), f"case{i}") for i, (f, cl, y) in enumerate(zip(feats, cls, labels))]
+    import argparse
+    for arch in ("ABMIL", "CLAM_SB", "DSMIL"):
+        if arch == "ABMIL":
+            model = r_abmil.ABMIL(c["d"], L=512, D=128, dim_out=c["C"])
+            model.load_state_dict(P.to_torch(P.abmil(73, dim_out=c["C"])))
+        elif arch == "CLAM_SB":
+            model = r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=c["C"], subtyping=True, in_dim=c["d"])
+            model.load_state_dict(P.to_torch(P.clam_sb(73)))
+        else:
+            model = r_dsmil.build_dsmil(c["d"], c["C"])
+            model.load_state_dict(P.to_torch(P.dsmil(73)))
+        fc = r_rlmil.Full_layer(512, 1024, True, c["C"])
+        fc.load_state_dict(P.to_torch(P.full_layer(73, 512, 1024, c["C"])))
+        args = argparse.Namespace(T=c["T"], device="cpu", num_clusters=c["K"], feat_size=c["fs"], train_stage=1, bag_weight=0.7)
+        draws = iter([T(a) for a in acts])
+        with mock.patch.object(torch, "rand", lambda *a, **k: next(draws)):
+            fn = {"ABMIL": r_train.test_ABMIL, "CLAM_SB": r_train.test_CLAM, "DSMIL": r_train.test_DSMIL}[arch]   # its TEST map
+            out = fn(args, test_set, model, fc, None, r_rlmil.Memory(), torch.nn.CrossEntropyLoss())
+        loss, acc, auc, prec, rec, f1, outputs, labs, case_ids = out
+        res[f"{arch}.loss"] = np.float64(loss)
+        res[f"{arch}.metrics"] = np.array([acc, auc, prec, rec, f1], dtype=np.float64)
+        res[f"{arch}.outputs"] = outputs.detach().numpy()
+        assert labs.tolist() == labels.tolist() and case_ids[2] == "case2"
+    np.savez(os.path.join(OUT, "g10_eval.npz"), **res)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer):
-        fn()
-        print("wrote", fn.__name__)
+    only = sys.argv[1:]
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval):
+        if not only or fn.__name__ in only:
+            fn()
+            print("wrote", fn.__name__)

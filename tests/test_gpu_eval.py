@@ -1,0 +1,89 @@
+"""SURVEY 8(f) rank 2 on MI355X: the validation / test path of train_RLMIL.py against goldens produced by the
+reference's own test_ABMIL / test_CLAM / test_DSMIL and utils/general.get_metrics (oracle/gen_goldens.py: g10_eval)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, params as P  # noqa: E402
+
+T = torch.from_numpy
+SPLIT = dict(S=7, K=4, fs=64, T=3, d=512, C=2)             # = oracle/gen_goldens.py G10_SPLIT
+
+
+def _inputs(seed=71):
+    c = SPLIT
+    Ns = [260 - 23 * b for b in range(c["S"])]
+    feats = [P.bags(seed, f"g10.f{b}", 1, Ns[b], c["d"])[0] for b in range(c["S"])]
+    cls = [P.cluster_lists(seed, f"g10.c{b}", Ns[b], c["K"]) for b in range(c["S"])]
+    labels = np.array([0, 1, 1, 0, 1, 0, 0], dtype=np.int64)
+    acts = [detrand.uniform(seed, f"g10.a{t}", (c["S"], c["K"])).astype(np.float32) for t in range(c["T"])]
+    return Ns, feats, cls, labels, acts
+
+
+class _Set:
+    def __init__(self, feats, cls, labels):
+        self.f, self.c, self.y = feats, cls, labels
+
+    def __len__(self):
+        return len(self.f)
+
+    def __getitem__(self, i):
+        return T(self.f[i]), self.c[i], int(self.y[i]), f"case{i}"
+
+
+@pytest.mark.parametrize("arch", ["ABMIL", "CLAM_SB", "DSMIL"])
+def test_whole_split_evaluation_matches_the_reference(golden, arch):
+    from murcl_amd.models import rlmil
+    from murcl_amd.train_RLMIL import create_model, evaluate_split, predictions_frame
+    from murcl_amd.utils.datasets import DeviceSlideStore
+    g = golden("g10_eval")
+    dev = torch.device("cuda:0")
+    c = SPLIT
+    Ns, feats, cls, labels, acts = _inputs()
+    model, fc = create_model(arch, c["d"], c["C"], dev)
+    pk = P.abmil(73, dim_out=c["C"]) if arch == "ABMIL" else {"CLAM_SB": P.clam_sb, "DSMIL": P.dsmil}[arch](73)
+    model.load_state_dict(P.to_torch(pk))
+    fc.load_state_dict(P.to_torch(P.full_layer(73, 512, 1024, c["C"])))
+    model.train(), fc.train()                                    # evaluate_split must switch to eval itself (CLAM dropout)
+    store = DeviceSlideStore.from_dataset(_Set(feats, cls, labels), dev)
+    y = T(store.labels).to(dev)
+    loss, acc, auc, prec, rec, f1, logits, labs = evaluate_split(arch, model, fc, None, rlmil.Memory(), store.pack(range(c["S"])), y,
+                                                                  T=c["T"], feat_size=c["fs"], actions=[T(a) for a in acts])
+    assert model.training and fc.training                        # restored
+    np.testing.assert_allclose(logits.cpu().numpy(), g[f"{arch}.outputs"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(loss, float(g[f"{arch}.loss"]), rtol=2e-4)
+    np.testing.assert_allclose([acc, auc, prec, rec, f1], g[f"{arch}.metrics"], rtol=1e-6, atol=1e-7)
+    df = predictions_frame(logits, labs, store.case_ids)
+    assert list(df.columns) == ["label", "pred", "correct", "prob0", "prob1"] and df.index.name == "case_id"
+    assert df.loc["case2", "label"] == 1 and abs(df.loc["case2", "prob0"] + df.loc["case2", "prob1"] - 1) < 1e-6
+    assert df["correct"].mean() == pytest.approx(acc)
+
+
+def test_fit_selects_the_best_epoch_and_trains(tmp_path):
+    """The epoch loop on resident splits: training moves the weights, the best validation epoch is kept with the
+    reference's checkpoint keys, predictions cover the test split."""
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.train_RLMIL import create_model, fit
+    from murcl_amd.utils.datasets import DeviceSlideStore
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+
+    def split(n, tag):
+        Ns = [200 + 7 * i for i in range(n)]
+        ys = np.arange(n) % 2
+        # class signal: class-1 slides carry a shifted first feature block
+        f = [P.bags(81, f"{tag}{i}", 1, Ns[i], 512)[0] + (0.8 * ys[i]) * (np.arange(512) < 64) for i in range(n)]
+        cl = [P.cluster_lists(81, f"{tag}c{i}", Ns[i], 4) for i in range(n)]
+        return DeviceSlideStore.from_dataset(_Set([x.astype(np.float32) for x in f], cl, ys), dev)
+
+    stores = (split(16, "tr"), split(6, "va"), split(6, "te"))
+    model, fc = create_model("ABMIL", 512, 2, dev)
+    opt = FlatAdam([{"params": list(model.parameters()) + list(fc.parameters()), "lr": 2e-4}])
+    w0 = model.encoder[0].weight.detach().clone()
+    lines = []
+    best, final, frame = fit("ABMIL", model, fc, None, opt, stores, epochs=3, batch_size=8, T=2, feat_size=64, rng=rng, log=lines.append)
+    assert len(lines) == 3 and not torch.equal(model.encoder[0].weight, w0)
+    assert {"epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"} <= set(best) and 1 <= best["epoch"] <= 3
+    assert final[0] == best["epoch"] and len(frame) == 6 and frame.index[0] == "case0"

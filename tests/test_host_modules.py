@@ -51,3 +51,28 @@ def test_abmil_type_error_and_guards():
 def test_shard_range():
     from murcl_amd.dist import shard_range
     assert [shard_range(r, 4, 16) for r in range(4)] == [(0, 16), (16, 32), (32, 48), (48, 64)]
+
+
+def test_get_metrics_and_score_match_the_reference(golden):
+    """utils/general.get_metrics / get_score (8(f) rank 2) against values computed by the reference (g10_eval)."""
+    import numpy as np
+    import torch
+    from oracle import detrand
+    from murcl_amd.train_RLMIL import BestPick, get_metrics, get_score
+    g = golden("g10_eval")
+    for name, n, C in (("bin", 14, 2), ("tri", 18, 3)):
+        out = torch.from_numpy(detrand.normal(72, f"g10.m.{name}", (n, C)).astype(np.float32))
+        tgt = torch.from_numpy(np.arange(n) % C)
+        m = get_metrics(out, tgt)
+        np.testing.assert_allclose(m, g[f"metrics.{name}"], rtol=1e-6)
+        assert get_score(*m) == __import__("pytest").approx(float(g[f"score.{name}"]), rel=1e-6)
+    pick = BestPick("loss")
+    assert pick.update(1, 0.9, 0.5, 0.5, 0.5, 0.5, 0.5) and not pick.update(2, 1.1, 0.9, 0.9, 0.9, 0.9, 0.9) and pick.update(3, 0.7, 0, 0, 0, 0, 0)
+    assert pick.epoch == 3
+    pick = BestPick("score")
+    assert pick.update(1, 0.9, 0.5, 0.5, 0.5, 0.5, 0.5) and pick.update(2, 1.1, 0.9, 0.9, 0.9, 0.9, 0.9) and pick.epoch == 2
+    try:
+        BestPick("f2")
+        assert False
+    except ValueError:
+        pass
