@@ -202,3 +202,109 @@ def fit(arch, model, fc, ppo, optimizer, stores, epochs, batch_size, T=6, feat_s
         log(f"epoch {epoch + 1}: train loss {tr_loss:.4f} acc {tr_acc:.4f} | valid loss {v[0]:.4f} acc {v[1]:.4f} auc {v[2]:.4f} | "
             f"test loss {te[0]:.4f} acc {te[1]:.4f} auc {te[2]:.4f} | final epoch {final[0]}")
     return best, final, frame
+
+
+# ------------------------------------------------------------------------------------------------------ script entry
+class _SyntheticLabelled:
+    """Random labelled slides in the WSIWithCluster item format; class-1 slides carry a shifted feature block."""
+
+    def __init__(self, n, n_patches, dim, num_clusters, seed):
+        import numpy as np
+        self.n, self.N, self.d, self.K, self.seed, self.np = n, n_patches, dim, num_clusters, seed, np
+        self.patch_dim, self.num_clusters = dim, num_clusters
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        np = self.np
+        r = np.random.default_rng(self.seed * 100003 + i)
+        y = i % 2
+        feat = np.abs(r.standard_normal((self.N, self.d), dtype=np.float32)) * 0.5
+        feat[:, : self.d // 8] += 0.5 * y
+        lab = r.integers(0, self.K, self.N)
+        return torch.from_numpy(feat), [np.nonzero(lab == k)[0].tolist() for k in range(self.K)], y, f"case{self.seed}_{i}"
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser("murcl_amd RL-MIL (supervised) on MI355X")
+    p.add_argument("--arch", default="ABMIL", choices=["ABMIL", "CLAM_SB", "DSMIL"])
+    p.add_argument("--data_csv", type=str, default=None)
+    p.add_argument("--data_split_json", type=str, default=None)
+    p.add_argument("--synthetic", type=str, default=None, help="n_train,n_valid,n_test,n_patches (random labelled slides)")
+    p.add_argument("--num_classes", default=2, type=int)
+    p.add_argument("--num_clusters", default=10, type=int)
+    p.add_argument("--feat_size", default=1024, type=int)
+    p.add_argument("--T", default=6, type=int)
+    p.add_argument("--train_method", default="scratch", choices=["scratch", "finetune", "linear"])
+    p.add_argument("--train_stage", default=1, type=int)
+    p.add_argument("--checkpoint_pretrained", default=None, type=str)
+    p.add_argument("--checkpoint_stage", default=None, type=str)
+    p.add_argument("--epochs", default=40, type=int)
+    p.add_argument("--batch_size", default=16, type=int)
+    p.add_argument("--backbone_lr", default=1e-4, type=float)
+    p.add_argument("--fc_lr", default=1e-4, type=float)
+    p.add_argument("--wdecay", default=1e-5, type=float)
+    p.add_argument("--bag_weight", default=0.7, type=float)
+    p.add_argument("--picked_method", default="score", choices=["acc", "loss", "auc", "score"])
+    p.add_argument("--model_dim", default=512, type=int)
+    p.add_argument("--policy_hidden_dim", default=512, type=int)
+    p.add_argument("--action_std", default=0.5, type=float)
+    p.add_argument("--ppo_lr", default=1e-5, type=float)
+    p.add_argument("--ppo_gamma", default=0.1, type=float)
+    p.add_argument("--K_epochs", default=3, type=int)
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    p.add_argument("--seed", default=985, type=int)
+    p.add_argument("--save_dir", default="./results/murcl_amd_rlmil/stage_1", type=str)
+    return p
+
+
+def main(argv=None):
+    import json
+    import os
+    import numpy as np
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.utils import checkpoint as C
+    from murcl_amd.utils.datasets import DeviceSlideStore
+    args = build_parser().parse_args(argv)
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    torch.manual_seed(args.seed)
+    dt_ = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.synthetic:
+        ntr, nva, nte, N = (int(v) for v in args.synthetic.split(","))
+        sets = [_SyntheticLabelled(n, N, 512, args.num_clusters, s) for n, s in ((ntr, 1), (nva, 2), (nte, 3))]
+    else:
+        from murcl_amd.train_MuRCL import WSIWithCluster
+        split = json.load(open(args.data_split_json))
+        sets = [WSIWithCluster(args.data_csv, split[k]) for k in ("train", "valid", "test")]
+        args.num_clusters = sets[0].num_clusters
+    stores = tuple(DeviceSlideStore.from_dataset(s, dev, dtype=dt_) for s in sets)
+    model, fc = create_model(args.arch, stores[0].patch_dim, args.num_classes, dev, model_dim=args.model_dim, dtype=dt_)
+    ppo = None
+    if args.train_stage in (2, 3):
+        ppo = rlmil.PPO(stores[0].patch_dim, args.model_dim, args.policy_hidden_dim, False, action_std=args.action_std, lr=args.ppo_lr,
+                        gamma=args.ppo_gamma, K_epochs=args.K_epochs, action_size=args.num_clusters)
+        stage_ck = args.checkpoint_stage or C.stage_checkpoint_path(args.save_dir, args.train_stage)
+        C.load_stage(model, fc, ppo, stage_ck, policy_ckpt=args.checkpoint_pretrained if args.train_stage == 2 else None)
+        if args.train_stage == 3 and args.train_method == "linear":
+            C.freeze_backbone(model)
+    elif args.train_method in ("finetune", "linear"):
+        print("pre-trained encoder loaded; starting from scratch:", C.load_pretrained(model, args.checkpoint_pretrained, args.train_method))
+    optimizer = None
+    if args.train_stage != 2:
+        groups = [{"params": [p for p in model.parameters() if p.requires_grad], "lr": args.backbone_lr},
+                  {"params": list(fc.parameters()), "lr": args.fc_lr}]
+        optimizer = FlatAdam([g for g in groups if g["params"]], betas=(0.9, 0.999), weight_decay=args.wdecay)
+    best, final, frame = fit(args.arch, model, fc, ppo, optimizer, stores, args.epochs, args.batch_size, args.T, args.feat_size,
+                             args.train_stage, args.bag_weight, args.picked_method, np.random.default_rng(args.seed))
+    os.makedirs(args.save_dir, exist_ok=True)
+    C.save_checkpoint(best, True, args.save_dir)
+    frame.to_csv(os.path.join(args.save_dir, "pred.csv"))
+    print("final (epoch, loss, acc, auc, precision, recall, f1):", tuple(round(float(v), 4) for v in final))
+    return final
+
+
+if __name__ == "__main__":
+    main()

@@ -366,10 +366,74 @@ def g10_eval():
     np.savez(os.path.join(OUT, "g10_eval.npz"), **res)
 
 
+def _exchange_checkpoints(mods):
+    """Real files across the boundary: the product's writer -> the reference's modules (strict), the reference's state
+    dicts -> the product's loader, and the reference's fine-tune key loop (train_RLMIL.py:121-130) vs the product's."""
+    import tempfile
+    from murcl_amd.models import abmil as p_abmil, cl as p_cl, rlmil as p_rlmil
+    from murcl_amd.utils import checkpoint as C
+    torch.manual_seed(4)
+    ours = (p_cl.CL(p_abmil.ABMIL(512, L=512, D=128, dim_out=128), 128, 512), p_rlmil.Full_layer(512, 1024, True, 128),
+            p_rlmil.ActorCritic(512, 512, 512, False, 0.5, 10))
+
+    class _P:
+        policy = ours[2]
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = C.save_checkpoint(C.make_state(3, ours[0], ours[1], ppo=_P), False, tmp)
+        ck = torch.load(path, map_location="cpu")
+        theirs = (mods["CL(ABMIL)"], r_rlmil.Full_layer(512, 1024, True, 128), mods["ActorCritic"])
+        theirs[0].load_state_dict(ck["model_state_dict"])            # strict
+        theirs[1].load_state_dict(ck["fc"])
+        theirs[2].load_state_dict(ck["policy"])
+        res["reference_loaded_product_file_strict"] = bool(
+            torch.equal(theirs[0].encoder.attention[0].weight, ours[0].encoder.attention[0].weight)
+            and torch.equal(theirs[2].gru.weight_hh_l0, ours[2].gru.weight_hh_l0))
+        sd = dict(ck["model_state_dict"])
+        for k in list(sd.keys()):                                    # the reference's loop, verbatim semantics
+            if k.startswith("encoder") and not k.startswith("encoder.fc") and not k.startswith("encoder.classifiers"):
+                sd[k[len("encoder."):]] = sd[k]
+            del sd[k]
+        mine = C.strip_pretrained_encoder(ck["model_state_dict"])
+        res["finetune_strip_identical"] = list(sd) == list(mine) and all(torch.equal(sd[k], mine[k]) for k in sd)
+        torch.manual_seed(5)
+        fresh = (r_cl.CL(r_abmil.ABMIL(512, L=512, D=128, dim_out=128), 128, 512), r_rlmil.Full_layer(512, 1024, True, 128),
+                 r_rlmil.ActorCritic(512, 512, 512, False, 0.5, 10))
+        torch.save({"epoch": 1, "model_state_dict": fresh[0].state_dict(), "fc": fresh[1].state_dict(), "optimizer": None,
+                    "ppo_optimizer": None, "policy": fresh[2].state_dict()}, os.path.join(tmp, "theirs.pth.tar"))
+        m, h = p_cl.CL(p_abmil.ABMIL(512, L=512, D=128, dim_out=128), 128, 512), p_rlmil.Full_layer(512, 1024, True, 128)
+
+        class _Q:
+            policy, policy_old = p_rlmil.ActorCritic(512, 512, 512, False, 0.5, 10), p_rlmil.ActorCritic(512, 512, 512, False, 0.5, 10)
+        C.load_stage(m, h, _Q, os.path.join(tmp, "theirs.pth.tar"))
+        res["product_loaded_reference_file_strict"] = bool(
+            torch.equal(m.encoder.decoder[0].bias, fresh[0].encoder.decoder[0].bias)
+            and torch.equal(_Q.policy_old.critic[0].weight, fresh[2].critic[0].weight))
+    return res
+
+
+def g11_manifest():
+    """8(f) rank 3: names and shapes of every state-dict entry of the reference modules, and its checkpoint dict keys."""
+    import json
+    mods = {
+        "ABMIL": r_abmil.ABMIL(512, L=512, D=128, dim_out=2),
+        "CLAM_SB": r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512),
+        "DSMIL": r_dsmil.build_dsmil(512, 2),
+        "CL(ABMIL)": r_cl.CL(r_abmil.ABMIL(512, L=512, D=128, dim_out=128), projection_dim=128, n_features=512),
+        "Full_layer": r_rlmil.Full_layer(512, 1024, True, 2),
+        "ActorCritic": r_rlmil.ActorCritic(512, 512, 512, False, 0.5, 10),
+    }
+    man = {k: [[n, list(v.shape)] for n, v in m.state_dict().items()] for k, m in mods.items()}
+    man["checkpoint_keys"] = ["epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"]   # train_MuRCL.py:322-329
+    man["exchange"] = _exchange_checkpoints(mods)
+    with open(os.path.join(OUT, "g11_state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

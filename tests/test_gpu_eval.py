@@ -87,3 +87,26 @@ def test_fit_selects_the_best_epoch_and_trains(tmp_path):
     assert len(lines) == 3 and not torch.equal(model.encoder[0].weight, w0)
     assert {"epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"} <= set(best) and 1 <= best["epoch"] <= 3
     assert final[0] == best["epoch"] and len(frame) == 6 and frame.index[0] == "case0"
+
+
+def test_rlmil_script_end_to_end_with_finetune_from_a_pretraining_checkpoint(tmp_path, capsys):
+    """train_RLMIL.main: synthetic labelled splits in HBM, encoder from a MuRCL pre-training checkpoint (prefix strip),
+    epochs with validation-based selection, model_best.pth.tar + pred.csv written."""
+    import pandas as pd
+    from murcl_amd import train_RLMIL
+    from murcl_amd.models import abmil, cl, rlmil
+    from murcl_amd.utils import checkpoint as C
+    torch.manual_seed(2)
+    pre = cl.CL(abmil.ABMIL(512, L=512, D=128, dim_out=128), 128, 512)
+    C.save_checkpoint(C.make_state(1, pre, rlmil.Full_layer(512, 1024, True, 128)), True, str(tmp_path / "pre"))
+    save = tmp_path / "ft" / "stage_1"
+    final = train_RLMIL.main(["--arch", "ABMIL", "--synthetic", "12,4,6,300", "--num_clusters", "4", "--feat_size", "64", "--T", "2",
+                              "--epochs", "2", "--batch_size", "4", "--train_method", "finetune",
+                              "--checkpoint_pretrained", str(tmp_path / "pre" / "model_best.pth.tar"), "--save_dir", str(save)])
+    out = capsys.readouterr().out
+    assert "starting from scratch: ['fc.weight', 'fc.bias']" in out and "epoch 2:" in out
+    df = pd.read_csv(save / "pred.csv", index_col="case_id")
+    assert len(df) == 6 and list(df.columns) == ["label", "pred", "correct", "prob0", "prob1"]
+    ck = torch.load(save / "model_best.pth.tar", map_location="cpu")
+    assert tuple(ck) == C.CHECKPOINT_KEYS and ck["epoch"] == final[0]
+    assert not torch.equal(ck["model_state_dict"]["encoder.0.weight"], pre.encoder.encoder[0].weight)   # trained on from the loaded weights
