@@ -195,6 +195,18 @@ int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stre
 int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, int zero_grad, murcl_stream_t stream);
 
+/* K-means (Lloyd) over the patch features of one slide - the clustering pre-step behind the cluster id lists
+ * (wsi_processing/features_clustering.py:10-16; sklearn KMeans).  One call = one iteration: labels[i] = argmin_k
+ * |x_i - c_k|^2 against `centers` [K,d] (first minimum on ties), then, if `update`, centers <- means of their rows (a
+ * cluster without rows keeps its centre).  X [N,d] f32, d in {256, 512, 1024}, K <= 16.  labels [N] int32 in/out (the
+ * previous labels are compared), counts [K], stats [3+K] = {sum of squared centre shifts, inertia of this assignment,
+ * rows whose label changed, rows per cluster...}, mind2 (may be NULL) [N] squared distance of every row to its centre
+ * (what scikit-learn's empty-cluster relocation ranks by).  Deterministic: no float atomics.
+ * workspace: murcl_kmeans_workspace_bytes(N, d, K). */
+long murcl_kmeans_workspace_bytes(int N, int d, int K);
+int murcl_kmeans_step(const float* X, int N, int d, int K, float* centers, int* labels, int* counts, float* stats,
+                      float* mind2, int update, void* workspace, murcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,8 @@ SIGNATURES = {
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_kmeans_workspace_bytes": [_I, _I, _I],
+    "murcl_kmeans_step": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "murcl_abmil_pool_combine": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
@@ -60,7 +62,7 @@ SIGNATURES = {
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L}
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L}
 
 _lib = None
 

@@ -110,3 +110,31 @@ def test_rlmil_script_end_to_end_with_finetune_from_a_pretraining_checkpoint(tmp
     ck = torch.load(save / "model_best.pth.tar", map_location="cpu")
     assert tuple(ck) == C.CHECKPOINT_KEYS and ck["epoch"] == final[0]
     assert not torch.equal(ck["model_state_dict"]["encoder.0.weight"], pre.encoder.encoder[0].weight)   # trained on from the loaded weights
+
+
+@pytest.mark.parametrize("N,dtype", [(23457, torch.float32), (40000, torch.bfloat16), (37, torch.float32)])
+def test_whole_slide_attention_scores_for_heatmaps(N, dtype):
+    """8(f) rank 4: CLAM_SB.bag_forward(attention_only=True) on every patch of a slide (no sub-sampling, N not a
+    multiple of any tile), the call scripts/create_heatmaps.py:159-162 makes - raw scores [1,N] vs the oracle."""
+    from oracle import mil_oracle as O
+    from murcl_amd.models.clam import CLAM_SB
+    dev = torch.device("cuda:0")
+    m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512)
+    pk = P.clam_sb(91)
+    m.load_state_dict(P.to_torch(pk))
+    m = m.to(dev).eval()
+    m.compute_dtype = dtype
+    x = P.bags(91, f"slide{N}", 1, N, 512)[0]
+    with torch.no_grad():
+        s = m.bag_forward(T(x).to(dev), attention_only=True)
+        s3 = m(T(x).unsqueeze(0).to(dev), attention_only=True)[0]           # the forward() spelling
+    assert s.shape == (1, N) and torch.allclose(s, s3, rtol=1e-5, atol=1e-6)   # (N <= 128 rows take the split-K atomics path)
+    want = O.clam_sb_forward(P.to_torch(pk), T(x).unsqueeze(0))[2]
+    if dtype == torch.float32:
+        np.testing.assert_allclose(s.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+    else:
+        err = (s.cpu() - want).abs().max().item()
+        assert err < 3e-2 * float(want.abs().max()) + 3e-2
+        # what a heat-map needs: the ranking of the hottest patches survives bf16
+        top = set(want[0].topk(50).indices.tolist())
+        assert len(top & set(s[0].cpu().topk(200).indices.tolist())) >= 45

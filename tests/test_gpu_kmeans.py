@@ -1,0 +1,79 @@
+"""the clustering pre-step (wsi_processing/features_clustering.py) on the HIP k-means kernel.
+
+The reference calls scikit-learn's KMeans; its random stream cannot be reproduced, so parity is pinned on the algorithm:
+from the SAME initial centres the device iterations are scikit-learn's Lloyd iterations."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detrand, params as P  # noqa: E402
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _blobs(seed, N, d, K, spread):
+    cent = detrand.normal(seed, "cent", (K, d)) * 2.0
+    lab = (detrand.uniform(seed, "lab", (N,)) * K).astype(np.int64).clip(0, K - 1)
+    return (cent[lab] + spread * detrand.normal(seed, "noise", (N, d))).astype(np.float32), lab
+
+
+@pytest.mark.parametrize("N,d,K,spread", [(5000, 512, 10, 0.5), (1237, 256, 3, 2.0), (3001, 1024, 16, 1.0), (20, 512, 2, 0.1)])
+def test_lloyd_iterations_equal_scikit_learn_from_the_same_centres(N, d, K, spread):
+    from sklearn.cluster import KMeans
+    from murcl_amd.utils.clustering import lloyd
+    X, _ = _blobs(101, N, d, K, spread)
+    init = X[np.linspace(0, N - 1, K).astype(int)].copy()
+    ref = KMeans(n_clusters=K, init=init, n_init=1, algorithm="lloyd", max_iter=300, tol=1e-4).fit(X.astype(np.float64))
+    labels, centers, inertia, it = lloyd(torch.from_numpy(X).to(_dev()), torch.from_numpy(init), max_iter=300, tol=1e-4)
+    lab = labels.cpu().numpy()
+    assert (lab == ref.labels_).mean() >= 0.999                       # float32 vs float64 distances: ties only
+    assert inertia == pytest.approx(ref.inertia_, rel=2e-4)
+    np.testing.assert_allclose(centers.cpu().numpy(), ref.cluster_centers_, rtol=1e-3, atol=1e-3)
+    assert it == ref.n_iter_ and lab.min() >= 0 and lab.max() < K
+
+
+def test_runs_are_bit_reproducible_and_recover_separated_clusters(tmp_path):
+    from murcl_amd.utils.clustering import clustering, kmeans, save_to_json
+    X, truth = _blobs(102, 8192, 512, 10, 0.3)
+    Xd = torch.from_numpy(X).to(_dev())
+    a = kmeans(Xd, 10, seed=985)
+    b = kmeans(Xd, 10, seed=985)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]      # no float atomics anywhere
+    lab = a[0].cpu().numpy()
+    # every true blob maps onto exactly one cluster
+    pairs = {(int(t), int(l)) for t, l in zip(truth, lab)}
+    assert len(pairs) == 10 and len({l for _, l in pairs}) == 10
+    # the reference's two file formats
+    idx = clustering(X, 10, filepath=str(tmp_path / "case.npz"))
+    assert idx.shape == (8192, 1) and np.array_equal(np.load(tmp_path / "case.npz")["features_cluster_indices"], idx)
+    lists = save_to_json(idx, 10, filepath=str(tmp_path / "case.json"))
+    assert json.load(open(tmp_path / "case.json")) == lists and len(lists) == 10
+    assert sorted(i for l in lists for i in l) == list(range(8192)) and all(l == sorted(l) for l in lists)
+    # ... which is what the sub-bag sampler consumes
+    from murcl_amd.utils.datasets import BagPack, select_indices
+    pack = BagPack.from_lists([Xd], [lists])
+    ids, cnt = select_indices(pack, torch.full((1, 10), 0.5, device=_dev()), 1024)
+    assert 1000 <= cnt.item() <= 1024 and (ids[0, :cnt.item()].diff() > 0).all()
+
+
+def test_kmeans_guards():
+    from murcl_amd import _lib
+    from murcl_amd.utils.clustering import lloyd
+    L = _lib.lib()
+    assert L.murcl_kmeans_step(None, 100, 500, 4, None, None, None, None, None, 1, None, None) == -1     # d not 256/512/1024
+    assert L.murcl_kmeans_step(None, 100, 512, 17, None, None, None, None, None, 1, None, None) == -1    # K > 16
+    with pytest.raises(RuntimeError):
+        lloyd(torch.zeros(8, 512), torch.zeros(2, 512))
+    # a centre nobody is closest to is relocated onto a far row (scikit-learn's rule), never left as NaN
+    X = torch.zeros((64, 256), device=_dev())
+    X[7] = 3.0
+    far = torch.full((1, 256), 50.0, device=_dev())
+    labels, centers, inertia, _ = lloyd(X, torch.cat([X[:1], far]), max_iter=5)
+    assert torch.isfinite(centers).all() and inertia == 0.0
+    assert labels[7].item() != labels[0].item() and (labels == labels[0]).sum().item() == 63

@@ -136,3 +136,22 @@ if "store" in only or not only:
     print(json.dumps({"row": "f1 device-resident split (8(f) rank 1)", "what": f"form one batch of {B} slides x {N} x 512",
                       "per_step_upload_ms": round(ms_ref, 2), "resident_store_pack_ms": round(ms_store, 4),
                       "store_GiB": round(store.bytes() / 2 ** 30, 2), "one_time_upload_s": round(build_s, 2)}), flush=True)
+# ---- f4: the clustering pre-step (features_clustering.py): one slide of 20 000 patches x 512, 10 clusters
+if "kmeans" in only or not only:
+    from murcl_amd.utils.clustering import kmeans, lloyd
+    N, d, K = 20000, 512, 10
+    rng = np.random.default_rng(985)
+    cent = rng.standard_normal((K, d)).astype(np.float32)
+    X = (cent[rng.integers(0, K, N)] * 0.6 + np.abs(rng.standard_normal((N, d), dtype=np.float32)) * 0.5)
+    Xd = torch.from_numpy(X).to(dev)
+    init = Xd[torch.linspace(0, N - 1, K).long()].clone()
+    lloyd(Xd, init, max_iter=3); kmeans(Xd, K, seed=1, n_init=1); torch.cuda.synchronize()      # warm: first-use module loads
+    t0 = time.perf_counter(); _, _, inertia, it = lloyd(Xd, init, max_iter=300); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); _, _, best = kmeans(Xd, K, seed=985, n_init=3); torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+    from sklearn.cluster import KMeans
+    t0 = time.perf_counter(); ref = KMeans(n_clusters=K, random_state=985).fit(X); dts = time.perf_counter() - t0
+    print(json.dumps({"row": "f4 k-means pre-step (8(f) rank 4)", "what": f"one slide {N} x {d}, K={K}",
+                      "lloyd_ms_per_iteration": round(dt / (it + 1) * 1e3, 4), "iterations": it,
+                      "GBps_of_X": round(N * d * 4 / (dt / (it + 1)) / 1e9, 1),
+                      "kmeans++_3_starts_ms": round(dt3 * 1e3, 1), "inertia": round(best, 1),
+                      "sklearn_host_ms": round(dts * 1e3, 1), "sklearn_inertia": round(float(ref.inertia_), 1)}), flush=True)
