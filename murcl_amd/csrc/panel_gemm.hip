@@ -47,8 +47,11 @@ enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3 };
 
 #define PG_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+#ifndef PG_STORE_POLICY
+#define PG_STORE_POLICY ""        // cache-policy suffix of the output stores: "" | " nt" | " sc0 sc1" (A/B: tools/ab_build.sh)
+#endif
 __device__ __forceinline__ void pg_store16(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" PG_STORE_POLICY "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void pg_store2(void* p, unsigned v) {
     asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
