@@ -39,6 +39,9 @@
 #ifndef PG_FLIP
 #define PG_FLIP 0
 #endif
+#ifndef PG_FUSE
+#define PG_FUSE 1         // bit 0: forward epilogues (bias / bias+ReLU), bit 1: the masked dgrad - every wave runs the epilogue of
+#endif                    // tile t-1 INSIDE the MFMA loop of tile t (see the tile loop).  Forward 147 -> 142 us; dgrad neutral, so off there
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             am[1] = rs[16 + r16];
         }
     };
-    auto mfma_phase = [&](int seq, f32x4 (&acc)[2][NJ]) {
+    auto mfma_phase = [&](int seq, f32x4 (&acc)[2][NJ], auto&& hook) {
         const char* tile = smem + (seq % PG_NSLOT) * SLOT;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][g * GK + k2], hq[g % NBUF][k2][i], acc[i][j], 0, 0, 0);
+                hook(g);                         // same scheduling region as the MFMAs above: VALU / LDS work rides under them
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -263,12 +267,14 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             }
         }
     };
-    auto epilogue = [&](int seq, f32x4 (&acc)[2][NJ], unsigned (&mw)[NJ / 2], float (&am)[2]) {
+    // part: -1 = everything; 0 / 1 = accumulator math + staging writes of row half i = part (1 also stores the mask
+    // words); 2 + g = row-wise store g.  The fused schedule runs the parts of tile t-1 between the k-groups of tile t.
+    auto epilogue = [&](int seq, f32x4 (&acc)[2][NJ], unsigned (&mw)[NJ / 2], float (&am)[2], int part = -1) {
         const int row0 = row0_of(seq);
         unsigned ones = 0x00010001u;
         asm volatile("" : "+v"(ones));
         // ---- accumulator-layout math: lane holds row 16i+r16, columns 16j+4q4+r
-        if (EPI == PG_RANK1_MASK) {
+        if (EPI == PG_RANK1_MASK && (part <= 0 || part == 10)) {
             const int bag = row0 / rows_per_bag;
             if (bag != cur_bag) {                                  // rare: compiler-visible loads, drains once per bag
                 cur_bag = bag;
@@ -280,10 +286,12 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (part >= 0 && part != i && (part < 10 || (part - 10) / NJ != i)) continue;
             const int row = 16 * i + r16;
             const float a_m = am[i];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                if (part >= 10 && (part - 10) % NJ != j) continue;       // 10 + NJ*i + j: one 16x16 block of the tile
                 f32x4 v = acc[i][j];
                 if (EPI == PG_BIAS_RELU) {
 #pragma unroll
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                 *(u32x2*)(stg + row * STG_LD + (16 * j + 4 * q4) * 2) = u32x2{w0, w1};
             }
         }
-        if (BM_OUT) {
+        if (BM_OUT && (part < 0 || part == 1 || part == 10 + 2 * NJ - 1)) {
             uint8_t* blk = bm_out + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128;
 #pragma unroll
             for (int bq = 0; bq < NJ / 2; ++bq) pg_store2(blk + bq * 128 + lane * 2, mw[bq] | (mw[bq] >> 8));
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         // ---- row-wise phase: lane owns 8 consecutive columns (one 16-byte chunk) of RPI rows per pass
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
+            if (part >= 0 && part != 2 + g) continue;
             const int row = RPI * g + crow;
             const u32x4 u = *(const u32x4*)(stg + row * STG_LD + cchunk * 16);
             pg_store16(C + (size_t)(row0 + row) * N + n0 + cchunk * 8, u);
@@ -337,8 +346,12 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // the workgroup therefore runs "epilogue of the previous tile, then MFMAs of this tile" between two barriers while
     // the lower half runs "MFMAs, then epilogue" of this tile: at any time one wave of a SIMD feeds the matrix cores
     // and its partner rounds, transposes and stores.
-    constexpr bool ROT = PG_ROTATE != 0;
-    const bool late = ROT && wave >= PG_NW / 2;
+    // Fused schedule (PG_FUSE, K = 512): every wave keeps the accumulators of tile t-1 and runs its epilogue in pieces
+    // between the k-groups of tile t, so VALU / LDS-staging / store work issues in the shadow of the MFMAs instead
+    // of after them with the matrix pipe idle.  Store counts lag by one tile, exactly like the rotated half.
+    constexpr bool FUSE = PAD && (((PG_FUSE & 1) && BIASED) || ((PG_FUSE & 2) && EPI == PG_MASK));   // (the K = 512 rank-1 variant would spill)
+    constexpr bool ROT = PG_ROTATE != 0 && !FUSE;
+    const bool late = FUSE || (ROT && wave >= PG_NW / 2);
     f32x4 acc[2][NJ];
     unsigned mw[NJ / 2];
     float am[2];
@@ -353,14 +366,47 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         }
         LDS_BARRIER();
         if (seq + 3 < my_tiles) issue(seq + 3);
-        if (!late) {
+        if (FUSE) {
+            // acc/mw/am still hold tile seq-1; the new tile accumulates into accn and is handed over at the end
+            f32x4 accn[2][NJ];
+            unsigned mwn[NJ / 2];
+            float amn[2];
+            load_side(seq, mwn, amn);
+            const bool prev = seq > 0;
+            mfma_phase(seq, accn, [&](int g) {
+                if (!prev) return;
+                // 8 k-groups per tile: math of row half 0, its store, math of row half 1 (+ mask words), its store(s)
+                if (NJ == 2) {       // one 16x16 block per k-group, the row-wise stores as soon as their rows are staged
+                    if (g == 0) epilogue(seq - 1, acc, mw, am, 10);
+                    if (g == 1) epilogue(seq - 1, acc, mw, am, 11);
+                    if (g == 2) epilogue(seq - 1, acc, mw, am, 2);
+                    if (g == 3) epilogue(seq - 1, acc, mw, am, 12);
+                    if (g == 4) epilogue(seq - 1, acc, mw, am, 13);
+                    if (g == 5) epilogue(seq - 1, acc, mw, am, 3);
+                } else {
+                    if (g == 0) epilogue(seq - 1, acc, mw, am, 0);
+                    if (g == 2) epilogue(seq - 1, acc, mw, am, 2);
+                    if (g == 3) epilogue(seq - 1, acc, mw, am, 1);
+                    if (g == 5) epilogue(seq - 1, acc, mw, am, 3);
+                    if (NS > 2 && g == 6) { epilogue(seq - 1, acc, mw, am, 4); epilogue(seq - 1, acc, mw, am, 5); }
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = accn[i][j];
+#pragma unroll
+            for (int bq = 0; bq < NJ / 2; ++bq) mw[bq] = mwn[bq];
+            am[0] = amn[0];
+            am[1] = amn[1];
+        } else if (!late) {
             load_side(seq, mw, am);          // requested ahead of the MFMA loop
-            mfma_phase(seq, acc);
+            mfma_phase(seq, acc, [](int) {});
             epilogue(seq, acc, mw, am);
         } else {
             if (seq > 0) epilogue(seq - 1, acc, mw, am);
             load_side(seq, mw, am);
-            mfma_phase(seq, acc);
+            mfma_phase(seq, acc, [](int) {});
         }
     }
     if (late) epilogue(my_tiles - 1, acc, mw, am);
