@@ -43,9 +43,10 @@ int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, in
 
 /* C[N1,N2] (f32, pre-zeroed or accumulated into) += A[M,N1]^T . B[M,N2]: weight gradients, i.e. what
  * autograd's mm_backward computes for every Linear above; reduction over the patch dimension M is
- * split over `splits` workgroup groups (<=0: auto). */
+ * split over `splits` workgroup groups (<=0: auto).  colsum_out (may be NULL) [N1] += column sums of A: the bias
+ * gradient of the same layer, from the same pass over A (one more MFMA per fragment against a fragment of ones). */
 int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
-                  int dtype, int splits, murcl_stream_t stream);
+                  int dtype, int splits, float* colsum_out, murcl_stream_t stream);
 
 /* Weight-stationary bf16 variant of murcl_gemm_nt for the patch-level layers (M = bags*patches rows, K in
  * {512,128}): same Linear forward / input-gradient as above (abmil.py:12-21,23-24 and their autograd), with

@@ -19,7 +19,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
 
 SIGNATURES = {
     "murcl_gemm_nt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
-    "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],

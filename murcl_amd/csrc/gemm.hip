@@ -406,7 +406,8 @@ __device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int la
 template <typename T, int NSLOT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                          float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
-                                                         int ldc, int m_per_split, int nsplit) {
+                                                         int ldc, int m_per_split, int nsplit,
+                                                         float* __restrict__ colsum_out) {
     typedef typename Frag<T>::type frag_t;
     typedef TnTraits<T> TT;
     // NSLOT = 2: double buffer per workgroup; TWO workgroups per CU desynchronise and cover each other's barrier /
@@ -466,6 +467,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int wr = wave >> 1, wc = wave & 1;
+    // bias gradient for free: the column sums of A are A^T . 1 - the workgroups of the first N2 tile run one more MFMA
+    // per A fragment against a fragment of ones (every column of that accumulator block holds the sums)
+    const bool do_cs = colsum_out != nullptr && t2 == 0 && wc == 0;
+    f32x4 accs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    frag_t ones;
+    if constexpr (sizeof(T) == 2) {
+        ones = bf16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    } else {
+        ones = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
 
     // bf16: the transposed-read offsets inside a slab are lane constants (the swizzle depends only on
     // row&3 and (row>>3)&1, both fixed per lane); k-group kk adds 32 rows = 8 KiB.
@@ -510,6 +523,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mma16<T>(af[i], bfr[j], acc[i][j]);
+            if (do_cs) {                       // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accs[i] = mma16<T>(af[i], ones, accs[i]);
+            }
         }
     };
 
@@ -546,6 +563,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
                 if (n1 < N1 && n2 < N2) atomicAdd(C + (size_t)n1 * ldc + n2, acc[i][j][r]);
             }
         }
+    if (do_cs && r16 == 0) {                   // one adder per column and M-split (<= 64 per address)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n10 + wr * 64 + i * 16 + 4 * q4 + r;
+                if (n1 < N1) atomicAdd(colsum_out + n1, accs[i][r]);
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------- TN, wide bf16 variant
@@ -721,8 +747,10 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     }
 }
 
+extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s);
+
 extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
-                             int dtype, int splits, hipStream_t stream) {
+                             int dtype, int splits, float* colsum_out, hipStream_t stream) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
     const int es = dtype == MURCL_DTYPE_BF16 ? 2 : 4, epc = 16 / es;
     if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
@@ -737,6 +765,10 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         int mps = (M + sp - 1) / sp;
         mps = ((mps + 63) / 64) * 64;
         if ((long)mps * (sp - 1) >= M) sp = (M + mps - 1) / mps;
+        if (colsum_out) {                        // the wide kernel has no spare MFMA slots for the ones-trick: separate pass
+            const int rc = murcl_colsum(A, colsum_out, M, N1, lda, dtype, 1, stream);
+            if (rc) return rc;
+        }
         auto k = gemm_tn_wide_kernel;
         constexpr int LDS = 3 * 49152;
         static bool once = false;
@@ -767,7 +799,7 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         static bool once = false;                                                                                   \
         if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768); once = true; } \
         hipLaunchKernelGGL(k, grid, dim3(256), NS * 32768, stream, (const T*)A, (const T*)B, C, M, N1, N2, lda, ldb, ldc, mps, \
-                           splits);                                                                                 \
+                           splits, colsum_out);                                                                     \
     }
     if (dtype == MURCL_DTYPE_BF16) {
         if (deep) TN_LAUNCH(bf16_t, 4) else TN_LAUNCH(bf16_t, 2)

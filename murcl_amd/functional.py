@@ -54,6 +54,14 @@ def _wgrad(dy, x, w):
     return ops.gemm_tn(dy, x)
 
 
+def _wbgrad(dy, x, w, b):
+    """(dW, db) of one Linear; in direct mode both are added to the flat gradient buffer by ONE launch."""
+    if _direct(w) and _direct(b):
+        ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1))
+        return None, None
+    return _wgrad(dy, x, w), _bgrad(dy, b)
+
+
 def _bgrad(dy, b):
     """db = column sums of dy."""
     if _direct(b):
@@ -91,10 +99,13 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dy2, ops.transposed(w)).view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = _wgrad(dy2, x2, w)
-        if ctx.needs_input_grad[2]:
-            db = _bgrad(dy2, b)
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dw, db = _wbgrad(dy2, x2, w, b)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(dy2, x2, w)
+            if ctx.needs_input_grad[2]:
+                db = _bgrad(dy2, b)
         return dx, dw, db, None
 
 
@@ -159,8 +170,7 @@ class ABMILFn(torch.autograd.Function):
             return (None,) * 13
         # decoder (bag level, f32)
         dpre = ops.relu_bwd(dout.contiguous(), out)
-        dwd = _wgrad(dpre, M, wd)
-        dbd = _bgrad(dpre, bd)
+        dwd, dbd = _wbgrad(dpre, M, wd, bd)
         dM = ops.gemm_nt(dpre, ops.transposed(wd))
         # attention pooling
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
@@ -226,13 +236,12 @@ class GRUStepFn(torch.autograd.Function):
         x, h_prev, w_ih, w_hh, gates, gh, b_ih, b_hh = ctx.saved_tensors
         dgi, dgh, dhp = ops.gru_gates_bwd(dh.contiguous(), gates, gh, h_prev)
         dx = ops.gemm_nt(dgi, ops.transposed(w_ih)) if ctx.needs_input_grad[0] else None
-        dw_ih = _wgrad(dgi, x, w_ih)
-        db_ih = _bgrad(dgi, b_ih)
-        db_hh = _bgrad(dgh, b_hh)
+        dw_ih, db_ih = _wbgrad(dgi, x, w_ih, b_ih)
         if h_prev is None:
+            db_hh = _bgrad(dgh, b_hh)
             dh_prev, dw_hh = None, (None if _direct(w_hh) else torch.zeros_like(w_hh))
         else:
-            dw_hh = _wgrad(dgh, h_prev, w_hh)
+            dw_hh, db_hh = _wbgrad(dgh, h_prev, w_hh, b_hh)
             dh_prev = None
             if ctx.needs_input_grad[1]:
                 dh_prev = ops.gemm_nt(dgh, ops.transposed(w_hh), out=dhp, accumulate=True)

@@ -159,8 +159,9 @@ def relu_bitmask(x):
     return bits
 
 
-def gemm_tn(A, B, *, splits=0, out=None):
-    """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given)."""
+def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None):
+    """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given).  ``colsum_into`` [N1] f32: the column sums
+    of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient)."""
     _need_cuda(A, B)
     A, B = _c(A), _c(B)
     M, N1 = A.shape
@@ -171,13 +172,17 @@ def gemm_tn(A, B, *, splits=0, out=None):
         Ap = A.new_zeros((M, ((N1 + epc - 1) // epc) * epc))
         Ap[:, :N1] = A
         res = gemm_tn(Ap, B, splits=splits)[:N1]
+        if colsum_into is not None:
+            colsum(A, out=colsum_into, accumulate=True)
         return out.add_(res) if out is not None else res.contiguous()
+    if colsum_into is not None:
+        assert colsum_into.dtype == torch.float32 and colsum_into.is_contiguous() and colsum_into.numel() == N1
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
     with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
-        check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, stream()),
-              "gemm_tn")
+        check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
+                                       stream()), "gemm_tn")
     return C
 
 

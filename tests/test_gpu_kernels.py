@@ -105,6 +105,28 @@ def test_gemm_tn(dtype, M, N1, N2):
     _close(C, ref, rtol=1e-4, atol=1e-4 * s if dtype == torch.float32 else 2e-2 * s, msg="tn")
 
 
+@pytest.mark.parametrize("dtype,M,N1,N2", [(torch.float32, 128, 3072, 512), (torch.float32, 128, 512, 512), (torch.float32, 77, 132, 260),
+                                           (torch.float32, 320, 10, 512), (torch.bfloat16, 4096, 128, 512), (torch.bfloat16, 8192, 512, 512),
+                                           (torch.bfloat16, 1000, 136, 72)])
+def test_gemm_tn_adds_the_bias_gradient_in_the_same_launch(dtype, M, N1, N2):
+    """colsum_into: the column sums of A (the bias gradient of the layer) from the pass that forms the weight gradient -
+    small and ragged shapes, several M splits, the wide-kernel dispatch (separate pass there) and the padded-N1 path."""
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(6, f"A{M}{N1}", (M, N1)).to(dtype)
+    B = _rand(6, f"B{M}{N2}", (M, N2)).to(dtype)
+    pre = _rand(6, f"p{N1}", (N1,))
+    cs = pre.clone().to(dev)
+    W0 = _rand(6, f"w{N1}{N2}", (N1, N2))
+    out = W0.clone().to(dev)
+    r = ops.gemm_tn(A.to(dev), B.to(dev), out=out, colsum_into=cs)
+    assert r.data_ptr() == out.data_ptr()
+    s = math.sqrt(M)
+    f32 = dtype == torch.float32
+    _close(out, W0.double() + A.double().t() @ B.double(), rtol=1e-4, atol=1e-4 * s if f32 else 2e-2 * s, msg="dW")
+    _close(cs, pre.double() + A.double().sum(0), rtol=1e-4, atol=1e-4 * s if f32 else 1e-3 * s, msg="db")     # ADDED, not overwritten
+
+
 # ------------------------------------------------------------------ K2 attention pool
 def _k2_inputs(seed, B, N):
     H = torch.relu(_rand(seed, "H", (B, N, 512)))
