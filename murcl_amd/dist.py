@@ -17,22 +17,26 @@ def shard_range(rank, world, b_local):
     return rank * b_local, (rank + 1) * b_local
 
 
-def _stacked(z_i, z_j):
-    """[z_i; z_j] - without a copy when the two are the halves of one tensor (Full_layer.forward_views)."""
+def _whole(z_i, z_j):
+    """The tensor whose two halves z_i and z_j are (Full_layer.forward_views hands out ``z.split(B)``), or None."""
     base = getattr(z_i, "_base", None)
     if (base is not None and base is getattr(z_j, "_base", None) and base.dim() == 2 and base.is_contiguous()
             and z_i.shape == z_j.shape and base.shape[0] == 2 * z_i.shape[0] and z_i.data_ptr() == base.data_ptr()
-            and z_j.data_ptr() == base.data_ptr() + z_i.numel() * z_i.element_size()):
-        return base.detach()
-    return torch.cat([z_i, z_j], 0)
+            and z_j.data_ptr() == base.data_ptr() + z_i.numel() * z_i.element_size()
+            and base.requires_grad == z_i.requires_grad and (base.grad_fn is not None or not base.requires_grad)):
+        return base
+    return None
 
 
 class _GatheredNTXent(torch.autograd.Function):
+    """z_j None: z_i already is the stacked [2*bl, P] batch (view 0 rows, then view 1 rows) - nothing is concatenated on
+    the way in and ONE gradient tensor goes back."""
+
     @staticmethod
     def forward(ctx, z_i, z_j, temperature, group, kernel):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        bl = z_i.shape[0]
-        local = _stacked(z_i, z_j).contiguous()                        # [2*bl, P]: view 0 rows, view 1 rows
+        local = (z_i if z_j is None else torch.cat([z_i, z_j], 0)).contiguous()
+        bl = local.shape[0] // 2
         # one collective into one buffer, used as it arrives: [rank][view][bag] (the kernel's pair_stride layout)
         zg = torch.empty((world * 2 * bl, local.shape[1]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(zg, local, group=group)
@@ -40,7 +44,7 @@ class _GatheredNTXent(torch.autograd.Function):
         loss, dz, sim = kernel(zg, temperature, grad_lo=lo, grad_hi=hi, pair_stride=bl)
         r0 = rank * 2 * bl
         ctx.save_for_backward(dz[r0:r0 + 2 * bl])
-        ctx.bl = bl
+        ctx.bl, ctx.joint = bl, z_j is None
         ctx.mark_non_differentiable(sim)
         ctx.set_materialize_grads(False)
         return loss.reshape(()), sim[lo:hi]
@@ -53,6 +57,8 @@ class _GatheredNTXent(torch.autograd.Function):
         from . import ops
         if not ops.is_unit_grad(dloss):
             dz = dz * dloss
+        if ctx.joint:
+            return dz, None, None, None, None
         return dz[:ctx.bl], dz[ctx.bl:], None, None, None
 
 
@@ -61,6 +67,9 @@ def gathered_nt_xent(z_i, z_j, temperature, group=None, kernel=None):
     if kernel is None:
         from . import ops
         kernel = lambda z, t, grad_lo, grad_hi, pair_stride: ops.ntxent(z, t, True, grad_lo, grad_hi, pair_stride)  # noqa: E731
+    whole = _whole(z_i, z_j)
+    if whole is not None:
+        return _GatheredNTXent.apply(whole, None, float(temperature), group, kernel)
     return _GatheredNTXent.apply(z_i, z_j, float(temperature), group, kernel)
 
 

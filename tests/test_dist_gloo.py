@@ -49,6 +49,16 @@ def _worker(rank, world, port, out):
     loss, sim = mdist.gathered_nt_xent(x_i @ W.t(), x_j @ W.t(), 0.5, kernel=_oracle_kernel)
     loss.backward()
     flat = W.grad.reshape(-1).clone()
+    # the same step with both views coming out of ONE projection (Full_layer.forward_views): the halves are recognised,
+    # nothing is concatenated and one gradient tensor flows back - identical numbers
+    W.grad = None
+    z = torch.cat([x_i, x_j]) @ W.t()
+    zi, zj = z.split(bl, 0)
+    assert mdist._whole(zi, zj) is z and mdist._whole(zj, zi) is None
+    loss2, sim2 = mdist.gathered_nt_xent(zi, zj, 0.5, kernel=_oracle_kernel)
+    loss2.backward()
+    assert abs(loss2.item() - loss.item()) < 1e-6 and torch.allclose(W.grad.reshape(-1), flat, rtol=1e-5, atol=1e-8)   # (the oracle kernel is f32)
+    assert torch.allclose(sim2, sim, rtol=1e-6)
     mdist.all_reduce_grads([flat])
     out[rank] = (loss.item(), flat.detach().numpy().copy(), sim.detach().numpy().copy())
     dist.destroy_process_group()
