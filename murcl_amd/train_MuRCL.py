@@ -88,6 +88,9 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     B, K, dev = pack.B, pack.K, pack.feats.device
     dt_ = model.encoder.compute_dtype
     train_enc = args.train_stage != 2
+    if (args.train_stage == 1 or injected is not None) and args.T > 1 and train_enc and world == 1 \
+            and not getattr(args, "no_batched_stage1", False):
+        return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected)
     losses, rewards, sim_last, states = [], [], None, None
     for t in range(args.T):
         if injected is not None:
@@ -125,6 +128,41 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
             ppo.update(m)                                                                    # :297-298
     for m in memory_list:
         m.clear_memory()
+    return loss.detach(), [l.detach() for l in losses], rewards
+
+
+def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected=None):
+    """Stage 1 draws every patch step's window positions at random (train_MuRCL.py:235,256-258): no step depends on the
+    aggregator states of the step before, so the sub-bags of all T steps are built into ONE buffer and the aggregator
+    runs ONCE over 2*T*B bags - each weight-stationary / wgrad kernel is launched once at full size instead of T times
+    at a fraction of it (a launch costs ~15 us before its first tile).  Only the recurrent head and the T NT-Xent
+    launches stay sequential.  The random draws are made in the reference's order (per step: two action tensors, then
+    lambda and the permutation of each view), so the sampled sub-bags are the ones the step-by-step loop would build."""
+    B, K, dev, T_ = pack.B, pack.K, pack.feats.device, args.T
+    acts, draws = [], []
+    for t in range(T_):
+        if injected is not None:
+            acts += [a.to(dev) for a in injected["actions"][t]]
+            draws += list(injected["draws"][t])
+        else:
+            acts += [torch.rand((B, K), device=dev) for _ in range(2)]                       # :235,256-258
+            for _ in range(2):                                                               # mixup's draws (datasets.py:265-267)
+                lam = args.alpha + torch.rand(size=(B, 1), device=dev) * (1 - args.alpha)
+                draws.append((lam, torch.randperm(B, device=dev)))
+    views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
+    outputs, _ = model(views)                                                                # 2*T*B bags, one batch
+    losses, rewards, sim_last = [], [], None
+    for t in range(T_):
+        z = fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))                      # :243,272
+        losses.append(criterion(z[0], z[1]))                                                 # :249,277
+        sim = criterion.last_similarity
+        if t > 0:
+            rewards.append((sim_last - sim).view(1, -1))                                     # :282-283
+        sim_last = sim
+    loss = sum(losses) / T_                                                                  # :291
+    optimizer.zero_grad()
+    loss.backward(ops.unit_grad(loss))
+    optimizer.step()                                                                         # :293-295
     return loss.detach(), [l.detach() for l in losses], rewards
 
 
@@ -238,6 +276,8 @@ def build_parser():
     p.add_argument("--synthetic", type=str, default=None, help="n_slides,n_patches (random bags instead of --data_csv)")
     p.add_argument("--feat_size", default=1024, type=int)
     p.add_argument("--T", default=6, type=int)
+    p.add_argument("--no_batched_stage1", action="store_true",
+                   help="stage 1: run the aggregator once per patch step like the reference instead of once per optimizer step")
     p.add_argument("--no_resident", action="store_true",
                    help="re-read and upload every slide on every step like the reference, instead of keeping the split in HBM")
     p.add_argument("--train_stage", default=1, type=int)

@@ -37,24 +37,46 @@ def _confidence(logits, labels):
     return torch.softmax(logits.detach(), 1).gather(1, labels.view(-1, 1)).view(1, -1)
 
 
-def _forward_loss(arch, model, fc, feats, labels, t, bag_weight):
-    """Aggregator + recurrent head + the arch's loss for one patch step -> (loss, logits, states)."""
+def _aggregate(arch, model, feats, labels):
+    """Aggregator over a batch of sub-bags -> (head input [B',F], states [B',S], extra): ``extra`` is what the arch's loss
+    needs besides the head logits - CLAM: instance loss per bag [B']; DSMIL: max-instance class scores [B',C]."""
     if arch == "ABMIL":
         out, states = model(feats)
-        logits = fc(out, restart=(t == 0))
-        loss = CrossEntropyFn.apply(logits, labels)                                    # :727
-    elif arch == "CLAM_SB":
+        return out, states, None
+    if arch == "CLAM_SB":
         out, states, res = model(feats, label=labels, instance_eval=True)
-        logits = fc(out, restart=(t == 0))
-        inst = torch.stack([r["instance_loss"] for r in res]).mean()
-        loss = bag_weight * CrossEntropyFn.apply(logits, labels) + (1 - bag_weight) * inst   # :336
-    else:
-        classes, bag, bag_det = model(feats)
-        states = bag_det.mean(1)                                                       # :515
-        cls = torch.stack(classes) if isinstance(classes, list) else classes.unsqueeze(0)
-        logits = fc(bag.mean(1), restart=(t == 0))                                     # :517-518
-        loss = 0.5 * CrossEntropyFn.apply(logits, labels) + 0.5 * CrossEntropyFn.apply(cls.max(1)[0], labels)   # :527-529
+        return out, states, torch.stack([r["instance_loss"] for r in res])
+    classes, bag, bag_det = model(feats)
+    cls = torch.stack(classes) if isinstance(classes, list) else (classes if classes.dim() == 3 else classes.unsqueeze(0))
+    return bag.mean(1), bag_det.mean(1), cls.max(1)[0]                                   # :515-518,527
+
+
+def _head_loss(arch, fc, head_in, extra, labels, t, bag_weight):
+    logits = fc(head_in, restart=(t == 0))
+    ce = CrossEntropyFn.apply(logits, labels)
+    if arch == "ABMIL":
+        return ce, logits                                                                  # :727
+    if arch == "CLAM_SB":
+        return bag_weight * ce + (1 - bag_weight) * extra.mean(), logits                   # :336
+    return 0.5 * ce + 0.5 * CrossEntropyFn.apply(extra, labels), logits                    # :527-529
+
+
+def _forward_loss(arch, model, fc, feats, labels, t, bag_weight):
+    """Aggregator + recurrent head + the arch's loss for one patch step -> (loss, logits, states)."""
+    head_in, states, extra = _aggregate(arch, model, feats, labels)
+    loss, logits = _head_loss(arch, fc, head_in, extra, labels, t, bag_weight)
     return loss, logits, states
+
+
+def _adjacent(views):
+    v0, n = views[0], views[0].numel()
+    return all(v.is_contiguous() and v.untyped_storage().data_ptr() == v0.untyped_storage().data_ptr()
+               and v.storage_offset() == v0.storage_offset() + i * n for i, v in enumerate(views))
+
+
+def _as_one(views):
+    v0 = views[0]
+    return torch.as_strided(v0, (len(views) * v0.shape[0],) + tuple(v0.shape[1:]), v0.stride(), v0.storage_offset())
 
 
 def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
@@ -66,13 +88,31 @@ def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
 
 
 def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, feat_size=1024, train_stage=1,
-                    bag_weight=0.7, actions=None, return_logits=False):
+                    bag_weight=0.7, actions=None, return_logits=False, batch_patch_steps=True):
     """One step on a BagPack with int64 labels [B].  Returns (loss, losses[T], rewards[T-1]) (+ the last patch step's
     logits with ``return_logits``)."""
     B, K, dev = pack.B, pack.K, pack.feats.device
     train_enc = train_stage != 2
     losses, rewards, conf_last, states = [], [], None, None
+    # stage 1 (and injected actions): no patch step depends on the states of the one before, so the sub-bags of all T
+    # steps go through the aggregator as ONE batch of T*B bags (cf. train_MuRCL._pretrain_step_all_patch_steps_at_once);
+    # the recurrent head and the losses stay per step
+    at_once = None
+    if (train_stage == 1 or actions is not None) and train_enc and T > 1 and batch_patch_steps:
+        acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
+        views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)
+        at_once = _aggregate(arch, model, torch.cat(views, 0) if not _adjacent(views) else _as_one(views), labels.repeat(T))
     for t in range(T):
+        if at_once is not None:
+            sl = slice(t * B, (t + 1) * B)
+            loss, logits = _head_loss(arch, fc, at_once[0][sl], None if at_once[2] is None else at_once[2][sl], labels, t, bag_weight)
+            losses.append(loss)
+            conf = _confidence(logits, labels)
+            if t > 0:
+                rewards.append(conf - conf_last)
+                memory.rewards.append(rewards[-1])
+            conf_last = conf
+            continue
         act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions)
         (feats,), _ = subbag_views(pack, [act], feat_size, out_dtype=model.compute_dtype)
         with torch.set_grad_enabled(train_enc):

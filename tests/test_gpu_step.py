@@ -155,3 +155,67 @@ def test_train_script_runs_from_the_resident_store_and_from_per_step_uploads(tmp
     assert {"epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"} <= set(ck)
     assert "encoder.encoder.0.weight" in ck["model_state_dict"] and "rnn.weight_ih_l0" in ck["fc"]
     assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values())
+
+
+def test_stage1_all_patch_steps_at_once_equals_the_step_by_step_loop():
+    """Stage 1 runs the aggregator once over the sub-bags of all T patch steps; with the same random seed it draws the same
+    windows / mix-up partners as the reference-order loop and lands on the same losses, rewards and updated weights."""
+    from murcl_amd.train_MuRCL import create_model, get_optimizer, pretrain_step
+    from murcl_amd.utils.datasets import BagPack
+    from murcl_amd.utils.losses import NT_Xent
+    from murcl_amd.models import rlmil
+    dev = torch.device("cuda:0")
+    B, N, K, fs, Tn = 4, 600, 10, 128, 4
+    feats = [T(P.bags(53, f"f{b}", 1, N + 31 * b, 512)[0]).to(dev) for b in range(B)]
+    pack = BagPack.from_lists(feats, [P.cluster_lists(53, f"c{b}", N + 31 * b, K) for b in range(B)])
+
+    def run(stepwise):
+        args = _args(T=Tn, feat_size=fs, batch_size=B, dtype="f32", train_stage=1, num_clusters=K, backbone_lr=1e-3, fc_lr=1e-3)
+        args.no_batched_stage1 = stepwise
+        model, fc, ppo = create_model(args, 512, dev)
+        model.encoder.load_state_dict(P.to_torch(P.abmil(985)))
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        opt = get_optimizer(args, model, fc)
+        torch.manual_seed(77)
+        loss, losses, rewards = pretrain_step(args, model, fc, ppo, NT_Xent(B, 1.0), opt, pack, [rlmil.Memory(), rlmil.Memory()])
+        return loss.item(), [l.item() for l in losses], torch.cat(rewards).cpu(), model.encoder.encoder[3].weight.detach().cpu(), \
+            fc.rnn.weight_hh_l0.detach().cpu()
+
+    a, b = run(False), run(True)
+    assert a[0] == pytest.approx(b[0], rel=1e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5)
+    np.testing.assert_allclose(a[2].numpy(), b[2].numpy(), rtol=1e-3, atol=1e-6)
+    for x, y in zip(a[3:], b[3:]):
+        # Adam's first step moves every weight by ~lr * sign(g): compare the moves
+        assert ((x - y).norm() / (1e-3 * x.numel() ** 0.5)).item() < 2e-2
+
+
+@pytest.mark.parametrize("arch", ["ABMIL", "CLAM_SB", "DSMIL"])
+def test_supervised_stage1_all_patch_steps_at_once_equals_the_loop(arch):
+    from murcl_amd.train_RLMIL import create_model, supervised_step
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.models import rlmil
+    from murcl_amd.utils.datasets import BagPack
+    dev = torch.device("cuda:0")
+    B, N, K, fs, C, Tn = 4, 400, 10, 64, 2, 3
+    pack = BagPack.from_lists([T(P.bags(62, f"f{b}", 1, N + 9 * b, 512)[0]).to(dev) for b in range(B)],
+                              [P.cluster_lists(62, f"c{b}", N + 9 * b, K) for b in range(B)])
+    labels = torch.tensor([1, 0, 1, 0], device=dev)
+    acts = [T(detrand.uniform(62, f"a{t}", (B, K))) for t in range(Tn)]
+
+    def run(at_once):
+        model, fc = create_model(arch, 512, C, dev)
+        model.eval() if arch == "CLAM_SB" else None                 # dropout draws differ between one call and three
+        pk = P.abmil(62, dim_out=C) if arch == "ABMIL" else {"CLAM_SB": P.clam_sb, "DSMIL": P.dsmil}[arch](62)
+        model.load_state_dict(P.to_torch(pk))
+        fc.load_state_dict(P.to_torch(P.full_layer(62, 512, 1024, C)))
+        opt = FlatAdam([{"params": list(model.parameters()) + list(fc.parameters()), "lr": 1e-3}])
+        loss, losses, rewards = supervised_step(arch, model, fc, None, opt, pack, labels, rlmil.Memory(), T=Tn, feat_size=fs,
+                                                actions=acts, batch_patch_steps=at_once)
+        return loss.item(), [l.item() for l in losses], torch.cat(rewards).cpu().numpy(), fc.fc.weight.detach().cpu()
+
+    a, b = run(True), run(False)
+    assert a[0] == pytest.approx(b[0], rel=2e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-5)
+    np.testing.assert_allclose(a[2], b[2], rtol=2e-3, atol=2e-6)
+    assert ((a[3] - b[3]).norm() / (1e-3 * a[3].numel() ** 0.5)).item() < 2e-2
