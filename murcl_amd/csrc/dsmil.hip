@@ -134,6 +134,9 @@ extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float*
     return MURCL_CHECK_LAUNCH();
 }
 
+#ifndef WR_UR
+#define WR_UR 4
+#endif
 // Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]      (one streaming pass over X; C <= 4)
 // grid (B, row splits).  A thread owns 8 consecutive columns (16-byte loads for bf16), G = d/8 column groups and
 // 256/G row lanes per workgroup; the row lanes meet in LDS and the workgroup adds its partial sums atomically.
@@ -155,18 +158,22 @@ __global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restric
             for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
         if (rl < RL) {
             int n = r0 + rl;
-            for (; n + 3 * RL < r1; n += 4 * RL) {               // four rows in flight per thread
-                float v[4][8];
+            constexpr int UR = WR_UR;                             // rows in flight per thread
+            for (; n + (UR - 1) * RL < r1; n += UR * RL) {
+                float v[UR][8], w[UR][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) load8<T>(x + (size_t)(n + u * RL) * d + c0, v[u]);
+                for (int u = 0; u < UR; ++u) load8<T>(x + (size_t)(n + u * RL) * d + c0, v[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < UR; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[u][c] = (c < C) ? a[(size_t)(n + u * RL) * C + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < UR; ++u)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (c < C) {
-                            const float w = a[(size_t)(n + u * RL) * C + c];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) acc[c][e] += w * v[u][e];
+                            for (int e = 0; e < 8; ++e) acc[c][e] += w[u][c] * v[u][e];
                         }
             }
             for (; n < r1; n += RL) {
