@@ -19,13 +19,8 @@ def shard_range(rank, world, b_local):
 
 def _whole(z_i, z_j):
     """The tensor whose two halves z_i and z_j are (Full_layer.forward_views hands out ``z.split(B)``), or None."""
-    base = getattr(z_i, "_base", None)
-    if (base is not None and base is getattr(z_j, "_base", None) and base.dim() == 2 and base.is_contiguous()
-            and z_i.shape == z_j.shape and base.shape[0] == 2 * z_i.shape[0] and z_i.data_ptr() == base.data_ptr()
-            and z_j.data_ptr() == base.data_ptr() + z_i.numel() * z_i.element_size()
-            and base.requires_grad == z_i.requires_grad and (base.grad_fn is not None or not base.requires_grad)):
-        return base
-    return None
+    from .utils.views import whole
+    return whole([z_i, z_j]) if z_i.shape == z_j.shape else None
 
 
 class _GatheredNTXent(torch.autograd.Function):

@@ -17,6 +17,7 @@ from torch import nn
 import math
 
 from ..functional import GRUSeqFn, GRUStepFn, LinearFn, PolicyHeadFn, PPOLossFn
+from ..utils.views import whole as _whole
 
 
 class Memory:
@@ -31,23 +32,6 @@ class Memory:
     def clear_memory(self):
         for f in self.FIELDS:
             del getattr(self, f)[:]
-
-
-def _whole(xs):
-    """The tensor whose consecutive row blocks ``xs`` are (``CL.forward`` hands out ``h.split(B)``), or None: lets the
-    batched head skip the concatenation and its backward."""
-    base = getattr(xs[0], "_base", None)
-    if base is None or base.dim() != 2 or not base.is_contiguous() or base.shape[0] != sum(x.shape[0] for x in xs):
-        return None
-    if base.requires_grad and base.grad_fn is None:
-        return None                                   # a leaf the caller may still want .grad on through its views
-    ptr, es = base.data_ptr(), base.element_size()
-    for x in xs:
-        if (getattr(x, "_base", None) is not base or x.requires_grad != base.requires_grad or x.dtype != base.dtype
-                or not x.is_contiguous() or x.data_ptr() != ptr):
-            return None
-        ptr += x.numel() * es
-    return base
 
 
 class Full_layer(nn.Module):

@@ -11,6 +11,7 @@ import torch
 from murcl_amd.functional import CrossEntropyFn
 from murcl_amd.models import abmil, clam, dsmil, rlmil
 from murcl_amd.utils.datasets import subbag_views
+from murcl_amd.utils.views import as_one
 
 
 def create_model(arch, dim_patch, num_classes, device, model_dim=512, D=128, size_arg="small", k_sample=8,
@@ -68,17 +69,6 @@ def _forward_loss(arch, model, fc, feats, labels, t, bag_weight):
     return loss, logits, states
 
 
-def _adjacent(views):
-    v0, n = views[0], views[0].numel()
-    return all(v.is_contiguous() and v.untyped_storage().data_ptr() == v0.untyped_storage().data_ptr()
-               and v.storage_offset() == v0.storage_offset() + i * n for i, v in enumerate(views))
-
-
-def _as_one(views):
-    v0 = views[0]
-    return torch.as_strided(v0, (len(views) * v0.shape[0],) + tuple(v0.shape[1:]), v0.stride(), v0.storage_offset())
-
-
 def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
     if actions is not None:
         return actions[t].to(dev)
@@ -101,7 +91,7 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     if (train_stage == 1 or actions is not None) and train_enc and T > 1 and batch_patch_steps:
         acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
         views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)
-        at_once = _aggregate(arch, model, torch.cat(views, 0) if not _adjacent(views) else _as_one(views), labels.repeat(T))
+        at_once = _aggregate(arch, model, as_one(views), labels.repeat(T))
     for t in range(T):
         if at_once is not None:
             sl = slice(t * B, (t + 1) * B)

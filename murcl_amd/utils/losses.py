@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from ..functional import NTXentFn
+from .views import whole
 
 
 class NT_Xent(nn.Module):
@@ -25,11 +26,8 @@ class NT_Xent(nn.Module):
     def forward(self, z_i, z_j):
         lo, hi = self._shard if self._shard is not None else (0, z_i.shape[0])
         zi, zj = z_i, z_j
-        base = getattr(z_i, "_base", None)
-        if (base is not None and base is getattr(z_j, "_base", None) and base.dim() == 2 and base.is_contiguous()
-                and base.requires_grad == z_i.requires_grad and (base.grad_fn is not None or not base.requires_grad)
-                and base.shape[0] == 2 * z_i.shape[0] and z_i.shape == z_j.shape and base.dtype == torch.float32
-                and z_i.data_ptr() == base.data_ptr() and z_j.data_ptr() == base.data_ptr() + z_i.numel() * 4):
+        base = whole([z_i, z_j]) if z_i.shape == z_j.shape and z_i.dtype == torch.float32 else None
+        if base is not None:
             zi, zj = base, None          # the two views are the halves of one tensor (Full_layer.forward_views): no cat
         loss, sim = NTXentFn.apply(zi, zj, float(self.temperature), lo, hi)
         self.last_similarity = sim
