@@ -465,3 +465,22 @@ def test_ppo_returns_and_loss_vs_oracle():
     assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
     np.testing.assert_allclose(dlp.cpu().numpy(), lp.grad.numpy(), rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(dv.cpu().numpy(), val.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_modules_accept_non_contiguous_inputs():
+    """inputs may arrive as strided views; the modules make them contiguous internally - same results."""
+    from murcl_amd.utils.losses import NT_Xent
+    dev = _dev()
+    m = _abmil(985)
+    x = T(P.bags(985, "nc.x", 2, 256, 512)).to(dev)
+    xt = x.transpose(1, 2).contiguous().transpose(1, 2)              # same values, strides (N*d, 1, N)
+    assert not xt.is_contiguous()
+    a, b = m(x)[0], m(xt)[0]
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    z = T(detrand.normal(7, "nc.z", (128, 16))).to(dev).t()          # [16,128] view of a [128,16] buffer
+    zi, zj = z[:8], z[8:]
+    assert not zi.is_contiguous()
+    crit = NT_Xent(8, 0.5)
+    l1 = crit(zi, zj)
+    l2 = crit(zi.contiguous(), zj.contiguous())
+    assert l1.item() == pytest.approx(l2.item(), rel=1e-6)

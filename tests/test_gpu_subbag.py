@@ -145,3 +145,29 @@ def test_device_slide_store_refuses_cpu():
     from murcl_amd.utils.datasets import DeviceSlideStore
     with pytest.raises(RuntimeError):
         DeviceSlideStore.from_dataset(_ListSet([np.zeros((4, 8), np.float32)], [[[0, 1], [2, 3]]]), "cpu")
+
+
+def test_get_feats_with_empty_and_singleton_clusters():
+    """A cluster may own no patch at all (k-means left it empty for this slide) or a single one: the window arithmetic
+    (size rounds to 0, slices of empty lists) must agree with the reference semantics bit for bit."""
+    from murcl_amd.utils.datasets import BagPack, select_indices
+    dev = _dev()
+    N, K, fs = 500, 6, 64
+    base = P.cluster_lists(33, "c", N, K)
+    merged = sorted(base[1] + base[2])
+    cases = [
+        [base[0], [], merged, base[3], base[4], base[5]],                # an empty cluster in the middle
+        [[], [], sorted(sum(base, [])), [], [], []],                     # everything in one cluster
+        [[0], [1], [2], sorted(set(range(N)) - {0, 1, 2, 499}), [499], []],   # singletons at both ends
+    ]
+    feats = [T(_marker_feats(N)).to(dev) for _ in cases]
+    act = detrand.uniform(33, "act", (len(cases), K))
+    act[1, 2], act[2, 0], act[2, 4] = 1.0, 0.0, 1.0
+    pack = BagPack.from_lists(feats, cases)
+    idx, cnt = select_indices(pack, T(act).to(dev), fs)
+    idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    for b, cl in enumerate(cases):
+        want = S.select_indices(N, cl, act[b], fs)[:fs]
+        assert cnt[b] == len(want), (b, cnt[b], len(want))
+        np.testing.assert_array_equal(idx[b, :len(want)], np.asarray(want, dtype=np.int64))
+        assert (idx[b, len(want):] == -1).all()
