@@ -153,6 +153,19 @@ class PPO:
         self.policy_old = ActorCritic(feature_dim, state_dim, hidden_state_dim, policy_conv, action_std, action_size).to(dev)
         self.policy_old.load_state_dict(self.policy.state_dict())
         self.optimizer = FlatAdam([{"params": list(self.policy.parameters()), "lr": lr}], betas=betas) if dev.type == "cuda" else None
+        self._old_flat = None
+        if self.optimizer is not None:
+            # policy_old's parameters as views of one buffer with the layout of the optimizer's flat parameter buffer: the
+            # sync after every update (rlmil.py:183) is one copy instead of a load_state_dict over twelve tensors
+            src = self.optimizer.groups[0]
+            flat, off = torch.empty_like(src["p"]), 0
+            for p_new, p_old in zip(src["params"], self.policy_old.parameters()):
+                assert p_new.shape == p_old.shape
+                k = p_old.numel()
+                flat[off:off + k].copy_(p_old.data.reshape(-1))
+                p_old.data = flat[off:off + k].view_as(p_old.data)
+                off += k
+            self._old_flat = flat
 
     def select_action(self, state, memory, restart_batch=False, training=True, eps=None):
         return self.policy_old.act(state, memory, restart_batch, training, eps)
@@ -173,4 +186,7 @@ class PPO:
             self.optimizer.zero_grad()
             loss.backward()
             self.optimizer.step()
-        self.policy_old.load_state_dict(self.policy.state_dict())
+        if self._old_flat is not None and self._old_flat.data_ptr() == next(self.policy_old.parameters()).data_ptr():
+            self._old_flat.copy_(self.optimizer.groups[0]["p"])
+        else:                                                      # someone re-seated policy_old's tensors (e.g. .to()): generic path
+            self.policy_old.load_state_dict(self.policy.state_dict())
