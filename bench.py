@@ -115,6 +115,43 @@ def cpu_baseline(bags, n, d, budget_s=12.0):
                        f"{torch.get_num_threads()}), {dt * 1e3:.0f} ms/step")
 
 
+def m_full(device, dtype, bags=64, raw=8192, steps=10):
+    """SURVEY 8(d) "M-full": the reference's whole stage-1 step (train_MuRCL.py:233-304) - T = 6 patch steps x 2 views of
+    1024 patches drawn from raw bags of 8192 by the cluster-window sampler + mix-up, aggregator, head, NT-Xent, one
+    backward, Adam - reported beside the headline (outside its timed region; tools/bench_full.py has stages 2 and 3)."""
+    import numpy as np
+    from murcl_amd.models import rlmil
+    from murcl_amd.train_MuRCL import build_parser, create_model, get_optimizer, pretrain_step
+    from murcl_amd.utils.datasets import BagPack
+    from murcl_amd.utils.losses import NT_Xent
+    args = build_parser().parse_args([])
+    args.T, args.feat_size, args.batch_size, args.train_stage, args.num_clusters = 6, 1024, bags, 1, 10
+    args.dtype = "bf16" if dtype == torch.bfloat16 else "f32"
+    torch.manual_seed(985)
+    model, fc, ppo = create_model(args, 512, device)
+    opt = get_optimizer(args, model, fc)
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    feats = [torch.randn((raw, 512), generator=g, device=device).abs_().mul_(0.5) for _ in range(bags)]
+    rng = np.random.default_rng(985)
+    clusters = []
+    for _ in range(bags):
+        lab = rng.integers(0, 10, raw)
+        clusters.append([np.nonzero(lab == k)[0].tolist() for k in range(10)])
+    pack = BagPack.from_lists(feats, clusters, dtype=dtype)
+    crit, mem = NT_Xent(bags, 1.0), [rlmil.Memory(), rlmil.Memory()]
+    for _ in range(3):
+        pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(workload=f"MuRCL stage-1 step: {bags} raw bags x {raw} x 512 -> T=6 x 2 views of 1024 (sampler + mix-up included)",
+                ms_per_step=round(dt * 1e3, 3), bags_per_s=round(bags / dt, 1), steps=steps)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +264,10 @@ def main():
         "kernel_ms_per_step": {k: round(v["ms_total"] / 2, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
     }
     if world == 1 and not args.no_cpu_baseline:
+        del model, fc, opt, views, step                    # free the headline step's activations before the second workload
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["m_full"] = m_full(device, dtype)
         out["cpu_baseline"] = cpu_baseline(B, N, D)
     if args.breakdown:
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):
