@@ -376,13 +376,20 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             mfma_phase(seq, accn, [&](int g) {
                 if (!prev) return;
                 // 8 k-groups per tile: math of row half 0, its store, math of row half 1 (+ mask words), its store(s)
-                if (NJ == 2) {       // one 16x16 block per k-group, the row-wise stores as soon as their rows are staged
+                constexpr int NGRP = NKK / PG_GK;
+                static_assert(!FUSE || NJ != 2 || NGRP >= 4, "the fused schedule needs four k-groups per tile");
+                if (NJ == 2 && NGRP >= 6) {   // one 16x16 block per k-group, the row-wise stores as soon as their rows are staged
                     if (g == 0) epilogue(seq - 1, acc, mw, am, 10);
                     if (g == 1) epilogue(seq - 1, acc, mw, am, 11);
                     if (g == 2) epilogue(seq - 1, acc, mw, am, 2);
                     if (g == 3) epilogue(seq - 1, acc, mw, am, 12);
                     if (g == 4) epilogue(seq - 1, acc, mw, am, 13);
                     if (g == 5) epilogue(seq - 1, acc, mw, am, 3);
+                } else if (NJ == 2) {         // four (longer) k-groups: a row half per group, its store in the next
+                    if (g == 0) { epilogue(seq - 1, acc, mw, am, 10); epilogue(seq - 1, acc, mw, am, 11); }
+                    if (g == 1) epilogue(seq - 1, acc, mw, am, 2);
+                    if (g == 2) { epilogue(seq - 1, acc, mw, am, 12); epilogue(seq - 1, acc, mw, am, 13); }
+                    if (g == 3) epilogue(seq - 1, acc, mw, am, 3);
                 } else {
                     if (g == 0) epilogue(seq - 1, acc, mw, am, 0);
                     if (g == 2) epilogue(seq - 1, acc, mw, am, 2);
