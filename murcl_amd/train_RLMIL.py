@@ -44,12 +44,14 @@ def _aggregate(arch, model, feats, labels):
     if arch == "ABMIL":
         out, states = model(feats)
         return out, states, None
+    # CLAM / DSMIL: the batched internals of the modules - same kernels as ``model(feats, ...)``, without unpacking the
+    # batch into the reference API's per-bag result dicts / lists (and, for CLAM, without the device->host copy of the
+    # instance predictions that nothing here reads): 384 bags per call made that 11 of 14.7 ms
     if arch == "CLAM_SB":
-        out, states, res = model(feats, label=labels, instance_eval=True)
-        return out, states, torch.stack([r["instance_loss"] for r in res])
-    classes, bag, bag_det = model(feats)
-    cls = torch.stack(classes) if isinstance(classes, list) else (classes if classes.dim() == 3 else classes.unsqueeze(0))
-    return bag.mean(1), bag_det.mean(1), cls.max(1)[0]                                   # :515-518,527
+        M, _, _, inst_loss, _, _ = model._run(feats if feats.dim() == 3 else feats.unsqueeze(0), labels, True)
+        return M, M.detach(), inst_loss
+    classes, bag = model._run(feats if feats.dim() == 3 else feats.unsqueeze(0))
+    return bag.mean(1), bag.detach().mean(1), classes.max(1)[0]                          # :515-518,527
 
 
 def _head_loss(arch, fc, head_in, extra, labels, t, bag_weight):

@@ -155,3 +155,31 @@ if "kmeans" in only or not only:
                       "GBps_of_X": round(N * d * 4 / (dt / (it + 1)) / 1e9, 1),
                       "kmeans++_3_starts_ms": round(dt3 * 1e3, 1), "inertia": round(best, 1),
                       "sklearn_host_ms": round(dts * 1e3, 1), "sklearn_inertia": round(float(ref.inertia_), 1)}), flush=True)
+# ---- a21: the supervised RL-MIL stage-1 step (train_RLMIL.py step bodies), 64 raw bags x 8192 -> T = 6 sub-bags of 1024
+if "supervised" in only or not only:
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.train_RLMIL import create_model, supervised_step
+    B, N, K = 64, 8192, 10
+    rng = np.random.default_rng(985)
+    feats = [(torch.randn((N, 512), generator=g, device=dev).abs() * 0.5) for _ in range(B)]
+    cls = []
+    for _ in range(B):
+        lab = rng.integers(0, K, N)
+        cls.append([np.nonzero(lab == k)[0].tolist() for k in range(K)])
+    pack = BagPack.from_lists(feats, cls, dtype=torch.bfloat16)
+    labels = torch.from_numpy(rng.integers(0, 2, B)).to(dev)
+    for arch in ("ABMIL", "CLAM_SB", "DSMIL"):
+        model, fc = create_model(arch, 512, 2, dev, dtype=torch.bfloat16)
+        opt = FlatAdam([{"params": list(model.parameters()) + list(fc.parameters()), "lr": 1e-4}])
+        mem = rlmil.Memory()
+        def step(at_once=True):
+            supervised_step(arch, model, fc, None, opt, pack, labels, mem, T=6, feat_size=1024, batch_patch_steps=at_once)
+        def wall(fn, reps=10):
+            for _ in range(3): fn()
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(reps): fn()
+            torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+        ms, ms_loop = wall(step), wall(lambda: step(False))
+        print(json.dumps({"row": "a21 supervised RL-MIL stage-1 step", "what": f"{arch}: {B} raw bags x {N} -> T=6 x 1024, bf16",
+                          "ms_per_step": round(ms, 3), "bags_per_s": round(B / ms * 1e3, 1),
+                          "ms_per_step_one_aggregator_pass_per_patch_step": round(ms_loop, 3)}), flush=True)
