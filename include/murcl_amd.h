@@ -152,7 +152,11 @@ int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d,
 int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, const float* g, int R, int d, int dtype,
                                   murcl_stream_t stream);
 int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
-                        long* preds, int group, murcl_stream_t stream);   /* loss[R/group]: mean per `group` rows */
+                        long* preds, int group, murcl_stream_t stream);   /* nn.Dropout keep mask (clam.py:47-48,71-72) in the compute dtype: out[i] = scale with probability keep_p (quantised to
+ * 1/256), else 0; a pure function of (seed, i) (splitmix64 counter hash), one write pass. */
+int murcl_dropout_mask(void* out, long n, float keep_p, float scale, unsigned long long seed, int dtype,
+                       murcl_stream_t stream);
+/* loss[R/group]: mean per `group` rows */
 int murcl_mul(const void* x, const void* k, void* y, long n, int dtype, murcl_stream_t stream);
 
 /* K10/K11 -- PPO head math (models/rlmil.py:66-127,152-184); MLP, GRU and heads are the GEMM / GRU-gate entries.

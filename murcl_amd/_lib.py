@@ -24,6 +24,7 @@ SIGNATURES = {
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_dropout_mask": [_P, _L, _F, _F, ctypes.c_ulonglong, _I, _P],
     "murcl_kmeans_workspace_bytes": [_I, _I, _I],
     "murcl_kmeans_step": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "murcl_abmil_pool_combine": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -437,6 +437,45 @@ __global__ void mul_kernel(const T* __restrict__ x, const T* __restrict__ k, T* 
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) y[i] = from_f<T>(to_f<T>(x[i]) * to_f<T>(k[i]));
 }
+// Dropout keep mask in the compute dtype: out[i] = scale with probability keep_p (quantised to 1/256), else 0.
+// Counter-based: element i takes byte (i & 7) of splitmix64(seed + i / 8), so a mask is a pure function of (seed, i) -
+// one write pass instead of torch's uniform draw + compare + cast + scale (four passes over an f32 tensor twice the size).
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_mask_kernel(T* __restrict__ out, long n8, long n, unsigned thresh, float scale,
+                                                           unsigned long long seed) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride) {
+        const unsigned long long r = splitmix64(seed + (unsigned long long)g * 0xD1342543DE82EF95ull);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((unsigned)(r >> (8 * e)) & 255u) < thresh ? scale : 0.f;
+        if (8 * g + 8 <= n) {
+            store8<T>(out + 8 * g, v);
+        } else {
+            for (int e = 0; 8 * g + e < n; ++e) out[8 * g + e] = from_f<T>(v[e]);
+        }
+    }
+}
+extern "C" int murcl_dropout_mask(void* out, long n, float keep_p, float scale, unsigned long long seed, int dtype,
+                                  hipStream_t st) {
+    if (n <= 0) return 0;
+    if (!(keep_p >= 0.f && keep_p <= 1.f)) return -1;
+    const unsigned thresh = (unsigned)(keep_p * 256.f + 0.5f);
+    const long n8 = (n + 7) / 8;
+    int grid = (int)((n8 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(dropout_mask_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, n8, n, thresh, scale, seed);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(dropout_mask_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (bf16_t*)out, n8, n, thresh, scale, seed);
+    else return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
 extern "C" int murcl_mul(const void* x, const void* k, void* y, long n, int dtype, hipStream_t st) {
     if (n <= 0) return 0;
     int grid = (int)((n + 255) / 256);

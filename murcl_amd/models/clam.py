@@ -65,9 +65,9 @@ class CLAM_SB(nn.Module):
         if self.training and self.dropout and keeps is None:
             BN, T = x.shape[0] * x.shape[1], x.dtype
             L, D = net[0].out_features, g.attention_c.in_features
-            # keep with probability 0.75, survivors scaled by 1/0.75 (nn.Dropout(0.25), clam.py:71-72,47-48): drawn in the
-            # compute dtype in place - two passes over the mask instead of four over an f32 uniform tensor twice its size
-            draw = lambda w: torch.empty((BN, w), dtype=T, device=x.device).bernoulli_(0.75).mul_(1.0 / 0.75)   # noqa: E731
+            # keep with probability 0.75, survivors scaled by 1/0.75 (nn.Dropout(0.25), clam.py:71-72,47-48): one write pass
+            # per mask (ops.dropout_mask) instead of uniform draw + compare + cast + scale
+            draw = lambda w: ops.dropout_mask((BN, w), T, 0.75, x.device)   # noqa: E731
             keeps = (draw(L), draw(D), draw(D))
         inst_w = inst_b = cfg = None
         if instance_eval:

@@ -588,6 +588,21 @@ def cross_entropy(logits, targets, group):
     return loss, dl, preds
 
 
+_DROP_COUNTER = 0
+
+
+def dropout_mask(shape, dtype, keep_p, device):
+    """Keep mask of ``nn.Dropout(1 - keep_p)``: ``1/keep_p`` where kept, 0 where dropped.  Seeded from torch's global
+    seed and a call counter (no device synchronisation; ``torch.manual_seed`` makes a run reproducible)."""
+    global _DROP_COUNTER
+    _DROP_COUNTER += 1
+    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_COUNTER * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    out = torch.empty(shape, dtype=dtype, device=device)
+    check(_lib.lib().murcl_dropout_mask(ptr(out), out.numel(), float(keep_p), 1.0 / float(keep_p), seed, dt(out), stream()),
+          "dropout_mask")
+    return out
+
+
 def mul(x, k, out=None):
     x, k = _c(x), _c(k)
     out = x if out is None else out

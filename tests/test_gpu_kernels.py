@@ -473,3 +473,30 @@ def test_panel_gemm_rank1_mask_k512(bags, n):
     ref = (dU.double() @ Wt.double().t() + a.double()[:, None] * dM.double().repeat_interleave(n, 0)) * (H.double() > 0)
     _close(C.float(), ref, rtol=1e-2, atol=1e-2, msg="C")
     _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_mask_values_rate_and_reproducibility(dtype):
+    from murcl_amd import ops
+    dev = _dev()
+    torch.manual_seed(123)
+    ops._DROP_COUNTER = 0
+    a = ops.dropout_mask((4099, 257), dtype, 0.75, dev)                 # ragged tail (not a multiple of 8)
+    b = ops.dropout_mask((4099, 257), dtype, 0.75, dev)
+    torch.manual_seed(123)
+    ops._DROP_COUNTER = 0
+    a2 = ops.dropout_mask((4099, 257), dtype, 0.75, dev)
+    assert torch.equal(a, a2) and not torch.equal(a, b)                 # (seed, call counter) decide the mask
+    vals = set(torch.unique(a.float()).tolist())
+    assert vals == {0.0, float(torch.tensor(1 / 0.75, dtype=dtype))}
+    keep = (a != 0).float()
+    n = keep.numel()
+    assert abs(keep.mean().item() - 0.75) < 5 * math.sqrt(0.75 * 0.25 / n)
+    # no structure along rows / columns / between the two draws
+    assert (keep.mean(0) - 0.75).abs().max().item() < 6 * math.sqrt(0.75 * 0.25 / 4099)
+    assert (keep.mean(1) - 0.75).abs().max().item() < 6 * math.sqrt(0.75 * 0.25 / 257)
+    both = (keep * (b != 0).float()).mean().item()
+    assert abs(both - 0.75 ** 2) < 5 * math.sqrt(0.5625 * 0.4375 / n)
+    lag = (keep[:, 1:] * keep[:, :-1]).mean().item()
+    assert abs(lag - 0.75 ** 2) < 5 * math.sqrt(0.5625 * 0.4375 / n)
+    assert ops.dropout_mask((3,), dtype, 1.0, dev).float().tolist() == [1.0, 1.0, 1.0]
