@@ -88,9 +88,9 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     B, K, dev = pack.B, pack.K, pack.feats.device
     dt_ = model.encoder.compute_dtype
     train_enc = args.train_stage != 2
-    if (args.train_stage == 1 or injected is not None) and args.T > 1 and train_enc and world == 1 \
+    if (args.train_stage == 1 or injected is not None) and args.T > 1 and train_enc \
             and not getattr(args, "no_batched_stage1", False):
-        return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected)
+        return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
     losses, rewards, sim_last, states = [], [], None, None
     for t in range(args.T):
         if injected is not None:
@@ -131,7 +131,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     return loss.detach(), [l.detach() for l in losses], rewards
 
 
-def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected=None):
+def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected=None, world=1):
     """Stage 1 draws every patch step's window positions at random (train_MuRCL.py:235,256-258): no step depends on the
     aggregator states of the step before, so the sub-bags of all T steps are built into ONE buffer and the aggregator
     runs ONCE over 2*T*B bags - each weight-stationary / wgrad kernel is launched once at full size instead of T times
@@ -154,14 +154,20 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
     losses, rewards, sim_last = [], [], None
     for t in range(T_):
         z = fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))                      # :243,272
-        losses.append(criterion(z[0], z[1]))                                                 # :249,277
-        sim = criterion.last_similarity
+        if world > 1:
+            loss_t, sim = mdist.gathered_nt_xent(z[0], z[1], args.temperature)               # global denominator (dist.py)
+            losses.append(loss_t)
+        else:
+            losses.append(criterion(z[0], z[1]))                                             # :249,277
+            sim = criterion.last_similarity
         if t > 0:
             rewards.append((sim_last - sim).view(1, -1))                                     # :282-283
         sim_last = sim
     loss = sum(losses) / T_                                                                  # :291
     optimizer.zero_grad()
     loss.backward(ops.unit_grad(loss))
+    if world > 1:
+        mdist.all_reduce_grads(optimizer.flat_grads())
     optimizer.step()                                                                         # :293-295
     return loss.detach(), [l.detach() for l in losses], rewards
 

@@ -20,9 +20,16 @@ ap.add_argument("--T", type=int, default=6)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--stage", type=int, default=1, help="1: MIL + contrastive head; 2: PPO sampler trained, encoder frozen; 3: both")
+ap.add_argument("--force-dist", action="store_true", help="single-rank RCCL group, the multi-GPU code path (world=2 semantics)")
 ap.add_argument("--cprofile", action="store_true", help="print the host-side cProfile of the timed steps")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+WORLD = 1
+if a.force_dist:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    WORLD = 2
 args = build_parser().parse_args([])
 args.T, args.feat_size, args.batch_size, args.dtype, args.train_stage, args.num_clusters = a.T, a.feat_size, a.bags, a.dtype, 1, 10
 torch.manual_seed(985)
@@ -43,7 +50,7 @@ pack = BagPack.from_lists(feats, clusters, dtype=torch.bfloat16 if a.dtype == "b
 crit = NT_Xent(a.bags, 1.0)
 mem = [rlmil.Memory(), rlmil.Memory()]
 for _ in range(3):
-    pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+    pretrain_step(args, model, fc, ppo, crit, opt, pack, mem, WORLD)
 torch.cuda.synchronize()
 ops.TIMERS = None
 if a.cprofile:
@@ -51,7 +58,7 @@ if a.cprofile:
     prof = cProfile.Profile(); prof.enable()
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    loss, _, _ = pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+    loss, _, _ = pretrain_step(args, model, fc, ppo, crit, opt, pack, mem, WORLD)
 host = (time.perf_counter() - t0) / a.steps
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
