@@ -105,6 +105,17 @@ class ActorCritic(nn.Module):
         g = self.gru
         return GRUStepFn.apply(e, hidden, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
+    def _trunk_no_grad(self, state, hidden):
+        """``_trunk`` for the sampler's forward-only steps: the same kernels called directly - ``act`` runs under
+        ``torch.no_grad()``, so three autograd-node constructions per call (ten calls per training step) buy nothing."""
+        from .. import ops
+        enc, g = self.state_encoder, self.gru
+        e = ops.gemm_nt(state, enc[0].weight, epi=ops.EPI_BIAS_RELU, bias=enc[0].bias)
+        e = ops.gemm_nt(e, enc[2].weight, epi=ops.EPI_BIAS_RELU, bias=enc[2].bias)
+        gi = ops.gemm_nt(e, g.weight_ih_l0, epi=ops.EPI_BIAS, bias=g.bias_ih_l0)
+        gh = ops.gemm_nt(hidden.contiguous(), g.weight_hh_l0, epi=ops.EPI_BIAS, bias=g.bias_hh_l0)
+        return ops.gru_gates_fwd(gi, gh, hidden.contiguous())[0]
+
     def act(self, state_ini, memory, restart_batch=False, training=False, eps=None):
         """One policy step (rlmil.py:66-97).  ``eps`` ~ N(0,1) [B,K] may be injected (parity tests)."""
         from .. import ops
@@ -112,7 +123,7 @@ class ActorCritic(nn.Module):
             if restart_batch:
                 del memory.hidden[:]
                 memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
-            h = self._trunk(state_ini.flatten(1).float().contiguous(), memory.hidden[-1][0])
+            h = self._trunk_no_grad(state_ini.flatten(1).float().contiguous(), memory.hidden[-1][0])
             memory.hidden.append(h.unsqueeze(0))
             z = ops.gemm_nt(h, self.actor[0].weight, epi=ops.EPI_BIAS, bias=self.actor[0].bias)
             if eps is None:
