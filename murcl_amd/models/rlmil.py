@@ -48,9 +48,24 @@ class Full_layer(nn.Module):
             for k in (2, 3, 4, 5):                                # cascaded variant (rlmil.py:203-206)
                 setattr(self, f"fc_{k}", nn.Linear(feature_num * k, class_num))
 
+    def _step_no_grad(self, x, h_prev):
+        """One GRU step + classifier with the kernels called directly (forward-only callers: frozen-encoder stage 2,
+        validation): no autograd nodes to build."""
+        from .. import ops
+        r = self.rnn
+        gi = ops.gemm_nt(x.contiguous(), r.weight_ih_l0, epi=ops.EPI_BIAS, bias=r.bias_ih_l0)
+        gh = r.bias_hh_l0.detach().view(1, -1) if h_prev is None else \
+            ops.gemm_nt(h_prev.contiguous(), r.weight_hh_l0, epi=ops.EPI_BIAS, bias=r.bias_hh_l0)
+        h = ops.gru_gates_fwd(gi, gh, None if h_prev is None else h_prev.contiguous())[0]
+        return h, ops.gemm_nt(h, self.fc.weight, epi=ops.EPI_BIAS, bias=self.fc.bias)
+
     def forward(self, x, restart=False):
         if self.fc_rnn:
             h_prev = None if restart else self.hidden[0]
+            if not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+                h, z = self._step_no_grad(x, h_prev)
+                self.hidden = h.unsqueeze(0)
+                return z
             r = self.rnn
             h = GRUStepFn.apply(x, h_prev, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
             self.hidden = h.unsqueeze(0)                          # [1,B,H] like nn.GRU's h_n
@@ -76,6 +91,11 @@ class Full_layer(nn.Module):
             return [self(x, restart) for x in xs]
         n = xs[0].shape[0]
         r = self.rnn
+        if not torch.is_grad_enabled() and xs[0].is_cuda and xs[0].dtype == torch.float32 and xs[0].dim() == 2:
+            x = _whole(xs)
+            h, z = self._step_no_grad(torch.cat(xs, 0) if x is None else x, None)
+            self.hidden = h[-n:].unsqueeze(0)
+            return list(z.split(n, 0))
         x = _whole(xs)
         h = GRUStepFn.apply(torch.cat(xs, 0) if x is None else x, None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         self.hidden = h[-n:].unsqueeze(0)

@@ -29,6 +29,13 @@ class NT_Xent(nn.Module):
         base = whole([z_i, z_j]) if z_i.shape == z_j.shape and z_i.dtype == torch.float32 else None
         if base is not None:
             zi, zj = base, None          # the two views are the halves of one tensor (Full_layer.forward_views): no cat
+        if not torch.is_grad_enabled() or not zi.requires_grad:
+            # nobody will differentiate this loss (frozen-encoder stage 2, validation): skip the gradient half of the kernel
+            from .. import ops
+            z = zi if zj is None else torch.cat([zi, zj], 0)
+            loss, _, sim = ops.ntxent(z, float(self.temperature), want_grad=False, grad_lo=lo, grad_hi=hi)
+            self.last_similarity = sim
+            return loss[0]
         loss, sim = NTXentFn.apply(zi, zj, float(self.temperature), lo, hi)
         self.last_similarity = sim
         return loss

@@ -484,3 +484,30 @@ def test_modules_accept_non_contiguous_inputs():
     l1 = crit(zi, zj)
     l2 = crit(zi.contiguous(), zj.contiguous())
     assert l1.item() == pytest.approx(l2.item(), rel=1e-6)
+
+
+def test_forward_only_fast_paths_equal_the_autograd_paths():
+    """Under torch.no_grad() (frozen-encoder stage 2, validation) Full_layer and NT_Xent call the kernels directly and
+    NT_Xent skips the gradient half of its kernel: same numbers, same hidden-state bookkeeping."""
+    from murcl_amd.models.rlmil import Full_layer
+    from murcl_amd.utils.losses import NT_Xent
+    dev = _dev()
+
+    def run(no_grad):
+        fc = Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        fc = fc.to(dev)
+        crit = NT_Xent(8, 0.5)
+        outs = []
+        with torch.set_grad_enabled(not no_grad):
+            for t in range(3):
+                xs = [T(detrand.normal(33, f"ff.x.{t}.{v}", (8, 512))).to(dev) for v in range(2)]
+                z = fc.forward_views(xs, restart=(t == 0))
+                loss = crit(z[0], z[1])
+                outs += [z[0].detach().cpu(), z[1].detach().cpu(), loss.detach().cpu().reshape(1), crit.last_similarity.cpu(),
+                         fc.hidden.detach().cpu().reshape(-1)]
+                assert loss.requires_grad != no_grad
+        return outs
+
+    for a, b in zip(run(True), run(False)):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=2e-6)
