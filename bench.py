@@ -124,7 +124,7 @@ def m_full(device, dtype, bags=64, raw=8192, steps=10):
     from murcl_amd.train_MuRCL import build_parser, create_model, get_optimizer, pretrain_step
     from murcl_amd.utils.datasets import BagPack
     from murcl_amd.utils.losses import NT_Xent
-    args = build_parser().parse_args([])
+    args = build_parser().parse_args(["--arch", "ABMIL", "--fc_lr", "5e-5"])
     args.T, args.feat_size, args.batch_size, args.train_stage, args.num_clusters = 6, 1024, bags, 1, 10
     args.dtype = "bf16" if dtype == torch.bfloat16 else "f32"
     torch.manual_seed(985)

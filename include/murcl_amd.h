@@ -162,14 +162,19 @@ int murcl_mul(const void* x, const void* k, void* y, long n, int dtype, murcl_st
 /* K10/K11 -- PPO head math (models/rlmil.py:66-127,152-184); MLP, GRU and heads are the GEMM / GRU-gate entries.
  * policy_head_fwd: mu = sigmoid(z); with eps: action = clamp(mu + std*eps, 0, 1) (act), else evaluates act_in;
  * logp of the diagonal Gaussian whose scale_tril is diag(std).  ppo_returns: discounted + normalised returns.
- * ppo_loss: clipped surrogate + 0.5 MSE - 0.01 entropy, mean over n, with d/dlogp and d/dvalue. */
+ * ppo_loss: clipped surrogate + 0.5 MSE - 0.01 entropy, mean over n_total rows (n local rows; n_total = n on one rank),
+ * with d/dlogp and d/dvalue.  ppo_returns_raw / ppo_returns_finish: the data-parallel split of ppo_returns (rlmil.py:162
+ * normalises over the whole batch): raw discounted returns + local (sum, sum of squares) as two doubles; after the
+ * caller's all-reduce of that pair, finish normalises with the global mean / unbiased std over n_total returns. */
 int murcl_policy_head_fwd(const float* z, const float* eps, const float* act_in, float std_, int R, int K, float* mu,
                           float* act_out, float* logp, murcl_stream_t stream);
 int murcl_policy_head_bwd(const float* mu, const float* act, const float* dlogp, float std_, int R, int K, float* dz,
                           murcl_stream_t stream);
 int murcl_ppo_returns(const float* rewards, float gamma, int T, int B, float* ret, murcl_stream_t stream);
+int murcl_ppo_returns_raw(const float* rewards, float gamma, int T, int B, float* ret, double* stats, murcl_stream_t stream);
+int murcl_ppo_returns_finish(float* ret, int n, const double* stats, long n_total, murcl_stream_t stream);
 int murcl_ppo_loss(const float* logp, const float* old_logp, const float* value, const float* ret, float eps_clip,
-                   float entropy, int n, float* loss, float* dlogp, float* dvalue, murcl_stream_t stream);
+                   float entropy, int n, long n_total, float* loss, float* dlogp, float* dvalue, murcl_stream_t stream);
 
 /* helpers */
 int murcl_cast(const void* x, void* y, long n, int dtype_in, int dtype_out, murcl_stream_t stream);
@@ -199,6 +204,10 @@ int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stre
  * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */
 int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, int zero_grad, murcl_stream_t stream);
+/* torch.optim.SGD.step for one flat tensor (train_MuRCL.py:158-163, train_RLMIL.py:258-263): L2 weight decay, momentum
+ * buffer (first != 0: the buffer is initialised with the gradient), dampening 0, optional Nesterov. */
+int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov, float weight_decay,
+                   int first, int zero_grad, murcl_stream_t stream);
 
 /* K-means (Lloyd) over the patch features of one slide - the clustering pre-step behind the cluster id lists
  * (wsi_processing/features_clustering.py:10-16; sklearn KMeans).  One call = one iteration: labels[i] = argmin_k

@@ -52,7 +52,9 @@ SIGNATURES = {
     "murcl_policy_head_fwd": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "murcl_policy_head_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
     "murcl_ppo_returns": [_P, _F, _I, _I, _P, _P],
-    "murcl_ppo_loss": [_P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P],
+    "murcl_ppo_returns_raw": [_P, _F, _I, _I, _P, _P, _P],
+    "murcl_ppo_returns_finish": [_P, _I, _P, _L, _P],
+    "murcl_ppo_loss": [_P, _P, _P, _P, _F, _F, _I, _L, _P, _P, _P, _P],
     "murcl_cast": [_P, _P, _L, _I, _I, _P],
     "murcl_transpose_cast": [_P, _P, _I, _I, _I, _P],
     "murcl_colsum": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -62,6 +64,7 @@ SIGNATURES = {
     "murcl_cast_batch": [_P, _I, _I, _P],
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
+    "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
 _RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L}
 

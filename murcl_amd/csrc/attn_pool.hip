@@ -291,10 +291,10 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
         typedef K2<T, K2F_NWO(T)> CL_;                                                                          \
         typedef K2Lds<T, K2F_NWO(T)> LL_;                                                                       \
         auto k = abmil_pool_fwd_kernel<T, EX>;                                                                  \
-        static bool once = false;                                                                               \
-        if (!once) {                                                                                            \
+        static MurclOncePerDevice once;                                                                                     \
+        if (once.first()) {                                                                                            \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LL_::BYTES);        \
-            once = true;                                                                                        \
+                                                                                                                   \
         }                                                                                                       \
         hipLaunchKernelGGL(k, dim3(grid), dim3(64 * CL_::NW), LL_::BYTES, stream, (const T*)H, (const T*)Wa,    \
                            ba, wb, bb, scores, part_ws, B, N, chunk, S);                                        \

@@ -276,10 +276,10 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
 #define KB_LAUNCH(T, EX)                                                                                       \
     {                                                                                                          \
         auto k = abmil_pool_bwd_kernel<T, EX>;                                                                 \
-        static bool once = false;                                                                              \
-        if (!once) {                                                                                           \
+        static MurclOncePerDevice once;                                                                                    \
+        if (once.first()) {                                                                                           \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, KBLds<T>::BYTES);  \
-            once = true;                                                                                       \
+                                                                                                                  \
         }                                                                                                      \
         hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), KBLds<T>::BYTES, stream, (const T*)H,         \
                            (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, part_ws, B, N, chunk, S, isn); \

@@ -17,6 +17,20 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define MURCL_CHECK_LAUNCH() ((int)hipGetLastError())
 
+// hipFuncSetAttribute applies to the current device only: call sites remember which devices they have prepared
+// (one process per GPU is the norm, but a process that drives several devices must raise the LDS limit on each).
+struct MurclOncePerDevice {
+    unsigned long long seen = 0;
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (seen & bit) return false;
+        seen |= bit;
+        return true;
+    }
+};
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN

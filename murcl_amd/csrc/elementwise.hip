@@ -313,3 +313,32 @@ extern "C" int murcl_adam_step(float* p, float* g, float* m, float* v, long n, f
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, zero_grad);
     return MURCL_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- SGD (torch.optim.SGD semantics: L2 decay, momentum
+// buffer initialised with the first gradient, dampening 0, optional Nesterov; train_MuRCL.py:158-163)
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, long n, float lr,
+                           float momentum, int nesterov, float wd, int first, int zero_grad) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i];
+        if (zero_grad) g[i] = 0.f;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        if (momentum != 0.f) {
+            const float b = first ? gi : momentum * buf[i] + gi;
+            buf[i] = b;
+            gi = nesterov ? gi + momentum * b : b;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+extern "C" int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov,
+                              float weight_decay, int first, int zero_grad, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (momentum != 0.f && buf == nullptr) return -1;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, s, p, g, buf, n, lr, momentum, nesterov, weight_decay, first, zero_grad);
+    return MURCL_CHECK_LAUNCH();
+}

@@ -211,10 +211,10 @@ static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, i
 #define NT_CASE(E)                                                                                             \
     case E: {                                                                                                  \
         auto k = gemm_nt_kernel<T, OutT, E>;                                                                   \
-        static bool once = false;                                                                              \
-        if (!once) {                                                                                           \
+        static MurclOncePerDevice once;                                                                                    \
+        if (once.first()) {                                                                                           \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);            \
-            once = true;                                                                                       \
+                                                                                                                  \
         }                                                                                                      \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), 65536, s, A, B, C, M, N, K, lda, ldb, ldc, e);           \
         break;                                                                                                 \
@@ -771,8 +771,8 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         }
         auto k = gemm_tn_wide_kernel;
         constexpr int LDS = 3 * 49152;
-        static bool once = false;
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+        static MurclOncePerDevice once;      
+        if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
         hipLaunchKernelGGL(k, dim3(tiles * sp), dim3(512), LDS, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2,
                            lda, ldb, ldc, mps, sp);
         return MURCL_CHECK_LAUNCH();
@@ -796,8 +796,8 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
 #define TN_LAUNCH(T, NS)                                                                                            \
     {                                                                                                               \
         auto k = gemm_tn_kernel<T, NS>;                                                                             \
-        static bool once = false;                                                                                   \
-        if (!once) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768); once = true; } \
+        static MurclOncePerDevice once;                                                                                         \
+        if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768); } \
         hipLaunchKernelGGL(k, grid, dim3(256), NS * 32768, stream, (const T*)A, (const T*)B, C, M, N1, N2, lda, ldb, ldc, mps, \
                            splits, colsum_out);                                                                     \
     }

@@ -468,21 +468,21 @@ extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperat
     if (n % (2 * ps)) return -1;
     if (n <= 128) {
         constexpr int LDS = (2 * 128 * NXS_LD + 128 * 5) * 4;
-        static bool once = false;
-        if (!once) {
+        static MurclOncePerDevice once;      
+        if (once.first()) {
             hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            once = true;
+                           
         }
         hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz, sim,
                            loss, grad_lo, grad_hi);
         return MURCL_CHECK_LAUNCH();
     }
     static_assert(NXT_LDS <= 160 * 1024, "LDS budget");
-    static bool once_t = false;
-    if (!once_t) {
+    static MurclOncePerDevice once_t;      
+    if (once_t.first()) {
         (void)hipFuncSetAttribute((const void*)ntxent_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NXT_LDS);
         (void)hipFuncSetAttribute((const void*)ntxent_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NXT_LDS);
-        once_t = true;
+                       
     }
     const int nblk = (n + 15) / 16, ntile = (n + NXT_TC - 1) / NXT_TC;
     if (ntile > 65535) return -1;

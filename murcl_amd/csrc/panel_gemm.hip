@@ -444,10 +444,10 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
                         (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
-    static bool once = false;
-    if (!once) {
+    static MurclOncePerDevice once;      
+    if (once.first()) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        once = true;
+                       
     }
     const int panels = N / (PG_NW * WN);
     int grid = 256;

@@ -93,39 +93,90 @@ extern "C" int murcl_ppo_returns(const float* rewards, float gamma, int T, int B
     return MURCL_CHECK_LAUNCH();
 }
 
-// clipped-surrogate loss + gradients (single workgroup)
+// Data-parallel form: the rollout rows are sharded by bag over ranks, but the returns are normalised with
+// the mean / unbiased std of ALL ranks' returns (rlmil.py:162 sees the whole batch).  `raw` leaves the discounted returns
+// un-normalised and the local (sum, sum of squares) in double precision; the caller all-reduces that pair (one 16-byte
+// collective) and `finish` normalises with n_total = all ranks' T*B.
+__device__ __forceinline__ double block_sum_256d(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double t = red[0];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(256) void ppo_returns_raw_kernel(const float* __restrict__ rewards, float gamma, int T, int B,
+                                                              float* __restrict__ ret, double* __restrict__ stats) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        float run = 0.f;
+        for (int t = T - 1; t >= 0; --t) {
+            run = rewards[(size_t)t * B + b] + gamma * run;
+            ret[(size_t)t * B + b] = run;
+            s += (double)run;
+            q += (double)run * (double)run;
+        }
+    }
+    s = block_sum_256d(s, red);
+    q = block_sum_256d(q, red);
+    if (tid == 0) { stats[0] = s; stats[1] = q; }
+}
+__global__ void ppo_returns_finish_kernel(float* __restrict__ ret, int n, const double* __restrict__ stats, double n_total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = stats[0] / n_total;
+    double var = (stats[1] - stats[0] * mean) / (n_total - 1.0);          // torch.std: unbiased
+    if (var < 0.0) var = 0.0;
+    ret[i] = (float)(((double)ret[i] - mean) / (sqrt(var) + 1e-5));
+}
+extern "C" int murcl_ppo_returns_raw(const float* rewards, float gamma, int T, int B, float* ret, double* stats, hipStream_t s) {
+    if (T <= 0 || B <= 0) return -1;
+    hipLaunchKernelGGL(ppo_returns_raw_kernel, dim3(1), dim3(256), 0, s, rewards, gamma, T, B, ret, stats);
+    return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_ppo_returns_finish(float* ret, int n, const double* stats, long n_total, hipStream_t s) {
+    if (n <= 0 || n_total < 2) return -1;
+    hipLaunchKernelGGL(ppo_returns_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ret, n, stats, (double)n_total);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// clipped-surrogate loss + gradients (single workgroup).  n_total >= n: the number of rollout rows over ALL ranks - the
+// loss is a mean over them, so gradients carry 1/n_total and a SUM all-reduce of the parameter gradients gives the
+// global mean's gradient; loss[0] is this rank's share of the global loss (the shares add up to it).
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* __restrict__ logp, const float* __restrict__ old_logp,
                                                        const float* __restrict__ value, const float* __restrict__ ret,
-                                                       float eps_clip, float entropy, int n, float* __restrict__ loss,
-                                                       float* __restrict__ dlogp, float* __restrict__ dvalue) {
+                                                       float eps_clip, float entropy, int n, float inv_n,
+                                                       float* __restrict__ loss, float* __restrict__ dlogp,
+                                                       float* __restrict__ dvalue) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
-    float mse = 0.f;
-    for (int i = tid; i < n; i += 256) { const float d = value[i] - ret[i]; mse += d * d; }
-    mse = block_sum_256(mse, red) / (float)n;                             // nn.MSELoss() mean, broadcast into every element
     float acc = 0.f;
-    const float inv_n = 1.f / (float)n;
     for (int i = tid; i < n; i += 256) {
         const float ratio = expf(logp[i] - old_logp[i]);
         const float adv = ret[i] - value[i];                              // value detached here (rlmil.py:174)
         const float s1 = ratio * adv;
         const float rc = fminf(fmaxf(ratio, 1.f - eps_clip), 1.f + eps_clip);
         const float s2 = rc * adv;
-        acc += -fminf(s1, s2) + 0.5f * mse - 0.01f * entropy;
+        // nn.MSELoss() is a scalar mean broadcast into every element: its mean over the rows is the mean of d^2 itself
+        const float dv = value[i] - ret[i];
+        acc += -fminf(s1, s2) + 0.5f * dv * dv - 0.01f * entropy;
         // d/dlogp of -min(s1,s2): torch.min sends the gradient to s1 when s1 <= s2 (ties included), else to s2,
         // whose ratio-gradient is zero outside the clip range (clamp passes gradient on the closed interval)
         float g;
         if (s1 <= s2) g = -s1;                                            // d(ratio*adv)/dlogp = ratio*adv
         else g = (ratio >= 1.f - eps_clip && ratio <= 1.f + eps_clip) ? -s2 : 0.f;
         dlogp[i] = g * inv_n;
-        dvalue[i] = 0.5f * 2.f * (value[i] - ret[i]) * inv_n;             // d(0.5*mse)/dv_i, summed over the n copies / n
+        dvalue[i] = dv * inv_n;                                           // d(0.5*mse)/dv_i, summed over the copies / their count
     }
     const float tot = block_sum_256(acc, red);
     if (tid == 0) loss[0] = tot * inv_n;
 }
 extern "C" int murcl_ppo_loss(const float* logp, const float* old_logp, const float* value, const float* ret, float eps_clip,
-                              float entropy, int n, float* loss, float* dlogp, float* dvalue, hipStream_t s) {
-    if (n <= 0) return -1;
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, s, logp, old_logp, value, ret, eps_clip, entropy, n, loss, dlogp, dvalue);
+                              float entropy, int n, long n_total, float* loss, float* dlogp, float* dvalue, hipStream_t s) {
+    if (n <= 0 || n_total < n) return -1;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(256), 0, s, logp, old_logp, value, ret, eps_clip, entropy, n,
+                       1.f / (float)n_total, loss, dlogp, dvalue);
     return MURCL_CHECK_LAUNCH();
 }

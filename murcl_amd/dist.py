@@ -17,6 +17,38 @@ def shard_range(rank, world, b_local):
     return rank * b_local, (rank + 1) * b_local
 
 
+def _gloo_on_device(t, group):
+    """True when the group's backend is gloo but the tensor lives in HBM (debug / single-GPU multi-process tests): the
+    collective is then staged through host memory.  The production backend is "nccl" (RCCL), which takes device buffers."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_rows(out, local, group=None):
+    """``out`` [world * n, ...] <- every rank's ``local`` [n, ...] in rank order (one collective)."""
+    if _gloo_on_device(local, group):
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, local.cpu(), group=group)
+        out.copy_(torch.cat(parts, 0))
+    else:
+        dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def all_reduce_sum(t, group=None, async_op=False):
+    """In-place SUM all-reduce; returns the work handle when ``async_op``."""
+    if _gloo_on_device(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
 def _whole(z_i, z_j):
     """The tensor whose two halves z_i and z_j are (Full_layer.forward_views hands out ``z.split(B)``), or None."""
     from .utils.views import whole
@@ -34,7 +66,7 @@ class _GatheredNTXent(torch.autograd.Function):
         bl = local.shape[0] // 2
         # one collective into one buffer, used as it arrives: [rank][view][bag] (the kernel's pair_stride layout)
         zg = torch.empty((world * 2 * bl, local.shape[1]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(zg, local, group=group)
+        all_gather_rows(zg, local, group)
         lo, hi = shard_range(rank, world, bl)
         loss, dz, sim = kernel(zg, temperature, grad_lo=lo, grad_hi=hi, pair_stride=bl)
         r0 = rank * 2 * bl
@@ -71,7 +103,7 @@ def gathered_nt_xent(z_i, z_j, temperature, group=None, kernel=None):
 def all_reduce_grads(flat_grads, group=None):
     """Sum the flat gradient buffers over ranks (one collective per optimizer group)."""
     for g in flat_grads:
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(g, group)
 
 
 class OverlappedGradReduce:
@@ -102,7 +134,7 @@ class OverlappedGradReduce:
 
     def _submit(self, gi, lo, hi):
         flat = self.opt.flat_grads()[gi]
-        self._works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._works.append(all_reduce_sum(flat[lo:hi], self.group, async_op=True))
         self._covered.setdefault(gi, []).append((lo, hi))
 
     def arm(self, aggregator_outputs):

@@ -46,10 +46,25 @@ def _direct(p):
     return _DIRECT and p is not None and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
 
 
+# Which parameters received a gradient since their optimizer last stepped.  torch.optim.Adam skips parameters whose
+# ``.grad`` is None (never reached by backward: ABMIL.fc, CLAM's classifiers in pre-training, DSMIL's fcc): no weight
+# decay, no moment update, no step count.  With pre-seated zeroed gradient views "never reached" is invisible in the
+# buffer, so every writer announces itself here: the direct-accumulation helpers below, and an autograd
+# post-accumulate hook that FlatAdam registers for gradients that arrive through AccumulateGrad.
+_TOUCHED = set()
+
+
+def _touch(*params):
+    for p in params:
+        if p is not None:
+            _TOUCHED.add(id(p))
+
+
 def _wgrad(dy, x, w):
     """dW = dy^T x [N1,N2]; returns it, or adds it to w.grad and returns None."""
     if _direct(w):
         ops.gemm_tn(dy, x, out=w.grad)
+        _touch(w)
         return None
     return ops.gemm_tn(dy, x)
 
@@ -58,6 +73,7 @@ def _wbgrad(dy, x, w, b):
     """(dW, db) of one Linear; in direct mode both are added to the flat gradient buffer by ONE launch."""
     if _direct(w) and _direct(b):
         ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1))
+        _touch(w, b)
         return None, None
     return _wgrad(dy, x, w), _bgrad(dy, b)
 
@@ -66,6 +82,7 @@ def _bgrad(dy, b):
     """db = column sums of dy."""
     if _direct(b):
         ops.colsum(dy, out=b.grad.view(-1), accumulate=True)
+        _touch(b)
         return None
     return ops.colsum(dy)
 
@@ -74,6 +91,7 @@ def _pgrad(g, p):
     """A gradient that a kernel already produced as its own tensor."""
     if _direct(p):
         p.grad.add_(g.view_as(p.grad))
+        _touch(p)
         return None
     return g
 
@@ -178,10 +196,15 @@ class ABMILFn(torch.autograd.Function):
                                                into=(ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None)
         dwa = _wgrad(dT, h3, wa)
         if direct_k2:
+            _touch(ba, wb, bb)
             _final(wa, ba, wb, bb, wd, bd)
         # encoder layer 3: dZ3 = (dT Wa + A (x) dM) * relu'(H3)
         if m3 is not None:
-            into = lambda b: b.grad.view(-1) if _direct(b) else None      # bias gradients straight from the epilogue
+            def into(b):                                                  # bias gradients straight from the epilogue
+                if _direct(b):
+                    _touch(b)
+                    return b.grad.view(-1)
+                return None
             dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3,
                                          rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_into=into(b3))
             dw3 = _wgrad(dz3, h2, w3)
@@ -239,6 +262,7 @@ class GRUStepFn(torch.autograd.Function):
         dw_ih, db_ih = _wbgrad(dgi, x, w_ih, b_ih)
         if h_prev is None:
             db_hh = _bgrad(dgh, b_hh)
+            _touch(w_hh)                       # nn.GRU from a zero state: a zero gradient, but a gradient (Adam applies decay)
             dh_prev, dw_hh = None, (None if _direct(w_hh) else torch.zeros_like(w_hh))
         else:
             dw_hh, db_hh = _wbgrad(dgh, h_prev, w_hh, b_hh)
@@ -293,6 +317,7 @@ class GRUSeqFn(torch.autograd.Function):
         if T > 1:
             dw_hh = _wgrad(dgh2[B:], hs.view(T * B, H)[:-B], w_hh)
         else:
+            _touch(w_hh)
             dw_hh = None if _direct(w_hh) else torch.zeros_like(w_hh)
         return dx, dw_ih, dw_hh, _bgrad(dgi2, b_ih), _bgrad(dgh2, b_hh)
 
@@ -531,15 +556,15 @@ class PPOLossFn(torch.autograd.Function):
     """mean(-min(surr1, surr2) + 0.5*MSE - 0.01*entropy) (PPO.update, rlmil.py:172-181)."""
 
     @staticmethod
-    def forward(ctx, logp, old_logp, value, ret, eps_clip, entropy):
-        loss, dlogp, dvalue = ops.ppo_loss(logp, old_logp, value, ret, eps_clip, entropy)
+    def forward(ctx, logp, old_logp, value, ret, eps_clip, entropy, n_total=None):
+        loss, dlogp, dvalue = ops.ppo_loss(logp, old_logp, value, ret, eps_clip, entropy, n_total)
         ctx.save_for_backward(dlogp, dvalue)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         dlogp, dvalue = ctx.saved_tensors
-        return dlogp * g, None, dvalue * g, None, None, None
+        return dlogp * g, None, dvalue * g, None, None, None, None
 
 
 class CrossEntropyFn(torch.autograd.Function):

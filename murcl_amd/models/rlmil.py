@@ -185,7 +185,9 @@ class PPO:
         self.policy_old.load_state_dict(self.policy.state_dict())
         self.optimizer = FlatAdam([{"params": list(self.policy.parameters()), "lr": lr}], betas=betas) if dev.type == "cuda" else None
         self._old_flat = None
-        if self.optimizer is not None:
+        self._k = _HipPolicyKernels            # device side of update()
+        self.data_parallel = None              # None: collectives when a process group with > 1 ranks exists; True: whenever
+        if self.optimizer is not None:         # one is initialised (single-rank runs of the multi-GPU code path); False: never
             # policy_old's parameters as views of one buffer with the layout of the optimizer's flat parameter buffer: the
             # sync after every update (rlmil.py:183) is one copy instead of a load_state_dict over twelve tensors
             src = self.optimizer.groups[0]
@@ -201,23 +203,79 @@ class PPO:
     def select_action(self, state, memory, restart_batch=False, training=True, eps=None):
         return self.policy_old.act(state, memory, restart_batch, training, eps)
 
-    def update(self, memory):
-        from .. import ops
+    def update(self, memory, group=None):
+        """PPO.update (rlmil.py:152-184).  Data-parallel (one process per GPU, rollout rows sharded by bag, SURVEY.md
+        8(e)): the reference normalises the returns over the WHOLE batch and takes the loss mean over all its rows, so
+        under an initialised process group the (sum, sum of squares) of the returns are all-reduced (one 16-byte
+        collective) and, per K_epoch, the flat policy gradient (14.7 MB) - every rank then applies the identical Adam
+        step and the N ranks keep ONE sampler, bit-identical across ranks."""
+        import torch.distributed as dist
+        from .. import dist as mdist
+        k = self._k
+        world = 1
+        if dist.is_available() and dist.is_initialized() and self.data_parallel is not False:
+            world = dist.get_world_size(group)
+        collectives = world > 1 or (self.data_parallel is True and dist.is_available() and dist.is_initialized())
         rewards = torch.cat([r.reshape(1, -1) for r in memory.rewards], 0)             # [T,B] (rlmil.py:156-160)
-        returns = ops.ppo_returns(rewards, self.gamma)
+        n_total = rewards.numel() * world                                              # equal shards: B_local bags per rank
+        if collectives:
+            returns, stats = k.returns_raw(rewards, self.gamma)
+            mdist.all_reduce_sum(stats, group)
+            returns = k.returns_finish(returns, stats, n_total)                        # rlmil.py:162 over all ranks' returns
+        else:
+            returns = k.returns(rewards, self.gamma)
         old_states = torch.stack(memory.states, 0).detach()
         old_actions = torch.stack(memory.actions, 0).detach()
         old_logprobs = torch.stack(memory.logprobs, 0).detach()
         for _ in range(self.K_epochs):
-            logp, value, ent = self.policy.evaluate(old_states, old_actions)
-            loss = PPOLossFn.apply(logp.reshape(-1), old_logprobs.reshape(-1), value.reshape(-1), returns.reshape(-1),
-                                   self.eps_clip, float(ent.flatten()[0]) if False else
-                                   0.5 * self.policy.action_size * (1.0 + math.log(2 * math.pi))
-                                   + self.policy.action_size * math.log(self.policy.action_std))
-            self.optimizer.zero_grad()
-            loss.backward()
-            self.optimizer.step()
-        if self._old_flat is not None and self._old_flat.data_ptr() == next(self.policy_old.parameters()).data_ptr():
-            self._old_flat.copy_(self.optimizer.groups[0]["p"])
+            k.epoch_grads(self, old_states, old_actions, old_logprobs, returns, n_total)   # rlmil.py:169-180
+            if collectives:
+                for g in k.flat_grads(self):                                           # gradients carry 1/n_total: SUM = global mean
+                    mdist.all_reduce_sum(g, group)
+            k.step(self)                                                               # rlmil.py:181
+        k.sync_old(self)                                                               # rlmil.py:183
+
+
+class _HipPolicyKernels:
+    """The device side of ``PPO.update``: every piece is a sequence of C-ABI launches (tests on a CPU-only box inject an
+    object with the same five methods built on the oracle, to exercise the collective glue under gloo)."""
+
+    @staticmethod
+    def returns(rewards, gamma):
+        from .. import ops
+        return ops.ppo_returns(rewards, gamma)
+
+    @staticmethod
+    def returns_raw(rewards, gamma):
+        from .. import ops
+        return ops.ppo_returns_raw(rewards, gamma)
+
+    @staticmethod
+    def returns_finish(ret, stats, n_total):
+        from .. import ops
+        return ops.ppo_returns_finish(ret, stats, n_total)
+
+    @staticmethod
+    def epoch_grads(ppo, states, actions, old_logp, returns, n_total):
+        pol = ppo.policy
+        logp, value, _ = pol.evaluate(states, actions)
+        entropy = 0.5 * pol.action_size * (1.0 + math.log(2 * math.pi)) + pol.action_size * math.log(pol.action_std)
+        loss = PPOLossFn.apply(logp.reshape(-1), old_logp.reshape(-1), value.reshape(-1), returns.reshape(-1),
+                               ppo.eps_clip, entropy, n_total)
+        ppo.optimizer.zero_grad()
+        loss.backward()
+
+    @staticmethod
+    def flat_grads(ppo):
+        return ppo.optimizer.flat_grads()
+
+    @staticmethod
+    def step(ppo):
+        ppo.optimizer.step()
+
+    @staticmethod
+    def sync_old(ppo):
+        if ppo._old_flat is not None and ppo._old_flat.data_ptr() == next(ppo.policy_old.parameters()).data_ptr():
+            ppo._old_flat.copy_(ppo.optimizer.groups[0]["p"])
         else:                                                      # someone re-seated policy_old's tensors (e.g. .to()): generic path
-            self.policy_old.load_state_dict(self.policy.state_dict())
+            ppo.policy_old.load_state_dict(ppo.policy.state_dict())

@@ -465,6 +465,13 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, zero_grad=False):
                                      stream()), "adam_step")
 
 
+def sgd_step(p, g, buf, lr, momentum, nesterov, weight_decay, first, zero_grad=False):
+    _need_cuda(p, g)
+    assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
+    check(_lib.lib().murcl_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), float(lr), float(momentum), int(bool(nesterov)),
+                                    float(weight_decay), int(bool(first)), int(zero_grad), stream()), "sgd_step")
+
+
 # ------------------------------------------------------------------------------------------ DSMIL (K6)
 def dsmil_argmax(scores_view, B, N, C):
     """scores_view: [B*N, >=C] f32 view (row stride = its stride(0)); -> m [B,C] int32."""
@@ -640,10 +647,27 @@ def ppo_returns(rewards, gamma):
     return ret
 
 
-def ppo_loss(logp, old_logp, value, ret, eps_clip, entropy):
+def ppo_returns_raw(rewards, gamma):
+    """rewards [T,B] f32 -> (raw discounted returns [T,B], stats f64 [2] = local (sum, sum of squares))."""
+    rewards = _c(rewards.float())
+    ret = torch.empty_like(rewards)
+    stats = torch.empty((2,), dtype=torch.float64, device=rewards.device)
+    check(_lib.lib().murcl_ppo_returns_raw(ptr(rewards), float(gamma), rewards.shape[0], rewards.shape[1], ptr(ret),
+                                           ptr(stats), stream()), "ppo_returns_raw")
+    return ret, stats
+
+
+def ppo_returns_finish(ret, stats, n_total):
+    """Normalise raw returns in place with the (all-reduced) sum / sum of squares over ``n_total`` returns."""
+    check(_lib.lib().murcl_ppo_returns_finish(ptr(ret), ret.numel(), ptr(stats), int(n_total), stream()), "ppo_returns_finish")
+    return ret
+
+
+def ppo_loss(logp, old_logp, value, ret, eps_clip, entropy, n_total=None):
     n = logp.numel()
     loss = torch.empty((1,), dtype=torch.float32, device=logp.device)
     dlogp, dvalue = torch.empty_like(logp), torch.empty_like(value)
     check(_lib.lib().murcl_ppo_loss(ptr(_c(logp)), ptr(_c(old_logp)), ptr(_c(value)), ptr(_c(ret)), float(eps_clip),
-                                    float(entropy), n, ptr(loss), ptr(dlogp), ptr(dvalue), stream()), "ppo_loss")
+                                    float(entropy), n, int(n if n_total is None else n_total), ptr(loss), ptr(dlogp),
+                                    ptr(dvalue), stream()), "ppo_loss")
     return loss, dlogp, dvalue

@@ -1,4 +1,4 @@
-"""Flat-buffer Adam on the HIP kernel (torch.optim.Adam semantics; train_MuRCL.py:154-171).
+"""Flat-buffer optimizers on the HIP kernels (torch.optim.Adam / torch.optim.SGD semantics; train_MuRCL.py:154-171).
 
 Parameters of each group are re-seated as views of one contiguous f32 buffer, and so are their
 ``.grad``s: ``zero_grad`` is one memset, ``step`` one kernel launch per group, and a data-parallel
@@ -8,28 +8,40 @@ Because every ``.grad`` exists (zeroed) before backward starts, the backward ker
 straight into the flat buffer (``functional.set_direct_grad``; pass ``direct_grad=False`` to keep autograd's own
 AccumulateGrad path, e.g. when per-parameter hooks are registered).  ``step`` also clears the gradient buffer in its
 own pass (``fused_zero``), so the ``zero_grad`` that follows costs nothing; gradients are therefore zero AFTER ``step``.
+
+Parameters that no backward pass reached since the last step are skipped like torch's optimizers skip ``grad is None``
+(no weight decay, no moment / momentum update, no step count): writers announce themselves through
+``functional._touch`` / an autograd post-accumulate hook; ``step`` launches the kernel over the contiguous runs of
+touched parameters (one launch per group when everything was touched, or when only a tail such as ABMIL's unused
+``fc`` was not).
 """
+import math
+
 import torch
 
 from . import ops
 
 
-class FlatAdam:
-    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True, fused_zero=True):
+class _FlatOptimizer:
+    STATE = ()                                   # names of the per-element state buffers
+
+    def __init__(self, param_groups, weight_decay=0.0, direct_grad=True, fused_zero=True):
         from . import functional
         functional.set_direct_grad(direct_grad)
-        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.weight_decay = weight_decay
         self.fused_zero, self._maybe_dirty = fused_zero, False      # the flat grads start as zeros
         self.groups = []
         self.step_count = 0
-        self._owned = set()
+        self._owned, self._ids = set(), set()
+        self._pstep = {}                                      # id(param) -> number of steps it took part in (torch: state['step'])
+        self._fn = functional
         for g in param_groups:
             params = [p for p in g["params"] if p.requires_grad]
             n = sum(p.numel() for p in params)
             dev = params[0].device
             flat_p = torch.empty(n, dtype=torch.float32, device=dev)
             flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
-            off = 0
+            off, segs = 0, []
             for p in params:
                 k = p.numel()
                 flat_p[off:off + k].copy_(p.data.reshape(-1))
@@ -37,9 +49,14 @@ class FlatAdam:
                 p.grad = flat_g[off:off + k].view_as(p.data)
                 ops.manage_param(p)                           # every raw update of p goes through step() below
                 self._owned.add(p.data_ptr())
+                self._ids.add(id(p))
+                p.register_post_accumulate_grad_hook(functional._touch)     # gradients that arrive through autograd
+                segs.append((id(p), off, off + k))
                 off += k
-            self.groups.append(dict(params=params, lr=g["lr"], p=flat_p, g=flat_g,
-                                    m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p)))
+            grp = dict(params=params, lr=g["lr"], initial_lr=g["lr"], p=flat_p, g=flat_g, segs=segs)
+            for name in self.STATE:
+                grp[name] = torch.zeros_like(flat_p)
+            self.groups.append(grp)
 
     @property
     def param_groups(self):            # lr schedulers poke group['lr']
@@ -54,11 +71,104 @@ class FlatAdam:
                 g["g"].zero_()
         self._maybe_dirty = True                   # a backward pass follows
 
+    def mark_all_touched(self):
+        """Treat every parameter as having a gradient (callers that fill the flat gradient buffers themselves)."""
+        self._fn._TOUCHED |= self._ids
+
+    def _runs(self, g):
+        """[lo, hi, step] over contiguous parameters that received a gradient and share a step count."""
+        touched, pstep, runs = self._fn._TOUCHED, self._pstep, []
+        for pid, lo, hi in g["segs"]:
+            if pid not in touched:
+                continue
+            n = pstep[pid] = pstep.get(pid, 0) + 1
+            if runs and runs[-1][1] == lo and runs[-1][2] == n:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi, n])
+        return runs
+
+    def _launch(self, g, lo, hi, n):
+        raise NotImplementedError
+
     def step(self):
         self.step_count += 1
         for g in self.groups:
-            ops.adam_step(g["p"], g["g"], g["m"], g["v"], g["lr"], self.betas, self.eps, self.weight_decay,
-                          self.step_count, zero_grad=self.fused_zero)
+            for lo, hi, n in self._runs(g):
+                self._launch(g, lo, hi, n)
+        self._fn._TOUCHED -= self._ids
         ops.refresh_views(self._owned)             # cached compute-dtype / transposed weight views: one launch
         if self.fused_zero:
             self._maybe_dirty = False
+
+    # -- checkpointing (the reference stores optimizer.state_dict() under 'optimizer' / 'ppo_optimizer', train_MuRCL.py:326-327)
+    def state_dict(self):
+        return {"kind": type(self).__name__, "step_count": self.step_count,
+                "groups": [dict(lr=g["lr"], initial_lr=g["initial_lr"], steps=[self._pstep.get(pid, 0) for pid, _, _ in g["segs"]],
+                                **{name: g[name].detach().cpu() for name in self.STATE}) for g in self.groups]}
+
+    def load_state_dict(self, sd):
+        if sd.get("kind") != type(self).__name__ or len(sd["groups"]) != len(self.groups):
+            raise ValueError("optimizer state does not match this optimizer")
+        self.step_count = int(sd["step_count"])
+        for g, s in zip(self.groups, sd["groups"]):
+            g["lr"], g["initial_lr"] = s["lr"], s["initial_lr"]
+            for (pid, _, _), n in zip(g["segs"], s["steps"]):
+                self._pstep[pid] = int(n)
+            for name in self.STATE:
+                g[name].copy_(s[name])
+
+
+class FlatAdam(_FlatOptimizer):
+    STATE = ("m", "v")
+
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True, fused_zero=True):
+        self.betas, self.eps = betas, eps
+        super().__init__(param_groups, weight_decay, direct_grad, fused_zero)
+
+    def _launch(self, g, lo, hi, n):
+        ops.adam_step(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], self.betas, self.eps,
+                      self.weight_decay, n, zero_grad=self.fused_zero)
+
+
+class FlatSGD(_FlatOptimizer):
+    """torch.optim.SGD(params, momentum, nesterov, weight_decay), dampening 0 (train_MuRCL.py:158-163)."""
+    STATE = ("buf",)
+
+    def __init__(self, param_groups, momentum=0.0, nesterov=False, weight_decay=0.0, direct_grad=True, fused_zero=True):
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        self.momentum, self.nesterov = momentum, nesterov
+        super().__init__(param_groups, weight_decay, direct_grad, fused_zero)
+
+    def _launch(self, g, lo, hi, n):
+        ops.sgd_step(g["p"][lo:hi], g["g"][lo:hi], g["buf"][lo:hi], g["lr"], self.momentum, self.nesterov,
+                     self.weight_decay, first=(n == 1), zero_grad=self.fused_zero)
+
+
+class LRSchedule:
+    """The two schedulers the reference's scripts offer (train_MuRCL.py:174-186), in closed form over the number of
+    ``step()`` calls: StepLR(step_size=7, gamma=0.1) and CosineAnnealingLR(T_max, eta_min=1e-6)."""
+
+    def __init__(self, optimizer, name, T_max=None, eta_min=1e-6, step_size=7, gamma=0.1):
+        if name not in ("StepLR", "CosineAnnealingLR"):
+            raise ValueError(name)
+        self.opt, self.name, self.T_max, self.eta_min, self.step_size, self.gamma, self.k = \
+            optimizer, name, T_max, eta_min, step_size, gamma, 0
+
+    def lr_at(self, base, k):
+        if self.name == "StepLR":
+            return base * self.gamma ** (k // self.step_size)
+        return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * k / max(1, self.T_max))) / 2
+
+    def step(self):
+        self.k += 1
+        for g in self.opt.param_groups:
+            g["lr"] = self.lr_at(g["initial_lr"], self.k)
+
+
+def make_scheduler(optimizer, name, epochs, warmup=0):
+    """get_scheduler (train_MuRCL.py:174-186): None for no optimizer / no name."""
+    if optimizer is None or name is None:
+        return None
+    return LRSchedule(optimizer, name, T_max=epochs - warmup)

@@ -14,7 +14,6 @@ or ``--synthetic B,N`` for random bags.
 import gc
 import argparse
 import json
-import math
 import os
 from pathlib import Path
 
@@ -24,7 +23,9 @@ import torch.distributed as dist
 
 from murcl_amd import dist as mdist, ops
 from murcl_amd.models import abmil, cl, clam, rlmil
-from murcl_amd.optim import FlatAdam
+from murcl_amd.optim import FlatAdam, FlatSGD, make_scheduler
+from murcl_amd.utils import general as G
+from murcl_amd.utils import checkpoint as C
 from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, subbag_views
 from murcl_amd.utils.losses import NT_Xent
 
@@ -48,6 +49,7 @@ def create_model(args, dim_patch, device):
     if args.train_stage in (2, 3):
         if args.checkpoint is None:
             args.checkpoint = str(Path(args.save_dir).parent / f"stage_{args.train_stage - 1}" / "model_best.pth.tar")
+        assert Path(args.checkpoint).exists(), f"{args.checkpoint} is not exist!"
         ckpt = torch.load(args.checkpoint, map_location="cpu")
         model.load_state_dict(ckpt["model_state_dict"])
         fc.load_state_dict(ckpt["fc"])
@@ -62,43 +64,52 @@ def create_model(args, dim_patch, device):
 
 
 def get_optimizer(args, model, fc):
-    """train_MuRCL.py:154-171 (Adam only; one flat buffer per parameter group)."""
+    """train_MuRCL.py:154-171: Adam or SGD over two parameter groups (one flat buffer each); none in stage 2, which
+    trains the sampler only and runs for ``--ppo_epochs``."""
     if args.train_stage == 2:
         args.epochs = args.ppo_epochs
         return None
-    if args.optimizer != "Adam":
-        raise NotImplementedError("murcl_amd ships the fused Adam only")
-    return FlatAdam([{"params": list(model.parameters()), "lr": args.backbone_lr},
-                     {"params": list(fc.parameters()), "lr": args.fc_lr}],
-                    betas=(args.beta1, args.beta2), weight_decay=args.wdecay)
+    groups = [{"params": list(model.parameters()), "lr": args.backbone_lr},
+              {"params": list(fc.parameters()), "lr": args.fc_lr}]
+    if args.optimizer == "SGD":
+        return FlatSGD(groups, momentum=args.momentum, nesterov=args.nesterov, weight_decay=args.wdecay)
+    if args.optimizer == "Adam":
+        return FlatAdam(groups, betas=(args.beta1, args.beta2), weight_decay=args.wdecay)
+    raise NotImplementedError(args.optimizer)
 
 
-def cosine_lr(base, epoch, epochs, warmup, eta_min=1e-6):
-    """CosineAnnealingLR(T_max=epochs-warmup, eta_min=1e-6) stepped after epoch >= warmup (train_MuRCL.py:181,312-313)."""
-    t = max(0, epoch + 1 - warmup)
-    return eta_min + (base - eta_min) * (1 + math.cos(math.pi * t / max(1, epochs - warmup))) / 2
+def get_scheduler(args, optimizer):
+    """train_MuRCL.py:174-186."""
+    return make_scheduler(optimizer, args.scheduler, args.epochs, args.warmup)
 
 
 # ------------------------------------------------------------------------------------------------ the hot step
 def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world=1, injected=None):
     """One optimizer step on a batch of raw bags (train_MuRCL.py:233-304).
 
-    ``pack``: BagPack of this rank's bags.  ``injected`` (tests): dict with 'actions' [T][2][B,K] and
-    'draws' [T][2](lambda [B,1], perm [B]) replacing the random draws.  Returns (loss, losses[T], rewards[T-1])."""
+    ``pack``: BagPack of this rank's bags.  ``injected`` (tests): dict replacing the random draws - 'actions'
+    [T][2][B,K] (stage 1: every patch step; stages 2/3: only entry 0 is read, the later window positions come from the
+    PPO sampler), 'draws' [T][2](lambda [B,1], perm [B]), and for stages 2/3 'eps' [T-1][2][B,K] ~ N(0,1), the sampler's
+    Gaussian noise (rlmil.py:85-86); an optional 'trace' list receives the action tensors of every patch step.
+    Returns (loss, losses[T], rewards[T-1])."""
     B, K, dev = pack.B, pack.K, pack.feats.device
     dt_ = model.encoder.compute_dtype
     train_enc = args.train_stage != 2
-    if (args.train_stage == 1 or injected is not None) and args.T > 1 and train_enc \
-            and not getattr(args, "no_batched_stage1", False):
+    if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
     losses, rewards, sim_last, states = [], [], None, None
     for t in range(args.T):
-        if injected is not None:
-            acts = [a.to(dev) for a in injected["actions"][t]]
-        elif t == 0 or args.train_stage == 1:
-            acts = [torch.rand((B, K), device=dev) for _ in range(2)]                        # :235,256-258
+        if t == 0 or args.train_stage == 1:
+            if injected is not None:
+                acts = [a.to(dev) for a in injected["actions"][t]]
+            else:
+                acts = [torch.rand((B, K), device=dev) for _ in range(2)]                    # :235,256-258
         else:
-            acts = [ppo.select_action(s, m, restart_batch=(t == 1)) for s, m in zip(states, memory_list)]   # :259-265
+            eps = [None, None] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
+            acts = [ppo.select_action(s, m, restart_batch=(t == 1), eps=e)
+                    for s, m, e in zip(states, memory_list, eps)]                            # :259-265
+        if injected is not None and injected.get("trace") is not None:
+            injected["trace"].append([a.detach().clone() for a in acts])
         views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=dt_,
                                 draws=None if injected is None else injected["draws"][t])   # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
@@ -126,6 +137,8 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     else:
         for m in memory_list:
             ppo.update(m)                                                                    # :297-298
+    if injected is not None and injected.get("trace") is not None and memory_list[0].logprobs:
+        injected["trace"].append({"logprobs": [torch.stack(m.logprobs, 0) for m in memory_list]})
     for m in memory_list:
         m.clear_memory()
     return loss.detach(), [l.detach() for l in losses], rewards
@@ -225,128 +238,191 @@ class WSIWithCluster:
 
 
 # ------------------------------------------------------------------------------------------------ driver
-def train(args, train_set, model, fc, ppo, criterion, optimizer, device, rank, world):
+def shard_slides(n_slides, rank, world):
+    """Slides of rank ``rank``: ``rank, rank + world, ...`` trimmed so that EVERY rank owns the same number
+    (``n_slides // world``) - ranks then run the same number of steps per epoch and their collectives pair up."""
+    per = n_slides // world
+    if per == 0:
+        raise ValueError(f"{n_slides} slides cannot be sharded over {world} ranks")
+    return list(range(rank, per * world, world))
+
+
+def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, device, rank, world, tb_writer=None):
+    """Epoch loop of train_MuRCL.py:189-343: per-epoch shuffle, batches of ``--batch_size`` bags (per rank), the hot step,
+    scheduler after ``--warmup`` epochs, best-of-run by the epoch average of the last patch step's loss (:315-321),
+    checkpoint every epoch (:322-330), csv logs, early stop."""
+    save_dir = Path(args.save_dir)
     (model.eval(), fc.eval()) if args.train_stage == 2 else (model.train(), fc.train())
     memory_list = [rlmil.Memory(), rlmil.Memory()]
-    best = float("inf")
-    base_lrs = [g["lr"] for g in optimizer.param_groups] if optimizer else []
+    best = G.Best("min")
+    losses_csv = results_csv = None
+    if rank == 0:
+        losses_csv = G.CsvLog(save_dir / "losses.csv", ["epoch", "train", "best_epoch", "best_train"])
+        results_csv = G.CsvLog(save_dir / "results.csv", ["epoch", "final_epoch", "final_loss"])
+    early_stop = G.EarlyStop(args.patience) if args.patience is not None else None
+    mine = shard_slides(len(train_set), rank, world)
     store = None
     if not args.no_resident:
-        # this rank's slides, uploaded once and kept in HBM for the whole run (SURVEY 8(e),(f)): a batch is an index list
-        store = DeviceSlideStore.from_dataset(train_set, device, dtype=model.encoder.compute_dtype,
-                                              indices=range(rank, len(train_set), world))
+        # this rank's slides, uploaded once and kept in HBM for the whole run (SURVEY 8(e),(f)): a batch is an index list.
+        # (--preload asks the reference to keep the split in host memory; the resident store subsumes it.)
+        store = DeviceSlideStore.from_dataset(train_set, device, dtype=model.encoder.compute_dtype, indices=mine)
         if rank == 0:
             print(f"resident slide store: {len(store)} slides, {store.bytes() / 2 ** 30:.2f} GiB on {device}", flush=True)
+    steps_per_epoch = len(mine) * args.data_repeat // args.batch_size          # identical on every rank by construction
     gc.collect()
     gc.freeze()          # models/optimizer state are long-lived: keep full collections (tens of ms) out of the step loop
     for epoch in range(args.epochs):
-        last = float("nan")
+        last_step = []                                                        # loss of patch step T-1, one entry per batch
+        if rank == 0 and optimizer is not None:
+            print(f"Training Stage: {args.train_stage}, lr: " + ", ".join(f"group[{k}]: {g['lr']}" for k, g in enumerate(optimizer.param_groups)), flush=True)
         if store is not None:
             order = np.random.permutation(len(store))
-            draws = len(store) * args.data_repeat
-            for s in range(0, draws - args.batch_size + 1, args.batch_size):
+            for it in range(steps_per_epoch):
+                s = it * args.batch_size
                 pack = store.pack(order[np.arange(s, s + args.batch_size) % len(store)])
-                loss, _, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
-                last = loss.item()
+                _, ls, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
+                last_step.append(ls[-1])
         else:
             train_set.shuffle()
             feats, clusters = [], []
-            for data_idx in range(rank, len(train_set) * args.data_repeat, world):       # bags shard by WSI across ranks
-                feat, cluster, *_ = train_set[data_idx % len(train_set)]
+            for it in range(steps_per_epoch * args.batch_size):                # bags shard by WSI across ranks
+                feat, cluster, *_ = train_set[mine[it % len(mine)]]
                 feats.append(feat.to(device, non_blocking=True))
                 clusters.append(cluster)
                 if len(feats) == args.batch_size:
                     pack = BagPack.from_lists(feats, clusters)
-                    loss, _, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
-                    last = loss.item()
+                    _, ls, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
+                    last_step.append(ls[-1])
                     feats, clusters = [], []
-        if optimizer is not None and epoch >= args.warmup:
-            for g, b in zip(optimizer.param_groups, base_lrs):
-                g["lr"] = cosine_lr(b, epoch, args.epochs, args.warmup)
+        if scheduler is not None and epoch >= args.warmup:
+            scheduler.step()                                                   # :312-313
+        train_loss = torch.stack(last_step).mean().item() if last_step else float("nan")   # losses[-1].avg (:315)
+        if tb_writer is not None:
+            tb_writer.add_scalar("train/1.train_loss", train_loss, epoch)
         if rank == 0:
-            is_best = last < best
-            best = min(best, last)
-            state = {"epoch": epoch + 1, "model_state_dict": model.state_dict(), "fc": fc.state_dict(),
-                     "optimizer": None, "ppo_optimizer": None, "policy": ppo.policy.state_dict() if ppo else None}
-            os.makedirs(args.save_dir, exist_ok=True)
-            torch.save(state, os.path.join(args.save_dir, "checkpoint.pth.tar"))          # utils/general.py:207-211
-            if is_best:
-                torch.save(state, os.path.join(args.save_dir, "model_best.pth.tar"))
-            print(f"epoch {epoch + 1}: loss {last:.4f} best {best:.4f}", flush=True)
+            is_best = best.compare(train_loss, epoch + 1, inplace=True)
+            C.save_checkpoint(C.make_state(epoch + 1, model, fc, optimizer, ppo), is_best, str(save_dir))      # :322-330
+            losses_csv.write_row([epoch + 1, train_loss, best.epoch, best.best])
+            results_csv.write_row([epoch + 1, best.epoch, best.best])
+            print(f"Loss: {train_loss:.4f}, Best: {best.best:.4f}, Epoch: {best.epoch:2}\n", flush=True)
+        else:
+            best.compare(train_loss, epoch + 1, inplace=True)                  # every rank sees the same (global) loss
+        if early_stop is not None:
+            early_stop.update(best.best)
+            if early_stop.is_stop():
+                break
+    if tb_writer is not None:
+        tb_writer.close()
 
 
 def build_parser():
-    p = argparse.ArgumentParser()       # flag names and defaults: train_MuRCL.py:386-477
-    p.add_argument("--data_csv", type=str, default=None)
-    p.add_argument("--data_split_json", type=str, default=None)
-    p.add_argument("--synthetic", type=str, default=None, help="n_slides,n_patches (random bags instead of --data_csv)")
+    """Every flag of the reference's parser with its type, default, choices and action (train_MuRCL.py:386-477; pinned by
+    tests/golden/g13_cli_flags.json), plus the murcl_amd extras at the end."""
+    p = argparse.ArgumentParser()
+    # Data
+    p.add_argument("--dataset", type=str, default="Camelyon16", help="dataset name (only names the result directory)")
+    p.add_argument("--data_csv", type=str, default="", help="the .csv filepath used")
+    p.add_argument("--data_split_json", type=str, default="/path/to/data_split.json")
+    p.add_argument("--preload", action="store_true", default=False,
+                   help="preload the patch features (murcl_amd keeps the split resident in HBM either way)")
+    p.add_argument("--data_repeat", type=int, default=10)
     p.add_argument("--feat_size", default=1024, type=int)
+    # Train
+    p.add_argument("--train_stage", default=1, type=int, help="1: warm-up, 2: learn to select patches with RL, 3: joint")
     p.add_argument("--T", default=6, type=int)
-    p.add_argument("--no_batched_stage1", action="store_true",
-                   help="stage 1: run the aggregator once per patch step like the reference instead of once per optimizer step")
-    p.add_argument("--no_resident", action="store_true",
-                   help="re-read and upload every slide on every step like the reference, instead of keeping the split in HBM")
-    p.add_argument("--train_stage", default=1, type=int)
-    p.add_argument("--checkpoint", default=None, type=str)
-    p.add_argument("--optimizer", default="Adam", type=str)
-    p.add_argument("--epochs", default=100, type=int)
-    p.add_argument("--ppo_epochs", default=30, type=int)
-    p.add_argument("--batch_size", default=128, type=int)
+    p.add_argument("--optimizer", type=str, default="Adam", choices=["Adam", "SGD"])
+    p.add_argument("--scheduler", type=str, default=None, choices=[None, "StepLR", "CosineAnnealingLR"])
+    p.add_argument("--batch_size", type=int, default=128, help="bags per step (per GPU when launched with several ranks)")
+    p.add_argument("--epochs", type=int, default=100)
+    p.add_argument("--ppo_epochs", type=int, default=30)
     p.add_argument("--backbone_lr", default=1e-4, type=float)
-    p.add_argument("--fc_lr", default=5e-5, type=float)
-    p.add_argument("--beta1", default=0.9, type=float)
-    p.add_argument("--beta2", default=0.999, type=float)
-    p.add_argument("--wdecay", default=1e-5, type=float)
+    p.add_argument("--fc_lr", default=1e-4, type=float)
+    p.add_argument("--temperature", type=float, default=1.0)
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--nesterov", action="store_true", default=True)
+    p.add_argument("--beta1", type=float, default=0.9)
+    p.add_argument("--beta2", type=float, default=0.999)
     p.add_argument("--warmup", default=0, type=float)
-    p.add_argument("--temperature", default=1.0, type=float)
-    p.add_argument("--alpha", default=0.9, type=float)
-    p.add_argument("--projection_dim", default=128, type=int)
-    p.add_argument("--arch", default="ABMIL", type=str, choices=["ABMIL", "CLAM_SB"])
-    p.add_argument("--model_dim", default=512, type=int)
-    p.add_argument("--policy_hidden_dim", default=512, type=int)
+    p.add_argument("--wdecay", default=1e-5, type=float)
+    p.add_argument("--patience", type=int, default=None)
+    # Architecture
+    p.add_argument("--checkpoint", default=None, type=str)
+    p.add_argument("--arch", default="CLAM_SB", type=str, choices=["ABMIL", "CLAM_SB"])
+    p.add_argument("--alpha", type=float, default=0.9)
+    p.add_argument("--projection_dim", type=int, default=128)
+    p.add_argument("--model_dim", type=int, default=512)
+    p.add_argument("--policy_hidden_dim", type=int, default=512)
     p.add_argument("--policy_conv", action="store_true", default=False)
-    p.add_argument("--action_std", default=0.5, type=float)
-    p.add_argument("--ppo_lr", default=1e-5, type=float)
-    p.add_argument("--ppo_gamma", default=0.1, type=float)
-    p.add_argument("--K_epochs", default=3, type=int)
-    p.add_argument("--feature_num", default=512, type=int)
-    p.add_argument("--fc_hidden_dim", default=1024, type=int)
+    p.add_argument("--action_std", type=float, default=0.5)
+    p.add_argument("--ppo_lr", type=float, default=0.00001)
+    p.add_argument("--ppo_gamma", type=float, default=0.1)
+    p.add_argument("--K_epochs", type=int, default=3)
+    p.add_argument("--feature_num", type=int, default=512)
+    p.add_argument("--fc_hidden_dim", type=int, default=1024)
     p.add_argument("--fc_rnn", action="store_true", default=True)
-    p.add_argument("--D", default=128, type=int)
-    p.add_argument("--dropout", default=0.0, type=float)
-    p.add_argument("--size_arg", default="small", type=str)
-    p.add_argument("--k_sample", default=8, type=int)
-    p.add_argument("--data_repeat", default=10, type=int)
-    p.add_argument("--num_clusters", default=10, type=int)
-    p.add_argument("--save_dir", default="./results/murcl_amd/stage_1", type=str)
-    p.add_argument("--seed", default=985, type=int)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--D", type=int, default=128)
+    p.add_argument("--dropout", type=float, default=0.0)
+    p.add_argument("--size_arg", type=str, default="small", choices=["small", "big"])
+    p.add_argument("--k_sample", type=int, default=8)
+    p.add_argument("--use_tensorboard", action="store_true", default=False)
+    # Save
+    p.add_argument("--base_save_dir", type=str, default="./results")
+    p.add_argument("--save_dir", type=str, default=None)
+    p.add_argument("--save_dir_flag", type=str, default=None)
+    p.add_argument("--exist_ok", action="store_true", default=False)
+    # Global
+    p.add_argument("--device", default="3", help="cuda device, i.e. 0 or 0,1,2,3 (one process per GPU takes its LOCAL_RANK-th entry)")
+    p.add_argument("--seed", type=int, default=985)
+    # murcl_amd extras
+    x = p.add_argument_group("murcl_amd")
+    x.add_argument("--synthetic", type=str, default=None, help="n_slides,n_patches (random bags instead of --data_csv)")
+    x.add_argument("--num_clusters", default=10, type=int, help="clusters per slide for --synthetic (else read from the csv name)")
+    x.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="storage type of patch-level tensors")
+    x.add_argument("--no_batched_stage1", action="store_true",
+                   help="stage 1: run the aggregator once per patch step like the reference instead of once per optimizer step")
+    x.add_argument("--no_resident", action="store_true",
+                   help="re-read and upload every slide on every step like the reference, instead of keeping the split in HBM")
     return p
 
 
-def main(argv=None):
-    args = build_parser().parse_args(argv)
+def run(args):
+    """train_MuRCL.py:346-383."""
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    G.init_seeds(args.seed)
+    if rank == 0:
+        G.prepare_run_dir(args, "MuRCL")
+    device = G.pick_device(args.device, local)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    torch.manual_seed(args.seed)
-    np.random.seed(args.seed)
+        box = [args.save_dir]
+        dist.broadcast_object_list(box, src=0)                 # rank 0 resolved (and possibly incremented) the directory
+        args.save_dir = box[0]
     if args.synthetic:
         n, N = (int(v) for v in args.synthetic.split(","))
         train_set = SyntheticWSI(n, N, 512, args.num_clusters, args.seed)
     else:
-        idx = json.load(open(args.data_split_json))["train"] if args.data_split_json else None
+        idx = json.load(open(args.data_split_json))["train"]
         train_set = WSIWithCluster(args.data_csv, idx, shuffle=True)
         args.num_clusters = train_set.num_clusters
+    args.num_data = len(train_set) * args.data_repeat
+    args.eval_step = int(args.num_data / args.batch_size)
     model, fc, ppo = create_model(args, train_set.patch_dim, device)
-    optimizer = get_optimizer(args, model, fc)
     criterion = NT_Xent(args.batch_size, args.temperature)
-    train(args, train_set, model, fc, ppo, criterion, optimizer, device, rank, world)
+    optimizer = get_optimizer(args, model, fc)
+    scheduler = get_scheduler(args, optimizer)
+    tb_writer = None
+    if rank == 0:
+        G.dump_args(args, args.save_dir)
+        tb_writer = G.tensorboard_writer(args.save_dir, args.use_tensorboard)
+    train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, device, rank, world, tb_writer)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    run(build_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

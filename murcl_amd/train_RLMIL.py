@@ -6,6 +6,8 @@ max-instance term), reward = increase of the true-class soft-max confidence, los
 PPO.update.  Unlike the reference (whose CLAM / DSMIL bodies only run at batch_size 1) the
 bodies here are batched over bags.  Model construction follows train_RLMIL.py:90-116.
 """
+import os
+
 import torch
 
 from murcl_amd.functional import CrossEntropyFn
@@ -201,17 +203,30 @@ class BestPick:
 
 
 def fit(arch, model, fc, ppo, optimizer, stores, epochs, batch_size, T=6, feat_size=1024, train_stage=1, bag_weight=0.7,
-        picked_method="score", rng=None, log=print):
+        picked_method="score", rng=None, log=print, scheduler=None, warmup=0, patience=None, save_dir=None, save_model=False,
+        tb_writer=None):
     """Epoch loop of the reference's ``train`` (train_RLMIL.py:856-975) on HBM-resident splits.
-    ``stores`` = (train, valid, test) DeviceSlideStore with labels.  Returns (best state dict, final test tuple, pred frame)."""
+    ``stores`` = (train, valid, test) DeviceSlideStore with labels.  Returns (best state dict, final test tuple, pred frame).
+    With ``save_dir``: the reference's csv logs (losses / accs / aucs / results) and, with ``save_model``, the best
+    checkpoint as soon as it improves (:938-941)."""
     import copy
     import numpy as np
     from murcl_amd.models import rlmil as _rl
+    from murcl_amd.utils import checkpoint as C, general as G
     rng = rng or np.random.default_rng(985)
     train, valid, test = stores
     dev = train.feats.device
     lab = [torch.from_numpy(s.labels).to(dev) for s in stores]
     memory, pick, best, final, frame = _rl.Memory(), BestPick(picked_method), None, None, None
+    logs = None
+    if save_dir is not None:
+        hdr = ["epoch", "train", "valid", "test", "best_train", "best_valid", "best_test"]
+        logs = {k: G.CsvLog(os.path.join(save_dir, f"{k}.csv"), hdr) for k in ("losses", "accs", "aucs")}
+        logs["results"] = G.CsvLog(os.path.join(save_dir, "results.csv"),
+                                   ["epoch", "final_epoch", "final_loss", "final_acc", "final_auc", "final_precision",
+                                    "final_recall", "final_f1_score"])
+    bests = {k: [G.Best("min" if k == "losses" else "max") for _ in range(3)] for k in ("losses", "accs", "aucs")}
+    early_stop = G.EarlyStop(patience) if patience is not None else None
     for epoch in range(epochs):
         order, tl, outs, ys = rng.permutation(len(train)), [], [], []
         for s in range(0, len(order) - batch_size + 1, batch_size):
@@ -221,18 +236,37 @@ def fit(arch, model, fc, ppo, optimizer, stores, epochs, batch_size, T=6, feat_s
             tl.append(loss)
             outs.append(logits)
             ys.append(lab[0][torch.from_numpy(sel).to(dev)])
+        if scheduler is not None and epoch >= warmup:
+            scheduler.step()                                                            # :400-401,598-599,789-790
         tr_loss = torch.stack(tl).mean().item()
-        tr_acc = (torch.cat(outs).argmax(1) == torch.cat(ys)).float().mean().item()
+        tr = (tr_loss, *get_metrics(torch.cat(outs), torch.cat(ys)))
         v = evaluate_split(arch, model, fc, ppo, memory, valid.pack(range(len(valid))), lab[1], T, feat_size, train_stage, bag_weight)
         te = evaluate_split(arch, model, fc, ppo, memory, test.pack(range(len(test))), lab[2], T, feat_size, train_stage, bag_weight)
+        if tb_writer is not None:
+            tb_writer.add_scalar("train/1.train_loss", tr_loss, epoch)
+            tb_writer.add_scalar("test/2.test_loss", v[0], epoch)
         if pick.update(epoch + 1, *v[:6]):
             final = (epoch + 1, *te[:6])
             frame = predictions_frame(te[6], te[7], test.case_ids)
-            best = {"epoch": epoch + 1, "model_state_dict": copy.deepcopy(model.state_dict()), "fc": copy.deepcopy(fc.state_dict()),
-                    "optimizer": None, "ppo_optimizer": None,
-                    "policy": copy.deepcopy(ppo.policy.state_dict()) if ppo else None}       # keys of :930-937
-        log(f"epoch {epoch + 1}: train loss {tr_loss:.4f} acc {tr_acc:.4f} | valid loss {v[0]:.4f} acc {v[1]:.4f} auc {v[2]:.4f} | "
+            best = copy.deepcopy(C.make_state(epoch + 1, model, fc, optimizer, ppo))         # keys of :930-937
+            if save_model and save_dir is not None:
+                C.save_checkpoint(best, True, save_dir)
+        for k, col in (("losses", 0), ("accs", 1), ("aucs", 2)):
+            vals = (tr[col], v[col], te[col])
+            for b_, x in zip(bests[k], vals):
+                b_.compare(x, epoch + 1, inplace=True)
+            if logs is not None:
+                logs[k].write_row([epoch + 1, *vals, *[(b_.best, b_.epoch) for b_ in bests[k]]])
+        if logs is not None:
+            logs["results"].write_row([epoch + 1, final[0], *te[:6]])
+        log(f"epoch {epoch + 1}: train loss {tr_loss:.4f} acc {tr[1]:.4f} | valid loss {v[0]:.4f} acc {v[1]:.4f} auc {v[2]:.4f} | "
             f"test loss {te[0]:.4f} acc {te[1]:.4f} auc {te[2]:.4f} | final epoch {final[0]}")
+        if early_stop is not None:
+            early_stop.update((bests["losses"][1].best, bests["accs"][1].best, bests["aucs"][1].best))    # :971-974
+            if early_stop.is_stop():
+                break
+    if tb_writer is not None:
+        tb_writer.close()
     return best, final, frame
 
 
@@ -259,50 +293,106 @@ class _SyntheticLabelled:
 
 
 def build_parser():
+    """Every flag of the reference's parser with its type, default, choices and action (train_RLMIL.py:1060-1153; pinned by
+    tests/golden/g13_cli_flags.json), plus the murcl_amd extras at the end."""
     import argparse
-    p = argparse.ArgumentParser("murcl_amd RL-MIL (supervised) on MI355X")
-    p.add_argument("--arch", default="ABMIL", choices=["ABMIL", "CLAM_SB", "DSMIL"])
-    p.add_argument("--data_csv", type=str, default=None)
-    p.add_argument("--data_split_json", type=str, default=None)
-    p.add_argument("--synthetic", type=str, default=None, help="n_train,n_valid,n_test,n_patches (random labelled slides)")
-    p.add_argument("--num_classes", default=2, type=int)
-    p.add_argument("--num_clusters", default=10, type=int)
+    p = argparse.ArgumentParser()
+    # Data
+    p.add_argument("--dataset", type=str, default="Camelyon16", help="dataset name (only names the result directory)")
+    p.add_argument("--data_csv", type=str, default="")
+    p.add_argument("--data_split_json", type=str, default="/path/to/data_split.json")
+    p.add_argument("--train_data", type=str, default="train", choices=["train", "train_sub_per10"])
+    p.add_argument("--preload", action="store_true", default=False,
+                   help="preload the patch features (murcl_amd keeps the splits resident in HBM either way)")
     p.add_argument("--feat_size", default=1024, type=int)
-    p.add_argument("--T", default=6, type=int)
-    p.add_argument("--train_method", default="scratch", choices=["scratch", "finetune", "linear"])
+    # Train
+    p.add_argument("--train_method", type=str, default="scratch", choices=["scratch", "finetune", "linear"])
     p.add_argument("--train_stage", default=1, type=int)
-    p.add_argument("--checkpoint_pretrained", default=None, type=str)
+    p.add_argument("--T", default=6, type=int)
     p.add_argument("--checkpoint_stage", default=None, type=str)
-    p.add_argument("--epochs", default=40, type=int)
-    p.add_argument("--batch_size", default=16, type=int)
+    p.add_argument("--checkpoint_pretrained", type=str, default=None)
+    p.add_argument("--optimizer", type=str, default="Adam", choices=["Adam", "SGD"])
+    p.add_argument("--scheduler", type=str, default=None, choices=[None, "StepLR", "CosineAnnealingLR"])
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--epochs", type=int, default=40)
+    p.add_argument("--ppo_epochs", type=int, default=10)
     p.add_argument("--backbone_lr", default=1e-4, type=float)
     p.add_argument("--fc_lr", default=1e-4, type=float)
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--nesterov", action="store_true", default=True)
+    p.add_argument("--beta1", type=float, default=0.9)
+    p.add_argument("--beta2", type=float, default=0.999)
+    p.add_argument("--warmup", default=0, type=float)
     p.add_argument("--wdecay", default=1e-5, type=float)
-    p.add_argument("--bag_weight", default=0.7, type=float)
-    p.add_argument("--picked_method", default="score", choices=["acc", "loss", "auc", "score"])
-    p.add_argument("--model_dim", default=512, type=int)
-    p.add_argument("--policy_hidden_dim", default=512, type=int)
-    p.add_argument("--action_std", default=0.5, type=float)
-    p.add_argument("--ppo_lr", default=1e-5, type=float)
-    p.add_argument("--ppo_gamma", default=0.1, type=float)
-    p.add_argument("--K_epochs", default=3, type=int)
-    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
-    p.add_argument("--seed", default=985, type=int)
-    p.add_argument("--save_dir", default="./results/murcl_amd_rlmil/stage_1", type=str)
+    p.add_argument("--picked_method", type=str, default="score")
+    p.add_argument("--patience", type=int, default=None)
+    # Architecture
+    p.add_argument("--arch", default="CLAM_SB", type=str, choices=["ABMIL", "CLAM_SB", "DSMIL"])
+    p.add_argument("--num_classes", type=int, default=2)
+    p.add_argument("--model_dim", type=int, default=512)
+    p.add_argument("--policy_hidden_dim", type=int, default=512)
+    p.add_argument("--policy_conv", action="store_true", default=False)
+    p.add_argument("--action_std", type=float, default=0.5)
+    p.add_argument("--ppo_lr", type=float, default=0.00001)
+    p.add_argument("--ppo_gamma", type=float, default=0.1)
+    p.add_argument("--K_epochs", type=int, default=3)
+    p.add_argument("--feature_num", type=int, default=512)
+    p.add_argument("--fc_hidden_dim", type=int, default=1024)
+    p.add_argument("--fc_rnn", action="store_true", default=True)
+    p.add_argument("--load_fc", action="store_true", default=False, help="accepted; the reference never reads it either")
+    p.add_argument("--L", type=int, default=512)
+    p.add_argument("--D", type=int, default=128)
+    p.add_argument("--dropout", type=float, default=0.0)
+    p.add_argument("--size_arg", type=str, default="small", choices=["small", "big"])
+    p.add_argument("--k_sample", type=int, default=8)
+    p.add_argument("--bag_weight", type=float, default=0.7)
+    p.add_argument("--loss", default="CrossEntropyLoss", type=str, choices=["CrossEntropyLoss"])
+    p.add_argument("--use_tensorboard", action="store_true", default=False)
+    # Save
+    p.add_argument("--base_save_dir", type=str, default="./results")
+    p.add_argument("--save_dir", type=str, default=None)
+    p.add_argument("--save_dir_flag", type=str, default=None)
+    p.add_argument("--exist_ok", action="store_true", default=False)
+    p.add_argument("--save_model", action="store_true", default=False)
+    # Global
+    p.add_argument("--device", default="2", help="cuda device, i.e. 0 or 0,1,2,3 (one process per GPU takes its LOCAL_RANK-th entry)")
+    p.add_argument("--seed", type=int, default=985)
+    # murcl_amd extras
+    x = p.add_argument_group("murcl_amd")
+    x.add_argument("--synthetic", type=str, default=None, help="n_train,n_valid,n_test,n_patches (random labelled slides)")
+    x.add_argument("--num_clusters", default=10, type=int, help="clusters per slide for --synthetic (else read from the csv name)")
+    x.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="storage type of patch-level tensors")
     return p
 
 
-def main(argv=None):
+def get_optimizer(args, model, fc):
+    """train_RLMIL.py:255-272 (frozen parameters of the linear protocol stay out of the flat buffers)."""
+    from murcl_amd.optim import FlatAdam, FlatSGD
+    if args.train_stage == 2:
+        args.epochs = args.ppo_epochs
+        return None
+    groups = [{"params": [p for p in model.parameters() if p.requires_grad], "lr": args.backbone_lr},
+              {"params": list(fc.parameters()), "lr": args.fc_lr}]
+    groups = [g for g in groups if g["params"]]
+    if args.optimizer == "SGD":
+        return FlatSGD(groups, momentum=args.momentum, nesterov=args.nesterov, weight_decay=args.wdecay)
+    if args.optimizer == "Adam":
+        return FlatAdam(groups, betas=(args.beta1, args.beta2), weight_decay=args.wdecay)
+    raise NotImplementedError(args.optimizer)
+
+
+def run(args):
+    """train_RLMIL.py:1005-1057."""
     import json
-    import os
     import numpy as np
-    from murcl_amd.optim import FlatAdam
-    from murcl_amd.utils import checkpoint as C
+    import pandas as pd
+    from murcl_amd.optim import make_scheduler
+    from murcl_amd.utils import checkpoint as C, general as G
     from murcl_amd.utils.datasets import DeviceSlideStore
-    args = build_parser().parse_args(argv)
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    G.init_seeds(args.seed)
+    G.prepare_run_dir(args, "RLMIL")
+    dev = G.pick_device(args.device, int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
-    torch.manual_seed(args.seed)
     dt_ = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.synthetic:
         ntr, nva, nte, N = (int(v) for v in args.synthetic.split(","))
@@ -310,32 +400,59 @@ def main(argv=None):
     else:
         from murcl_amd.train_MuRCL import WSIWithCluster
         split = json.load(open(args.data_split_json))
-        sets = [WSIWithCluster(args.data_csv, split[k]) for k in ("train", "valid", "test")]
+        sets = [WSIWithCluster(args.data_csv, split[k]) for k in (args.train_data, "valid", "test")]
         args.num_clusters = sets[0].num_clusters
     stores = tuple(DeviceSlideStore.from_dataset(s, dev, dtype=dt_) for s in sets)
-    model, fc = create_model(args.arch, stores[0].patch_dim, args.num_classes, dev, model_dim=args.model_dim, dtype=dt_)
+    dim_patch = stores[0].patch_dim
+    # train_RLMIL.py:88-116: ABMIL takes --L, the head's input width follows the aggregator's output
+    model, fc = create_model(args.arch, dim_patch, args.num_classes, dev, model_dim=args.L, D=args.D, size_arg=args.size_arg,
+                             k_sample=args.k_sample, fc_hidden_dim=args.fc_hidden_dim, dtype=dt_)
+    args.feature_num = fc.feature_num
     ppo = None
     if args.train_stage in (2, 3):
-        ppo = rlmil.PPO(stores[0].patch_dim, args.model_dim, args.policy_hidden_dim, False, action_std=args.action_std, lr=args.ppo_lr,
+        if args.policy_conv:
+            raise NotImplementedError("--policy_conv is never enabled by the reference's launch scripts and is not built")
+        ppo = rlmil.PPO(dim_patch, args.model_dim, args.policy_hidden_dim, False, action_std=args.action_std, lr=args.ppo_lr,
                         gamma=args.ppo_gamma, K_epochs=args.K_epochs, action_size=args.num_clusters)
-        stage_ck = args.checkpoint_stage or C.stage_checkpoint_path(args.save_dir, args.train_stage)
-        C.load_stage(model, fc, ppo, stage_ck, policy_ckpt=args.checkpoint_pretrained if args.train_stage == 2 else None)
-        if args.train_stage == 3 and args.train_method == "linear":
-            C.freeze_backbone(model)
+        if args.checkpoint_stage is None:
+            args.checkpoint_stage = C.stage_checkpoint_path(args.save_dir, args.train_stage)
+        assert os.path.exists(args.checkpoint_stage), f"{args.checkpoint_stage} is not exist!"
+        if args.train_stage == 2:
+            # scratch: a fresh sampler (:199-214); finetune / linear: the pre-trained one (:150-163)
+            pretrained = args.train_method in ("finetune", "linear")
+            if pretrained:
+                assert args.checkpoint_pretrained is not None and os.path.exists(args.checkpoint_pretrained), \
+                    f"{args.checkpoint_pretrained} is not exists!"
+            C.load_stage(model, fc, ppo, args.checkpoint_stage, policy_ckpt=args.checkpoint_pretrained if pretrained else None,
+                         load_policy=pretrained)
+        else:
+            C.load_stage(model, fc, ppo, args.checkpoint_stage)
+            if args.train_method == "linear":
+                C.freeze_backbone(model)
+    elif args.train_stage != 1:
+        raise ValueError(args.train_stage)
     elif args.train_method in ("finetune", "linear"):
-        print("pre-trained encoder loaded; starting from scratch:", C.load_pretrained(model, args.checkpoint_pretrained, args.train_method))
-    optimizer = None
-    if args.train_stage != 2:
-        groups = [{"params": [p for p in model.parameters() if p.requires_grad], "lr": args.backbone_lr},
-                  {"params": list(fc.parameters()), "lr": args.fc_lr}]
-        optimizer = FlatAdam([g for g in groups if g["params"]], betas=(0.9, 0.999), weight_decay=args.wdecay)
+        assert args.checkpoint_pretrained is not None and os.path.exists(args.checkpoint_pretrained), \
+            f"{args.checkpoint_pretrained} is not exists!"
+        print("msg_model missing_keys:", C.load_pretrained(model, args.checkpoint_pretrained, args.train_method))
+    optimizer = get_optimizer(args, model, fc)
+    scheduler = make_scheduler(optimizer, args.scheduler, args.epochs, args.warmup)
+    G.dump_args(args, args.save_dir)
+    tb_writer = G.tensorboard_writer(args.save_dir, args.use_tensorboard)
     best, final, frame = fit(args.arch, model, fc, ppo, optimizer, stores, args.epochs, args.batch_size, args.T, args.feat_size,
-                             args.train_stage, args.bag_weight, args.picked_method, np.random.default_rng(args.seed))
-    os.makedirs(args.save_dir, exist_ok=True)
-    C.save_checkpoint(best, True, args.save_dir)
-    frame.to_csv(os.path.join(args.save_dir, "pred.csv"))
+                             args.train_stage, args.bag_weight, args.picked_method, np.random.default_rng(args.seed),
+                             scheduler=scheduler, warmup=args.warmup, patience=args.patience, save_dir=args.save_dir,
+                             save_model=args.save_model, tb_writer=tb_writer)
+    frame.to_csv(os.path.join(args.save_dir, "pred.csv"))                               # :1051-1056
+    res = pd.DataFrame(columns=["loss", "acc", "auc", "precision", "recall", "f1_score"])
+    res.loc[f"seed{args.seed}"] = [float(v) for v in final[1:]]
+    res.to_csv(os.path.join(args.save_dir, "final_res.csv"))
     print("final (epoch, loss, acc, auc, precision, recall, f1):", tuple(round(float(v), 4) for v in final))
     return final
+
+
+def main(argv=None):
+    return run(build_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -58,12 +58,14 @@ def stage_checkpoint_path(save_dir, train_stage):
     return str(Path(save_dir).parent / f"stage_{train_stage - 1}" / "model_best.pth.tar")
 
 
-def load_stage(model, fc, ppo, ckpt, policy_ckpt=None):
-    """Aggregator + head from ``ckpt``; the policy (both copies) from ``policy_ckpt`` (default: the same file)."""
+def load_stage(model, fc, ppo, ckpt, policy_ckpt=None, load_policy=True):
+    """Aggregator + head from ``ckpt``; the policy (both copies) from ``policy_ckpt`` (default: the same file).
+    ``load_policy=False``: keep the freshly initialised sampler - stage 2 of training from scratch, whose stage-1
+    checkpoint has no policy yet (train_RLMIL.py:199-214, train_MuRCL.py:104-122)."""
     ck = _read(ckpt)
     model.load_state_dict(ck["model_state_dict"])
     fc.load_state_dict(ck["fc"])
-    if ppo is not None:
+    if ppo is not None and load_policy:
         pol = _read(policy_ckpt)["policy"] if policy_ckpt is not None else ck.get("policy")
         if pol is None:
             raise KeyError("checkpoint holds no 'policy' (stage 2 takes it from the pre-training checkpoint)")
@@ -75,8 +77,11 @@ def load_stage(model, fc, ppo, ckpt, policy_ckpt=None):
 def make_state(epoch, model, fc, optimizer=None, ppo=None):
     """The reference's checkpoint dictionary; tensors on the host so that either side can ``torch.load`` it anywhere."""
     cpu = lambda sd: {k: v.detach().cpu() for k, v in sd.items()}  # noqa: E731
-    return {"epoch": epoch, "model_state_dict": cpu(model.state_dict()), "fc": cpu(fc.state_dict()), "optimizer": None,
-            "ppo_optimizer": None, "policy": cpu(ppo.policy.state_dict()) if ppo is not None else None}
+    ppo_opt = getattr(ppo, "optimizer", None) if ppo is not None else None
+    return {"epoch": epoch, "model_state_dict": cpu(model.state_dict()), "fc": cpu(fc.state_dict()),
+            "optimizer": optimizer.state_dict() if optimizer is not None else None,           # train_MuRCL.py:326-327
+            "ppo_optimizer": ppo_opt.state_dict() if ppo_opt is not None else None,
+            "policy": cpu(ppo.policy.state_dict()) if ppo is not None else None}
 
 
 def save_checkpoint(state, is_best, checkpoint, filename="checkpoint.pth.tar"):

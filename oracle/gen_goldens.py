@@ -366,6 +366,183 @@ def g10_eval():
     np.savez(os.path.join(OUT, "g10_eval.npz"), **res)
 
 
+def _ref_train_murcl():
+    """The reference's train_MuRCL module (stand-in for the absent tensorboard import, SURVEY 8(c) shim 2)."""
+    import types
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.modules.setdefault("tensorboard", types.ModuleType("tensorboard"))
+    sys.path.insert(0, REF)
+    try:
+        import train_MuRCL as r_tm
+    finally:
+        sys.path.pop(0)
+    return r_tm
+
+
+from oracle.recipes import G12, g12_inputs, window_margin as _window_margin  # noqa: E402
+
+
+def g12_rl_step():
+    """BASELINE config 4's body: ONE batch through the reference's own ``train()`` (train_MuRCL.py:189-343) at
+    train_stage 2 and 3, T = 3 and 6, with torch.rand / torch.randperm / MultivariateNormal.sample replaced by the
+    injected draws.  Stored: the sampler's actions and log-probs per patch step, the patch ids those actions select,
+    per-step losses, rewards, and fingerprints of the policy (stage 2) / model + head (stage 3) after the update."""
+    import argparse
+    import tempfile
+    from oracle import select_oracle as S
+    r_tm = _ref_train_murcl()
+    c = G12
+    seed, B, K, fs, std = c["seed"], c["B"], c["K"], c["fs"], c["std"]
+    MVN = torch.distributions.multivariate_normal.MultivariateNormal
+    res = {}
+    for Tn in (3, 6):
+        Ns, feats, cls, inj = g12_inputs(Tn)
+        for stage in (2, 3):
+            tag = f"T{Tn}.s{stage}"
+            enc = r_abmil.ABMIL(c["d"], L=512, D=128, dim_out=128)
+            enc.load_state_dict(P.to_torch(P.abmil(seed)))
+            model = torch.nn.DataParallel(r_cl.CL(enc, projection_dim=128, n_features=512))      # train_MuRCL.py:145 (no GPU: pass-through)
+            fc = r_rlmil.Full_layer(512, 1024, True, 128)
+            fc.load_state_dict(P.to_torch(P.full_layer(seed)))
+            ppo = r_rlmil.PPO(c["d"], 512, 512, False, action_std=std, lr=c["ppo_lr"], gamma=c["gamma"], K_epochs=c["K_epochs"],
+                              action_size=K)
+            sd = P.to_torch(P.actor_critic(seed, 512, 512, K))
+            ppo.policy.load_state_dict(sd)
+            ppo.policy_old.load_state_dict(sd)
+            optimizer = None if stage == 2 else torch.optim.Adam(
+                [{"params": model.parameters(), "lr": c["lr"]}, {"params": fc.parameters(), "lr": c["lr"]}],
+                betas=(0.9, 0.999), weight_decay=c["wd"])                                          # train_MuRCL.py:165
+            args = argparse.Namespace(T=Tn, device="cpu", num_clusters=K, feat_size=fs, train_stage=stage, batch_size=B,
+                                      epochs=1, num_data=B, eval_step=1, alpha=c["alpha"], patience=None, warmup=0)
+
+            class _Set:
+                def shuffle(self):
+                    pass
+
+                def __len__(self):
+                    return B
+
+                def __getitem__(self, i):
+                    return T(feats[i]), cls[i], 0, f"case{i}"
+
+            act_draws = iter([T(a) for a in inj["actions"][0]])
+            u_draws = iter([T(inj["u"][t][v]) for t in range(Tn) for v in range(2)])
+            perm_draws = iter([T(inj["perm"][t][v]) for t in range(Tn) for v in range(2)])
+            eps_draws = iter([T(inj["eps"][t][v]) for t in range(Tn - 1) for v in range(2)])
+
+            def fake_rand(*a, **k):
+                size = tuple(k["size"]) if "size" in k else (tuple(a[0]) if isinstance(a[0], (tuple, list)) else tuple(a))
+                return next(act_draws) if size == (B, K) else next(u_draws)
+
+            snaps, step_losses = [], []
+            inner = r_losses.NT_Xent(B, 1.0)
+
+            class _Crit(torch.nn.Module):
+                def forward(self, zi, zj):
+                    l = inner(zi, zj)
+                    step_losses.append(l.item())
+                    return l
+
+            def snap_clear(self):
+                snaps.append({f: [x.detach().clone() for x in getattr(self, f)] for f in ("actions", "states", "logprobs", "rewards")})
+                for f in ("actions", "states", "logprobs", "rewards", "is_terminals", "hidden"):
+                    del getattr(self, f)[:]
+
+            real_to = torch.Tensor.to
+
+            def to_ignoring_ordinals(self, *a, **k):              # `s.to(0)` (train_MuRCL.py:262,265): device 0 == here
+                return self if (a and isinstance(a[0], int)) else real_to(self, *a, **k)
+
+            with tempfile.TemporaryDirectory() as tmp, \
+                    mock.patch("torch.rand", fake_rand), mock.patch("torch.randperm", lambda *a, **k: next(perm_draws)), \
+                    mock.patch.object(MVN, "sample", lambda self, *a, **k: self.loc + std * next(eps_draws)), \
+                    mock.patch.object(r_rlmil.Memory, "clear_memory", snap_clear), \
+                    mock.patch.object(torch.Tensor, "to", to_ignoring_ordinals):
+                r_tm.train(args, _Set(), model, fc, ppo, _Crit(), optimizer, None, None, tmp)
+            assert len(snaps) == 2 and len(step_losses) == Tn
+            for it in (act_draws, u_draws, perm_draws, eps_draws):
+                assert next(it, None) is None, "an injected draw was not consumed"
+            res[f"{tag}.losses"] = np.array(step_losses)
+            res[f"{tag}.rewards"] = torch.cat(snaps[0]["rewards"], 0).numpy()                     # [T-1, B]
+            assert all(torch.equal(a, b) for a, b in zip(snaps[0]["rewards"], snaps[1]["rewards"]))
+            margin = 1.0
+            for v in range(2):
+                res[f"{tag}.actions.{v}"] = torch.stack(snaps[v]["actions"], 0).numpy()            # [T-1, B, K]
+                res[f"{tag}.logp.{v}"] = torch.stack(snaps[v]["logprobs"], 0).numpy()
+                res[f"{tag}.states.{v}"] = np.stack([_summ(s_) for s_ in snaps[v]["states"]])
+                for t in range(Tn - 1):
+                    a_t = snaps[v]["actions"][t].numpy()
+                    _, ids = S.get_feats(feats, cls, a_t, fs)
+                    res[f"{tag}.ids.{t + 1}.{v}"] = np.array([i + [-1] * (fs - len(i)) for i in ids], dtype=np.int32)
+                    margin = min(margin, min(_window_margin(Ns[b], cls[b], a_t[b], fs) for b in range(B)))
+            assert margin > 2e-3, f"golden window margin too small ({margin}): pick another seed"
+            res[f"{tag}.window_margin"] = np.float64(margin)
+            pre = P.to_torch(P.actor_critic(seed, 512, 512, K))
+            for k, v in ppo.policy.state_dict().items():
+                res[f"{tag}.policy.{k}"] = _summ(v)
+                res[f"{tag}.policy_delta.{k}"] = _summ(v - pre[k])
+            if stage == 3:
+                pre_m, pre_f = P.to_torch(P.abmil(seed)), P.to_torch(P.full_layer(seed))
+                for k, v in model.module.encoder.state_dict().items():
+                    res[f"{tag}.model.{k}"] = _summ(v)
+                    res[f"{tag}.model_delta.{k}"] = _summ(v - pre_m[k])
+                for k, v in fc.state_dict().items():
+                    res[f"{tag}.fc.{k}"] = _summ(v)
+                    res[f"{tag}.fc_delta.{k}"] = _summ(v - pre_f[k])
+    np.savez(os.path.join(OUT, "g12_rl_step.npz"), **res)
+
+
+
+def _reference_parser(mod, globals_needed):
+    """The ArgumentParser that the reference's ``main()`` builds (it is local to main): run main() with parse_args
+    replaced by a hook that keeps the parser and stops."""
+    import argparse
+    for k, v in globals_needed.items():
+        setattr(mod, k, v)
+    box = {}
+
+    class _Stop(Exception):
+        pass
+
+    def grab(self, *a, **k):
+        box["p"] = self
+        raise _Stop
+
+    with mock.patch.object(argparse.ArgumentParser, "parse_args", grab):
+        try:
+            mod.main()
+        except _Stop:
+            pass
+    return box["p"]
+
+
+def g13_cli_flags():
+    """Drop-in CLI: every flag of the reference's two entry scripts - option strings, dest, type, default,
+    choices, action - and the namespaces its parsers produce for the invocations of runs/*.sh."""
+    import json
+    from oracle.recipes import run_script_argvs
+    r_tm = _ref_train_murcl()
+    r_tr, _ = _ref_train_rlmil()
+    parsers = {"train_MuRCL": _reference_parser(r_tm, {"MODELS": ["ABMIL", "CLAM_SB"]}),
+               "train_RLMIL": _reference_parser(r_tr, {"MODELS": ["ABMIL", "CLAM_SB", "DSMIL"], "LOSSES": ["CrossEntropyLoss"]})}
+    man = {"flags": {}, "runs": {}}
+    for name, p in parsers.items():
+        rows = []
+        for a in p._actions:
+            if a.dest == "help":
+                continue
+            rows.append({"options": list(a.option_strings), "dest": a.dest, "type": getattr(a.type, "__name__", None),
+                         "default": a.default, "choices": list(a.choices) if a.choices is not None else None,
+                         "action": type(a).__name__, "nargs": a.nargs})
+        man["flags"][name] = rows
+    for script, (entry, argvs) in run_script_argvs().items():
+        man["runs"][script] = {"entry": entry, "namespaces": [vars(parsers[entry].parse_args(av)) for av in argvs]}
+    with open(os.path.join(OUT, "g13_cli_flags.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+
+
 def _exchange_checkpoints(mods):
     """Real files across the boundary: the product's writer -> the reference's modules (strict), the reference's state
     dicts -> the product's loader, and the reference's fine-tune key loop (train_RLMIL.py:121-130) vs the product's."""
@@ -433,7 +610,7 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

@@ -1,0 +1,73 @@
+"""The multi-GPU branch of the MuRCL batch step, executed:
+
+* one rank on RCCL ("nccl" backend, group initialised before any other GPU call in a child process): the
+  all-gathered NT-Xent + flat gradient all-reduce + PPO collectives path gives the single-process step's numbers;
+* two ranks sharing this box's one GPU over gloo (RCCL refuses two ranks per device): B/2 bags per rank with the real
+  kernels == one process with B bags - same global loss, and after the update the ranks hold ONE policy (stage 2) /
+  ONE model (stages 1, 3), bit-identical across ranks.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CHILD = os.path.join(HERE, "_dist_child.py")
+
+
+def _spawn(mode, rank, world, port, workdir):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.Popen([sys.executable, CHILD, mode, str(rank), str(world), str(port), str(workdir)], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _wait(procs, timeout=600):
+    for p in procs:
+        out, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, out[-4000:]
+
+
+def _moved(a, b):
+    return (a - b).abs().max().item()
+
+
+def test_single_rank_rccl_path_equals_single_process_step(tmp_path):
+    _wait([_spawn("nccl1", 0, 1, 29640 + os.getpid() % 300, tmp_path)])
+    res = torch.load(tmp_path / "nccl1_0.pt")
+    for stage in (1, 2, 3):
+        a, b = res[f"s{stage}.plain"], res[f"s{stage}.dist"]
+        np.testing.assert_allclose(b["losses"].numpy(), a["losses"].numpy(), rtol=2e-6)
+        np.testing.assert_allclose(b["rewards"].numpy(), a["rewards"].numpy(), rtol=1e-3, atol=1e-6)
+        for part in ("model", "fc") + (("policy",) if stage > 1 else ()):
+            for k in a[part]:
+                np.testing.assert_allclose(b[part][k].numpy(), a[part][k].numpy(), rtol=1e-5, atol=2e-6, err_msg=f"s{stage} {part}.{k}")
+
+
+def test_two_ranks_equal_one_process_and_stay_identical(tmp_path):
+    port = 29950 + os.getpid() % 300
+    _wait([_spawn("gloo2", r, 2, port, tmp_path) for r in range(2)])
+    _wait([_spawn("single", 0, 1, 0, tmp_path)])
+    r0, r1, one = (torch.load(tmp_path / f) for f in ("gloo2_0.pt", "gloo2_1.pt", "single_0.pt"))
+    from oracle import params as P
+    pre = {"model": {"encoder." + k: v for k, v in P.to_torch(P.abmil(41)).items()}, "fc": P.to_torch(P.full_layer(41)),
+           "policy": P.to_torch(P.actor_critic(41, 512, 512, 6))}
+    for stage in (1, 2, 3):
+        a, b, w = r0[f"s{stage}"], r1[f"s{stage}"], one[f"s{stage}"]
+        # every rank evaluates the GLOBAL contrastive loss (all-gathered embeddings)
+        np.testing.assert_allclose(a["losses"].numpy(), w["losses"].numpy(), rtol=1e-5)
+        assert torch.equal(a["losses"], b["losses"])
+        np.testing.assert_allclose(torch.cat([a["rewards"], b["rewards"]], 1).numpy(), w["rewards"].numpy(), rtol=2e-3, atol=2e-6)
+        trained = ("policy",) if stage == 2 else ("model", "fc")
+        for part in trained:
+            for k in a[part]:
+                assert torch.equal(a[part][k], b[part][k]), f"stage {stage}: ranks diverged on {part}.{k}"
+                mv = _moved(w[part][k], pre[part][k])
+                if mv == 0.0:
+                    assert torch.equal(a[part][k], pre[part][k]), k          # parameters no gradient reaches (ABMIL.fc)
+                    continue
+                assert _moved(a[part][k], w[part][k]) <= 3e-2 * mv, f"stage {stage} {part}.{k}"

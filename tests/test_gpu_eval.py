@@ -102,9 +102,12 @@ def test_rlmil_script_end_to_end_with_finetune_from_a_pretraining_checkpoint(tmp
     save = tmp_path / "ft" / "stage_1"
     final = train_RLMIL.main(["--arch", "ABMIL", "--synthetic", "12,4,6,300", "--num_clusters", "4", "--feat_size", "64", "--T", "2",
                               "--epochs", "2", "--batch_size", "4", "--train_method", "finetune",
-                              "--checkpoint_pretrained", str(tmp_path / "pre" / "model_best.pth.tar"), "--save_dir", str(save)])
+                              "--checkpoint_pretrained", str(tmp_path / "pre" / "model_best.pth.tar"), "--save_dir", str(save),
+                              "--device", "0", "--save_model", "--scheduler", "CosineAnnealingLR"])
     out = capsys.readouterr().out
-    assert "starting from scratch: ['fc.weight', 'fc.bias']" in out and "epoch 2:" in out
+    assert "msg_model missing_keys: ['fc.weight', 'fc.bias']" in out and "epoch 2:" in out
+    for f in ("args.yaml", "losses.csv", "accs.csv", "aucs.csv", "results.csv", "final_res.csv"):      # train_RLMIL.py:868-878,1033,1056
+        assert (save / f).exists(), f
     df = pd.read_csv(save / "pred.csv", index_col="case_id")
     assert len(df) == 6 and list(df.columns) == ["label", "pred", "correct", "prob0", "prob1"]
     ck = torch.load(save / "model_best.pth.tar", map_location="cpu")
@@ -138,3 +141,21 @@ def test_whole_slide_attention_scores_for_heatmaps(N, dtype):
         # what a heat-map needs: the ranking of the hottest patches survives bf16
         top = set(want[0].topk(50).indices.tolist())
         assert len(top & set(s[0].cpu().topk(200).indices.tolist())) >= 45
+
+
+def test_scratch_three_stage_pipeline_runs_end_to_end(tmp_path, capsys):
+    """``--train_method scratch`` (the parser default) through stages 1 -> 2 -> 3 with the default
+    ``../stage_{k-1}/model_best.pth.tar`` hand-off: stage 2 starts from a FRESH sampler (train_RLMIL.py:199-214; the
+    stage-1 checkpoint holds no policy), stage 3 loads the stage-2 policy."""
+    from murcl_amd import train_RLMIL
+    common = ["--arch", "ABMIL", "--synthetic", "8,4,4,200", "--num_clusters", "4", "--feat_size", "64", "--T", "3",
+              "--batch_size", "4", "--device", "0", "--save_model", "--exist_ok", "--train_method", "scratch"]
+    for stage in (1, 2, 3):
+        train_RLMIL.main(common + ["--train_stage", str(stage), "--epochs", "1", "--ppo_epochs", "1",
+                                   "--save_dir", str(tmp_path / "run" / f"stage_{stage}")])
+        ck = torch.load(tmp_path / "run" / f"stage_{stage}" / "model_best.pth.tar", map_location="cpu")
+        assert (ck["policy"] is None) == (stage == 1)
+        assert (ck["optimizer"] is None) == (stage == 2) and (ck["ppo_optimizer"] is None) == (stage == 1)
+    s2 = torch.load(tmp_path / "run" / "stage_2" / "model_best.pth.tar", map_location="cpu")
+    s1 = torch.load(tmp_path / "run" / "stage_1" / "model_best.pth.tar", map_location="cpu")
+    assert all(torch.equal(s1["model_state_dict"][k], s2["model_state_dict"][k]) for k in s1["model_state_dict"])   # stage 2 trains the sampler only

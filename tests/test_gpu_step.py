@@ -13,7 +13,7 @@ T = torch.from_numpy
 
 def _args(**kw):
     from murcl_amd.train_MuRCL import build_parser
-    a = build_parser().parse_args([])
+    a = build_parser().parse_args(["--arch", "ABMIL"])             # (the reference's default arch is CLAM_SB)
     for k, v in kw.items():
         setattr(a, k, v)
     return a
@@ -146,13 +146,17 @@ def test_train_script_runs_from_the_resident_store_and_from_per_step_uploads(tmp
     from murcl_amd import train_MuRCL
     save = tmp_path / ("res" if resident else "stream") / "stage_1"
     argv = ["--synthetic", "6,300", "--batch_size", "3", "--feat_size", "64", "--T", "2", "--epochs", "2", "--data_repeat", "2",
-            "--num_clusters", "4", "--dtype", "f32", "--save_dir", str(save)] + ([] if resident else ["--no_resident"])
+            "--num_clusters", "4", "--dtype", "f32", "--arch", "ABMIL", "--device", "0", "--scheduler", "CosineAnnealingLR",
+            "--patience", "10", "--save_dir", str(save)] + ([] if resident else ["--no_resident"])
     train_MuRCL.main(argv)
     out = capsys.readouterr().out
     assert ("resident slide store: 6 slides" in out) == resident
-    assert "epoch 2: loss" in out
+    assert out.count("Loss: ") == 2 and "Epoch:" in out
+    for f in ("args.yaml", "losses.csv", "results.csv", "checkpoint.pth.tar"):                 # train_MuRCL.py:196-199,330,375
+        assert (save / f).exists(), f
     ck = torch.load(save / "model_best.pth.tar", map_location="cpu")
     assert {"epoch", "model_state_dict", "fc", "optimizer", "ppo_optimizer", "policy"} <= set(ck)
+    assert ck["optimizer"]["kind"] == "FlatAdam" and ck["optimizer"]["step_count"] >= 4        # Adam state is saved (:326)
     assert "encoder.encoder.0.weight" in ck["model_state_dict"] and "rnn.weight_ih_l0" in ck["fc"]
     assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values())
 

@@ -230,3 +230,58 @@ def test_g9_full_layer_interleaved_hidden(golden):
             z, hidden = O.full_layer_step(p, x, None if t == 0 else hidden)
             np.testing.assert_allclose(z.numpy(), g[f"z.{t}.{v}"], rtol=1e-4, atol=2e-6)
             np.testing.assert_allclose(hidden.numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------ G12: BASELINE config 4's body (PPO sampler in the loop)
+def _fp(x):
+    return _summ(x if torch.is_tensor(x) else torch.as_tensor(x))
+
+
+def _close_summ(got, want, rtol, scale=None, msg=""):
+    """Fingerprints (norm, max, first 32 values): norm/max relative, values absolute to the tensor's max."""
+    scale = want[1] if scale is None else scale
+    np.testing.assert_allclose(got[:2], want[:2], rtol=rtol, atol=rtol * scale, err_msg=msg)
+    np.testing.assert_allclose(got[2:], want[2:], rtol=rtol, atol=rtol * scale, err_msg=msg)
+
+
+@pytest.mark.parametrize("Tn", [3, 6])
+@pytest.mark.parametrize("stage", [2, 3])
+def test_g12_rl_step_oracle_vs_reference_train_loop(golden, Tn, stage):
+    """oracle/step_oracle.pretrain_step_rl == one batch of the reference's own train() at stage 2 / 3 (same injected draws):
+    sampler actions + log-probs, selected patch ids (bit-exact), per-step losses, rewards, updated policy / model."""
+    from oracle import step_oracle as SO
+    from oracle.recipes import G12, g12_inputs
+    g, c = golden("g12_rl_step"), G12
+    tag = f"T{Tn}.s{stage}"
+    Ns, feats, cls, inj = g12_inputs(Tn)
+    mp, fp, pp = _leaf(P.abmil(c["seed"])), _leaf(P.full_layer(c["seed"])), P.to_torch(P.actor_critic(c["seed"], 512, 512, c["K"]))
+    r = SO.pretrain_step_rl(mp, fp, pp, feats, cls, inj, T=Tn, feat_size=c["fs"], stage=stage, action_std=c["std"],
+                            gamma=c["gamma"], K_epochs=c["K_epochs"], ppo_lr=c["ppo_lr"])
+    np.testing.assert_allclose([l.item() for l in r["losses"]], g[f"{tag}.losses"], rtol=2e-6)
+    np.testing.assert_allclose(torch.stack(r["rewards"]).numpy(), g[f"{tag}.rewards"], rtol=2e-3, atol=2e-7)
+    for v in range(2):
+        acts = torch.stack([r["actions"][t][v] for t in range(1, Tn)]).numpy()
+        np.testing.assert_allclose(acts, g[f"{tag}.actions.{v}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(torch.stack(r["memories"][v]["logprobs"]).numpy(), g[f"{tag}.logp.{v}"], rtol=1e-5, atol=1e-5)
+        for t in range(1, Tn):
+            ids = np.array([i + [-1] * (c["fs"] - len(i)) for i in r["ids"][t][v]], dtype=np.int32)
+            assert np.array_equal(ids, g[f"{tag}.ids.{t}.{v}"]), (t, v)
+    pre = P.to_torch(P.actor_critic(c["seed"], 512, 512, c["K"]))
+    for k, v in r["policy"].items():
+        want = g[f"{tag}.policy_delta.{k}"]
+        if stage == 3:
+            assert want[0] == 0.0 and torch.equal(v, pre[k])            # the joint stage never updates the sampler (:293-298)
+        else:
+            _close_summ(_fp(v.detach() - pre[k]), want, 2e-2, msg=k)
+            _close_summ(_fp(v.detach()), g[f"{tag}.policy.{k}"], 1e-4, msg=k)
+    if stage == 3:
+        r["loss"].backward()
+        for name, params, base, lr in (("model", mp, P.to_torch(P.abmil(c["seed"])), c["lr"]), ("fc", fp, P.to_torch(P.full_layer(c["seed"])), c["lr"])):
+            used = {k: v for k, v in params.items() if v.grad is not None}
+            new = O.adam_step({k: v.detach() for k, v in used.items()}, {k: v.grad for k, v in used.items()}, {}, lr, weight_decay=c["wd"])
+            for k in params:
+                want = g[f"{tag}.{name}_delta.{k}"]
+                if k not in used:                                       # e.g. ABMIL.fc: never applied (abmil.py:33) -> Adam skips it
+                    assert want[0] == 0.0, k
+                    continue
+                _close_summ(_fp(new[k] - base[k]), want, 3e-2, msg=k)
