@@ -72,9 +72,10 @@ class _GatheredNTXent(torch.autograd.Function):
         r0 = rank * 2 * bl
         ctx.save_for_backward(dz[r0:r0 + 2 * bl])
         ctx.bl, ctx.joint = bl, z_j is None
+        sim = sim[lo:hi]                                   # this rank's bags (the tensor that is returned must be the marked one)
         ctx.mark_non_differentiable(sim)
         ctx.set_materialize_grads(False)
-        return loss.reshape(()), sim[lo:hi]
+        return loss.reshape(()), sim
 
     @staticmethod
     def backward(ctx, dloss, _dsim):

@@ -81,6 +81,7 @@ def run_step(workdir, stage, lo, hi, dist_path):
             "eps": [[T(e).to(dev) for e in row] for row in inj["eps"]]}
     loss, losses, rewards = pretrain_step(args, model, fc, ppo, NT_Xent(hi - lo, 1.0), opt, pack,
                                           [rlmil.Memory(), rlmil.Memory()], world=2 if dist_path else 1, injected=dinj)
+    assert not any(r.requires_grad for r in rewards)
     out = {"losses": torch.stack(losses).cpu(), "rewards": torch.cat(rewards).cpu(),
            "model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
            "fc": {k: v.detach().cpu().clone() for k, v in fc.state_dict().items()}}

@@ -204,12 +204,14 @@ def test_flat_adam_refreshes_cached_weight_views_in_its_step():
     assert torch.equal(ta, a.weight.t()) and torch.equal(tb, b.weight.t())
     for step in range(2):
         a.weight.grad.fill_(1.0)
+        oa.mark_all_touched()                  # gradients written by hand, not by a backward pass
         b_before = b.weight.detach().clone()
         oa.step()
         assert torch.equal(ta, a.weight.detach().t()) and torch.equal(ca, a.weight.detach().bfloat16())   # refreshed in place
         assert ops.transposed(a.weight).data_ptr() == ta.data_ptr()
         assert ops.transposed(b.weight).data_ptr() == tb.data_ptr() and torch.equal(tb, b_before.t())
     b.weight.grad.fill_(-1.0)
+    ob.mark_all_touched()
     ob.step()
     assert torch.equal(ops.transposed(b.weight), b.weight.detach().t()) and not torch.equal(tb, b_before.t())
     with torch.no_grad():
