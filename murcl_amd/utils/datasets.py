@@ -148,16 +148,23 @@ def _gather(pack, idx, feat_size, out, lam=None, perm=None):
     return out
 
 
-_PACK_CACHE = {}
+_PACK_CACHE = []          # [(feat tensors, their versions, cluster lists, pack)] - at most one entry
 
 
 def _pack_for(feat_list, clusters_list):
-    key = (tuple(f.data_ptr() for f in feat_list), tuple(id(c) for c in clusters_list))
-    p = _PACK_CACHE.get(key)
-    if p is None:
+    """The BagPack of the reference-style (feat_list, clusters_list) pair, reused while a step calls ``get_feats`` on the
+    SAME objects (T x 2 times per batch).  The entry holds strong references to the keyed tensors and lists and is matched
+    by identity (+ tensor versions): addresses or ids recycled by the allocator for the next batch cannot alias it."""
+    if _PACK_CACHE:
+        feats, vers, cls, pack = _PACK_CACHE[0]
+        if (len(feats) == len(feat_list) and len(cls) == len(clusters_list)
+                and all(a is b for a, b in zip(feats, feat_list)) and all(a is b for a, b in zip(cls, clusters_list))
+                and vers == [f._version for f in feat_list]):
+            return pack
         _PACK_CACHE.clear()                      # one live batch at a time, like the reference's feat_list
-        p = _PACK_CACHE[key] = BagPack.from_lists(feat_list, clusters_list)
-    return p
+    pack = BagPack.from_lists(feat_list, clusters_list)
+    _PACK_CACHE.append((list(feat_list), [f._version for f in feat_list], list(clusters_list), pack))
+    return pack
 
 
 def get_feats(feat_list, clusters_list, action_sequence, feat_size=1024):
