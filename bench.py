@@ -80,48 +80,48 @@ def make_step(model, fc, opt, crit, views, world):
     return step
 
 
-def _cpu_step_timer(sample, n, d, threads, budget_s, max_steps=50):
-    """Time the CPU oracle's step (oracle/mil_oracle.py: the reference's ABMIL + Full_layer + NT-Xent view-pair step with
-    backward and Adam, fp32) on ``sample`` bags per view with ``threads`` torch threads: one untimed step, then timed
-    steps until ``budget_s`` is used (at least one)."""
-    from oracle import mil_oracle as O, params as P
-    torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    mp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(985)).items()}
-    fp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.full_layer(985)).items()}
-    xs = [torch.randn(sample, n, d).abs_() * 0.5 for _ in range(2)]
-    st_m, st_f = {}, {}
-
-    def one():
-        for p in list(mp.values()) + list(fp.values()):
-            p.grad = None
-        loss, *_ = O.pretrain_step(mp, fp, [xs], 1.0)
-        loss.backward()
-        gm = {k: v.grad for k, v in mp.items() if v.grad is not None}
-        gf = {k: v.grad for k, v in fp.items() if v.grad is not None}
-        with torch.no_grad():
-            newm = O.adam_step({k: mp[k].detach() for k in gm}, gm, st_m, 1e-4, weight_decay=1e-5)
-            newf = O.adam_step({k: fp[k].detach() for k in gf}, gf, st_f, 5e-5, weight_decay=1e-5)
-            for k, v in newm.items():
-                mp[k].copy_(v)
-            for k, v in newf.items():
-                fp[k].copy_(v)
-    t0 = time.time()
-    one()                                                   # untimed: allocator / thread-pool warm-up
-    first = time.time() - t0
-    t0, k = time.time(), 0
-    while k < 1 or (time.time() - t0 + first < budget_s and k < max_steps):
-        one()
-        k += 1
-    return (time.time() - t0) / k, k
-
-
 def cpu_baseline(bags, n, d, budget_s=14.0):
     """The CPU oracle (a port of the reference step) timed on this host beside the GPU number: with all
     cores on the FULL headline input (64 bags x 2 views), and with one thread - the reference's own setting
     (train_MuRCL.py:484) - on a bounded sample (a full single-thread step takes ~35 s; bags are independent through the
     aggregator, so bags/s is the comparable figure)."""
     import os as _os
+    from oracle import mil_oracle as O, params as P        # the checker, timed here as the CPU baseline - nowhere else
+
+    def _cpu_step_timer(sample, n, d, threads, budget_s, max_steps=50):
+        """Time the CPU oracle's step (oracle/mil_oracle.py: the reference's ABMIL + Full_layer + NT-Xent view-pair step with
+        backward and Adam, fp32) on ``sample`` bags per view with ``threads`` torch threads: one untimed step, then timed
+        steps until ``budget_s`` is used (at least one)."""
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        mp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(985)).items()}
+        fp = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.full_layer(985)).items()}
+        xs = [torch.randn(sample, n, d).abs_() * 0.5 for _ in range(2)]
+        st_m, st_f = {}, {}
+
+        def one():
+            for p in list(mp.values()) + list(fp.values()):
+                p.grad = None
+            loss, *_ = O.pretrain_step(mp, fp, [xs], 1.0)
+            loss.backward()
+            gm = {k: v.grad for k, v in mp.items() if v.grad is not None}
+            gf = {k: v.grad for k, v in fp.items() if v.grad is not None}
+            with torch.no_grad():
+                newm = O.adam_step({k: mp[k].detach() for k in gm}, gm, st_m, 1e-4, weight_decay=1e-5)
+                newf = O.adam_step({k: fp[k].detach() for k in gf}, gf, st_f, 5e-5, weight_decay=1e-5)
+                for k, v in newm.items():
+                    mp[k].copy_(v)
+                for k, v in newf.items():
+                    fp[k].copy_(v)
+        t0 = time.time()
+        one()                                                   # untimed: allocator / thread-pool warm-up
+        first = time.time() - t0
+        t0, k = time.time(), 0
+        while k < 1 or (time.time() - t0 + first < budget_s and k < max_steps):
+            one()
+            k += 1
+        return (time.time() - t0) / k, k
+
     cores = _os.cpu_count() or torch.get_num_threads()
     dt_all, k_all = _cpu_step_timer(bags, n, d, cores, budget_s)
     one_sample = max(2, bags // 8)
