@@ -189,6 +189,29 @@ int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, fl
                         int gh_bcast, murcl_stream_t stream);
 int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
                         float* dgh, float* dhprev, int B, int H, int gh_bcast, murcl_stream_t stream);
+/* the same; accumulate != 0: dhprev += dh * z (back-propagation through time, where dhprev already holds that step's own
+ * upstream gradient) */
+int murcl_gru_gates_bwd_into(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
+                             float* dgh, float* dhprev, int B, int H, int gh_bcast, int accumulate, murcl_stream_t stream);
+
+/* The PPO sampler as native launch sequences (models/rlmil.py:66-97 act, :99-127,169-181 evaluate + loss + backward):
+ * one call enqueues the whole chain of GEMM / GRU / head launches, so the host pays one call instead of one per launch
+ * (the rollouts are a few hundred rows: launch-bound).  params / grads: HOST arrays of 12 device pointers in
+ * ActorCritic.parameters() order (state_encoder.0.{weight,bias}, state_encoder.2.{weight,bias},
+ * gru.{weight_ih,weight_hh,bias_ih,bias_hh}_l0, actor.0.{weight,bias}, critic.0.{weight,bias}); S = state_dim, H = hidden
+ * (both multiples of 32), K = action_size <= 16.  Workspaces: *_workspace() bytes of f32.
+ * murcl_ppo_act: hidden_prev NULL = zeros (restart_batch); eps ~ N(0,1) [B,K]; writes hidden_new [B,H], action [B,K]
+ * (clamped to [0,1]), logp [B].
+ * murcl_ppo_epoch: states [T,B,S], actions [T,B,K], old_logp / returns [T,B]; parameter gradients are ADDED to grads[];
+ * the loss is a mean over n_total >= T*B rows (all ranks' rows: gradients carry 1/n_total); loss_out (may be NULL) [1]. */
+long murcl_ppo_act_workspace(int B, int S, int H);
+int murcl_ppo_act(const float* const* params, int S, int H, int K, const float* state, const float* hidden_prev,
+                  const float* eps, float std_, int B, float* hidden_new, float* action, float* logp, float* ws,
+                  murcl_stream_t stream);
+long murcl_ppo_epoch_workspace(int T, int B, int S, int H);
+int murcl_ppo_epoch(const float* const* params, float* const* grads, int S, int H, int K, const float* states,
+                    const float* actions, const float* old_logp, const float* returns, int T, int B, long n_total,
+                    float std_, float eps_clip, float entropy, float* ws, float* loss_out, murcl_stream_t stream);
 
 /* 1-bit ReLU' mask (x > 0) of an activation tensor x [M,N] in murcl_panel_gemm's bit-mask layout (M*N/8 bytes;
  * M % 32 == 0, N % 32 == 0), for layers whose forward did not emit it (clam.py:69 with a 1024-wide input). */

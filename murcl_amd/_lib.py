@@ -61,12 +61,18 @@ SIGNATURES = {
     "murcl_relu_bwd": [_P, _P, _P, _L, _P],
     "murcl_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "murcl_gru_gates_bwd_into": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "murcl_ppo_act_workspace": [_I, _I, _I],
+    "murcl_ppo_act": [_P, _I, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P],
+    "murcl_ppo_epoch_workspace": [_I, _I, _I, _I],
+    "murcl_ppo_epoch": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _L, _F, _F, _F, _P, _P, _P],
     "murcl_cast_batch": [_P, _I, _I, _P],
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L}
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L,
+            "murcl_ppo_epoch_workspace": _L}
 
 _lib = None
 

@@ -252,7 +252,7 @@ __global__ void gru_gates_fwd_kernel(const float* __restrict__ gi, const float* 
 __global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ gates,
                                      const float* __restrict__ gh, const float* __restrict__ hprev,
                                      float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dhprev,
-                                     int B, int H, int gh_bcast) {
+                                     int B, int H, int gh_bcast, int accumulate) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)B * H) return;
     const int b = (int)(idx / H), k = (int)(idx % H);
@@ -268,7 +268,7 @@ __global__ void gru_gates_bwd_kernel(const float* __restrict__ dh, const float* 
     float* c = dgh + (size_t)b * 3 * H;
     a[k] = dr; a[H + k] = dz; a[2 * H + k] = dn;
     c[k] = dr; c[H + k] = dz; c[2 * H + k] = dn * r;
-    if (dhprev) dhprev[idx] = d * z;
+    if (dhprev) dhprev[idx] = accumulate ? dhprev[idx] + d * z : d * z;
 }
 extern "C" int murcl_gru_gates_fwd(const float* gi, const float* gh, const float* hprev, float* hnew, float* gates,
                                    int B, int H, int gh_bcast, hipStream_t s) {
@@ -281,7 +281,15 @@ extern "C" int murcl_gru_gates_bwd(const float* dh, const float* gates, const fl
                                    float* dgh, float* dhprev, int B, int H, int gh_bcast, hipStream_t s) {
     const long n = (long)B * H;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H, gh_bcast);
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H, gh_bcast, 0);
+    return MURCL_CHECK_LAUNCH();
+}
+// the same with dhprev += dh * z when accumulate != 0 (backward through time: dhprev already holds the step's own upstream)
+extern "C" int murcl_gru_gates_bwd_into(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
+                                        float* dgh, float* dhprev, int B, int H, int gh_bcast, int accumulate, hipStream_t s) {
+    const long n = (long)B * H;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dh, gates, gh, hprev, dgi, dgh, dhprev, B, H, gh_bcast, accumulate);
     return MURCL_CHECK_LAUNCH();
 }
 

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __
                                                                  int k_per_split, int relu, int accumulate) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q4 = lane >> 4, r16 = lane & 15;
-    const int n0 = blockIdx.x * 32, m0 = wave * 32;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.z * 128 + wave * 32;       // blockIdx.z: 128-row chunks (M <= 1024)
     if (m0 >= M) return;
     const int kb = blockIdx.y * k_per_split, ke = min(K, kb + k_per_split);
     f32x4 acc[2][2];
@@ -310,8 +310,11 @@ __global__ void relu_inplace_kernel(float* x, long n) {
 
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s) {
-    const int slabs = (N + 31) / 32;
-    int splits = (384 + slabs - 1) / slabs;                 // ~1.5 workgroups per CU
+    const int slabs = (N + 31) / 32, chunks = (M + 127) / 128;
+    int splits = (384 + slabs * chunks - 1) / (slabs * chunks);         // ~1.5 workgroups per CU
+    // 64 or more single-writer workgroups: no K split - one launch instead of memset + atomics (+ a ReLU pass), and a
+    // result that does not depend on the order of float atomics
+    if (slabs * chunks >= 64) splits = 1;
     const int kmax = (K + 127) / 128;                       // at least one 128-k chunk per split
     if (splits > kmax) splits = kmax;
     if (splits < 1) splits = 1;
@@ -324,7 +327,7 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
         if (e != hipSuccess) return (int)e;
     }
     const bool relu = epi == EPI_BIAS_RELU;
-    hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(slabs, splits), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+    hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(slabs, splits, chunks), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
                        (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, kps, (int)(relu && direct),
                        (int)(accumulate && direct));
     int rc = MURCL_CHECK_LAUNCH();
@@ -349,7 +352,9 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
     if ((lda * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16 || (ldb * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16)
         return -1;
     if (accumulate && dtype_out != MURCL_DTYPE_F32) return -1;
-    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && M <= 128 && K % 16 == 0 && !colsum_ws &&
+    // bag-level / rollout-level f32 layers (a few hundred rows): 32-column slabs x K splits x 128-row chunks fill the chip;
+    // the 128 x 128 tile kernel would put e.g. [320 x 2048] x [512 x 2048]^T on 12 workgroups (86 us against ~15)
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && M <= 1024 && K % 16 == 0 && !colsum_ws &&
         (epilogue == EPI_NONE || epilogue == EPI_BIAS || (epilogue == EPI_BIAS_RELU && !accumulate && ldc == N)))
         return launch_skinny((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, epilogue, bias,
                              accumulate, stream);

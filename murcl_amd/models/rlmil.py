@@ -136,6 +136,23 @@ class ActorCritic(nn.Module):
         gh = ops.gemm_nt(hidden.contiguous(), g.weight_hh_l0, epi=ops.EPI_BIAS, bias=g.bias_hh_l0)
         return ops.gru_gates_fwd(gi, gh, hidden.contiguous())[0]
 
+    def _native_ok(self, S):
+        """Shapes the native launch sequences (csrc/ppo_seq.hip) cover: the reference's own (S = 512, H = 512, K = 10)."""
+        return (self.state_encoder[0].out_features == 2048 and S % 32 == 0 and self.hidden_state_dim % 32 == 0
+                and self.action_size <= 16 and self.state_encoder[0].weight.is_cuda)
+
+    def pointer_table(self, grads=False):
+        """ctypes table of this module's 12 parameter (or gradient) pointers, rebuilt when a tensor was re-seated."""
+        from .. import ops
+        ts = [p.grad if grads else p for p in self.parameters()]
+        key = (ts[0].data_ptr(), ts[-1].data_ptr())
+        slot = "_gtab" if grads else "_ptab"
+        cur = getattr(self, slot, None)
+        if cur is None or cur[0] != key:
+            cur = (key, ops.pointer_table(ts))
+            object.__setattr__(self, slot, cur)
+        return cur[1]
+
     def act(self, state_ini, memory, restart_batch=False, training=False, eps=None):
         """One policy step (rlmil.py:66-97).  ``eps`` ~ N(0,1) [B,K] may be injected (parity tests)."""
         from .. import ops
@@ -143,7 +160,19 @@ class ActorCritic(nn.Module):
             if restart_batch:
                 del memory.hidden[:]
                 memory.hidden.append(torch.zeros(1, state_ini.size(0), self.hidden_state_dim, device=state_ini.device))
-            h = self._trunk_no_grad(state_ini.flatten(1).float().contiguous(), memory.hidden[-1][0])
+            state = state_ini.flatten(1)
+            if training and state.is_cuda and self._native_ok(state.shape[1]):
+                # the whole step - encoder, GRU cell, actor head, sampling, log-prob - as one native launch sequence
+                if eps is None:
+                    eps = torch.randn((state.shape[0], self.action_size), device=state.device)
+                h, action, logp = ops.ppo_act(self.pointer_table(), state.shape[1], self.hidden_state_dim, self.action_size,
+                                              state.float(), None if restart_batch else memory.hidden[-1][0], eps, self.action_std)
+                memory.hidden.append(h.unsqueeze(0))
+                memory.states.append(state_ini)
+                memory.actions.append(action)
+                memory.logprobs.append(logp)
+                return action
+            h = self._trunk_no_grad(state.float().contiguous(), memory.hidden[-1][0])
             memory.hidden.append(h.unsqueeze(0))
             z = ops.gemm_nt(h, self.actor[0].weight, epi=ops.EPI_BIAS, bias=self.actor[0].bias)
             if eps is None:
@@ -257,9 +286,18 @@ class _HipPolicyKernels:
 
     @staticmethod
     def epoch_grads(ppo, states, actions, old_logp, returns, n_total):
+        from .. import ops
         pol = ppo.policy
-        logp, value, _ = pol.evaluate(states, actions)
         entropy = 0.5 * pol.action_size * (1.0 + math.log(2 * math.pi)) + pol.action_size * math.log(pol.action_std)
+        S = states[0].flatten(1).shape[1]
+        if pol._native_ok(S) and all(p.grad is not None and p.grad.is_contiguous() for p in pol.parameters()):
+            # evaluate() forward + loss + backward as ONE native launch sequence adding into the flat gradient buffer
+            ppo.optimizer.zero_grad()
+            ops.ppo_epoch(pol.pointer_table(), pol.pointer_table(grads=True), S, pol.hidden_state_dim, pol.action_size,
+                          states.flatten(2), actions, old_logp, returns, n_total, pol.action_std, ppo.eps_clip, entropy)
+            ppo.optimizer.mark_all_touched()
+            return
+        logp, value, _ = pol.evaluate(states, actions)
         loss = PPOLossFn.apply(logp.reshape(-1), old_logp.reshape(-1), value.reshape(-1), returns.reshape(-1),
                                ppo.eps_clip, entropy, n_total)
         ppo.optimizer.zero_grad()

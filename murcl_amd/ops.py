@@ -638,6 +638,41 @@ def policy_head_bwd(mu, act, dlogp, std):
     return dz
 
 
+def pointer_table(tensors):
+    """Host array of device pointers (the ``const float* const*`` arguments of the sequence entry points)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def ppo_act(ptable, S, H, K, state, hidden_prev, eps, std):
+    """One sampling step of the policy behind ONE native call (murcl_ppo_act: 6 launches).
+    state [B,S] f32, hidden_prev [B,H] or None (zeros), eps [B,K] -> (hidden_new [B,H], action [B,K], logp [B])."""
+    _need_cuda(state, eps)
+    state, eps = _c(state), _c(eps)
+    B, dev = state.shape[0], state.device
+    hnew = torch.empty((B, H), dtype=torch.float32, device=dev)
+    action = torch.empty((B, K), dtype=torch.float32, device=dev)
+    logp = torch.empty((B,), dtype=torch.float32, device=dev)
+    ws = torch.empty((_lib.lib().murcl_ppo_act_workspace(B, S, H) // 4,), dtype=torch.float32, device=dev)
+    check(_lib.lib().murcl_ppo_act(ptable, S, H, K, ptr(state), ptr(_c(hidden_prev)) if hidden_prev is not None else None,
+                                   ptr(eps), float(std), B, ptr(hnew), ptr(action), ptr(logp), ptr(ws), stream()), "ppo_act")
+    return hnew, action, logp
+
+
+def ppo_epoch(ptable, gtable, S, H, K, states, actions, old_logp, returns, n_total, std, eps_clip, entropy, want_loss=False):
+    """One K_epoch of PPO.update minus the optimizer step behind ONE native call (murcl_ppo_epoch): evaluate() forward,
+    loss, backward; parameter gradients are ADDED into the tensors behind ``gtable``."""
+    _need_cuda(states, actions)
+    states, actions, old_logp, returns = _c(states.float()), _c(actions.float()), _c(old_logp), _c(returns)
+    T_, B = states.shape[0], states.shape[1]
+    dev = states.device
+    ws = torch.empty((_lib.lib().murcl_ppo_epoch_workspace(T_, B, S, H) // 4,), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev) if want_loss else None
+    check(_lib.lib().murcl_ppo_epoch(ptable, gtable, S, H, K, ptr(states), ptr(actions), ptr(old_logp), ptr(returns), T_, B,
+                                     int(n_total), float(std), float(eps_clip), float(entropy), ptr(ws), ptr(loss), stream()),
+          "ppo_epoch")
+    return loss
+
+
 def ppo_returns(rewards, gamma):
     """rewards [T,B] f32 -> normalised discounted returns [T,B]."""
     rewards = _c(rewards.float())

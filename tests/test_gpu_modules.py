@@ -478,7 +478,7 @@ def test_modules_accept_non_contiguous_inputs():
     xt = x.transpose(1, 2).contiguous().transpose(1, 2)              # same values, strides (N*d, 1, N)
     assert not xt.is_contiguous()
     a, b = m(x)[0], m(xt)[0]
-    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)   # (split-K float atomics: order varies)
     z = T(detrand.normal(7, "nc.z", (128, 16))).to(dev).t()          # [16,128] view of a [128,16] buffer
     zi, zj = z[:8], z[8:]
     assert not zi.is_contiguous()
