@@ -170,16 +170,90 @@ def m_full(device, dtype, bags=64, raw=8192, steps=10):
         clusters.append([np.nonzero(lab == k)[0].tolist() for k in range(10)])
     pack = BagPack.from_lists(feats, clusters, dtype=dtype)
     crit, mem = NT_Xent(bags, 1.0), [rlmil.Memory(), rlmil.Memory()]
-    for _ in range(3):
-        pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+
+    def run():
+        for _ in range(3):
+            pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    dt = run()
+    out = dict(workload=f"MuRCL stage-1 step: {bags} raw bags x {raw} x 512 -> T=6 x 2 views of 1024 (sampler + mix-up included)",
+               ms_per_step=round(dt * 1e3, 3), bags_per_s=round(bags / dt, 1), steps=steps)
+    # BASELINE configs[3]'s body on one GPU's 64 bags: the PPO sampler in the loop - stage 2 (encoder frozen, two
+    # PPO.update per step) and stage 3 (joint: sampler picks the windows, encoder + head train)
+    for stage in (2, 3):
+        args.train_stage = stage
+        ppo = rlmil.PPO(512, args.model_dim, args.policy_hidden_dim, args.policy_conv, action_std=args.action_std, lr=args.ppo_lr,
+                        gamma=args.ppo_gamma, K_epochs=args.K_epochs, action_size=args.num_clusters)
+        dts = run()
+        out[f"stage{stage}"] = dict(ms_per_step=round(dts * 1e3, 3), bags_per_s=round(bags / dts, 1))
+    return out
+
+
+def _timed_ms(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return dict(workload=f"MuRCL stage-1 step: {bags} raw bags x {raw} x 512 -> T=6 x 2 views of 1024 (sampler + mix-up included)",
-                ms_per_step=round(dt * 1e3, 3), bags_per_s=round(bags / dt, 1), steps=steps)
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def other_rows(device):
+    """The other aggregators of SURVEY section 8 at their BASELINE shapes, beside the headline (outside its timed
+    region): BASELINE configs[2] CLAM-SB + instance loss 64 x 4096 x 512 (bf16 storage) and one GPU's share of configs[4]
+    DSMIL 16 x 8192 x 1024 (fp32 like the reference), forward + backward through the batched internals the training
+    steps use (train_RLMIL.supervised_step), median of 10 HIP-event timings.  `frac_of_8TBps` uses the pass counts of
+    the un-fused operator chain as the algorithmic bytes (15 passes over [B*N,512] for CLAM, 4 over X for DSMIL)."""
+    from murcl_amd.models.clam import CLAM_SB
+    from murcl_amd.models.dsmil import build_dsmil
+    g = torch.Generator(device=device)
+    g.manual_seed(3)
+    out = {}
+    B, N = 64, 4096
+    m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512).to(device)
+    m.compute_dtype = torch.bfloat16
+    m.eval()
+    x = (torch.randn((B, N, 512), generator=g, device=device).abs() * 0.5).bfloat16()
+    labels = [int(v) for v in torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1))]
+
+    def clam_fb(inst):
+        for p in m.parameters():
+            p.grad = None
+        M, _, _, il, _, _ = m._run(x, labels if inst else None, inst)
+        (M.sum() + il.sum()).backward() if inst else M.sum().backward()
+    for name, inst in (("clam_sb_c3_fwd_bwd_instance_loss", True), ("clam_sb_c3_fwd_bwd_aggregator", False)):
+        ms = _timed_ms(lambda: clam_fb(inst))
+        nbytes = 15 * B * N * 512 * 2
+        out[name] = dict(workload=f"CLAM_SB {B} bags x {N} x 512 bf16", ms=round(ms, 4), bags_per_s=round(B / ms * 1e3, 1),
+                         algorithmic_GB=round(nbytes / 1e9, 3), frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+    del m, x
+    B, N, d = 16, 8192, 1024
+    md = build_dsmil(d, 2).to(device)
+    xd = torch.randn((B, N, d), generator=g, device=device).abs() * 0.5
+
+    def dsmil_fb():
+        for p in md.parameters():
+            p.grad = None
+        classes, bag = md._run(xd)
+        (bag.sum() + classes.max(1)[0].sum()).backward()            # bag term + max-instance term (train_RLMIL.py:516-529)
+    ms = _timed_ms(dsmil_fb)
+    nbytes = 4 * B * N * d * 4
+    out["dsmil_c5_share_fwd_bwd"] = dict(workload=f"DSMIL {B} bags x {N} x {d} f32 (one GPU's share of 128 bags)", ms=round(ms, 4),
+                                         bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
+                                         frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+    return out
 
 
 def main():
@@ -317,6 +391,10 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         out["m_full"] = m_full(device, dtype)
+        torch.cuda.empty_cache()
+        out["rows"] = other_rows(device)
+        gc.collect()
+        torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(B, N, D)
     if args.breakdown:
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):

@@ -6,6 +6,16 @@
 //   instance eval: top-k / bottom-k ids of A (lowest index wins ties), CE on 2-way instance logits
 #include "common.h"
 
+// tanh / sigmoid of the gate pre-activations.  f32 (parity path): ocml tanhf / expf.  bf16 storage: U itself carries 8
+// significant bits, so the hardware v_exp_f32 / v_rcp_f32 forms (1 ulp each) are exact to storage precision - and with
+// ~35 VALU operations per ocml call the streaming kernels below were VALU-bound (115 us for a 268 MB pass), not HBM-bound.
+template <typename T> __device__ __forceinline__ float gs_tanh(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float gs_tanh<bf16_t>(float x) { return fast_tanh(x); }
+template <typename T> __device__ __forceinline__ float gs_sigmoid(float x) { return sigmoidf_(x); }
+template <> __device__ __forceinline__ float gs_sigmoid<bf16_t>(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 // ---------------------------------------------------------------- gated attention score
 // Streaming kernels over U [rows, 2D]: a thread owns 8 consecutive columns of both gate halves (16-byte loads for
 // bf16), G = D/8 column groups, 256/G rows in flight per workgroup pass, a workgroup walks `rows_per_block` rows.
@@ -46,10 +56,10 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
                     load8<T>(keep_a + n * D + 8 * cg, ka);
                     load8<T>(keep_b + n * D + 8 * cg, kb);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[u] += (tanhf(ua[u][e]) * ka[e]) * (sigmoidf_(ub[u][e]) * kb[e]) * w[e];
+                    for (int e = 0; e < 8; ++e) acc[u] += (gs_tanh<T>(ua[u][e]) * ka[e]) * (gs_sigmoid<T>(ub[u][e]) * kb[e]) * w[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[u] += tanhf(ua[u][e]) * sigmoidf_(ub[u][e]) * w[e];
+                    for (int e = 0; e < 8; ++e) acc[u] += gs_tanh<T>(ua[u][e]) * gs_sigmoid<T>(ub[u][e]) * w[e];
                 }
             }
         }
@@ -71,19 +81,21 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
     }
 }
 // dU[n,d] = ds_n wc_d g (1-a^2) ka kb ; dU[n,D+d] = ds_n wc_d a g (1-g) ka kb ; dwc_d += ds_n a g ka kb ; dbc += ds_n
+// and, from the same pass, the column sums of dU (the bias gradients of the two gate Linears: a separate column-sum
+// launch re-read all of dU, 54 us at the C3 shape)
 template <typename T>
 __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
                                                               const float* __restrict__ ds, T* __restrict__ dU,
                                                               float* __restrict__ part,
                                                               long rows, int D, int rows_per_block) {
-    __shared__ float red[256][9];
+    __shared__ float red[256][25];
     const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
     const int cg = tid % G, rl = tid / G;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    float w[8], wacc[8], dbc_acc = 0.f;
+    float w[8], wacc[8], csa[8], csb[8], dbc_acc = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = csa[e] = csb[e] = 0.f; }
     if (rl < RL) {
         constexpr int UR = 2;                             // rows in flight per thread
         for (long n0 = r0 + rl; n0 < r1; n0 += UR * RL) {
@@ -115,58 +127,69 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                 if (cg == 0) dbc_acc += dsn[u];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float a = tanhf(ua[u][e]), g = sigmoidf_(ub[u][e]);
+                    const float a = gs_tanh<T>(ua[u][e]), g = gs_sigmoid<T>(ub[u][e]);
                     da[e] = dsn[u] * w[e] * g * (1.f - a * a) * k[e];
                     db[e] = dsn[u] * w[e] * a * g * (1.f - g) * k[e];
                     wacc[e] += dsn[u] * a * g * k[e];
+                    csa[e] += da[e];
+                    csb[e] += db[e];
                 }
                 store8<T>(dU + n * 2 * D + 8 * cg, da);
                 store8<T>(dU + n * 2 * D + D + 8 * cg, db);
             }
         }
     }
-    // reduce over the row lanes, then this workgroup's row of partial sums (part [grid][D+1]; summed by
-    // gated_score_reduce_kernel - thousands of atomic adders on D addresses would serialise at the memory side)
+    // reduce over the row lanes, then this workgroup's row of partial sums (part [grid][3D+1] = dwc | dbc | colsum of
+    // dU; summed by gated_score_reduce_kernel - thousands of atomic adders on D addresses would serialise at the memory side)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[tid][e] = wacc[e];
+    for (int e = 0; e < 8; ++e) { red[tid][e] = wacc[e]; red[tid][9 + e] = csa[e]; red[tid][17 + e] = csb[e]; }
     red[tid][8] = dbc_acc;
     __syncthreads();
     if (rl == 0) {
-        float t[9];
+        float t[25];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) t[e] = 0.f;
+        for (int e = 0; e < 25; ++e) t[e] = 0.f;
         for (int r = 0; r < RL; ++r)
 #pragma unroll
-            for (int e = 0; e < 9; ++e) t[e] += red[r * G + cg][e];
-        float* prow = part + (size_t)blockIdx.x * (D + 1);
+            for (int e = 0; e < 25; ++e) t[e] += red[r * G + cg][e];
+        float* prow = part + (size_t)blockIdx.x * (3 * D + 1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) prow[8 * cg + e] = t[e];
+        for (int e = 0; e < 8; ++e) {
+            prow[8 * cg + e] = t[e];
+            prow[D + 1 + 8 * cg + e] = t[9 + e];
+            prow[2 * D + 1 + 8 * cg + e] = t[17 + e];
+        }
         if (cg == 0) prow[D] = t[8];
     }
 }
-// dwc[c] = sum_w part[w][c], dbc = sum_w part[w][D]   (16 columns x 16 row lanes per workgroup)
+// dwc[c] = sum_w part[w][c], dbc = sum_w part[w][D], dbab[c'] = sum_w part[w][D+1+c']   (16 columns x 16 row lanes per
+// workgroup; dbab may be NULL)
 __global__ __launch_bounds__(256) void gated_score_reduce_kernel(const float* __restrict__ part, int n_wg, int D,
-                                                                 float* __restrict__ dwc, float* __restrict__ dbc) {
+                                                                 float* __restrict__ dwc, float* __restrict__ dbc,
+                                                                 float* __restrict__ dbab) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    const int W = 3 * D + 1;
     float s = 0.f;
-    if (c <= D) {
+    if (c < W) {
         float t4[4] = {0.f, 0.f, 0.f, 0.f};             // four independent chains: the loads of a pass are all in flight
         int w = rl;
         for (; w + 48 < n_wg; w += 64)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t4[u] += part[(size_t)(w + 16 * u) * (D + 1) + c];
-        for (; w < n_wg; w += 16) t4[0] += part[(size_t)w * (D + 1) + c];
+            for (int u = 0; u < 4; ++u) t4[u] += part[(size_t)(w + 16 * u) * W + c];
+        for (; w < n_wg; w += 16) t4[0] += part[(size_t)w * W + c];
         s = (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
     red[rl][cl] = s;
     __syncthreads();
-    if (rl == 0 && c <= D) {
+    if (rl == 0 && c < W) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][cl];
-        if (c < D) dwc[c] = t; else dbc[0] = t;
+        if (c < D) dwc[c] = t;
+        else if (c == D) dbc[0] = t;
+        else if (dbab) dbab[c - D - 1] = t;
     }
 }
 static bool gs_shape_ok(int D) { return D >= 8 && D <= 2048 && D % 8 == 0; }
@@ -191,12 +214,12 @@ extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
-                                     const float* ds, void* dU, float* dwc, float* dbc, float* part_ws, long rows, int D,
-                                     int dtype, hipStream_t st) {
+                                     const float* ds, void* dU, float* dwc, float* dbc, float* dbab, float* part_ws,
+                                     long rows, int D, int dtype, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D) || !part_ws) return -1;
     const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
-    long rpb = (rows + 1023) / 1024;                       // <= 1024 workgroups = rows of part_ws [1024][D+1]
+    long rpb = (rows + 1023) / 1024;                       // <= 1024 workgroups = rows of part_ws [1024][3D+1]
     rpb = ((rpb + RL - 1) / RL) * RL;
     if (rpb < 4 * RL) rpb = 4 * RL;
     const int grid = (int)((rows + rpb - 1) / rpb);
@@ -207,7 +230,7 @@ extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void*
     else return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((D + 1 + 15) / 16), dim3(256), 0, st, part_ws, grid, D, dwc, dbc);
+    hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((3 * D + 1 + 15) / 16), dim3(256), 0, st, part_ws, grid, D, dwc, dbc, dbab);
     return MURCL_CHECK_LAUNCH();
 }
 

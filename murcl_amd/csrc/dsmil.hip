@@ -249,18 +249,35 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
                 const long row = min(rb + u, row1 - 1);
                 load8<T>(X + row * d + k, xv[u]);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long row = min(rb + u, row1 - 1);
-                const float* v = V + (size_t)(row / N) * C * d;
+            const long bag0 = rb / N, bag3 = min(rb + 3, row1 - 1) / N;
+            if (bag0 == bag3) {
+                // the four rows belong to one bag (always, when N % 4 == 0): its slice of V is loaded once for all of them
+                // (per row it was as many load instructions again as X itself: the kernel was load-issue-bound)
+                const float* v = V + (size_t)bag0 * C * d;
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < C) {
                         float w[8];
                         load8<float>(v + (size_t)c * d + k, w);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][e] * w[e];
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][e] * w[e];
                     }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long row = min(rb + u, row1 - 1);
+                    const float* v = V + (size_t)(row / N) * C * d;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < C) {
+                            float w[8];
+                            load8<float>(v + (size_t)c * d + k, w);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][e] * w[e];
+                        }
+                }
             }
         }
 #pragma unroll

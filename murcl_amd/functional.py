@@ -506,16 +506,18 @@ class CLAMFn(torch.autograd.Function):
         # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
         dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
         ds = ops.softmax_rows_bwd(A, dA).view(-1)
-        dU, dwc, dbc = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb)
+        dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb)   # dbab: column sums, same pass
         dwab = ops.gemm_tn(dU, h)                                                     # [2D, L]
-        dbab = ops.colsum(dU)
         wab = torch.cat([wa, wb], 0)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
         if (T == torch.bfloat16 and 2 * D == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
-            dz1, _, _ = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
-                                       bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
-                                       rowscale=A.view(-1), rank1=dM, rows_per_bag=N)
+            # (the instance branch adds a few rows to dz1 afterwards, so the fused column sums only serve without it)
+            dz1, _, db1 = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
+                                         bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
+                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N,
+                                         colsum=not (ctx.saved_inst is not None and dinst is not None))
         else:
+            db1 = None
             dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1),
                               rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
@@ -529,7 +531,8 @@ class CLAMFn(torch.autograd.Function):
             g = ops.gemm_nt(dlog, inst_w.reshape(n_cls * 2, -1).t().contiguous())      # [B*2k, L]; K = 2 n_cls is padded
             ops.scatter_add_rows_masked(dz1, h, rows_all, g)
         dw1 = ops.gemm_tn(dz1, x2)
-        db1 = ops.colsum(dz1)
+        if db1 is None:
+            db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
             dw1, db1 = dw1 / 0.75, db1 / 0.75
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),

@@ -541,10 +541,11 @@ def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None):
     dU = torch.empty_like(U)
     dwc = torch.empty((D2 // 2,), dtype=torch.float32, device=U.device)
     dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
-    part = torch.empty((1024 * (D2 // 2 + 1),), dtype=torch.float32, device=U.device)     # per-workgroup partial rows
+    dbab = torch.empty((D2,), dtype=torch.float32, device=U.device)                       # column sums of dU, same pass
+    part = torch.empty((1024 * (3 * (D2 // 2) + 1),), dtype=torch.float32, device=U.device)     # per-workgroup partial rows
     check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(keep_a), ptr(keep_b), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
-                                           ptr(part), M, D2 // 2, dt(U), stream()), "gated_score_bwd")
-    return dU, dwc, dbc
+                                           ptr(dbab), ptr(part), M, D2 // 2, dt(U), stream()), "gated_score_bwd")
+    return dU, dwc, dbc, dbab
 
 
 def softmax_rows(s):
