@@ -226,7 +226,7 @@ def other_rows(device):
     m.compute_dtype = torch.bfloat16
     m.eval()
     x = (torch.randn((B, N, 512), generator=g, device=device).abs() * 0.5).bfloat16()
-    labels = [int(v) for v in torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1))]
+    labels = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1)).to(device)    # a device tensor, as in training
 
     def clam_fb(inst):
         for p in m.parameters():
@@ -253,6 +253,13 @@ def other_rows(device):
     out["dsmil_c5_share_fwd_bwd"] = dict(workload=f"DSMIL {B} bags x {N} x {d} f32 (one GPU's share of 128 bags)", ms=round(ms, 4),
                                          bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
                                          frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+    md.compute_dtype = torch.bfloat16                               # patch features stored in bf16, f32 accumulation
+    xd = xd.bfloat16()
+    ms = _timed_ms(dsmil_fb)
+    nbytes = 4 * B * N * d * 2
+    out["dsmil_c5_share_fwd_bwd_bf16"] = dict(workload=f"DSMIL {B} bags x {N} x {d} bf16 storage", ms=round(ms, 4),
+                                              bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
+                                              frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
     return out
 
 

@@ -150,8 +150,9 @@ int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t st
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);
 int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d, int dtype, murcl_stream_t stream);
-int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, const float* g, int R, int d, int dtype,
-                                  murcl_stream_t stream);
+/* write_back != 0: g[r,k] is zeroed where the mask dropped it, so that on return g holds exactly what was added */
+int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, float* g, int R, int d, int dtype,
+                                  int write_back, murcl_stream_t stream);
 int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
                         long* preds, int group, murcl_stream_t stream);   /* nn.Dropout keep mask (clam.py:47-48,71-72) in the compute dtype: out[i] = scale with probability keep_p (quantised to
  * 1/256), else 0; a pure function of (seed, i) (splitmix64 counter hash), one write pass. */

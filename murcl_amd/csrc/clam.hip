@@ -386,12 +386,15 @@ __global__ void take_rows_kernel(const T* __restrict__ src, const long* __restri
 // dst[rows[r],:] += g[r,:] * (h[rows[r],:] > 0)      (rows distinct within a launch)
 template <typename T>
 __global__ void scatter_add_rows_masked_kernel(T* __restrict__ dst, const T* __restrict__ h, const long* __restrict__ rows,
-                                               const float* __restrict__ g, int d) {
+                                               float* g, int d, int write_back) {
     const long r = blockIdx.x;
     T* o = dst + rows[r] * d;
     const T* m = h + rows[r] * d;
-    for (int k = threadIdx.x; k < d; k += blockDim.x)
-        if (to_f<T>(m[k]) > 0.f) o[k] = from_f<T>(to_f<T>(o[k]) + g[r * d + k]);
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const bool on = to_f<T>(m[k]) > 0.f;
+        if (on) o[k] = from_f<T>(to_f<T>(o[k]) + g[r * d + k]);
+        else if (write_back) g[r * d + k] = 0.f;            // g becomes what was added: its column sums extend dst's
+    }
 }
 extern "C" int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d, int dtype, hipStream_t st) {
     if (R <= 0) return 0;
@@ -400,11 +403,11 @@ extern "C" int murcl_take_rows(const void* src, const long* rows, float* out, in
     else return -1;
     return MURCL_CHECK_LAUNCH();
 }
-extern "C" int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, const float* g, int R, int d,
-                                             int dtype, hipStream_t st) {
+extern "C" int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, float* g, int R, int d,
+                                             int dtype, int write_back, hipStream_t st) {
     if (R <= 0) return 0;
-    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(scatter_add_rows_masked_kernel<float>, dim3(R), dim3(256), 0, st, (float*)dst, (const float*)h, rows, g, d);
-    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(scatter_add_rows_masked_kernel<bf16_t>, dim3(R), dim3(256), 0, st, (bf16_t*)dst, (const bf16_t*)h, rows, g, d);
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(scatter_add_rows_masked_kernel<float>, dim3(R), dim3(256), 0, st, (float*)dst, (const float*)h, rows, g, d, write_back);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(scatter_add_rows_masked_kernel<bf16_t>, dim3(R), dim3(256), 0, st, (bf16_t*)dst, (const bf16_t*)h, rows, g, d, write_back);
     else return -1;
     return MURCL_CHECK_LAUNCH();
 }

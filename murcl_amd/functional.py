@@ -412,6 +412,26 @@ class DSMILFn(torch.autograd.Function):
         return None, dwc, dbc, dwq, dbq, dwv, dbv
 
 
+_INST_CONST = {}
+
+
+def _inst_constants(dev, B, N, k, n_cls, subtyping):
+    """Index / target constants of CLAM's instance branch, built once per shape (they were five tiny launches and three
+    host->device copies per call): bag row offsets [B,1], class ids [1,n_cls], in-class targets [1,1,2k] = [1]*k + [0]*k
+    (clam.py:105-119), out-of-class targets [0]*k (subtyping, clam.py:122-132) or none, the rest ignored (-1)."""
+    key = (dev, B, N, k, n_cls, bool(subtyping))
+    c = _INST_CONST.get(key)
+    if c is None:
+        if len(_INST_CONST) > 32:
+            _INST_CONST.clear()
+        base = (torch.arange(B, device=dev, dtype=torch.int64) * N).unsqueeze(1)
+        cls_ids = torch.arange(n_cls, device=dev).view(1, n_cls)
+        t_in = torch.tensor([1] * k + [0] * k, dtype=torch.int64, device=dev).view(1, 1, -1)
+        t_out = torch.tensor(([0] * k if subtyping else [-1] * k) + [-1] * k, dtype=torch.int64, device=dev).view(1, 1, -1)
+        c = _INST_CONST[key] = (base, cls_ids, t_in, t_out)
+    return c
+
+
 class CLAMFn(torch.autograd.Function):
     """CLAM_SB.bag_forward for a batch of equal-length bags, optionally with the instance-level loss
     (models/clam.py:134-181,103-132).
@@ -466,17 +486,16 @@ class CLAMFn(torch.autograd.Function):
             labels, k, subtyping = inst_cfg
             n_cls = inst_w.shape[0]
             ids = ops.topk_ids(A, k)                                                   # [B, 2k]
-            base = (torch.arange(B, device=dev, dtype=torch.int64) * N).unsqueeze(1)
+            base, cls_ids, t_in, t_out = _inst_constants(dev, B, N, k, n_cls, subtyping)
             rows_all = (base + ids.to(torch.int64)).reshape(-1)                        # [B*2k] rows of h
             feats = ops.take_rows(h, rows_all)                                         # [B*2k, L] f32
             w_st = inst_w.reshape(n_cls * 2, -1).contiguous()
             logits = ops.gemm_nt(feats, w_st, epi=ops.EPI_BIAS, bias=inst_b.reshape(-1).contiguous())   # [B*2k, 2 n_cls]
             logits_g = logits.view(B, 2 * k, n_cls, 2).permute(0, 2, 1, 3).contiguous()                 # [B, n_cls, 2k, 2]
-            lab = torch.as_tensor([int(v) for v in labels], dtype=torch.int64).to(dev)
-            same = lab.view(B, 1) == torch.arange(n_cls, device=dev).view(1, n_cls)                     # [B, n_cls]
-            t_in = torch.tensor([1] * k + [0] * k, dtype=torch.int64, device=dev)
-            t_out = torch.tensor(([0] * k if subtyping else [-1] * k) + [-1] * k, dtype=torch.int64, device=dev)
-            targets = torch.where(same.unsqueeze(2), t_in.view(1, 1, -1), t_out.view(1, 1, -1)).contiguous()   # [B, n_cls, 2k]
+            lab = labels.to(device=dev, dtype=torch.int64) if isinstance(labels, torch.Tensor) else \
+                torch.as_tensor([int(v) for v in labels], dtype=torch.int64).to(dev)
+            same = lab.view(B, 1) == cls_ids                                                            # [B, n_cls]
+            targets = torch.where(same.unsqueeze(2), t_in, t_out).contiguous()                          # [B, n_cls, 2k]
             loss_g, dl_g, preds_g = ops.cross_entropy(logits_g.view(-1, 2), targets.view(-1), 2 * k)
             scale = 1.0 / n_cls if subtyping else 1.0                                  # clam.py:167-168
             inst_loss = loss_g.view(B, n_cls).sum(1) * scale
@@ -511,11 +530,11 @@ class CLAMFn(torch.autograd.Function):
         wab = torch.cat([wa, wb], 0)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
         if (T == torch.bfloat16 and 2 * D == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
-            # (the instance branch adds a few rows to dz1 afterwards, so the fused column sums only serve without it)
+            # column sums (the bias gradient) come out of the same launch; the instance branch below extends them by the
+            # few rows it adds
             dz1, _, db1 = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
                                          bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
-                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N,
-                                         colsum=not (ctx.saved_inst is not None and dinst is not None))
+                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
         else:
             db1 = None
             dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1),
@@ -529,7 +548,9 @@ class CLAMFn(torch.autograd.Function):
             dinst_w = ops.gemm_tn(dlog, feats).view(n_cls, 2, -1)                      # (gemm_tn pads narrow N1 itself)
             dinst_b = ops.colsum(dlog).view(n_cls, 2)
             g = ops.gemm_nt(dlog, inst_w.reshape(n_cls * 2, -1).t().contiguous())      # [B*2k, L]; K = 2 n_cls is padded
-            ops.scatter_add_rows_masked(dz1, h, rows_all, g)
+            ops.scatter_add_rows_masked(dz1, h, rows_all, g, write_back=db1 is not None)
+            if db1 is not None:
+                ops.colsum(g, out=db1, accumulate=True)                                  # [B*2k, L] f32: the rows just added
         dw1 = ops.gemm_tn(dz1, x2)
         if db1 is None:
             db1 = ops.colsum(dz1)

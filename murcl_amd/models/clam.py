@@ -73,7 +73,9 @@ class CLAM_SB(nn.Module):
         if instance_eval:
             inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)
             inst_b = torch.stack([c.bias for c in self.instance_classifiers], 0)
-            lab = [int(l) for l in (labels.reshape(-1).tolist() if isinstance(labels, torch.Tensor) else labels)]
+            # labels stay where they are: a device tensor goes to the kernels as it is (no .tolist() round trip, which would
+            # stall the host on everything queued so far)
+            lab = labels.reshape(-1) if isinstance(labels, torch.Tensor) else [int(l) for l in labels]
             cfg = (lab, self.k_sample, self.subtyping)
         M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias,
                                                g.attention_a[0].weight, g.attention_a[0].bias,

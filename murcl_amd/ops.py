@@ -578,9 +578,11 @@ def take_rows(src, rows):
     return out
 
 
-def scatter_add_rows_masked(dst, h, rows, g):
-    check(_lib.lib().murcl_scatter_add_rows_masked(ptr(dst), ptr(h), ptr(_c(rows)), ptr(_c(g)), rows.numel(), dst.shape[1],
-                                                   dt(dst), stream()), "scatter_add_rows_masked")
+def scatter_add_rows_masked(dst, h, rows, g, write_back=False):
+    """dst[rows[r]] += g[r] * (h[rows[r]] > 0).  ``write_back``: g (f32, contiguous) is masked in place to what was added."""
+    assert g.is_contiguous() and g.dtype == torch.float32
+    check(_lib.lib().murcl_scatter_add_rows_masked(ptr(dst), ptr(h), ptr(_c(rows)), ptr(g), rows.numel(), dst.shape[1],
+                                                   dt(dst), int(write_back), stream()), "scatter_add_rows_masked")
 
 
 def cross_entropy(logits, targets, group):
