@@ -55,9 +55,10 @@ int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2,
  * epilogue: 0 = relu(.+bias) (K=512), 1 = . * mask (K=512), 2 = (. + rowscale[m]*rank1[m/rows_per_bag][n]) * mask
  * (K=128 with N=512, or K=512), 3 = . + bias (K=512).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
  * when colsum_accumulate != 0 (accumulation straight into a gradient buffer); the workgroups' partial sums pass through
- * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.  walk_reverse != 0: the
+ * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.  walk_reverse bit 0: the
  * row tiles are visited from the last to the first (same result; use it when the kernel that has just produced A
- * walked forward, so that this pass starts on the rows that are still in the Infinity Cache).
+ * walked forward, so that this pass starts on the rows that are still in the Infinity Cache); bit 1 (K=512): A is
+ * loaded with the non-temporal cache policy (read once: it should not displace the output from the Infinity Cache).
  * murcl_panel_gemm_supported tells whether a shape is covered (else use murcl_gemm_nt). */
 int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag);
 int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue, const float* bias,

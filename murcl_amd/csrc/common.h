@@ -132,6 +132,13 @@ __device__ __forceinline__ void glds16_u(const void* sbase, unsigned voff, unsig
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// the same with the non-temporal cache policy: a stream that is read once should not displace what the NEXT kernel will
+// read from the 256 MiB Infinity Cache (e.g. the activations this kernel is writing)
+__device__ __forceinline__ void glds16_u_nt(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // Raw workgroup barrier that does NOT drain vmcnt (LDS-DMA tiles stay in flight across it):

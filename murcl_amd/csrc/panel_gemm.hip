@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 
     auto issue = [&](int seq) {
         const int tix = tile0 + seq * tstep;
-        const bool rev = (walk_reverse != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
+        const bool rev = ((walk_reverse & 1) != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
         const int row0 = (rev ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
         const char* base = (const char*)(A + (size_t)row0 * K);
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         for (int j = 0; j < GT; ++j) {
             if (PAD) {
                 const int row = j * PG_NW + wave;                       // wave-uniform: scalar base, lane offset lane*16
-                glds16_u(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
+                if (walk_reverse & 2) glds16_u_nt(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
+                else glds16_u(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
             } else {
                 const int ci = (j * PG_NW + wave) * 64 + lane;
                 const int row = ci / CPR, pos = ci % CPR;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // ---- the two phases of a tile, as lambdas so that the two halves of the workgroup can run them in opposite order
     auto row0_of = [&](int seq) {
         const int tix = tile0 + seq * tstep;
-        const bool rev = (walk_reverse != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
+        const bool rev = ((walk_reverse & 1) != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
         return (rev ? n_tiles - 1 - tix : tix) * PG_TR;
     };
     // side inputs of the epilogue that live in the tile's LDS slot: this lane's mask words (one per 32-column block

@@ -125,10 +125,12 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False, colsum_into=None, reverse=False):
+               colsum=False, colsum_into=None, reverse=False, stream_a=False):
     """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
     ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None.
-    ``reverse``: visit the row tiles last-to-first (cache reuse after a producer that walked forward; same result)."""
+    ``reverse``: visit the row tiles last-to-first (cache reuse after a producer that walked forward; same result).
+    ``stream_a``: load A with the non-temporal policy (K = 512): it is read once and should not displace the output, which
+    the next kernel reads, from the Infinity Cache."""
     _need_cuda(A, W)
     A, W = _c(A), _c(W)
     M, K = A.shape
@@ -145,7 +147,8 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                           ptr(rowscale), ptr(rank1), rows_per_bag,
                                           ptr(colsum_into if colsum_into is not None else cs),
-                                          int(colsum_into is not None), ptr(ws), int(reverse), stream()), "panel_gemm")
+                                          int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0), stream()),
+              "panel_gemm")
     return C, bm, cs
 
 
@@ -499,6 +502,12 @@ def weighted_rowsum(X, A):
     X, A = _c(X), _c(A)
     B, N, d = X.shape
     C = A.shape[2]
+    if B == 1 and N >= 1 << 16 and N % 64 == 0:
+        # one long "bag" (a weight gradient over all patches): the kernel's row splits all add atomically into the same
+        # C*d addresses - 1024 adders per address serialise at the memory side (250 us for a 537 MB pass).  Cut the rows
+        # into 64 pseudo-bags (16 adders per address) and sum their rows afterwards.
+        Zp = weighted_rowsum(X.view(64, N // 64, d), A.view(64, N // 64, C))
+        return colsum(Zp.view(64, C * d)).view(1, C, d)
     Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
     with _span(lambda: (f"weighted_rowsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
         check(_lib.lib().murcl_weighted_rowsum(ptr(X), ptr(A), ptr(Z), B, N, d, C, dt(X), stream()), "weighted_rowsum")
