@@ -47,6 +47,12 @@ int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, in
  * gradient of the same layer, from the same pass over A (one more MFMA per fragment against a fragment of ones). */
 int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
                   int dtype, int splits, float* colsum_out, murcl_stream_t stream);
+/* The same with a caller-provided workspace (murcl_gemm_tn_workspace_bytes; 0 = this shape needs none): the big bf16
+ * weight gradients (N1, N2 multiples of 256, M >= 16384) run on 256 x 256 tiles whose per-split partial sums go to the
+ * workspace as plain stores and are added to C by a second launch - no float atomics; other shapes behave as murcl_gemm_tn. */
+long murcl_gemm_tn_workspace_bytes(int M, int N1, int N2, int dtype);
+int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc, int dtype,
+                     int splits, float* colsum_out, float* ws, long ws_bytes, murcl_stream_t stream);
 
 /* Weight-stationary bf16 variant of murcl_gemm_nt for the patch-level layers (M = bags*patches rows, K in
  * {512,128}): same Linear forward / input-gradient as above (abmil.py:12-21,23-24 and their autograd), with

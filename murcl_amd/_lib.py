@@ -20,6 +20,8 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float
 SIGNATURES = {
     "murcl_gemm_nt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "murcl_gemm_tn_workspace_bytes": [_I, _I, _I, _I],
+    "murcl_gemm_tn_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
@@ -71,7 +73,7 @@ SIGNATURES = {
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L,
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
 
 _lib = None

@@ -752,6 +752,178 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------- TN, square-tile bf16 variant
+// 256 x 256 output tiles (N1 % 256 == 0, N2 % 256 == 0), split over the patch rows, partial tiles stored to a workspace
+// and summed by a second launch - no float atomics.  Against the 256 x 128 kernel above: every slab byte is moved
+// L2 -> LDS twice instead of three times (the big weight gradients are bound by that traffic: 1.6 GB at ~12 TB/s for
+// 537 MB of operands), each wave takes all 32 rows of a slab (no k-group halves, no final LDS reduction), and the
+// 64 MB of partial tiles leave as plain 64-byte row segments (~6 TB/s) instead of 32 MB of memory-side atomics (~1.3 TB/s).
+// Eight waves as 2 (n1) x 4 (n2) wave tiles of 128 x 64; slabs of 32 patch rows x (256 + 256) columns = 32 KiB run
+// through a four-slot ring with three slabs in flight.
+__global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         float* __restrict__ part, int M, int N1, int N2, int lda,
+                                                         int ldb, int m_per_split, int nsplit) {
+    constexpr int ROWS = 32, PITCH = 512, A_BYTES = ROWS * PITCH, SLOT = 2 * A_BYTES, NSLOT = 4;   // 32 KiB slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T1 = N1 >> 8, T2 = N2 >> 8, tiles = T1 * T2;
+    int tile, sp;
+    if ((nsplit & 7) == 0) {                      // all tiles of one M-split on one XCD (they share the slabs in its L2)
+        const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
+        sp = xcd + 8 * (w / tiles);
+        tile = w % tiles;
+    } else {
+        tile = blockIdx.x % tiles;
+        sp = blockIdx.x / tiles;
+    }
+    const int t1 = tile % T1, t2 = tile / T1;
+    const int n10 = t1 << 8, n20 = t2 << 8;
+    const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
+    const int nslab = mbeg < mend ? (mend - mbeg + ROWS - 1) / ROWS : 0;
+    const unsigned lds0 = lds_off(smem);
+    auto swz = [](int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); };
+
+    // LDS-DMA chunk maps: a slab half = 32 rows x 32 chunks of 16 B = 1024 chunks, two per thread; linear LDS image,
+    // swizzle applied to the global source chunk.  Row pointers advance by a constant per slab (no per-load 64-bit math).
+    const bf16_t* ap[2];
+    const bf16_t* bp[2];
+    int srow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ci = t * 512 + tid, row = ci >> 5;
+        srow[t] = row;
+        ap[t] = A + (size_t)n10 + (((ci & 31) ^ swz(row)) << 3);
+        bp[t] = B + (size_t)n20 + (((ci & 31) ^ swz(row)) << 3);
+    }
+    auto stage = [&](int s) {
+        const int mrow0 = mbeg + (nslab - 1 - s) * ROWS;                 // slabs are walked from the high rows down
+        const unsigned la = lds0 + (s % NSLOT) * SLOT, lb = la + A_BYTES;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const size_t r = (size_t)min(mrow0 + srow[t], M - 1);
+            glds16(ap[t] + r * lda, la + (t * 512 + wave * 64) * 16);
+            glds16(bp[t] + r * ldb, lb + (t * 512 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // transposed-read offsets (lane constants): rows 8g + rq (+4), 16-column group t -> chunks 2t, 2t+1; tile index i
+    // (j) -> offset ^ (i << 5) as in the kernel above
+    unsigned abase, bbase;
+    {
+        const int g = lane >> 4, u = lane & 15, rq = u >> 2, p4 = u & 3;
+        const int row = 8 * g + rq;
+        const int ca = 2 * (wr * 8) + (p4 >> 1), cb = 2 * (wc * 4) + (p4 >> 1);
+        abase = row * PITCH + ((ca ^ swz(row)) << 4) + ((p4 & 1) << 3);
+        bbase = A_BYTES + row * PITCH + ((cb ^ swz(row)) << 4) + ((p4 & 1) << 3);
+    }
+    auto tr_frag = [&](const char* slab, unsigned o0) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4* lp;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(slab + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(slab + o0 + 4 * PITCH));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    const int pre = min(3, nslab);
+    for (int s = 0; s < pre; ++s) stage(s);
+    for (int s = 0; s < nslab; ++s) {
+        // slab s landed (up to two younger slabs stay in flight: 4 LDS-DMA ops per thread and slab), visible to all waves;
+        // then the slot of slab s-1 - every wave has its fragments in registers - takes slab s+3
+        if (s + 2 < nslab) { WAIT_VMCNT(8); } else if (s + 1 < nslab) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
+        LDS_BARRIER();
+        if (s + 3 < nslab) stage(s + 3);
+        char* slab = smem + (s % NSLOT) * SLOT;
+        const int rows_here = min(ROWS, mend - (mbeg + (nslab - 1 - s) * ROWS));
+        if (rows_here < ROWS) {                                              // ragged tail of the split: zero the missing rows
+            for (int idx = tid; idx < (ROWS - rows_here) * 32; idx += 512) {
+                *(u32x4*)(slab + (rows_here + (idx >> 5)) * PITCH + (idx & 31) * 16) = u32x4{0, 0, 0, 0};
+                *(u32x4*)(slab + A_BYTES + (rows_here + (idx >> 5)) * PITCH + (idx & 31) * 16) = u32x4{0, 0, 0, 0};
+            }
+            LDS_BARRIER();
+        }
+        bf16x8 bfr[4], af[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(slab, bbase ^ (j << 5));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = tr_frag(slab, abase ^ (i << 5));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);          // B (8 reads) + A0, A1 (4 reads)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                                // MFMAs of A_i with the reads of A_{i+2} between them
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    // ---- this split's partial tile -> part[sp][N1][N2] (plain stores; 16 lanes write 64 contiguous bytes of a row)
+    float* pt = part + (size_t)sp * N1 * N2;
+    const int q4 = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n2 = n20 + wc * 64 + j * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n10 + wr * 128 + i * 16 + 4 * q4 + r;
+                pt[(size_t)n1 * N2 + n2] = acc[i][j][r];
+            }
+        }
+}
+// C[n] += sum_s part[s][n]   (n over N1*N2 elements as float4; eight splits of loads in flight per thread)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long n4,
+                                                        int nsplit, int N2, int ldc) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = (const f32x4*)part + i;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {
+        const f32x4 v0 = p[(size_t)s * n4], v1 = p[(size_t)(s + 1) * n4], v2 = p[(size_t)(s + 2) * n4], v3 = p[(size_t)(s + 3) * n4];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < nsplit; ++s) a0 += p[(size_t)s * n4];
+    const f32x4 t = (a0 + a1) + (a2 + a3);
+    const long e = i * 4, row = e / N2, col = e % N2;
+    f32x4* c = (f32x4*)(C + row * ldc + col);
+    *c = *c + t;
+}
+static int tn_sq_plan(int M, int N1, int N2, int* splits_out, int* mps_out) {
+    const int tiles = (N1 / 256) * (N2 / 256);
+    int sp = (256 + tiles - 1) / tiles;                   // one 128 KiB-LDS workgroup per CU
+    sp = ((sp + 7) / 8) * 8;
+    while (sp > 8 && (long)(sp - 8) * 32 * 8 >= M) sp -= 8;             // keep >= 8 slabs per split
+    int mps = (M + sp - 1) / sp;
+    mps = ((mps + 31) / 32) * 32;
+    if ((long)mps * (sp - 1) >= M) sp = (M + mps - 1) / mps;
+    *splits_out = sp;
+    *mps_out = mps;
+    return tiles;
+}
+static bool tn_sq_ok(int M, int N1, int N2, int ldc, int dtype) {
+    return dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 256 == 0 && M >= 16384 && ldc % 4 == 0;
+}
+// bytes of workspace murcl_gemm_tn_ws wants for this shape (0: the shape takes the atomics path, no workspace needed)
+extern "C" long murcl_gemm_tn_workspace_bytes(int M, int N1, int N2, int dtype) {
+    if (!tn_sq_ok(M, N1, N2, N2, dtype)) return 0;
+    int sp, mps;
+    tn_sq_plan(M, N1, N2, &sp, &mps);
+    return (long)sp * N1 * N2 * 4;
+}
+
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s);
 
 extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
@@ -814,5 +986,33 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         return -1;
     }
 #undef TN_LAUNCH
+    return MURCL_CHECK_LAUNCH();
+}
+
+// murcl_gemm_tn with a caller-provided workspace: the big bf16 weight gradients (N1, N2 multiples of 256, M >= 16384) run
+// on 256 x 256 tiles with the split partial sums stored to `ws` and added to C by a reduce launch (no float atomics);
+// every other shape, or a workspace that is too small, falls through to murcl_gemm_tn.
+extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
+                                int dtype, int splits, float* colsum_out, float* ws, long ws_bytes, hipStream_t stream) {
+    if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    if (splits > 0 || !ws || !tn_sq_ok(M, N1, N2, ldc, dtype) || (lda * 2) % 16 || (ldb * 2) % 16 ||
+        ws_bytes < murcl_gemm_tn_workspace_bytes(M, N1, N2, dtype))
+        return murcl_gemm_tn(A, B, C, M, N1, N2, lda, ldb, ldc, dtype, splits, colsum_out, stream);
+    int sp, mps;
+    const int tiles = tn_sq_plan(M, N1, N2, &sp, &mps);
+    if (colsum_out) {
+        const int rc = murcl_colsum(A, colsum_out, M, N1, lda, dtype, 1, stream);
+        if (rc) return rc;
+    }
+    auto k = gemm_tn_sq_kernel;
+    constexpr int LDS = 4 * 32768;
+    static MurclOncePerDevice once;
+    if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
+    hipLaunchKernelGGL(k, dim3(tiles * sp), dim3(512), LDS, stream, (const bf16_t*)A, (const bf16_t*)B, ws, M, N1, N2, lda, ldb,
+                       mps, sp);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    const long n4 = (long)N1 * N2 / 4;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, ws, C, n4, sp, N2, ldc);
     return MURCL_CHECK_LAUNCH();
 }

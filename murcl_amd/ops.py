@@ -162,6 +162,10 @@ def relu_bitmask(x):
     return bits
 
 
+import os as _os
+_TN_SQ = _os.environ.get("MURCL_TN_SQ", "1") == "1"          # dev A/B switch: 0 keeps the 256 x 128 atomics kernel
+
+
 def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None):
     """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given).  ``colsum_into`` [N1] f32: the column sums
     of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient)."""
@@ -182,6 +186,14 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None):
         assert colsum_into.dtype == torch.float32 and colsum_into.is_contiguous() and colsum_into.numel() == N1
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
+    wsb = _lib.lib().murcl_gemm_tn_workspace_bytes(M, N1, N2, dt(A)) if (splits <= 0 and _TN_SQ) else 0
+    if wsb:         # 256 x 256 tiles, partial sums through a workspace + reduce launch (no float atomics)
+        ws = torch.empty((wsb // 4,), dtype=torch.float32, device=A.device)
+        with _span(lambda: (f"gemm_tn_sq<{_DT_NAME[A.dtype]}>",
+                   dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
+            check(_lib.lib().murcl_gemm_tn_ws(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
+                                              ptr(ws), wsb, stream()), "gemm_tn_ws")
+        return C
     with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
         check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
