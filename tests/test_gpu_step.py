@@ -223,3 +223,46 @@ def test_supervised_stage1_all_patch_steps_at_once_equals_the_loop(arch):
     np.testing.assert_allclose(a[1], b[1], rtol=2e-5)
     np.testing.assert_allclose(a[2], b[2], rtol=2e-3, atol=2e-6)
     assert ((a[3] - b[3]).norm() / (1e-3 * a[3].numel() ** 0.5)).item() < 2e-2
+
+
+def test_bf16_training_tracks_f32_over_a_step_sequence():
+    """per-kernel bf16 tolerances say little about training.  40 Adam steps of the contrastive view-pair step
+    (CL(ABMIL) + Full_layer + NT-Xent) on the same bags, same initial weights, once with f32 patch tensors and once with
+    bf16 storage: the loss trajectories must stay together (every step within 2 %, final loss within 1 %) and both must
+    actually train."""
+    from murcl_amd.models.abmil import ABMIL
+    from murcl_amd.models.cl import CL
+    from murcl_amd.models.rlmil import Full_layer
+    from murcl_amd.optim import FlatAdam
+    from murcl_amd.utils.losses import NT_Xent
+    dev = torch.device("cuda:0")
+    B, N = 16, 512
+    xs = [T(P.bags(97, f"v{v}", B, N, 512)).to(dev) for v in range(2)]
+
+    def run(dtype):
+        enc = ABMIL(512, L=512, D=128, dim_out=128)
+        enc.load_state_dict(P.to_torch(P.abmil(985)))
+        enc.compute_dtype = dtype
+        model = CL(enc, 128, 512).to(dev)
+        fc = Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        fc = fc.to(dev)
+        opt = FlatAdam([{"params": list(model.parameters()), "lr": 1e-4}, {"params": list(fc.parameters()), "lr": 5e-5}],
+                       weight_decay=1e-5)
+        crit = NT_Xent(B, 1.0)
+        views = [x.to(dtype) for x in xs]
+        out = []
+        for _ in range(40):
+            opt.zero_grad()
+            outs, _ = model(views)
+            z = fc.forward_views(outs, restart=True)
+            loss = crit(z[0], z[1])
+            loss.backward()
+            opt.step()
+            out.append(loss.item())
+        return np.array(out)
+
+    f32, bf16 = run(torch.float32), run(torch.bfloat16)
+    assert f32[-1] < 0.9 * f32[0] and bf16[-1] < 0.9 * bf16[0], (f32[0], f32[-1], bf16[0], bf16[-1])      # both learn
+    np.testing.assert_allclose(bf16, f32, rtol=2e-2)
+    assert abs(bf16[-1] - f32[-1]) <= 1e-2 * f32[-1]
