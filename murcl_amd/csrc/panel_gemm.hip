@@ -67,6 +67,19 @@ __device__ __forceinline__ unsigned pg_pos_flags(unsigned w, unsigned ones) {
     asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(t) : "v"(w), "v"(ones));
     return t;
 }
+// ReLU on a packed bf16 pair: as signed 16-bit integers every negative bf16 (and -0.0) is < 0, every positive one > 0, so
+// max(., 0) per half IS the ReLU - after the rounding to bf16, which commutes with it (rounding is monotonic).  One VALU
+// operation per pair instead of two v_max_f32; the > 0 flags of the result are then min(., 1) per half.
+__device__ __forceinline__ unsigned pg_relu_pk(unsigned w) {
+    unsigned t;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(t) : "v"(w));
+    return t;
+}
+__device__ __forceinline__ unsigned pg_pos_flags_nonneg(unsigned w, unsigned ones) {
+    unsigned t;
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(w), "v"(ones));
+    return t;
+}
 
 template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
 __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
@@ -226,7 +239,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) {
+                // the bias is the accumulators' start value: no add in the epilogue (a move either way)
+                if (BIASED) acc[i][j] = f32x4{bias_r[j][0], bias_r[j][1], bias_r[j][2], bias_r[j][3]};
+                else acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         const char* hb = tile + r16 * PADB + NKK * q4 * 16;               // PAD: base + immediates only
         if (PAD) {
             // explicit software pipeline: the fragments of k-group g+PG_PF are requested before the MFMAs of group g
@@ -294,14 +311,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             for (int j = 0; j < NJ; ++j) {
                 if (part >= 10 && (part - 10) % NJ != j) continue;       // 10 + NJ*i + j: one 16x16 block of the tile
                 f32x4 v = acc[i][j];
-                if (EPI == PG_BIAS_RELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + bias_r[j][r], 0.f);
-                }
-                if (EPI == PG_BIAS) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bias_r[j][r];
-                }
+                // (PG_BIAS / PG_BIAS_RELU: the bias is already in the accumulator, the ReLU is applied to the packed pairs below)
                 if (EPI == PG_RANK1_MASK) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += a_m * rk[j][r];
@@ -314,13 +324,15 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                         v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
                     }
                 }
-                if (colsum_part) {         // bias gradient from the f32 values, before they are rounded to bf16
+                if (MASKED && colsum_part) {         // bias gradient from the f32 values, before they are rounded to bf16 (backward variants only)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) csum[j][r] += v[r];
                 }
-                const unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
+                unsigned w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]);
+                if (EPI == PG_BIAS_RELU) { w0 = pg_relu_pk(w0); w1 = pg_relu_pk(w1); }
                 if (BM_OUT) {
-                    const unsigned f0 = pg_pos_flags(w0, ones), f1 = pg_pos_flags(w1, ones);
+                    const unsigned f0 = (EPI == PG_BIAS_RELU) ? pg_pos_flags_nonneg(w0, ones) : pg_pos_flags(w0, ones);
+                    const unsigned f1 = (EPI == PG_BIAS_RELU) ? pg_pos_flags_nonneg(w1, ones) : pg_pos_flags(w1, ones);
                     mw[j >> 1] = (mw[j >> 1] << 1) | f0;
                     mw[j >> 1] = (mw[j >> 1] << 1) | f1;
                 }
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
     if (late) epilogue(my_tiles - 1, acc, mw, am);
 
-    if (colsum_part) {
+    if (MASKED && colsum_part) {
         // the 16 lanes of a quarter hold the same columns for different rows: reduce over them and publish this
         // workgroup's partial sums as row `stream` of colsum_part [streams][N] (plain stores; murcl_colsum adds the rows
         // up afterwards - 128 atomic adders per column from here cost 10-15 us per launch)
