@@ -257,20 +257,25 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < 2; ++j) bp[j] = B + (size_t)min(n0 + 16 * j + r16, N - 1) * ldb + 4 * q4;
     // K % 16 == 0 (checked by the launcher).  The weights stream from HBM and nothing else hides that latency (a
-    // workgroup's whole job is a few KiB), so the loads of eight k-steps (128 k) are all issued before the first
-    // MFMA: one memory round trip per chunk instead of one per k-step (28 -> 6 us on the GRU input projection).
-    for (int k0 = kb; k0 < ke; k0 += 128) {
-        f32x4 a[8][2], b[8][2];
+    // workgroup's whole job is a few KiB), so the loads of four k-steps (a 64-k chunk) are all issued before its first
+    // MFMA, and the NEXT chunk's loads are issued before this chunk's MFMAs (two register sets, ping-pong): after the
+    // first round trip the chunks arrive back to back instead of one memory round trip each (a 512-deep layer was four
+    // serial round trips: 13-26 us per launch, the largest single item of the sampler-in-the-loop steps).
+    constexpr int CH = 64, NU = CH / 16;
+    f32x4 a0[NU][2], b0[NU][2], a1[NU][2], b1[NU][2];
+    auto load_chunk = [&](f32x4 (&a)[NU][2], f32x4 (&b)[NU][2], int k0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int kk = min(k0 + 16 * u, ke - 16);
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[u][i] = *(const f32x4*)(ap[i] + kk);
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[u][j] = *(const f32x4*)(bp[j] + kk);
         }
+    };
+    auto mma_chunk = [&](f32x4 (&a)[NU][2], f32x4 (&b)[NU][2], int k0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             if (k0 + 16 * u < ke) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -278,6 +283,13 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __
                     for (int j = 0; j < 2; ++j) acc[i][j] = mma16<float>(a[u][i], b[u][j], acc[i][j]);   // rows <- m, cols <- n
             }
         }
+    };
+    load_chunk(a0, b0, kb);
+    for (int k0 = kb; k0 < ke; k0 += 2 * CH) {
+        if (k0 + CH < ke) load_chunk(a1, b1, k0 + CH);
+        mma_chunk(a0, b0, k0);
+        if (k0 + 2 * CH < ke) load_chunk(a0, b0, k0 + 2 * CH);
+        if (k0 + CH < ke) mma_chunk(a1, b1, k0 + CH);
     }
     // lane holds C[m0 + 16i + 4q4 + r][n0 + 16j + r16]: the 16 lanes of a quarter add to 64 contiguous bytes of a row
     // (float atomics execute at the memory side per 64-byte request; one lane per line would be ~10x slower)
@@ -313,7 +325,8 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
     const int slabs = (N + 31) / 32, chunks = (M + 127) / 128;
     int splits = (384 + slabs * chunks - 1) / (slabs * chunks);         // ~1.5 workgroups per CU
     // 64 or more single-writer workgroups: no K split - one launch instead of memset + atomics (+ a ReLU pass), and a
-    // result that does not depend on the order of float atomics
+    // result that does not depend on the order of float atomics.  (Fewer, longer streams are slower even with two chunks
+    // in flight per workgroup: a 512-deep layer on 16 single-writer workgroups took 20 % longer than 64 x 128-k splits.)
     if (slabs * chunks >= 64) splits = 1;
     const int kmax = (K + 127) / 128;                       // at least one 128-k chunk per split
     if (splits > kmax) splits = kmax;
