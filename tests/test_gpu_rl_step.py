@@ -216,3 +216,44 @@ def test_ppo_returns_sharded_statistics_equal_the_single_kernel():
     np.testing.assert_allclose(got.cpu().numpy(), whole.cpu().numpy(), rtol=2e-5, atol=2e-6)
     ref = O.ppo_returns([rw[t:t + 1].cpu() for t in range(Tn)], 0.1)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_native_ppo_sequences_equal_the_per_launch_autograd_path():
+    """csrc/ppo_seq.hip (one C call per sampling step / per K_epoch) against the same math driven launch by launch through
+    autograd (ActorCritic.evaluate + PPOLossFn, the round-1 path, still used for shapes the sequences do not cover):
+    actions, log-probs, hidden states, and every parameter gradient of one epoch."""
+    from murcl_amd.models.rlmil import PPO, ActorCritic, Memory, _HipPolicyKernels
+    dev = torch.device("cuda:0")
+    seed, B, S_, H, K, Tm = 57, 12, 512, 512, 10, 4
+    sd = P.to_torch(P.actor_critic(seed, S_, H, K))
+
+    def rollout(native):
+        ppo = PPO(512, S_, H, False, action_std=0.5, lr=1e-4, gamma=0.1, K_epochs=1, action_size=K)
+        ppo.policy.load_state_dict(sd)
+        ppo.policy_old.load_state_dict(sd)
+        if not native:
+            for m in (ppo.policy, ppo.policy_old):
+                m._native_ok = lambda S: False
+        mem = Memory()
+        for t in range(Tm):
+            st = T(detrand.normal(seed, f"s{t}", (B, S_))).to(dev)
+            eps = T(detrand.normal(seed, f"e{t}", (B, K))).to(dev)
+            ppo.select_action(st, mem, restart_batch=(t == 0), eps=eps)
+            mem.rewards.append((T(detrand.normal(seed, f"r{t}", (1, B))) * 0.01).to(dev))
+        from murcl_amd import ops
+        rewards = torch.cat(mem.rewards, 0)
+        returns = ops.ppo_returns(rewards, 0.1)
+        _HipPolicyKernels.epoch_grads(ppo, torch.stack(mem.states, 0), torch.stack(mem.actions, 0), torch.stack(mem.logprobs, 0),
+                                      returns, rewards.numel())
+        grads = {k: p.grad.detach().clone() for k, p in ppo.policy.named_parameters()}
+        return (torch.stack(mem.actions, 0), torch.stack(mem.logprobs, 0), torch.cat(mem.hidden[1:], 0)), grads
+
+    (a_n, lp_n, h_n), g_n = rollout(True)
+    (a_r, lp_r, h_r), g_r = rollout(False)
+    np.testing.assert_allclose(a_n.cpu().numpy(), a_r.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp_n.cpu().numpy(), lp_r.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(h_n.cpu().numpy(), h_r.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    for k in g_r:
+        ref = g_r[k]
+        assert ref.abs().max().item() > 0, k
+        np.testing.assert_allclose(g_n[k].cpu().numpy(), ref.cpu().numpy(), rtol=2e-3, atol=2e-4 * ref.abs().max().item(), err_msg=k)

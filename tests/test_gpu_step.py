@@ -266,3 +266,28 @@ def test_bf16_training_tracks_f32_over_a_step_sequence():
     assert f32[-1] < 0.9 * f32[0] and bf16[-1] < 0.9 * bf16[0], (f32[0], f32[-1], bf16[0], bf16[-1])      # both learn
     np.testing.assert_allclose(bf16, f32, rtol=2e-2)
     assert abs(bf16[-1] - f32[-1]) <= 1e-2 * f32[-1]
+
+
+@pytest.mark.parametrize("arch", ["CLAM_SB", "ABMIL"])
+def test_pretrain_script_three_stages_like_runs_pretrain_sh(tmp_path, arch, capsys):
+    """runs/pretrain.sh drives train_MuRCL.py through stages 1, 2 (sampler only, ``--ppo_epochs``) and 3 (joint, halved
+    learning rates) with CLAM_SB, a cosine schedule and ``--patience``; each stage picks up ``../stage_{k-1}/model_best.pth.tar``.
+    Same sequence here on synthetic slides (the reference's default arch included)."""
+    from murcl_amd import train_MuRCL
+    base = ["--synthetic", "8,320", "--num_clusters", "4", "--feat_size", "64", "--T", "3", "--batch_size", "4", "--data_repeat", "1",
+            "--arch", arch, "--device", "0", "--scheduler", "CosineAnnealingLR", "--patience", "10", "--exist_ok", "--dtype", "f32",
+            "--base_save_dir", str(tmp_path), "--dataset", "Synth"]
+    for stage, lrs in ((1, ("0.0001", "0.00005")), (2, ("0.0001", "0.00005")), (3, ("0.00005", "0.00001"))):
+        train_MuRCL.main(base + ["--train_stage", str(stage), "--epochs", "2", "--ppo_epochs", "2", "--backbone_lr", lrs[0], "--fc_lr", lrs[1]])
+    out = capsys.readouterr().out
+    assert out.count("Loss: ") == 6
+    runs = sorted(p for p in tmp_path.rglob("stage_*") if p.is_dir())
+    assert [p.name for p in runs] == ["stage_1", "stage_2", "stage_3"] and len({p.parent for p in runs}) == 1   # one run directory
+    assert f"Synth_np_64/MuRCL/T3_pd128_as0.5_pg0.1_tau1.0_alpha0.9/{arch}" in str(runs[0])
+    ck = [torch.load(p / "model_best.pth.tar", map_location="cpu") for p in runs]
+    assert ck[0]["policy"] is None and ck[1]["policy"] is not None and ck[2]["policy"] is not None
+    key = next(iter(ck[0]["model_state_dict"]))
+    assert torch.equal(ck[0]["model_state_dict"][key], ck[1]["model_state_dict"][key])         # stage 2 trains the sampler only
+    assert not torch.equal(ck[1]["model_state_dict"][key], ck[2]["model_state_dict"][key])     # stage 3 trains the aggregator again
+    assert all(torch.equal(ck[1]["policy"][k], ck[2]["policy"][k]) for k in ck[1]["policy"])   # ... and only samples with the policy
+    assert all(torch.isfinite(v).all() for c in ck for v in c["model_state_dict"].values())
