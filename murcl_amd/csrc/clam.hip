@@ -19,7 +19,8 @@ template <> __device__ __forceinline__ float gs_sigmoid<bf16_t>(float x) {
 // ---------------------------------------------------------------- gated attention score
 // Streaming kernels over U [rows, 2D]: a thread owns 8 consecutive columns of both gate halves (16-byte loads for
 // bf16), G = D/8 column groups, 256/G rows in flight per workgroup pass, a workgroup walks `rows_per_block` rows.
-template <typename T>
+// GATED = false: the plain attention net (clam.py:18-34): U has D columns, s_n = sum_d tanh(U[n,d]) wc[d] + bc.
+template <typename T, bool GATED>
 __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const float* __restrict__ bc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
@@ -43,15 +44,25 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
             live[u] = rl < RL && n < r1;
             acc[u] = 0.f;
             if (live[u]) {
-                load8<T>(U + n * 2 * D + 8 * cg, ua[u]);
-                load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
+                load8<T>(U + n * (GATED ? 2 : 1) * D + 8 * cg, ua[u]);
+                if (GATED) load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
             }
         }
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const long n = base + u * RL + rl;
             if (live[u]) {
-                if (keep_a) {
+                if (!GATED) {
+                    if (keep_a) {
+                        float ka[8];
+                        load8<T>(keep_a + n * D + 8 * cg, ka);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[u] += gs_tanh<T>(ua[u][e]) * ka[e] * w[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[u] += gs_tanh<T>(ua[u][e]) * w[e];
+                    }
+                } else if (keep_a) {
                     float ka[8], kb[8];
                     load8<T>(keep_a + n * D + 8 * cg, ka);
                     load8<T>(keep_b + n * D + 8 * cg, kb);
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
 // dU[n,d] = ds_n wc_d g (1-a^2) ka kb ; dU[n,D+d] = ds_n wc_d a g (1-g) ka kb ; dwc_d += ds_n a g ka kb ; dbc += ds_n
 // and, from the same pass, the column sums of dU (the bias gradients of the two gate Linears: a separate column-sum
 // launch re-read all of dU, 54 us at the C3 shape)
-template <typename T>
+template <typename T, bool GATED>
 __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
                                                               const float* __restrict__ ds, T* __restrict__ dU,
@@ -105,8 +116,8 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                 const long n = n0 + u * RL;
                 dsn[u] = 0.f;
                 if (n < r1) {
-                    load8<T>(U + n * 2 * D + 8 * cg, ua[u]);
-                    load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
+                    load8<T>(U + n * (GATED ? 2 : 1) * D + 8 * cg, ua[u]);
+                    if (GATED) load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
                     dsn[u] = ds[n];
                 }
             }
@@ -120,22 +131,22 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                 if (keep_a) {
                     float ka[8], kb[8];
                     load8<T>(keep_a + n * D + 8 * cg, ka);
-                    load8<T>(keep_b + n * D + 8 * cg, kb);
+                    if (GATED) load8<T>(keep_b + n * D + 8 * cg, kb);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) k[e] = ka[e] * kb[e];
+                    for (int e = 0; e < 8; ++e) k[e] = GATED ? ka[e] * kb[e] : ka[e];
                 }
                 if (cg == 0) dbc_acc += dsn[u];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float a = gs_tanh<T>(ua[u][e]), g = gs_sigmoid<T>(ub[u][e]);
+                    const float a = gs_tanh<T>(ua[u][e]), g = GATED ? gs_sigmoid<T>(ub[u][e]) : 1.f;
                     da[e] = dsn[u] * w[e] * g * (1.f - a * a) * k[e];
                     db[e] = dsn[u] * w[e] * a * g * (1.f - g) * k[e];
                     wacc[e] += dsn[u] * a * g * k[e];
                     csa[e] += da[e];
                     csb[e] += db[e];
                 }
-                store8<T>(dU + n * 2 * D + 8 * cg, da);
-                store8<T>(dU + n * 2 * D + D + 8 * cg, db);
+                store8<T>(dU + n * (GATED ? 2 : 1) * D + 8 * cg, da);
+                if (GATED) store8<T>(dU + n * 2 * D + D + 8 * cg, db);
             }
         }
     }
@@ -201,21 +212,21 @@ static int gs_rows_per_block(long rows, int D) {
     return (int)rpb;
 }
 extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a,
-                                     const void* keep_b, float* s, long rows, int D, int dtype, hipStream_t st) {
+                                     const void* keep_b, float* s, long rows, int D, int dtype, int gated, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D)) return -1;
     const int rpb = gs_rows_per_block(rows, D);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-    if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(gated_score_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)U, wc, bc, (const float*)keep_a, (const float*)keep_b, s, rows, D, rpb);
-    else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(gated_score_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)U, wc, bc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, s, rows, D, rpb);
+#define GS_FWD(T, G) hipLaunchKernelGGL((gated_score_fwd_kernel<T, G>), grid, dim3(256), 0, st, (const T*)U, wc, bc, (const T*)keep_a, (const T*)keep_b, s, rows, D, rpb)
+    if (dtype == MURCL_DTYPE_F32) { if (gated) GS_FWD(float, true); else GS_FWD(float, false); }
+    else if (dtype == MURCL_DTYPE_BF16) { if (gated) GS_FWD(bf16_t, true); else GS_FWD(bf16_t, false); }
     else return -1;
+#undef GS_FWD
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
                                      const float* ds, void* dU, float* dwc, float* dbc, float* dbab, float* part_ws,
-                                     long rows, int D, int dtype, hipStream_t st) {
+                                     long rows, int D, int dtype, int gated, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D) || !part_ws) return -1;
     const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
@@ -223,11 +234,11 @@ extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void*
     rpb = ((rpb + RL - 1) / RL) * RL;
     if (rpb < 4 * RL) rpb = 4 * RL;
     const int grid = (int)((rows + rpb - 1) / rpb);
-    if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(gated_score_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)U, wc, (const float*)keep_a, (const float*)keep_b, ds, (float*)dU, part_ws, rows, D, (int)rpb);
-    else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(gated_score_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)U, wc, (const bf16_t*)keep_a, (const bf16_t*)keep_b, ds, (bf16_t*)dU, part_ws, rows, D, (int)rpb);
+#define GS_BWD(T, G) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb)
+    if (dtype == MURCL_DTYPE_F32) { if (gated) GS_BWD(float, true); else GS_BWD(float, false); }
+    else if (dtype == MURCL_DTYPE_BF16) { if (gated) GS_BWD(bf16_t, true); else GS_BWD(bf16_t, false); }
     else return -1;
+#undef GS_BWD
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
     hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((3 * D + 1 + 15) / 16), dim3(256), 0, st, part_ws, grid, D, dwc, dbc, dbab);

@@ -467,15 +467,17 @@ class CLAMFn(torch.autograd.Function):
         if keeps is not None:
             k1, ka, kb = keeps
             ops.mul(h, k1)                                                             # Dropout(0.25) after ReLU
-        wab = torch.cat([wa, wb], 0)
-        bab = torch.cat([ba, bb], 0)
+        gated = wb is not None                   # False: the plain Attn_Net (CLAM_SB(gate=False), clam.py:18-34,80-81)
+        wab = torch.cat([wa, wb], 0) if gated else wa
+        bab = torch.cat([ba, bb], 0) if gated else ba
+        GW = wab.shape[0]                        # gate columns: 2D / D
         # bf16 with 512-wide h and gates: the weight-stationary panel kernel (same GEMM, half the time of the tile kernel)
-        panel = (T == torch.bfloat16 and L == 512 and ops.panel_supported(B * N, 2 * D, 512, ops.PG_BIAS))
+        panel = (T == torch.bfloat16 and L == 512 and ops.panel_supported(B * N, GW, 512, ops.PG_BIAS))
         if panel:
             U, _, _ = ops.panel_gemm(h, c(wab), ops.PG_BIAS, bias=bab)                  # both gate branches, one pass
         else:
             U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
-        s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb).view(B, N)
+        s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
         A = ops.softmax_rows(s)                                                        # clam.py:144
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
         dev = x.device
@@ -508,6 +510,7 @@ class CLAMFn(torch.autograd.Function):
             inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
             saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
         ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1), m1)
+        ctx.gated = gated
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
             ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
@@ -531,11 +534,12 @@ class CLAMFn(torch.autograd.Function):
         # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
         dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
         ds = ops.softmax_rows_bwd(A, dA).view(-1)
-        dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb)   # dbab: column sums, same pass
-        dwab = ops.gemm_tn(dU, h)                                                     # [2D, L]
-        wab = torch.cat([wa, wb], 0)
+        gated = ctx.gated
+        dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb, gated=gated)   # dbab: column sums, same pass
+        dwab = ops.gemm_tn(dU, h)                                                     # [2D, L] (gated) / [D, L]
+        wab = torch.cat([wa, wb], 0) if gated else wa
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
-        if (T == torch.bfloat16 and 2 * D == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
+        if (T == torch.bfloat16 and wab.shape[0] == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
             # column sums (the bias gradient) come out of the same launch; the instance branch below extends them by the
             # few rows it adds
             dz1, _, db1 = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
@@ -562,6 +566,8 @@ class CLAMFn(torch.autograd.Function):
             db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
             dw1, db1 = dw1 / 0.75, db1 / 0.75
+        if not gated:
+            return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),
                 dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
 

@@ -5,7 +5,8 @@ return tuples ``(M, M.detach()[, results])`` and state-dict keys (``attention_ne
 ``attention_net.3.attention_{a,b}.0.*``, ``attention_net.3.attention_c.*``, ``classifiers.*``,
 ``instance_classifiers.{i}.*``; index 3 when ``dropout=True``, 2 otherwise) follow the reference, as do
 Xavier-normal weights / zero biases (clam.py:7-15).  The math runs in murcl_amd.functional.CLAMFn for
-all bags of a batch at once.  Only the gated attention (gate=True) of the training scripts is built.
+all bags of a batch at once.  ``gate=False`` builds the plain ``Attn_Net`` (clam.py:18-34; keys
+``attention_net.{2|3}.module.0.*`` and ``.module.{2|3}.*``) on the same kernels with the sigmoid branch switched off.
 """
 import numpy as np
 import torch
@@ -25,6 +26,18 @@ class Attn_Net_Gated(nn.Module):
         self.attention_c = nn.Linear(D, n_classes)
 
 
+class Attn_Net(nn.Module):
+    """clam.py:18-34: Linear(L, D) -> Tanh [-> Dropout(0.25)] -> Linear(D, n_classes), kept in ``module`` for the key names."""
+
+    def __init__(self, L=1024, D=256, dropout=False, n_classes=1):
+        super().__init__()
+        mods = [nn.Linear(L, D), nn.Tanh()]
+        if dropout:
+            mods.append(nn.Dropout(0.25))
+        mods.append(nn.Linear(D, n_classes))
+        self.module = nn.Sequential(*mods)
+
+
 def initialize_weights(module):
     for m in module.modules():
         if isinstance(m, nn.Linear):
@@ -36,13 +49,12 @@ class CLAM_SB(nn.Module):
     def __init__(self, gate=True, size_arg="small", dropout=False, k_sample=8, n_classes=2,
                  instance_loss_fn=None, subtyping=False, in_dim=512):
         super().__init__()
-        if not gate:
-            raise NotImplementedError("murcl_amd builds the gated attention only (the scripts use gate=True)")
         size = {"small": [in_dim, 512, 256], "big": [in_dim, 512, 384]}[size_arg]
         fc = [nn.Linear(size[0], size[1]), nn.ReLU()]
         if dropout:
             fc.append(nn.Dropout(0.25))
-        fc.append(Attn_Net_Gated(L=size[1], D=size[2], dropout=dropout, n_classes=1))
+        fc.append((Attn_Net_Gated if gate else Attn_Net)(L=size[1], D=size[2], dropout=dropout, n_classes=1))   # clam.py:72-76
+        self.gate = gate
         self.attention_net = nn.Sequential(*fc)
         self.classifiers = nn.Linear(size[1], n_classes)
         self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
@@ -62,13 +74,19 @@ class CLAM_SB(nn.Module):
             x = ops.cast(x.float().contiguous(), self.compute_dtype)
         net = self.attention_net
         g = net[-1]
+        if self.gate:
+            wa, ba, wb, bb = g.attention_a[0].weight, g.attention_a[0].bias, g.attention_b[0].weight, g.attention_b[0].bias
+            wc, bc = g.attention_c.weight, g.attention_c.bias
+        else:                                                  # Attn_Net: no sigmoid branch
+            wa, ba, wb, bb = g.module[0].weight, g.module[0].bias, None, None
+            wc, bc = g.module[-1].weight, g.module[-1].bias
         if self.training and self.dropout and keeps is None:
             BN, T = x.shape[0] * x.shape[1], x.dtype
-            L, D = net[0].out_features, g.attention_c.in_features
+            L, D = net[0].out_features, wc.shape[1]
             # keep with probability 0.75, survivors scaled by 1/0.75 (nn.Dropout(0.25), clam.py:71-72,47-48): one write pass
             # per mask (ops.dropout_mask) instead of uniform draw + compare + cast + scale
             draw = lambda w: ops.dropout_mask((BN, w), T, 0.75, x.device)   # noqa: E731
-            keeps = (draw(L), draw(D), draw(D))
+            keeps = (draw(L), draw(D), draw(D) if self.gate else None)
         inst_w = inst_b = cfg = None
         if instance_eval:
             inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)
@@ -77,10 +95,8 @@ class CLAM_SB(nn.Module):
             # stall the host on everything queued so far)
             lab = labels.reshape(-1) if isinstance(labels, torch.Tensor) else [int(l) for l in labels]
             cfg = (lab, self.k_sample, self.subtyping)
-        M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias,
-                                               g.attention_a[0].weight, g.attention_a[0].bias,
-                                               g.attention_b[0].weight, g.attention_b[0].bias,
-                                               g.attention_c.weight, g.attention_c.bias, inst_w, inst_b, keeps, cfg)
+        M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias, wa, ba, wb, bb, wc, bc,
+                                                         inst_w, inst_b, keeps, cfg)
         self.last_attention = A
         return M, A, s, inst_loss, ids, inst_out
 

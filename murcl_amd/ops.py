@@ -546,27 +546,31 @@ def dsmil_attn_bwd(A, dA, Y, qcol0, qmax, dY, B, N, C):
 
 
 # ------------------------------------------------------------------------------------------ CLAM-SB (K4/K5)
-def gated_score_fwd(U, wc, bc, keep_a=None, keep_b=None):
-    """U [M,2D] -> s [M] f32: sum_d tanh(U[:, :D]) * sigmoid(U[:, D:]) * wc + bc."""
+def gated_score_fwd(U, wc, bc, keep_a=None, keep_b=None, gated=True):
+    """gated: U [M,2D] -> s [M] f32: sum_d tanh(U[:, :D]) * sigmoid(U[:, D:]) * wc + bc (Attn_Net_Gated);
+    not gated: U [M,D] -> sum_d tanh(U[:, d]) * wc + bc (Attn_Net, clam.py:18-34)."""
     U = _c(U)
-    M, D2 = U.shape
+    M, W = U.shape
+    D = W // 2 if gated else W
     s = torch.empty((M,), dtype=torch.float32, device=U.device)
-    check(_lib.lib().murcl_gated_score_fwd(ptr(U), ptr(wc), ptr(bc), ptr(keep_a), ptr(keep_b), ptr(s), M, D2 // 2, dt(U),
+    check(_lib.lib().murcl_gated_score_fwd(ptr(U), ptr(wc), ptr(bc), ptr(keep_a), ptr(keep_b), ptr(s), M, D, dt(U), int(gated),
                                            stream()), "gated_score_fwd")
     return s
 
 
-def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None):
+def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None, gated=True):
+    """-> dU (shape of U), dwc [D], dbc [1], column sums of dU [U.shape[1]] (the bias gradients of the gate Linears)."""
     U, ds = _c(U), _c(ds)
-    M, D2 = U.shape
+    M, W = U.shape
+    D = W // 2 if gated else W
     dU = torch.empty_like(U)
-    dwc = torch.empty((D2 // 2,), dtype=torch.float32, device=U.device)
+    dwc = torch.empty((D,), dtype=torch.float32, device=U.device)
     dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
-    dbab = torch.empty((D2,), dtype=torch.float32, device=U.device)                       # column sums of dU, same pass
-    part = torch.empty((1024 * (3 * (D2 // 2) + 1),), dtype=torch.float32, device=U.device)     # per-workgroup partial rows
+    dbab = torch.empty((2 * D,), dtype=torch.float32, device=U.device)                    # column sums of dU, same pass
+    part = torch.empty((1024 * (3 * D + 1),), dtype=torch.float32, device=U.device)       # per-workgroup partial rows
     check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(keep_a), ptr(keep_b), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
-                                           ptr(dbab), ptr(part), M, D2 // 2, dt(U), stream()), "gated_score_bwd")
-    return dU, dwc, dbc, dbab
+                                           ptr(dbab), ptr(part), M, D, dt(U), int(gated), stream()), "gated_score_bwd")
+    return dU, dwc, dbc, dbab[:W]
 
 
 def softmax_rows(s):

@@ -165,6 +165,36 @@ def g4_clam():
     np.savez(os.path.join(OUT, "g4_clam.npz"), **res)
 
 
+def g14_clam_plain():
+    """CLAM_SB(gate=False): the plain Attn_Net (clam.py:18-34,80-81) - pooled M, soft-max A, raw scores, the instance
+    branch for label 1 and the gradients of a combined objective, eval mode."""
+    seed, B, N, d = 11, 3, 300, 512
+    x = T(P.bags(seed, "g4.x", B, N, d))
+    m = r_clam.CLAM_SB(gate=False, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=d)
+    m.load_state_dict(P.to_torch(P.clam_sb_plain(seed)))
+    m.eval()
+    res = {}
+    with torch.no_grad():
+        raw = torch.cat([m.bag_forward(x[b], attention_only=True) for b in range(B)])
+        A = torch.softmax(raw, 1)
+        for b in range(B):
+            assert _topk_margin(A[b], 8) > 1e-4, "golden top-k margin too small"
+        res["raw"], res["A"] = raw.numpy(), A.numpy()
+        res["top_p"], res["top_n"] = torch.topk(A, 8)[1].numpy(), torch.topk(-A, 8)[1].numpy()
+        res["M_batch"] = m(x)[0].numpy()
+    tot, losses = 0, []
+    for b in range(B):
+        Mb, rdb = m.bag_forward(x[b], label=torch.tensor([1]), instance_eval=True)
+        tot = tot + Mb.sum() + rdb["instance_loss"]
+        losses.append(float(rdb["instance_loss"]))
+    tot.backward()
+    res["inst_loss"] = np.array(losses)
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _summ(v.grad)
+    np.savez(os.path.join(OUT, "g14_clam_plain.npz"), **res)
+
+
 def g5_dsmil():
     seed, B, N, d, C = 5, 3, 200, 512, 2
     m = r_dsmil.build_dsmil(d, C)
@@ -610,7 +640,7 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

@@ -57,6 +57,13 @@ def clam_sb_forward(p, x, drop_mask=None):
     h = torch.relu(_lin(x, p, "attention_net.0"))                  # clam.py:69
     if drop_mask is not None:
         h = h * drop_mask[0] / 0.75
+    if "attention_net.3.module.0.weight" in p:                     # gate=False: Attn_Net (clam.py:18-34), dropout layout
+        a = torch.tanh(_lin(h, p, "attention_net.3.module.0"))
+        if drop_mask is not None:
+            a = a * drop_mask[1] / 0.75
+        s = _lin(a, p, "attention_net.3.module.3").squeeze(-1)
+        A = torch.softmax(s, dim=1)
+        return torch.einsum("bn,bnl->bl", A, h), A, s, h
     a = torch.tanh(_lin(h, p, "attention_net.3.attention_a.0"))    # clam.py:40-41,56
     g = torch.sigmoid(_lin(h, p, "attention_net.3.attention_b.0"))  # clam.py:44-45,57
     if drop_mask is not None:

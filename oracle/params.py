@@ -44,6 +44,18 @@ def clam_sb(seed, in_dim=512, size=(512, 256), n_classes=2):
     return d
 
 
+def clam_sb_plain(seed, in_dim=512, size=(512, 256), n_classes=2):
+    """CLAM_SB(gate=False, dropout=True): Attn_Net keys (clam.py:18-34,80-81)."""
+    d = {}
+    _linear(seed, "attention_net.0", size[0], in_dim, d, gain=1.7)
+    _linear(seed, "attention_net.3.module.0", size[1], size[0], d, gain=2.0)
+    _linear(seed, "attention_net.3.module.3", 1, size[1], d, gain=6.0)
+    _linear(seed, "classifiers", n_classes, size[0], d)
+    for i in range(n_classes):
+        _linear(seed, f"instance_classifiers.{i}", 2, size[0], d)
+    return d
+
+
 def dsmil(seed, dim_feat=512, num_classes=2):
     """models/dsmil.py:9,55-62,116-119."""
     d = {}

@@ -513,3 +513,40 @@ def test_forward_only_fast_paths_equal_the_autograd_paths():
 
     for a, b in zip(run(True), run(False)):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_clam_plain_attention_net_gate_false(golden, dtype):
+    """CLAM_SB(gate=False): Attn_Net (clam.py:18-34,80-81) on the gate kernels with the sigmoid branch off - raw scores,
+    soft-max, pooled vector, top-k ids, instance loss and gradients vs the reference golden G14 (f32), and the bf16 path
+    against the f32 one."""
+    from murcl_amd.models.clam import CLAM_SB
+    g = golden("g14_clam_plain")
+    dev = _dev()
+    pk = P.clam_sb_plain(11)
+    m = CLAM_SB(gate=False, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512)
+    assert sorted(m.state_dict()) == sorted(pk)                       # the reference's key names
+    m.load_state_dict(P.to_torch(pk))
+    m = m.to(dev).eval()
+    m.compute_dtype = dtype
+    x = T(P.bags(11, "g4.x", 3, 300, 512)).to(dev)
+    M, A, s, il, ids, _ = m._run(x, [1, 1, 1], True)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(s.cpu().numpy(), g["raw"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(A.cpu().numpy(), g["A"], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(M.detach().cpu().numpy(), g["M_batch"], rtol=1e-4, atol=1e-5)
+        assert np.array_equal(ids[:, :8].cpu().numpy(), g["top_p"]) and np.array_equal(ids[:, 8:].cpu().numpy(), g["top_n"])
+        np.testing.assert_allclose(il.detach().cpu().numpy(), g["inst_loss"], rtol=2e-4)
+        (M.sum() + il.sum()).backward()
+        for k, v in m.named_parameters():
+            key = "grad." + k
+            if key in g.files and not k.endswith("module.3.bias"):
+                got = _summ(v.grad)
+                np.testing.assert_allclose(got, g[key], rtol=2e-3, atol=3e-4 * g[key][1], err_msg=k)
+        out = m(x[0:1].squeeze(0).unsqueeze(0), attention_only=True)[0]
+        assert out.shape == (1, 300)
+    else:
+        assert (s.cpu() - T(g["raw"])).abs().max().item() < 3e-2 * float(np.abs(g["raw"]).max()) + 3e-2
+        assert (M.detach().cpu() - T(g["M_batch"])).abs().max().item() < 3e-2 * float(np.abs(g["M_batch"]).max())
+        (M.sum() + il.sum()).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)

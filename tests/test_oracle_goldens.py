@@ -30,7 +30,7 @@ def _check_grads(gold, prefix, named, rtol=2e-4):
         if key in gold.files:
             assert v.grad is not None, key
             got, want = _summ(v.grad), gold[key]
-            if k.endswith("attention.2.bias") or k.endswith("attention_c.bias"):
+            if k.endswith("attention.2.bias") or k.endswith("attention_c.bias") or k.endswith("module.3.bias"):
                 # d softmax / d(uniform shift) == 0 exactly: both sides hold only rounding noise
                 ref_scale = _summ(named[k[:-4] + "weight"].grad)[0]
                 assert got[0] < 1e-4 * ref_scale and want[0] < 1e-4 * ref_scale, key
@@ -285,3 +285,20 @@ def test_g12_rl_step_oracle_vs_reference_train_loop(golden, Tn, stage):
                     assert want[0] == 0.0, k
                     continue
                 _close_summ(_fp(new[k] - base[k]), want, 3e-2, msg=k)
+
+
+def test_g14_clam_plain_attention_net(golden):
+    """CLAM_SB(gate=False): the oracle's Attn_Net branch vs the reference (scores, soft-max, pooled vector, gradients)."""
+    g = golden("g14_clam_plain")
+    p = _leaf(P.clam_sb_plain(11))
+    x = T(P.bags(11, "g4.x", 3, 300, 512))
+    M, A, s, h = O.clam_sb_forward(p, x)
+    np.testing.assert_allclose(s.detach().numpy(), g["raw"], **TOL)
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(M.detach().numpy(), g["M_batch"], **TOL)
+    tot = 0
+    for b in range(3):
+        loss, *_ = O.clam_instance_eval(p, A[b], h[b], 1, 2, 8, True)
+        tot = tot + M[b].sum() + loss
+    tot.backward()
+    _check_grads(g, "grad.", p)
