@@ -315,13 +315,83 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __
             }
         }
 }
+// Second skinny form: a workgroup owns 64 rows x 16 columns (one 16 x 16 MFMA tile per wave) and the whole K range with a
+// SINGLE writer per element.  Against the 128 x 32 form above: four times the workgroups for the same output (a 128-row
+// layer with 512 outputs is 64 workgroups instead of 16 - on the exact-f32 matrix pipe, 64 FLOP/clk/SIMD, a workgroup of
+// the wide form spends ~8 us in MFMAs alone at K = 512), 256 k of both operands in flight per wave in each of two
+// register sets (K <= 512: one memory round trip), no memset, no float atomics, bias / ReLU in the epilogue.
+__global__ __launch_bounds__(256) void gemm_nt_skinny16_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                   float* __restrict__ C, int M, int N, int K, int lda,
+                                                                   int ldb, int ldc, const float* __restrict__ bias,
+                                                                   int relu, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64 + wave * 16;
+    if (m0 >= M) return;
+    const float* ap = A + (size_t)min(m0 + r16, M - 1) * lda + 4 * q4;
+    const float* bp = B + (size_t)min(n0 + r16, N - 1) * ldb + 4 * q4;
+    constexpr int NU = 16;                                   // 16-k steps per register set (256 k)
+    f32x4 a0[NU], b0[NU], a1[NU], b1[NU];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: the f32 MFMA's dependent latency exceeds its issue time
+    auto load_set = [&](f32x4 (&a)[NU], f32x4 (&b)[NU], int k0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int kk = min(k0 + 16 * u, K - 16);
+            a[u] = *(const f32x4*)(ap + kk);
+            b[u] = *(const f32x4*)(bp + kk);
+        }
+    };
+    auto mma_set = [&](f32x4 (&a)[NU], f32x4 (&b)[NU], int k0) {
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+            if (k0 + 16 * u < K) acc0 = mma16<float>(a[u], b[u], acc0);
+            if (k0 + 16 * (u + 1) < K) acc1 = mma16<float>(a[u + 1], b[u + 1], acc1);
+        }
+    };
+    load_set(a0, b0, 0);
+    for (int k0 = 0; k0 < K; k0 += 2 * 16 * NU) {
+        if (k0 + 16 * NU < K) load_set(a1, b1, k0 + 16 * NU);
+        mma_set(a0, b0, k0);
+        if (k0 + 2 * 16 * NU < K) load_set(a0, b0, k0 + 2 * 16 * NU);
+        if (k0 + 16 * NU < K) mma_set(a1, b1, k0 + 16 * NU);
+    }
+    // lane holds C[m0 + 4q4 + r][n0 + r16]: the 16 lanes of a quarter write 64 contiguous bytes of a row
+    const int n = n0 + r16;
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * q4 + r;
+            if (m < M) {
+                float v = acc0[r] + acc1[r] + bv;
+                float* cp = C + (size_t)m * ldc + n;
+                if (accumulate) v += *cp;
+                *cp = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
 __global__ void relu_inplace_kernel(float* x, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fmaxf(x[i], 0.f);
 }
 
+static int skinny16_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MURCL_SKINNY16"); v = (e && e[0] == '0') ? 0 : 1; }     // dev A/B switch
+    return v;
+}
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s) {
+    if (K <= 512 && (long)((N + 15) / 16) * ((M + 63) / 64) <= 384 && skinny16_enabled()) {
+        // short reductions that fit one wave of workgroups: 64 x 16 single-writer workgroups, the whole K range in one memory
+        // round trip (measured per shape, tools/skinny_shapes.py: [128 x 512 x 512] 14.4 -> 11.1 us, [64 x 2048 x 512]
+        // 15.4 -> 11.3 us; K = 1024 with few outputs and grids beyond ~1.5 workgroups per CU are faster on the split form)
+        hipLaunchKernelGGL(gemm_nt_skinny16_f32_kernel, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, A, B, C, M, N, K, lda,
+                           ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, (int)(epi == EPI_BIAS_RELU),
+                           accumulate);
+        return MURCL_CHECK_LAUNCH();
+    }
     const int slabs = (N + 31) / 32, chunks = (M + 127) / 128;
     int splits = (384 + slabs * chunks - 1) / (slabs * chunks);         // ~1.5 workgroups per CU
     // 64 or more single-writer workgroups: no K split - one launch instead of memset + atomics (+ a ReLU pass), and a
