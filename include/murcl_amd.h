@@ -138,6 +138,13 @@ int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N,
                           murcl_stream_t stream);
 int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
                    murcl_stream_t stream);
+/* rows_dot and the weighted row sum sum_n G[b,n,c] X[b,n,:] over ONE pass of X (DSMIL backward: dA = X dZ^T and
+ * dWc = dcls^T X both need every row of X).  murcl_rows_dot_wsum_plan returns the rows a wave takes (0: shape not covered:
+ * C <= 2, d <= 1024, d % 8 == 0); part [B*N / that][C][d] receives per-wave partial sums of the weighted rows, which the
+ * caller adds up (murcl_colsum). */
+int murcl_rows_dot_wsum_plan(int B, int N, int d, int C);
+int murcl_rows_dot_wsum(const void* X, const float* V, const float* G, float* out, float* part, int B, int N, int d, int C,
+                        int dtype, murcl_stream_t stream);
 int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ldq, int qcol0, const float* qmax, int B,
                          int N, int C, float* dY, int ldy, float* dqmax, float* dots_ws /* [B*C] */, murcl_stream_t stream);
 

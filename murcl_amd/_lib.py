@@ -41,6 +41,8 @@ SIGNATURES = {
     "murcl_dsmil_attn": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
     "murcl_weighted_rowsum": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_rows_dot_wsum_plan": [_I, _I, _I, _I],
+    "murcl_rows_dot_wsum": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P],
     "murcl_gated_score_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "murcl_gated_score_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],

@@ -305,6 +305,112 @@ extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, 
     return MURCL_CHECK_LAUNCH();
 }
 
+// rows_dot and a weighted row sum over the SAME pass of X (DSMIL backward: dA = X dZ^T needs every row of X, and so does
+// dWc = dcls^T X - two sweeps of 537 MB at the C5 shape):
+//   out[b,n,c] = X[b,n,:] . V[b,c,:]           and           part[w][c][:] = sum over wave w's rows of G[b,n,c] X[b,n,:]
+// A wave walks `rows_per_wave` consecutive rows (inside one bag: rows_per_wave divides N), four rows in flight, a lane owns
+// 8 consecutive columns per 512-column step; its weighted partial sums stay in registers and leave as one row of `part`
+// ([n_waves][C][d]; the caller sums the rows - no float atomics).  d <= 1024, C <= 2 (register budget).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_dot_wsum_kernel(const T* __restrict__ X, const float* __restrict__ V,
+                                                            const float* __restrict__ G, int N, int d, int C,
+                                                            int rows_per_wave, float* __restrict__ out,
+                                                            float* __restrict__ part, long rows_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long row0 = wid * rows_per_wave;
+    if (row0 >= rows_total) return;
+    const long row1 = min(rows_total, row0 + rows_per_wave);
+    const float* v = V + (size_t)(row0 / N) * C * d;
+    float wsum[2][2][8];                                    // [class][512-column step][8 columns]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wsum[c][st][e] = 0.f;
+    float vr[2][2][8];                                      // this bag's V slice, loaded once for all of the wave's rows
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int k = st * 512 + lane * 8;
+            if (c < C && k < d) load8<float>(v + (size_t)c * d + k, vr[c][st]);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vr[c][st][e] = 0.f;
+        }
+    for (long rb = row0; rb < row1; rb += 4) {
+        float acc[4][2], xv[4][2][8], gw[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long row = min(rb + u, row1 - 1);
+            const bool live = rb + u < row1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { acc[u][c] = 0.f; gw[u][c] = (live && c < C) ? G[row * C + c] : 0.f; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int k = st * 512 + lane * 8;
+                if (k < d) load8<T>(X + row * d + k, xv[u][st]);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[u][st][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        acc[u][c] += xv[u][st][e] * vr[c][st][e];
+                        wsum[c][st][e] += gw[u][c] * xv[u][st][e];
+                    }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rb + u >= row1) break;
+            for (int c = 0; c < C; ++c) {
+                const float sdot = wave_sum(acc[u][c]);
+                if (lane == 0) out[(rb + u) * C + c] = sdot;
+            }
+        }
+    }
+    float* pr = part + (size_t)wid * C * d;
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int k = st * 512 + lane * 8;
+            if (k < d) {
+                *(f32x4*)(pr + (size_t)c * d + k) = f32x4{wsum[c][st][0], wsum[c][st][1], wsum[c][st][2], wsum[c][st][3]};
+                *(f32x4*)(pr + (size_t)c * d + k + 4) = f32x4{wsum[c][st][4], wsum[c][st][5], wsum[c][st][6], wsum[c][st][7]};
+            }
+        }
+}
+// rows_per_wave (out): how many rows a wave takes = the number of `part` rows the caller must provide is ceil(B*N / it)
+extern "C" int murcl_rows_dot_wsum_plan(int B, int N, int d, int C) {
+    if (B <= 0 || N <= 0 || C < 1 || C > 2 || d % 8 || d > 1024) return 0;
+    int rpw = 256;                                          // >= 4096 waves (a wave keeps four rows in flight and reduces between
+    while (rpw > 4 && (N % rpw || (long)B * N / rpw < 4096)) rpw >>= 1;       // loads: the chip needs them all resident)
+    return (N % rpw == 0) ? rpw : 0;
+}
+extern "C" int murcl_rows_dot_wsum(const void* X, const float* V, const float* G, float* out, float* part, int B, int N,
+                                   int d, int C, int dtype, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int rpw = murcl_rows_dot_wsum_plan(B, N, d, C);
+    if (!rpw) return -1;
+    const long rows = (long)B * N, waves = rows / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(rows_dot_wsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, V, G, N, d, C, rpw, out, part, rows);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(rows_dot_wsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, V, G, N, d, C, rpw, out, part, rows);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
 // Soft-max backward over N per (bag, class) + the two small products that follow it:
 //   dS = A * (dA - sum_n A dA);  dY[b,n, qcol0:qcol0+128] = sum_c dS[n,c] qmax[c,:] * scale;
 //   dqmax[b,c,:] = sum_n dS[n,c] Q[b,n,:] * scale

@@ -400,7 +400,12 @@ class DSMILFn(torch.autograd.Function):
         dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
         dbv = ops.colsum(dbag2)
         dZ = ops.gemm_nt(dbag2, ops.transposed(wv)).view(B, C, d)
-        dA = ops.rows_dot(x, dZ)
+        # dA = X dZ^T and, when the instance scores carry a gradient, dWc = dcls^T X from the SAME pass over X
+        fused = None
+        if dclasses is not None:
+            dcls = dclasses.reshape(B, N, C).float().contiguous()
+            fused = ops.rows_dot_wsum(x, dZ, dcls)
+        dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
         dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                      # written in full below
         dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
         dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2)                # [128, d]: one tile row
@@ -413,7 +418,7 @@ class DSMILFn(torch.autograd.Function):
             # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile
             # for 2 columns would read X a second time through the GEMM path)
             dcls = dclasses.reshape(1, B * N, C).float().contiguous()
-            dwc = ops.weighted_rowsum(x2.view(1, B * N, d), dcls).view(C, d)
+            dwc = fused[1] if fused is not None else ops.weighted_rowsum(x2.view(1, B * N, d), dcls).view(C, d)
             dbc = dcls.view(B * N, C).sum(0)
         return None, dwc, dbc, dwq, dbq, dwv, dbv
 

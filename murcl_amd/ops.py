@@ -537,6 +537,23 @@ def rows_dot(X, V):
     return out
 
 
+def rows_dot_wsum(X, V, G):
+    """(out[b,n,c] = X[b,n,:] . V[b,c,:],  W[c,:] = sum_{b,n} G[b,n,c] X[b,n,:]) from ONE pass over X, or None when the
+    shape is not covered (then: rows_dot + weighted_rowsum).  X [B,N,d] (f32/bf16), V [B,C,d] f32, G [B,N,C] f32."""
+    X, V, G = _c(X), _c(V), _c(G)
+    B, N, d = X.shape
+    C = V.shape[1]
+    rpw = _lib.lib().murcl_rows_dot_wsum_plan(B, N, d, C)
+    if not rpw:
+        return None
+    out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
+    part = torch.empty((B * N // rpw, C * d), dtype=torch.float32, device=X.device)
+    with _span(lambda: (f"rows_dot_wsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=4.0 * B * N * d * C))):
+        check(_lib.lib().murcl_rows_dot_wsum(ptr(X), ptr(V), ptr(G), ptr(out), ptr(part), B, N, d, C, dt(X), stream()),
+              "rows_dot_wsum")
+    return out, colsum(part).view(C, d)
+
+
 def dsmil_attn_bwd(A, dA, Y, qcol0, qmax, dY, B, N, C):
     dqmax = torch.empty((B * C, qmax.shape[1]), dtype=torch.float32, device=Y.device)
     dots = torch.empty((B * C,), dtype=torch.float32, device=Y.device)
