@@ -74,8 +74,54 @@ def _wgrad(dy, x, w):
     return ops.gemm_tn(dy, x)
 
 
+# Deferred weight gradients.  A recurrent head that is stepped T times per optimizer step (the MuRCL loop: T patch steps
+# through ONE Full_layer) produces T weight gradients per parameter, each a skinny [128 x N]^T [128 x K] product whose
+# [N x K] f32 output leaves as float atomics (6.3 MB for W_ih, 12.6 MB for W_hh - 15 us apiece, T times).  Inside a
+# ``deferred_wgrads()`` block the (dy, x) pairs are only queued; on exit each parameter gets ONE product over the
+# concatenated T*128 rows: the same sum, one launch and one pass of atomics instead of T.
+_DEFERRED = None
+_DEFER_ON = _os.environ.get("MURCL_DEFER_WGRADS", "1") == "1"      # dev A/B switch
+
+
+class deferred_wgrads:
+    def __enter__(self):
+        global _DEFERRED
+        self.prev, _DEFERRED = _DEFERRED, ({} if _DEFER_ON else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        queue, _DEFERRED = _DEFERRED, self.prev
+        if exc[0] is None and queue:
+            for w, b, dys, xs in queue.values():
+                dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
+                x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+                if b is not None:
+                    ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1))
+                else:
+                    ops.gemm_tn(dy, x, out=w.grad)
+        return False
+
+
+def _defer(dy, x, w, b):
+    """Queue (dy, x) for w (and b) when a deferral block is active and both accumulate directly; True if queued."""
+    if _DEFERRED is None or not _direct(w) or (b is not None and not _direct(b)):
+        return False
+    ent = _DEFERRED.get(id(w))
+    if ent is None:
+        ent = _DEFERRED[id(w)] = (w, b, [], [])
+    elif (ent[1] is None) != (b is None):
+        return False
+    ent[2].append(dy)
+    ent[3].append(x)
+    _touch(w, b)
+    return True
+
+
 def _wbgrad(dy, x, w, b):
     """(dW, db) of one Linear; in direct mode both are added to the flat gradient buffer by ONE launch."""
+    if _defer(dy, x, w, b):
+        return None, None
     if _direct(w) and _direct(b):
         ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1))
         _touch(w, b)

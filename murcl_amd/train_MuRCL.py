@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from murcl_amd import dist as mdist, ops
+from murcl_amd import dist as mdist, functional, ops
 from murcl_amd.models import abmil, cl, clam, rlmil
 from murcl_amd.optim import FlatAdam, FlatSGD, make_scheduler
 from murcl_amd.utils import general as G
@@ -130,7 +130,8 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     loss = sum(losses) / args.T                                                              # :291
     if train_enc:
         optimizer.zero_grad()
-        loss.backward(ops.unit_grad(loss))
+        with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each
+            loss.backward(ops.unit_grad(loss))
         if world > 1:
             mdist.all_reduce_grads(optimizer.flat_grads())
         optimizer.step()                                                                     # :293-295
@@ -178,7 +179,8 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
         sim_last = sim
     loss = sum(losses) / T_                                                                  # :291
     optimizer.zero_grad()
-    loss.backward(ops.unit_grad(loss))
+    with functional.deferred_wgrads():              # the head's T weight gradients per parameter as one product each
+        loss.backward(ops.unit_grad(loss))
     if world > 1:
         mdist.all_reduce_grads(optimizer.flat_grads())
     optimizer.step()                                                                         # :293-295

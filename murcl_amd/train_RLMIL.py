@@ -10,6 +10,7 @@ import os
 
 import torch
 
+from murcl_amd import functional
 from murcl_amd.functional import CrossEntropyFn
 from murcl_amd.models import abmil, clam, dsmil, rlmil
 from murcl_amd.utils.datasets import subbag_views
@@ -120,7 +121,8 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     loss = sum(losses) / T
     if train_enc:
         optimizer.zero_grad()
-        loss.backward()
+        with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each
+            loss.backward()
         optimizer.step()
     else:
         ppo.update(memory)
