@@ -368,6 +368,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     f32x4 acc[2][NJ];
     unsigned mw[NJ / 2];
     float am[2];
+    // (measured in round 2: a static s_setprio(1) for the second-dispatched half of the workgroup changes nothing here)
     for (int seq = 0; seq < my_tiles; ++seq) {
         // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between (the late
         // half issues the stores of a tile one iteration later: its counts lag by one)
