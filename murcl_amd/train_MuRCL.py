@@ -26,7 +26,7 @@ from murcl_amd.models import abmil, cl, clam, rlmil
 from murcl_amd.optim import FlatAdam, FlatSGD, make_scheduler
 from murcl_amd.utils import general as G
 from murcl_amd.utils import checkpoint as C
-from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, subbag_views
+from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, draw_mixups, subbag_views
 from murcl_amd.utils.losses import NT_Xent
 
 
@@ -98,20 +98,24 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
     losses, rewards, sim_last, states = [], [], None, None
+    if injected is None:
+        # every random number of the step in four launches (uniform window positions, mix-up draws, the sampler's Gaussian
+        # noise) instead of ~10 tiny launches per view and patch step; none of them depends on anything computed in the step
+        rl = args.train_stage != 1
+        acts_u = torch.rand((1 if rl else args.T, 2, B, K), device=dev)                      # :235,256-258
+        mix = draw_mixups(2 * args.T, B, args.alpha, dev)                                    # datasets.py:265-267
+        noise = torch.randn((args.T - 1, 2, B, K), device=dev) if rl and args.T > 1 else None    # rlmil.py:85-86
     for t in range(args.T):
         if t == 0 or args.train_stage == 1:
-            if injected is not None:
-                acts = [a.to(dev) for a in injected["actions"][t]]
-            else:
-                acts = [torch.rand((B, K), device=dev) for _ in range(2)]                    # :235,256-258
+            acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else [acts_u[t, 0], acts_u[t, 1]]
         else:
-            eps = [None, None] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
+            eps = [noise[t - 1, 0], noise[t - 1, 1]] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
             acts = [ppo.select_action(s, m, restart_batch=(t == 1), eps=e)
                     for s, m, e in zip(states, memory_list, eps)]                            # :259-265
         if injected is not None and injected.get("trace") is not None:
             injected["trace"].append([a.detach().clone() for a in acts])
         views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=dt_,
-                                draws=None if injected is None else injected["draws"][t])   # :237-239,266-269
+                                draws=mix[2 * t:2 * t + 2] if injected is None else injected["draws"][t])   # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
             outputs, states = model(views)                                                   # :242,271
             outputs = fc.forward_views(outputs, restart=(t == 0))                            # :243,272
@@ -150,19 +154,17 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
     aggregator states of the step before, so the sub-bags of all T steps are built into ONE buffer and the aggregator
     runs ONCE over 2*T*B bags - each weight-stationary / wgrad kernel is launched once at full size instead of T times
     at a fraction of it (a launch costs ~15 us before its first tile).  Only the recurrent head and the T NT-Xent
-    launches stay sequential.  The random draws are made in the reference's order (per step: two action tensors, then
-    lambda and the permutation of each view), so the sampled sub-bags are the ones the step-by-step loop would build."""
+    launches stay sequential.  The random draws of the whole step are made up front in a few launches
+    (``datasets.draw_mixups``); injected draws keep the reference's per-step order."""
     B, K, dev, T_ = pack.B, pack.K, pack.feats.device, args.T
     acts, draws = [], []
-    for t in range(T_):
-        if injected is not None:
+    if injected is not None:
+        for t in range(T_):
             acts += [a.to(dev) for a in injected["actions"][t]]
             draws += list(injected["draws"][t])
-        else:
-            acts += [torch.rand((B, K), device=dev) for _ in range(2)]                       # :235,256-258
-            for _ in range(2):                                                               # mixup's draws (datasets.py:265-267)
-                lam = args.alpha + torch.rand(size=(B, 1), device=dev) * (1 - args.alpha)
-                draws.append((lam, torch.randperm(B, device=dev)))
+    else:
+        acts = list(torch.rand((2 * T_, B, K), device=dev).unbind(0))                        # :235,256-258
+        draws = draw_mixups(2 * T_, B, args.alpha, dev)                                      # datasets.py:265-267
     views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch
     losses, rewards, sim_last = [], [], None

@@ -196,6 +196,18 @@ def mixup_with(inputs, lambda_, rand_idx):
     return out
 
 
+def draw_mixups(n_views, B, alpha, device):
+    """``n_views`` independent mix-up draws (datasets.py:265-267: lambda ~ alpha + U(0,1)(1-alpha) per bag, a uniform random
+    permutation of the bags) in five launches for ALL the views of a step: one uniform tensor, lambda by two elementwise
+    ops, the permutations as the row-wise argsort of i.i.d. uniforms (uniform over permutations; an exact tie, ~B^2/2^25,
+    still yields a valid permutation).  View by view the same draws are ``torch.rand`` + ``torch.randperm``: ten tiny
+    launches each, 120 per sampler-in-the-loop step at T = 6.  Returns [(lambda [B,1] f32, perm [B] int32)] * n_views."""
+    u = torch.rand((2, n_views, B), device=device)
+    lam = u[0].mul(1 - alpha).add_(alpha).unsqueeze(-1)
+    perm = u[1].argsort(dim=1).to(torch.int32)
+    return [(lam[v], perm[v]) for v in range(n_views)]
+
+
 def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None):
     """Fused K12+K13 for V views: returns (views: list of [B,feat_size,d] slices of ONE buffer, draws).
 
