@@ -371,6 +371,86 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny16_f32_kernel(const float* 
         }
     }
 }
+// Third skinny form: the operands go through LDS.  The two register forms above read their fragments straight from global
+// memory: one 16-byte load per lane covers 16 ROWS x 64 bytes - sixteen cache lines per instruction, half of each unused -
+// and the texture-address path, not the matrix pipe or the memory system, sets their time (a 64 x 16 x 512 workgroup
+// takes ~9 us however hot its operands are; `tools/skinny_trace.sh`).  Here a workgroup owns a 32 x 32 output tile; its 32
+// rows of A and 32 rows of B arrive by LDS-DMA as whole 1 KiB row pieces (256 k, eight full lines per instruction, shared by
+// the four waves) into two chunk buffers with rows at a stride of 1024 + 16 bytes (conflict-free 16-byte fragment reads,
+// the K2 layout); K <= 512 is in flight at once, longer reductions ping-pong.  Single writer per element: no memset, no
+// atomics, bias / ReLU / accumulate in the epilogue, a result that does not depend on the order of float atomics.
+constexpr int SL_K = 256, SL_ROW = 1024 + 16, SL_T = 32, SL_BUF = 2 * SL_T * SL_ROW;
+#define SL_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+__global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ C, int M, int N, int K, int lda,
+                                                                int ldb, int ldc, const float* __restrict__ bias,
+                                                                int relu, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int n0 = blockIdx.x * SL_T, m0 = blockIdx.y * SL_T;
+    const unsigned lds0 = lds_off(sl_smem);
+    const int nch = (K + SL_K - 1) / SL_K;
+    // chunk image: rows 0..31 = A rows m0.., rows 32..63 = B rows n0..; wave w copies image rows 16w..16w+15 (waves 0,1: A;
+    // waves 2,3: B), one LDS-DMA instruction per row.  Rows past M / N are clamped (their results are never stored); in a
+    // partial last chunk the lanes past K re-read the row's last 16 bytes (never consumed: the k loop stops at K).
+    auto issue = [&](int c) {
+        const int k0 = c * SL_K;
+        const unsigned voff = (unsigned)min(lane * 16, (K - k0) * 4 - 16);
+        const unsigned dst = lds0 + (c & 1) * SL_BUF + wave * 16 * SL_ROW;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = (wave & 1) * 16 + j;
+            const float* src = wave < 2 ? A + (size_t)min(m0 + r, M - 1) * lda + k0 : B + (size_t)min(n0 + r, N - 1) * ldb + k0;
+            glds16_u(src, voff, dst + j * SL_ROW);
+        }
+    };
+    issue(0);
+    if (nch > 1) issue(1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: the f32 MFMA's dependent latency exceeds its issue time
+    const int wm = wave & 1, wn = wave >> 1;
+    for (int c = 0; c < nch; ++c) {
+        if (c + 1 < nch) { SL_WAIT(16); } else { SL_WAIT(0); }
+        LDS_BARRIER();                                       // every wave's rows of chunk c have landed
+        const char* ab = sl_smem + (c & 1) * SL_BUF + (16 * wm + r16) * SL_ROW + 16 * q4;
+        const char* bb = sl_smem + (c & 1) * SL_BUF + (SL_T + 16 * wn + r16) * SL_ROW + 16 * q4;
+        const int ku = min(SL_K, K - c * SL_K) / 16;
+        if (ku == SL_K / 16) {
+#pragma unroll
+            for (int u = 0; u < SL_K / 16; u += 2) {
+                acc0 = mma16<float>(*(const f32x4*)(ab + 64 * u), *(const f32x4*)(bb + 64 * u), acc0);
+                acc1 = mma16<float>(*(const f32x4*)(ab + 64 * (u + 1)), *(const f32x4*)(bb + 64 * (u + 1)), acc1);
+            }
+        } else {
+            for (int u = 0; u < ku; ++u) acc0 = mma16<float>(*(const f32x4*)(ab + 64 * u), *(const f32x4*)(bb + 64 * u), acc0);
+        }
+        if (c + 2 < nch) {
+            LDS_BARRIER();                                   // buffer c & 1 has been read by every wave
+            issue(c + 2);
+        }
+    }
+    // lane holds C[m0 + 16wm + 4q4 + r][n0 + 16wn + r16]: the 16 lanes of a quarter write 64 contiguous bytes of a row
+    const int n = n0 + 16 * wn + r16;
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wm + 4 * q4 + r;
+            if (m < M) {
+                float v = acc0[r] + acc1[r] + bv;
+                float* cp = C + (size_t)m * ldc + n;
+                if (accumulate) v += *cp;
+                *cp = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+static int skinny_lds_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MURCL_SKINNY_LDS"); v = (e && e[0] == '0') ? 0 : 1; }    // dev A/B switch
+    return v;
+}
 __global__ void relu_inplace_kernel(float* x, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fmaxf(x[i], 0.f);
@@ -383,6 +463,19 @@ static int skinny16_enabled() {
 }
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s) {
+    // LDS form unless the reduction is long AND the output has few tiles (per 256-k chunk a workgroup needs ~2 us - one DMA
+    // round trip is not covered by one chunk of MFMAs - so e.g. [128 x 512 x 3072] on 64 workgroups x 12 chunks takes 26 us
+    // against 23 us for the K-split atomics form below, which spreads the same work over 384 workgroups)
+    const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
+    if (skinny_lds_enabled() && !((K + SL_K - 1) / SL_K >= 8 && sl_tiles <= 64)) {
+        static MurclOncePerDevice once;
+        if (once.first())
+            hipFuncSetAttribute((const void*)gemm_nt_lds32_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL_BUF);
+        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T), dim3(256), 2 * SL_BUF, s, A, B,
+                           C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
+                           (int)(epi == EPI_BIAS_RELU), accumulate);
+        return MURCL_CHECK_LAUNCH();
+    }
     if (K <= 512 && (long)((N + 15) / 16) * ((M + 63) / 64) <= 384 && skinny16_enabled()) {
         // short reductions that fit one wave of workgroups: 64 x 16 single-writer workgroups, the whole K range in one memory
         // round trip (measured per shape, tools/skinny_shapes.py: [128 x 512 x 512] 14.4 -> 11.1 us, [64 x 2048 x 512]
