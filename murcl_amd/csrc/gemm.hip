@@ -1102,6 +1102,83 @@ extern "C" long murcl_gemm_tn_workspace_bytes(int M, int N1, int N2, int dtype) 
 
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s);
 
+// Bag-level f32 weight gradients (M = a few hundred rows, outputs up to [3072 x 512]): C[N1,N2] += A[M,N1]^T B[M,N2].
+// The 128 x 128-tile kernel above puts such a product on N1*N2/16384 workgroups of 512 exact-f32 MFMAs per wave and 128 rows
+// (6.8 us of matrix pipe each; [512 x 512] is 16 workgroups on a 256-CU chip).  Here a workgroup owns a 32 x 32 output
+// tile - one 16 x 16 MFMA tile per wave, single writer, no atomics - and the whole reduction (<= 512 rows per pass) sits in
+// LDS: rows of 32 floats of both operands arrive by LDS-DMA, eight rows per instruction, the 16-byte chunks of a row
+// XOR-swizzled at the SOURCE by bit 1 of the row index so that the four lane quarters of a fragment read (rows k..k+3, 16
+// consecutive floats each) fall on four disjoint 16-bank groups.  Column sums of A (the bias gradient) come from one more
+// MFMA per step against a fragment of ones in the workgroups of the first N2 tile.
+constexpr int TS_T = 32, TS_MAXM = 512;
+__global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ C, int M, int N1, int N2, int lda,
+                                                                int ldb, int ldc, float* __restrict__ colsum_out) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int n10 = blockIdx.x * TS_T, n20 = blockIdx.y * TS_T;
+    const unsigned lds0 = lds_off(ts_smem);
+    const int wm = wave & 1, wn = wave >> 1;
+    const bool do_cs = colsum_out != nullptr && blockIdx.y == 0 && wn == 0;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
+    // fragment addresses: row 16u + 4e + q4, column 16w + r16 -> chunk (4w + r16/4) ^ swz(row), swz = 4 * bit 1 of the row = 4 * (q4 >> 1)
+    const int sw = (q4 >> 1) << 2;
+    const unsigned aoff = q4 * 128 + ((((4 * wm + (r16 >> 2)) ^ sw) << 4) | ((r16 & 3) << 2));
+    const unsigned boff = q4 * 128 + ((((4 * wn + (r16 >> 2)) ^ sw) << 4) | ((r16 & 3) << 2));
+    for (int mb = 0; mb < M; mb += TS_MAXM) {
+        const int mc = min(TS_MAXM, M - mb), mp = (mc + 15) & ~15, ng = (mc + 7) >> 3;
+        const unsigned slab_b = (unsigned)mp * 128;
+        if (mb) __syncthreads();                                  // the previous pass has been read by every wave
+        for (int i = wave; i < 2 * ng; i += 4) {                  // wave-uniform: one LDS-DMA instruction = 8 rows of one slab
+            const bool isb = i >= ng;
+            const int gi = isb ? i - ng : i;
+            const int lrow = 8 * gi + (lane >> 3);
+            const int g = (lane & 7) ^ (((lrow >> 1) & 1) << 2);
+            const int row = mb + min(lrow, mc - 1);               // rows past the end: a valid row, zeroed below
+            const float* src = isb ? B + (size_t)row * ldb + min(n20 + 4 * g, N2 - 4) : A + (size_t)row * lda + min(n10 + 4 * g, N1 - 4);
+            glds16(src, lds0 + (isb ? slab_b : 0u) + gi * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (mc & 15) {                                            // ragged tail of the last 16-row group: zeros
+            const int nz = (mp - mc) * 32;
+            for (int i = tid; i < 2 * nz; i += 256) {
+                const int which = i >= nz, j = which ? i - nz : i;
+                *(float*)(ts_smem + (which ? slab_b : 0u) + (mc * 32 + j) * 4) = 0.f;
+            }
+            __syncthreads();
+        }
+        const char* la = ts_smem + aoff;
+        const char* lb = ts_smem + slab_b + boff;
+        for (int u = 0; u < mp / 16; ++u) {
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = *(const float*)(la + (16 * u + 4 * e) * 128);
+                b[e] = *(const float*)(lb + (16 * u + 4 * e) * 128);
+            }
+            if (u & 1) acc1 = mma16<float>(a, b, acc1); else acc0 = mma16<float>(a, b, acc0);
+            if (do_cs) accs = mma16<float>(a, f32x4{1.f, 1.f, 1.f, 1.f}, accs);
+        }
+    }
+    // lane holds C[n10 + 16wm + 4q4 + r][n20 + 16wn + r16]: the 16 lanes of a quarter update 64 contiguous bytes of a row
+    const int n2 = n20 + 16 * wn + r16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n1 = n10 + 16 * wm + 4 * q4 + r;
+        if (n1 < N1 && n2 < N2) C[(size_t)n1 * ldc + n2] += acc0[r] + acc1[r];
+        if (do_cs && r16 == 0 && n1 < N1) colsum_out[n1] += accs[r];
+    }
+}
+static int tn_small_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MURCL_TN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }       // dev A/B switch
+    return v;
+}
+
+
 extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
                              int dtype, int splits, float* colsum_out, hipStream_t stream) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
@@ -1128,6 +1205,18 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
         hipLaunchKernelGGL(k, dim3(tiles * sp), dim3(512), LDS, stream, (const bf16_t*)A, (const bf16_t*)B, C, M, N1, N2,
                            lda, ldb, ldc, mps, sp);
+        return MURCL_CHECK_LAUNCH();
+    }
+    // one pass only: at M = 768 (the deferred head gradients of a T = 6 step) two serial passes per 32 x 32 tile take 78 us where
+    // the 128 x 128 ring kernel below takes 55 us ([768 x 3072 x 512], tools/tn_trace.sh); up to 512 rows the small tiles win
+    // (16.6 -> 12.2 us [128 x 3072 x 512], 7.7 -> 5.8 us [128 x 512 x 512], 23.7 -> 18.0 us [320 x 2048 x 512])
+    if (dtype == MURCL_DTYPE_F32 && splits <= 0 && M <= TS_MAXM && tn_small_enabled()) {
+        const int mp = ((M < TS_MAXM ? M : TS_MAXM) + 15) & ~15;
+        static MurclOncePerDevice once;
+        if (once.first())
+            hipFuncSetAttribute((const void*)gemm_tn_small_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_MAXM * 128);
+        hipLaunchKernelGGL(gemm_tn_small_f32_kernel, dim3((N1 + TS_T - 1) / TS_T, (N2 + TS_T - 1) / TS_T), dim3(256), 2 * mp * 128,
+                           stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, colsum_out);
         return MURCL_CHECK_LAUNCH();
     }
     const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
