@@ -384,8 +384,16 @@ constexpr int SL_K = 256, SL_ROW = 1024 + 16, SL_T = 32, SL_BUF = 2 * SL_T * SL_
 __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ C, int M, int N, int K, int lda,
                                                                 int ldb, int ldc, const float* __restrict__ bias,
-                                                                int relu, int accumulate) {
+                                                                int relu, int accumulate, int k_per_split) {
     extern __shared__ __attribute__((aligned(16))) char sl_smem[];
+    // gridDim.z > 1: K split over workgroups (long reductions with few output tiles); the partial tiles are added
+    // atomically into a zeroed C (bias from split 0; a ReLU, if any, is the launcher's separate pass)
+    if (gridDim.z > 1) {
+        const int kb = blockIdx.z * k_per_split;
+        A += kb;
+        B += kb;
+        K = min(K - kb, k_per_split);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
@@ -433,15 +441,19 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
     // lane holds C[m0 + 16wm + 4q4 + r][n0 + 16wn + r16]: the 16 lanes of a quarter write 64 contiguous bytes of a row
     const int n = n0 + 16 * wn + r16;
     if (n < N) {
-        const float bv = bias ? bias[n] : 0.f;
+        const float bv = (bias && blockIdx.z == 0) ? bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * wm + 4 * q4 + r;
             if (m < M) {
                 float v = acc0[r] + acc1[r] + bv;
                 float* cp = C + (size_t)m * ldc + n;
-                if (accumulate) v += *cp;
-                *cp = relu ? fmaxf(v, 0.f) : v;
+                if (gridDim.z > 1) {
+                    atomicAdd(cp, v);                        // 16 lanes of a quarter: 64 contiguous bytes per request
+                } else {
+                    if (accumulate) v += *cp;
+                    *cp = relu ? fmaxf(v, 0.f) : v;
+                }
             }
         }
     }
@@ -463,18 +475,39 @@ static int skinny16_enabled() {
 }
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s) {
-    // LDS form unless the reduction is long AND the output has few tiles (per 256-k chunk a workgroup needs ~2 us - one DMA
-    // round trip is not covered by one chunk of MFMAs - so e.g. [128 x 512 x 3072] on 64 workgroups x 12 chunks takes 26 us
-    // against 23 us for the K-split atomics form below, which spreads the same work over 384 workgroups)
-    const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
-    if (skinny_lds_enabled() && !((K + SL_K - 1) / SL_K >= 8 && sl_tiles <= 64)) {
+    // LDS form.  Long reductions with few output tiles (per 256-k chunk a workgroup needs ~2 us - one DMA round trip is not
+    // covered by one chunk of MFMAs - so [128 x 512 x 3072] on 64 workgroups x 12 chunks takes 26 us) are split over K so that
+    // every workgroup has its whole share (two chunks) in flight at once; those partial tiles meet in a zeroed C by atomics.
+    if (skinny_lds_enabled()) {
+        const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
+        const int nch = (K + SL_K - 1) / SL_K;
+        int sp = 1;
+        if (nch >= 6 && sl_tiles <= 96) {
+            sp = (int)((384 + sl_tiles - 1) / sl_tiles);
+            if (sp > nch / 2) sp = nch / 2;
+        }
+        const int kps = ((nch + sp - 1) / sp) * SL_K;
+        sp = (K + kps - 1) / kps;
+        if (sp > 1 && !accumulate) {
+            hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        const bool relu = epi == EPI_BIAS_RELU;
         static MurclOncePerDevice once;
         if (once.first())
             hipFuncSetAttribute((const void*)gemm_nt_lds32_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL_BUF);
-        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T), dim3(256), 2 * SL_BUF, s, A, B,
-                           C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
-                           (int)(epi == EPI_BIAS_RELU), accumulate);
-        return MURCL_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T, sp), dim3(256), 2 * SL_BUF, s, A,
+                           B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
+                           (int)(relu && sp == 1), (int)(accumulate && sp == 1), kps);
+        int rc = MURCL_CHECK_LAUNCH();
+        if (rc) return rc;
+        if (relu && sp > 1) {
+            if (ldc != N) return -1;
+            const long n = (long)M * N;
+            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, n);
+            rc = MURCL_CHECK_LAUNCH();
+        }
+        return rc;
     }
     if (K <= 512 && (long)((N + 15) / 16) * ((M + 63) / 64) <= 384 && skinny16_enabled()) {
         // short reductions that fit one wave of workgroups: 64 x 16 single-writer workgroups, the whole K range in one memory
