@@ -52,7 +52,11 @@ int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2,
  * workspace as plain stores and are added to C by a second launch - no float atomics; other shapes behave as murcl_gemm_tn. */
 long murcl_gemm_tn_workspace_bytes(int M, int N1, int N2, int dtype);
 int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc, int dtype,
-                     int splits, float* colsum_out, float* ws, long ws_bytes, murcl_stream_t stream);
+                     int splits, float* colsum_out, float* ws, long ws_bytes, const float* colsum_part, int colsum_rows,
+                     murcl_stream_t stream);
+/* colsum_part (may be NULL) [colsum_rows][N1] f32: instead of the column sums of A, colsum_out += the sum of these rows -
+ * the partial bias-gradient rows murcl_panel_gemm leaves in its colsum_ws when called without colsum_out - folded into the
+ * launch that adds up the workspace (a small launch of its own on the other paths). */
 
 /* Weight-stationary bf16 variant of murcl_gemm_nt for the patch-level layers (M = bags*patches rows, K in
  * {512,128}): same Linear forward / input-gradient as above (abmil.py:12-21,23-24 and their autograd), with
@@ -67,6 +71,9 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * loaded with the non-temporal cache policy (read once: it should not displace the output from the Infinity Cache).
  * murcl_panel_gemm_supported tells whether a shape is covered (else use murcl_gemm_nt). */
 int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag);
+/* colsum_ws given WITHOUT colsum_out: the partial rows stay in colsum_ws ([murcl_panel_gemm_colsum_rows][N] f32) and no second
+ * launch runs; the caller adds them up (murcl_gemm_tn_ws's colsum_part: the weight gradient of the same layer comes next). */
+int murcl_panel_gemm_colsum_rows(int M, int N, int K, int epilogue);
 int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue, const float* bias,
                      void* bitmask_out, const void* bitmask_in, const float* rowscale, const float* rank1,
                      int rows_per_bag, float* colsum_out, int colsum_accumulate, float* colsum_ws /* [256*N] */,

@@ -21,7 +21,8 @@ SIGNATURES = {
     "murcl_gemm_nt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "murcl_gemm_tn_workspace_bytes": [_I, _I, _I, _I],
-    "murcl_gemm_tn_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P],
+    "murcl_gemm_tn_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
+    "murcl_panel_gemm_colsum_rows": [_I, _I, _I, _I],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],

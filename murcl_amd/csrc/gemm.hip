@@ -1093,9 +1093,46 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
         }
 }
 // C[n] += sum_s part[s][n]   (n over N1*N2 elements as float4; eight splits of loads in flight per thread)
+// Blocks past the matrix part (cs_part given) add up [cs_rows][N1] partial column-sum rows into cs_out the same way: the
+// bias gradient of the layer, whose partial rows the input-gradient kernel left behind, rides along in this launch.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long n4,
-                                                        int nsplit, int N2, int ldc) {
+                                                        int nsplit, int N2, int ldc, const float* __restrict__ cs_part,
+                                                        int cs_rows, int N1, float* __restrict__ cs_out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long mat_blocks = (n4 + 255) / 256;
+    if ((long)blockIdx.x >= mat_blocks) {
+        // column-sum blocks: 16 four-column groups x 16 row slices per block, every thread's rows in flight at once, the
+        // slices meet in LDS (one serial pass over all rows per thread would take one memory round trip per few rows)
+        if (cs_part == nullptr) return;
+        __shared__ f32x4 red[256];
+        const int cg = threadIdx.x & 15, rs = threadIdx.x >> 4;
+        const long j = ((long)blockIdx.x - mat_blocks) * 16 + cg;
+        const int ng = N1 / 4;
+        f32x4 b0 = {0, 0, 0, 0}, b1 = b0;
+        if (j < ng) {
+            const f32x4* q = (const f32x4*)cs_part + j;
+            for (int r0 = 0; r0 < cs_rows; r0 += 256) {           // <= 256 rows per pass: 16 independent loads per thread
+                f32x4 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int r = r0 + rs + 16 * k;
+                    v[k] = r < cs_rows ? q[(size_t)r * ng] : f32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) { b0 += v[k]; b1 += v[k + 1]; }
+            }
+        }
+        red[threadIdx.x] = b0 + b1;
+        __syncthreads();
+        if (rs == 0 && j < ng) {
+            f32x4 t = red[cg];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t += red[16 * k + cg];
+            f32x4* o = (f32x4*)cs_out + j;
+            *o = *o + t;
+        }
+        return;
+    }
     if (i >= n4) return;
     const f32x4* p = (const f32x4*)part + i;
     f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
@@ -1291,14 +1328,22 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
 // on 256 x 256 tiles with the split partial sums stored to `ws` and added to C by a reduce launch (no float atomics);
 // every other shape, or a workspace that is too small, falls through to murcl_gemm_tn.
 extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
-                                int dtype, int splits, float* colsum_out, float* ws, long ws_bytes, hipStream_t stream) {
+                                int dtype, int splits, float* colsum_out, float* ws, long ws_bytes, const float* colsum_part,
+                                int colsum_rows, hipStream_t stream) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    if (colsum_part && (!colsum_out || colsum_rows <= 0 || N1 % 4)) return -1;
     if (splits > 0 || !ws || !tn_sq_ok(M, N1, N2, ldc, dtype) || (lda * 2) % 16 || (ldb * 2) % 16 ||
-        ws_bytes < murcl_gemm_tn_workspace_bytes(M, N1, N2, dtype))
+        ws_bytes < murcl_gemm_tn_workspace_bytes(M, N1, N2, dtype)) {
+        if (colsum_part) {                      // the partial rows are added up by their own small launch
+            const int rc = murcl_colsum(colsum_part, colsum_out, colsum_rows, N1, N1, MURCL_DTYPE_F32, 1, stream);
+            if (rc) return rc;
+            colsum_out = nullptr;
+        }
         return murcl_gemm_tn(A, B, C, M, N1, N2, lda, ldb, ldc, dtype, splits, colsum_out, stream);
+    }
     int sp, mps;
     const int tiles = tn_sq_plan(M, N1, N2, &sp, &mps);
-    if (colsum_out) {
+    if (colsum_out && !colsum_part) {
         const int rc = murcl_colsum(A, colsum_out, M, N1, lda, dtype, 1, stream);
         if (rc) return rc;
     }
@@ -1311,6 +1356,8 @@ extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, i
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
     const long n4 = (long)N1 * N2 / 4;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, ws, C, n4, sp, N2, ldc);
+    const unsigned cs_blocks = colsum_part ? (unsigned)((N1 / 4 + 15) / 16) : 0u;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256) + cs_blocks), dim3(256), 0, stream, ws, C, n4, sp, N2, ldc,
+                       colsum_part, colsum_rows, N1, colsum_out);
     return MURCL_CHECK_LAUNCH();
 }

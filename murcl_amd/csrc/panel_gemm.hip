@@ -447,6 +447,14 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
 }
 
+// workgroups of a launch: one per CU, fewer (a multiple of 8 per column panel) when there are not enough row tiles
+static int pg_grid(int M, int panels) {
+    int grid = 256;
+    const int n_tiles = M / PG_TR;
+    if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
+    return grid;
+}
+
 template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
@@ -464,9 +472,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
                        
     }
     const int panels = N / (PG_NW * WN);
-    int grid = 256;
-    const int n_tiles = M / PG_TR;
-    if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
+    const int grid = pg_grid(M, panels);
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * PG_NW), LDS, s, A, W, C, M, N, bias, bm_out, bm_in, rowscale, rank1,
                        rows_per_bag, colsum_part, walk_reverse);
     *streams_out = grid / panels;
@@ -485,13 +491,21 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
     return 0;
 }
 
+extern "C" int murcl_panel_gemm_colsum_rows(int M, int N, int K, int epilogue) {
+    if (M <= 0 || N <= 0) return 0;
+    const int panels = K == 128 ? N / 512 : N / 256;         // columns per workgroup: 8 waves x 64 (K = 128) / 256 (K = 512)
+    if (panels <= 0) return 0;
+    (void)epilogue;
+    return pg_grid(M, panels) / panels;
+}
+
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
                                 const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
                                 float* colsum_ws, int walk_reverse, hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
     if (colsum_out && !colsum_ws) return -1;
-    float* part = colsum_out ? colsum_ws : nullptr;
+    float* part = colsum_ws;                 // without colsum_out: the partial rows are the result (the caller adds them up)
     int streams = 0, rc = -1;
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* w = (const bf16_t*)W;

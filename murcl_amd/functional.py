@@ -32,6 +32,7 @@ import os as _os
 # the backward pass, while its output (H3) is what the pooling kernel streams next: kept out of the Infinity Cache, H2
 # leaves more of H3 there (K2 forward 67.6 -> 62.4 us inside the step; the other layers measured neutral-to-slower).
 _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
+_FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
 
 def set_grad_milestone(callback):
@@ -65,12 +66,19 @@ def _touch(*params):
             _TOUCHED.add(id(p))
 
 
-def _wgrad(dy, x, w):
-    """dW = dy^T x [N1,N2]; returns it, or adds it to w.grad and returns None."""
+def _wgrad(dy, x, w, b=None, bias_parts=None):
+    """dW = dy^T x [N1,N2]; returns it, or adds it to w.grad and returns None.  ``bias_parts`` (direct mode only): the
+    partial column-sum rows of dy that the kernel which produced dy left behind - the bias gradient, added to b.grad by
+    the same launches."""
     if _direct(w):
-        ops.gemm_tn(dy, x, out=w.grad)
-        _touch(w)
+        if bias_parts is not None:
+            ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1), colsum_parts=bias_parts)
+            _touch(w, b)
+        else:
+            ops.gemm_tn(dy, x, out=w.grad)
+            _touch(w)
         return None
+    assert bias_parts is None
     return ops.gemm_tn(dy, x)
 
 
@@ -257,16 +265,22 @@ class ABMILFn(torch.autograd.Function):
                     _touch(b)
                     return b.grad.view(-1)
                 return None
-            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3,
-                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_into=into(b3))
-            dw3 = _wgrad(dz3, h2, w3)
+            # bias gradients: the dgrad kernels leave per-workgroup partial column sums; when weight AND bias accumulate
+            # directly into the flat gradient buffer the rows are added up inside the weight gradient's reduce launch
+            fold = lambda w, b: _FOLD_BIAS and _direct(w) and _direct(b)      # noqa: E731
+            f3, f2, f1 = fold(w3, b3), fold(w2, b2), fold(w1, b1)
+            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N,
+                                         colsum=True, colsum_into=None if f3 else into(b3), colsum_defer=f3)
+            dw3 = _wgrad(dz3, h2, w3, b3, db3 if f3 else None)
+            db3 = None if f3 else db3
             _final(w3, b3)
             dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True,
-                                         colsum_into=into(b2))
-            dw2 = _wgrad(dz2, h1, w2)
+                                         colsum_into=None if f2 else into(b2), colsum_defer=f2)
+            dw2 = _wgrad(dz2, h1, w2, b2, db2 if f2 else None)
+            db2 = None if f2 else db2
             _final(w2, b2)
             dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True,
-                                         colsum_into=into(b1))
+                                         colsum_into=None if f1 else into(b1), colsum_defer=f1)
         else:
             dz3, ws = ops.gemm_nt(dT, wat, epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
                                   rank1=dM, rows_per_bag=N, colsum=True)
@@ -279,7 +293,10 @@ class ABMILFn(torch.autograd.Function):
             _final(w2, b2)
             dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
             db1 = _bgrad(ws, b1)
-        dw1 = _wgrad(dz1, x2, w1)
+        if m3 is not None and f1:
+            dw1, db1 = _wgrad(dz1, x2, w1, b1, db1), None
+        else:
+            dw1 = _wgrad(dz1, x2, w1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(dz1, ops.transpose_cast(w1, T)).view(B, N, d)

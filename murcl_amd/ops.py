@@ -125,9 +125,11 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False, colsum_into=None, reverse=False, stream_a=False):
+               colsum=False, colsum_into=None, colsum_defer=False, reverse=False, stream_a=False):
     """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
     ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None.
+    ``colsum_defer``: no second launch - the third result is (partial rows [R,N] f32, R) for ``gemm_tn(colsum_parts=...)``,
+    the weight gradient of the same layer, whose reduce launch adds them up on the way.
     ``reverse``: visit the row tiles last-to-first (cache reuse after a producer that walked forward; same result).
     ``stream_a``: load A with the non-temporal policy (K = 512): it is read once and should not displace the output, which
     the next kernel reads, from the Infinity Cache."""
@@ -138,10 +140,11 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
     C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     bm = torch.empty((M, N // 8), dtype=torch.uint8, device=A.device) if want_bitmask else None
-    cs = torch.empty((N,), dtype=torch.float32, device=A.device) if (colsum and colsum_into is None) else None
+    cs = torch.empty((N,), dtype=torch.float32, device=A.device) if (colsum and colsum_into is None and not colsum_defer) else None
     if colsum_into is not None:
+        assert not colsum_defer
         assert colsum_into.is_contiguous() and colsum_into.dtype == torch.float32 and colsum_into.numel() == N
-    ws = torch.empty((256 * N,), dtype=torch.float32, device=A.device) if (colsum or colsum_into is not None) else None
+    ws = torch.empty((256 * N,), dtype=torch.float32, device=A.device) if (colsum or colsum_into is not None or colsum_defer) else None
     with _span(lambda: (f"panel_gemm<K{K},{_PG_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0)))):
         check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
@@ -149,6 +152,8 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
                                           ptr(colsum_into if colsum_into is not None else cs),
                                           int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0), stream()),
               "panel_gemm")
+    if colsum_defer:
+        return C, bm, (ws, _lib.lib().murcl_panel_gemm_colsum_rows(M, N, K, epi))
     return C, bm, cs
 
 
@@ -166,15 +171,18 @@ import os as _os
 _TN_SQ = _os.environ.get("MURCL_TN_SQ", "1") == "1"          # dev A/B switch: 0 keeps the 256 x 128 atomics kernel
 
 
-def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None):
+def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None):
     """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given).  ``colsum_into`` [N1] f32: the column sums
-    of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient)."""
+    of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient); with
+    ``colsum_parts`` = (rows [R,N1] f32, R) from ``panel_gemm(colsum_defer=True)`` those rows are summed instead."""
     _need_cuda(A, B)
     A, B = _c(A), _c(B)
     M, N1 = A.shape
     N2 = B.shape[1]
     assert B.shape[0] == M and A.dtype == B.dtype
     epc = 4 if A.dtype == torch.float32 else 8
+    if colsum_parts is not None and (colsum_into is None or N1 % 4):
+        raise ValueError("colsum_parts needs colsum_into and N1 % 4 == 0")
     if N1 % epc:                    # tiny head gradients (N1 = 1, 2, 10): zero-pad the columns of A, slice the result
         Ap = A.new_zeros((M, ((N1 + epc - 1) // epc) * epc))
         Ap[:, :N1] = A
@@ -192,8 +200,12 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None):
         with _span(lambda: (f"gemm_tn_sq<{_DT_NAME[A.dtype]}>",
                    dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
             check(_lib.lib().murcl_gemm_tn_ws(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
-                                              ptr(ws), wsb, stream()), "gemm_tn_ws")
+                                              ptr(ws), wsb, ptr(colsum_parts[0]) if colsum_parts else None,
+                                              colsum_parts[1] if colsum_parts else 0, stream()), "gemm_tn_ws")
         return C
+    if colsum_parts is not None:                      # other paths: the partial rows get their own small launch
+        colsum(colsum_parts[0].view(-1, N1)[:colsum_parts[1]], out=colsum_into, accumulate=True)
+        colsum_into = None
     with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
         check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
