@@ -88,6 +88,43 @@ def test_gemm_nt_accumulate():
     _close(C, C0.double() + A.double() @ B.double().t(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 512, 512), (128, 3072, 512), (320, 2048, 512), (33, 40, 16), (65, 100, 272), (1, 8, 1024),
+                                   (128, 128, 1024), (128, 512, 3072), (64, 512, 2048), (1024, 96, 1536), (17, 2048, 144)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_relu"])
+def test_gemm_nt_bag_level_f32_forms(M, N, K, epi):
+    """The LDS-staged 32 x 32-tile form of the bag-level f32 layers (M <= 1024): ragged M / N tiles, partial 256-k chunks,
+    one / two / many chunks (ping-pong buffers), and the K-split atomics path of long reductions with few tiles."""
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(11, f"A{M}{K}", (M, K))
+    B = _rand(11, f"B{N}{K}", (N, K), 1 / math.sqrt(K))
+    bias = _rand(11, f"b{N}", (N,))
+    ref = A.double() @ B.double().t()
+    if epi == "none":
+        C = ops.gemm_nt(A.to(dev), B.to(dev))
+    elif epi == "bias":
+        C, ref = ops.gemm_nt(A.to(dev), B.to(dev), epi=ops.EPI_BIAS, bias=bias.to(dev)), ref + bias.double()
+    else:
+        C, ref = ops.gemm_nt(A.to(dev), B.to(dev), epi=ops.EPI_BIAS_RELU, bias=bias.to(dev)), torch.relu(ref + bias.double())
+    assert C.shape == (M, N) and C.dtype == torch.float32
+    _close(C, ref, rtol=2e-5, atol=2e-5, msg=f"{epi} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 384, 512), (128, 512, 3072), (40, 72, 2048)])
+def test_gemm_nt_bag_level_accumulate_and_row_views(M, N, K):
+    """accumulate=True adds onto C on the single-writer AND the K-split path; operands may be row blocks of wider tensors
+    (leading dimension > K) as the GRU / head code passes them."""
+    from murcl_amd import ops
+    dev = _dev()
+    Aw = _rand(12, f"A{M}{K}", (M, K + 64)).to(dev)
+    Bw = _rand(12, f"B{N}{K}", (N + 3, K), 1 / math.sqrt(K)).to(dev)
+    A, B = Aw[:, :K], Bw[1:N + 1]
+    C0 = _rand(12, f"C{M}{N}", (M, N))
+    C = C0.to(dev).clone()
+    ops.gemm_nt(A, B, out=C, accumulate=True)
+    _close(C, C0.double() + A.double().cpu() @ B.double().cpu().t(), rtol=2e-5, atol=2e-5)
+
+
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (1000, 128, 512), (130, 3072, 512), (77, 16, 1024), (20000, 512, 128),
@@ -125,6 +162,49 @@ def test_gemm_tn_adds_the_bias_gradient_in_the_same_launch(dtype, M, N1, N2):
     f32 = dtype == torch.float32
     _close(out, W0.double() + A.double().t() @ B.double(), rtol=1e-4, atol=1e-4 * s if f32 else 2e-2 * s, msg="dW")
     _close(cs, pre.double() + A.double().sum(0), rtol=1e-4, atol=1e-4 * s if f32 else 1e-3 * s, msg="db")     # ADDED, not overwritten
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1, 4, 4), (15, 36, 100), (128, 1024, 128), (320, 2048, 512), (500, 60, 3072), (512, 512, 512),
+                                     (513, 64, 64), (768, 3072, 512)])
+def test_gemm_tn_bag_level_f32_forms(M, N1, N2):
+    """The 32 x 32 single-writer form (whole reduction in LDS, M <= 512) and its boundary with the ring kernel: ragged 16-row
+    tail groups, ragged column tiles, the bias gradient from the ones-fragment, accumulation onto existing gradients."""
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(13, f"A{M}{N1}", (M, N1))
+    B = _rand(13, f"B{M}{N2}", (M, N2))
+    W0, b0 = _rand(13, f"w{N1}{N2}", (N1, N2)), _rand(13, f"c{N1}", (N1,))
+    out, cs = W0.clone().to(dev), b0.clone().to(dev)
+    ops.gemm_tn(A.to(dev), B.to(dev), out=out, colsum_into=cs)
+    s = math.sqrt(M)
+    _close(out, W0.double() + A.double().t() @ B.double(), rtol=2e-5, atol=2e-5 * s, msg="dW")
+    _close(cs, b0.double() + A.double().sum(0), rtol=2e-5, atol=2e-5 * s, msg="db")
+    out2 = ops.gemm_tn(A.to(dev), B.to(dev))
+    _close(out2, A.double().t() @ B.double(), rtol=2e-5, atol=2e-5 * s, msg="fresh")
+
+
+@pytest.mark.parametrize("M", [64, 8192, 65536])
+def test_panel_dgrad_partial_bias_rows_fold_into_the_weight_gradient(M):
+    """panel_gemm(colsum_defer=True) leaves [R, N] partial column sums; gemm_tn(colsum_parts=...) adds them to the bias
+    gradient - inside the reduce launch of the workspace path (M >= 16384), by a small launch of its own otherwise."""
+    from murcl_amd import ops
+    dev = _dev()
+    N = 512
+    dY = _rand(14, f"dY{M}", (M, N), 0.5).bfloat16().to(dev)
+    Wt = _rand(14, "Wt", (N, N), 1 / math.sqrt(N)).bfloat16().to(dev)
+    H = _rand(14, f"H{M}", (M, N)).to(dev)
+    X = _rand(14, f"X{M}", (M, N), 0.5).bfloat16().to(dev)
+    bits = ops.relu_bitmask(H)
+    dZ, _, parts = ops.panel_gemm(dY, Wt, ops.PG_MASK, bitmask=bits, colsum=True, colsum_defer=True)
+    dZr, _, cs_ref = ops.panel_gemm(dY, Wt, ops.PG_MASK, bitmask=bits, colsum=True)
+    assert torch.equal(dZ, dZr) and parts[1] >= 1 and parts[0].numel() >= parts[1] * N
+    g0, b0 = _rand(14, "g0", (N, N)), _rand(14, "b0", (N,))
+    gw, gb = g0.clone().to(dev), b0.clone().to(dev)
+    ops.gemm_tn(dZ, X, out=gw, colsum_into=gb, colsum_parts=parts)
+    gw2 = g0.clone().to(dev)
+    ops.gemm_tn(dZ, X, out=gw2)
+    _close(gw, gw2.double().cpu(), rtol=1e-6, atol=1e-4 * math.sqrt(M), msg="dW unchanged by the fold")
+    _close(gb, b0.double() + cs_ref.double().cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(M), msg="db")
 
 
 # ------------------------------------------------------------------ K2 attention pool
