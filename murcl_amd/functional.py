@@ -218,11 +218,12 @@ class ABMILFn(torch.autograd.Function):
                 and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
         if fast:
             nt = _STREAM_A
-            h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=True, stream_a=bool(nt & 1))
+            keep = any(ctx.needs_input_grad)     # forward-only passes (frozen encoder of stage 2, validation): no ReLU masks to write
+            h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=keep, stream_a=bool(nt & 1))
             # layer 2 walks the rows backwards (layer 1 has just written the high rows of h1), layer 3 forwards again,
             # and the pooling kernel backwards: every pass starts on what its producer left in the Infinity Cache
-            h2, m2, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=True, reverse=True, stream_a=bool(nt & 2))
-            h3, m3, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=True, stream_a=bool(nt & 4))
+            h2, m2, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=keep, reverse=True, stream_a=bool(nt & 2))
+            h3, m3, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=keep, stream_a=bool(nt & 4))
         else:
             m1 = m2 = m3 = None
             h1 = ops.gemm_nt(x2, w1c, epi=ops.EPI_BIAS_RELU, bias=b1)
