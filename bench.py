@@ -254,9 +254,17 @@ def other_rows(device):
         (bag.sum() + classes.max(1)[0].sum()).backward()            # bag term + max-instance term (train_RLMIL.py:516-529)
     ms = _timed_ms(dsmil_fb)
     nbytes = 4 * B * N * d * 4
+    # In f32 two of the row's kernels are bound by the exact-f32 matrix pipe, not by HBM: the query projection X Wq^T and its
+    # weight gradient dQ^T X (2 * B*N*d*128 FLOP each at PEAK["mfma_f32_TFLOPs"]); the other passes over X (scores + pooling
+    # forward, the fused dA / dWc sweep backward) are HBM passes.  The row's floor is the sum of its kernels' own floors.
+    gemm_flops = 2.0 * B * N * d * 128
+    floor_ms = 2 * gemm_flops / (PEAK["mfma_f32_TFLOPs"] * 1e12) * 1e3 + 3 * (B * N * d * 4) / (PEAK["hbm_GBps"] * 1e9) * 1e3
     out["dsmil_c5_share_fwd_bwd"] = dict(workload=f"DSMIL {B} bags x {N} x {d} f32 (one GPU's share of 128 bags)", ms=round(ms, 4),
                                          bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
-                                         frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+                                         frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4),
+                                         kernelwise_floor_ms=round(floor_ms, 4), frac_of_kernelwise_floor=round(floor_ms / ms, 4),
+                                         floor_note="2 f32-MFMA-bound GEMMs (query projection, its weight gradient: 34.4 GFLOP each at "
+                                                    "157 TFLOP/s) + 3 HBM passes over X at 8 TB/s")
     md.compute_dtype = torch.bfloat16                               # patch features stored in bf16, f32 accumulation
     xd = xd.bfloat16()
     ms = _timed_ms(dsmil_fb)
