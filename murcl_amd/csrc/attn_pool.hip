@@ -29,6 +29,9 @@
 #ifndef K2_GK
 #define K2_GK 4                  // k-steps per LDS prefetch group in the score MFMA loop
 #endif
+#ifndef K2_PAIR
+#define K2_PAIR 1                // bf16 forward: two 16-row tiles per iteration (see the paired loop)
+#endif
 
 template <typename T, bool EXACT_TANH>
 __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::MIN_WAVES)) void abmil_pool_fwd_kernel(
@@ -44,7 +47,7 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     const int q4 = lane >> 4, r16 = lane & 15;
     const unsigned lds0 = lds_off(smem);
     float* spart = (float*)(smem + L_::OFF_SPART);
-    unsigned* pbuf = (unsigned*)(smem + L_::OFF_PBUF) + wave * 16;   // wave-private
+    unsigned* pbuf = (unsigned*)(smem + L_::OFF_PBUF) + wave * 32;   // wave-private (16 words per tile of a pair)
     float* sbuf = (float*)(smem + L_::OFF_SBUF);
 
     const int n_items = B * S;
@@ -63,7 +66,8 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                          lds0 + (seq & (K2_NSLOT - 1)) * C_::SLOT, wave, lane);
         ip.next(tiles_per_item, gridDim.x, S);
     };
-    const int pre = min(3, my_tiles);
+    constexpr bool PAIR = K2_PAIR && sizeof(T) == 2 && !EXACT_TANH;
+    const int pre = min(PAIR ? 4 : 3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
 
     // ---- this wave's DW columns of Wa as MFMA "a" operands: row d = DW*wave + 16j + r16; quarter q4 of k-step
@@ -104,6 +108,133 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     // row 1 the high halves, every other row zeros (v_perm_b32: 0x0c = constant zero byte)
     const unsigned psel = (r16 == 0) ? 0x05040100u : (r16 == 1 ? 0x07060302u : 0x0c0c0c0cu);
 
+    if constexpr (PAIR) {
+        // Paired loop: TWO consecutive 16-row tiles (same item: an item is a multiple of 32 rows) per iteration.  The per-tile
+        // chain - fragment reads, 32 MFMAs, tanh, cross-wave sum, barrier, weights, pooling MFMAs - is latency-bound, not
+        // throughput-bound (matrix pipe ~30 % busy); two independent chains in one instruction stream give the scheduler
+        // twice the work between the same two barriers.  Ring: the pair in use + the next pair in flight (64 KiB per CU with
+        // two workgroups; the LDS-DMA skeleton of that shape still streams 6.1 TB/s, tools/stream_probe.py).
+        float* spart1 = spart + C_::NW * 16;
+        const int npair = my_tiles >> 1;
+        for (int pr = 0; pr < npair; ++pr) {
+            const int seq = 2 * pr;
+            if (pr == 0 && my_tiles > 2) { K2_WAIT(2 * C_::GT); } else { K2_WAIT(0); }
+            LDS_BARRIER();                     // both tiles of this pair landed; the slots of the previous pair are free
+            if (pr >= 1 && seq + 2 < my_tiles) { issue(seq + 2); issue(seq + 3); }
+            const int tin = cp.tin;
+            const int row0 = cp.ch * chunk_rows + tin * C_::TR;
+            const char* tile0 = smem + (seq & (K2_NSLOT - 1)) * C_::SLOT;
+            const char* tile1 = smem + ((seq + 1) & (K2_NSLOT - 1)) * C_::SLOT;
+            f32x4 acc0[C_::NJ], acc1[C_::NJ];
+#pragma unroll
+            for (int j = 0; j < C_::NJ; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = acc0[j]; }
+            {
+                const char* h0 = tile0 + r16 * C_::PADB + C_::NKK * q4 * 16;
+                const char* h1 = tile1 + r16 * C_::PADB + C_::NKK * q4 * 16;
+                constexpr int GK = 2, NG = C_::NKK / GK;
+                frag_t hq0[2][GK], hq1[2][GK];
+#pragma unroll
+                for (int k2 = 0; k2 < GK; ++k2) { hq0[0][k2] = *(const frag_t*)(h0 + k2 * 16); hq1[0][k2] = *(const frag_t*)(h1 + k2 * 16); }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int k2 = 0; k2 < GK; ++k2) {
+                            hq0[(g + 1) & 1][k2] = *(const frag_t*)(h0 + ((g + 1) * GK + k2) * 16);
+                            hq1[(g + 1) & 1][k2] = *(const frag_t*)(h1 + ((g + 1) * GK + k2) * 16);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k2 = 0; k2 < GK; ++k2)
+#pragma unroll
+                        for (int j = 0; j < C_::NJ; ++j) {
+                            acc0[j] = k2_mma<T>(wa[j][g * GK + k2], hq0[g & 1][k2], acc0[j]);
+                            acc1[j] = k2_mma<T>(wa[j][g * GK + k2], hq1[g & 1][k2], acc1[j]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < C_::NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ps0 += wb_r[j][r] * fast_tanh(acc0[j][r] + ba_r[j][r]);
+                    ps1 += wb_r[j][r] * fast_tanh(acc1[j][r] + ba_r[j][r]);
+                }
+            ps0 = quarters_sum(ps0);
+            ps1 = quarters_sum(ps1);
+            if (q4 == 0) { spart[wave * 16 + r16] = ps0; spart1[wave * 16 + r16] = ps1; }
+            LDS_BARRIER();
+
+            // phase B (every wave redundantly): lanes 0..15 <-> rows of tile 0, lanes 16..31 <-> rows of tile 1
+            float s = -INFINITY;
+            if (lane < 2 * C_::TR) {
+                const float* sp = (lane < C_::TR) ? spart : spart1;
+                s = bb;
+#pragma unroll
+                for (int w = 0; w < C_::NW; ++w) s += sp[w * 16 + r16];
+                if (row0 + lane >= N) s = -INFINITY;
+                if (wave == 0) sbuf[tin * C_::TR + lane] = s;
+            }
+            float p;
+            if (fixed_ref) {
+                p = (s == -INFINITY) ? 0.f : fast_exp(s - smax);
+                l_run += p;                                   // per-lane partial (lanes 0..31), reduced at item end
+            } else {
+                const float tmax = half_wave_max(s);
+                const float m_new = fmaxf(m_run, tmax);
+                const float scale = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);
+                p = (s == -INFINITY) ? 0.f : fast_exp(s - m_new);
+                l_run = l_run * scale + half_wave_sum(lane < 2 * C_::TR ? p : 0.f);
+                m_run = m_new;
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) macc[j] *= scale;
+            }
+            if (lane < 2 * C_::TR) {
+                const bf16_t hi = f2bf(p);
+                pbuf[lane] = (unsigned)hi | ((unsigned)f2bf(p - bf2f(hi)) << 16);
+            }
+            {
+                const u32x4 pa0 = *(const u32x4*)(pbuf + 4 * q4);
+                const u32x4 pa1 = *(const u32x4*)(pbuf + 16 + 4 * q4);
+                const u32x2 w0 = u32x2{__builtin_amdgcn_perm(pa0[1], pa0[0], psel), __builtin_amdgcn_perm(pa0[3], pa0[2], psel)};
+                const u32x2 w1 = u32x2{__builtin_amdgcn_perm(pa1[1], pa1[0], psel), __builtin_amdgcn_perm(pa1[3], pa1[2], psel)};
+                const s16x4 af0 = __builtin_bit_cast(s16x4, w0), af1 = __builtin_bit_cast(s16x4, w1);
+                const int u = lane & 15, rq = u >> 2, pp4 = u & 3;
+                const unsigned toff = (4 * q4 + rq) * C_::PADB + (C_::PC * wave + 4 * pp4) * 2;
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) {
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile0 + toff + j * 32));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile1 + toff + j * 32));
+                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af0, b0, macc[j], 0, 0, 0);
+                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af1, b1, macc[j], 0, 0, 0);
+                }
+            }
+            if (tin + 1 == tiles_per_item - 1) {    // ---- end of item: publish partial + raw scores
+                float* pp = part + ((size_t)cp.bag * S + cp.ch) * (K2_L + 2);
+                if (q4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < C_::NPJ; ++j) pp[2 + C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
+                }
+                {
+                    const float l_tot = fixed_ref ? half_wave_sum(lane < 2 * C_::TR ? l_run : 0.f) : l_run;
+                    if (tid == 0) { pp[0] = fixed_ref ? smax : m_run; pp[1] = l_tot; }
+                }
+                __syncthreads();                    // sbuf complete
+                const int rbeg = cp.ch * chunk_rows;
+                for (int r = tid; r < chunk_rows && rbeg + r < N; r += 64 * C_::NW) scores[(size_t)cp.bag * N + rbeg + r] = sbuf[r];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                m_run = -INFINITY; l_run = 0.f;
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) macc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            cp.next(tiles_per_item, gridDim.x, S);
+            cp.next(tiles_per_item, gridDim.x, S);
+        }
+        return;
+    }
     for (int seq = 0; seq < my_tiles; ++seq) {
         const int ahead = min(2, my_tiles - 1 - seq);
         if (ahead == 2) { K2_WAIT(2 * C_::GT); } else if (ahead == 1) { K2_WAIT(C_::GT); } else { K2_WAIT(0); }

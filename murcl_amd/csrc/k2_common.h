@@ -33,7 +33,7 @@ template <typename T, int NWO = 0> struct K2 {      // NWO: waves per workgroup 
 template <typename T, int NWO = 0> struct K2Lds {
     static constexpr int OFF_SPART = K2_NSLOT * K2<T, NWO>::SLOT;
     static constexpr int OFF_PBUF = OFF_SPART + 2 * K2<T, NWO>::NW * 16 * 4;    // spart is double-buffered
-    static constexpr int OFF_SBUF = OFF_PBUF + K2<T, NWO>::NW * 16 * 4;
+    static constexpr int OFF_SBUF = OFF_PBUF + K2<T, NWO>::NW * 32 * 4;         // pbuf: two tiles' weights per wave (paired forward)
     static constexpr int BYTES = OFF_SBUF + K2_MAX_CHUNK * 4;
 };
 
