@@ -176,7 +176,10 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
 #pragma unroll
                 for (int w = 0; w < C_::NW; ++w) s += sp[w * 16 + r16];
                 if (row0 + lane >= N) s = -INFINITY;
-                if (wave == 0) sbuf[tin * C_::TR + lane] = s;
+                // raw scores straight to HBM (128 B per pair): every wait at the top of this loop after the first is
+                // vmcnt(0), so a compiler-visible store among the hand-counted LDS-DMA operations cannot be miscounted, and
+                // the item end needs no staging buffer, workgroup barrier or drain
+                if (wave == 0 && row0 + lane < N) scores[(size_t)cp.bag * N + row0 + lane] = s;
             }
             float p;
             if (fixed_ref) {
@@ -222,10 +225,6 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                     const float l_tot = fixed_ref ? half_wave_sum(lane < 2 * C_::TR ? l_run : 0.f) : l_run;
                     if (tid == 0) { pp[0] = fixed_ref ? smax : m_run; pp[1] = l_tot; }
                 }
-                __syncthreads();                    // sbuf complete
-                const int rbeg = cp.ch * chunk_rows;
-                for (int r = tid; r < chunk_rows && rbeg + r < N; r += 64 * C_::NW) scores[(size_t)cp.bag * N + rbeg + r] = sbuf[r];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 m_run = -INFINITY; l_run = 0.f;
 #pragma unroll
                 for (int j = 0; j < C_::NPJ; ++j) macc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
