@@ -76,3 +76,24 @@ def test_get_metrics_and_score_match_the_reference(golden):
         assert False
     except ValueError:
         pass
+
+
+def test_draw_mixups_are_valid_draws():
+    """datasets.draw_mixups: every view gets lambda in [alpha, 1] per bag and a permutation of the bags (the step-wide form
+    of the reference's per-view torch.rand + torch.randperm, datasets.py:265-267); views differ from one another."""
+    from murcl_amd.utils.datasets import draw_mixups
+    torch.manual_seed(3)
+    B, alpha, n = 64, 0.9, 12
+    draws = draw_mixups(n, B, alpha, torch.device("cpu"))
+    assert len(draws) == n
+    for lam, perm in draws:
+        assert lam.shape == (B, 1) and lam.dtype == torch.float32 and lam.is_contiguous()
+        assert float(lam.min()) >= alpha and float(lam.max()) <= 1.0
+        assert perm.shape == (B,) and perm.dtype == torch.int32 and perm.is_contiguous()
+        assert sorted(perm.tolist()) == list(range(B))
+    assert len({tuple(p.tolist()) for _, p in draws}) == n
+    # mean of lambda ~ alpha + (1 - alpha) / 2 over n * B draws
+    m = torch.cat([l for l, _ in draws]).mean().item()
+    assert abs(m - (alpha + (1 - alpha) / 2)) < 0.01
+    lam1, perm1 = draw_mixups(1, 2, 1.0, torch.device("cpu"))[0]
+    assert torch.all(lam1 == 1.0) and sorted(perm1.tolist()) == [0, 1]
