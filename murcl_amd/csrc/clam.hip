@@ -20,6 +20,9 @@ template <> __device__ __forceinline__ float gs_sigmoid<bf16_t>(float x) {
 // Streaming kernels over U [rows, 2D]: a thread owns 8 consecutive columns of both gate halves (16-byte loads for
 // bf16), G = D/8 column groups, 256/G rows in flight per workgroup pass, a workgroup walks `rows_per_block` rows.
 // GATED = false: the plain attention net (clam.py:18-34): U has D columns, s_n = sum_d tanh(U[n,d]) wc[d] + bc.
+#ifndef GS_UR_BF16
+#define GS_UR_BF16 4
+#endif
 template <typename T, bool GATED>
 __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const float* __restrict__ bc,
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
     for (int e = 0; e < 8; ++e) w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f;
     const float b0 = bc[0];
     const bool pow2 = G <= 64 && (G & (G - 1)) == 0;
-    constexpr int UR = 4;                                 // rows in flight per thread
+    constexpr int UR = sizeof(T) == 2 ? GS_UR_BF16 : 4;   // rows in flight per thread
     for (long base = r0; base < r1; base += UR * RL) {
         float ua[UR][8], ub[UR][8], acc[UR];
         bool live[UR];

@@ -137,6 +137,12 @@ extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float*
 #ifndef WR_UR
 #define WR_UR 4
 #endif
+#ifndef WR_UR_BF16
+#define WR_UR_BF16 4
+#endif
+#ifndef WR_WGS
+#define WR_WGS 512                // workgroups per launch, two per CU (each adds its partial sums atomically: WR_WGS / B adders per address).
+#endif                            // 16 x 8192 x 1024: 256 -> 102 us, 512 -> 82 us, 1024 -> 116 us, 2048 -> 180 us (bf16); 64 x 4096 x 512: 85 / 54 / 61 / 70 us
 // Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]      (one streaming pass over X; C <= 4)
 // grid (B, row splits).  A thread owns 8 consecutive columns (16-byte loads for bf16), G = d/8 column groups and
 // 256/G row lanes per workgroup; the row lanes meet in LDS and the workgroup adds its partial sums atomically.
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restric
             for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
         if (rl < RL) {
             int n = r0 + rl;
-            constexpr int UR = WR_UR;                             // rows in flight per thread
+            constexpr int UR = sizeof(T) == 2 ? WR_UR_BF16 : WR_UR;   // rows in flight per thread
             for (; n + (UR - 1) * RL < r1; n += UR * RL) {
                 float v[UR][8], w[UR][4];
 #pragma unroll
@@ -212,7 +218,7 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
     if (C > 4 || d % 8) return -1;
     hipError_t e = hipMemsetAsync(Z, 0, (size_t)B * C * d * 4, s);
     if (e != hipSuccess) return (int)e;
-    int splits = (1024 + B - 1) / B;
+    int splits = (WR_WGS + B - 1) / B;
     if (splits > (N + 63) / 64) splits = (N + 63) / 64;
     if (splits < 1) splits = 1;
     const int rpb = (N + splits - 1) / splits;
@@ -228,7 +234,12 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
 
 // out[b,n,c] = X[b,n,:] . V[b,c,:]      (dA = X dZ^T; C <= 4).  A wave walks `RPW` rows; a lane owns 8 consecutive
 // columns per 512-column step (16-byte loads for bf16) and keeps its slice of V in registers when d <= 512.
-#define RD_RPW 16
+#ifndef RD_RPW
+#define RD_RPW 4                // rows per wave = rows in flight: one round of loads per wave, the hardware scheduler does the rest
+#endif                          // (16 rows in four serial rounds: 76 us at 64 x 4096 x 512 bf16; 4 rows: 66 us; 64: 98 us; 256: 175 us)
+#ifndef RD_UR_BF16
+#define RD_UR_BF16 4             // rows in flight per wave for bf16 rows (half the bytes of an f32 row)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, const float* __restrict__ V, int N, int d,
                                                        int C, float* __restrict__ out, long rows_total) {
@@ -236,20 +247,21 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
     const long row0 = ((long)blockIdx.x * 4 + wave) * RD_RPW;
     if (row0 >= rows_total) return;
     const long row1 = min(rows_total, row0 + RD_RPW);
-    for (long rb = row0; rb < row1; rb += 4) {                  // four rows in flight per wave
-        float acc[4][4];
+    constexpr int UR = sizeof(T) == 2 ? RD_UR_BF16 : 4;         // rows in flight per wave
+    for (long rb = row0; rb < row1; rb += UR) {
+        float acc[UR][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UR; ++u)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[u][c] = 0.f;
         for (int k = lane * 8; k < d; k += 512) {
-            float xv[4][8];
+            float xv[UR][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UR; ++u) {
                 const long row = min(rb + u, row1 - 1);
                 load8<T>(X + row * d + k, xv[u]);
             }
-            const long bag0 = rb / N, bag3 = min(rb + 3, row1 - 1) / N;
+            const long bag0 = rb / N, bag3 = min(rb + UR - 1, row1 - 1) / N;
             if (bag0 == bag3) {
                 // the four rows belong to one bag (always, when N % 4 == 0): its slice of V is loaded once for all of them
                 // (per row it was as many load instructions again as X itself: the kernel was load-issue-bound)
@@ -260,13 +272,13 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
                         float w[8];
                         load8<float>(v + (size_t)c * d + k, w);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                        for (int u = 0; u < UR; ++u)
 #pragma unroll
                             for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][e] * w[e];
                     }
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UR; ++u) {
                     const long row = min(rb + u, row1 - 1);
                     const float* v = V + (size_t)(row / N) * C * d;
 #pragma unroll
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UR; ++u) {
             if (rb + u >= row1) break;
             for (int c = 0; c < C; ++c) {
                 const float s = wave_sum(acc[u][c]);
@@ -389,10 +401,13 @@ __global__ __launch_bounds__(256) void rows_dot_wsum_kernel(const T* __restrict_
         }
 }
 // rows_per_wave (out): how many rows a wave takes = the number of `part` rows the caller must provide is ceil(B*N / it)
+#ifndef RDW_MIN_WAVES
+#define RDW_MIN_WAVES 2048        // 1024 -> 235 us, 2048 -> 138 us, 4096 -> 149 us, 8192 -> 165 us (16 x 8192 x 1024 bf16; every wave leaves a [C][d] partial row)
+#endif
 extern "C" int murcl_rows_dot_wsum_plan(int B, int N, int d, int C) {
     if (B <= 0 || N <= 0 || C < 1 || C > 2 || d % 8 || d > 1024) return 0;
     int rpw = 256;                                          // >= 4096 waves (a wave keeps four rows in flight and reduces between
-    while (rpw > 4 && (N % rpw || (long)B * N / rpw < 4096)) rpw >>= 1;       // loads: the chip needs them all resident)
+    while (rpw > 4 && (N % rpw || (long)B * N / rpw < RDW_MIN_WAVES)) rpw >>= 1;       // loads: the chip needs them all resident)
     return (N % rpw == 0) ? rpw : 0;
 }
 extern "C" int murcl_rows_dot_wsum(const void* X, const float* V, const float* G, float* out, float* part, int B, int N,

@@ -65,6 +65,30 @@ def main():
         "tn_512": (lambda: ops.gemm_tn(X, H), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
         "tn_128": (lambda: ops.gemm_tn(dT, H), M * 640 * 2, 2.0 * M * 512 * 128),
     }
+    # CLAM / DSMIL streaming passes at the C3 shape (64 bags x 4096 x 512 = the same 268 MB) and DSMIL's d = 1024 share
+    Bc, Nc = 64, 4096
+    Xc = X.view(Bc, Nc, 512)
+    V1 = torch.randn((Bc, 1, 512), generator=g, device=dev)
+    A1 = torch.rand((Bc, Nc, 1), generator=g, device=dev)
+    wc = torch.randn((256,), generator=g, device=dev) * 0.1
+    bc1 = torch.zeros((1,), device=dev)
+    Xd = (torch.randn((16, 8192, 1024), generator=g, device=dev).abs() * 0.5).bfloat16()
+    V2 = torch.randn((16, 2, 1024), generator=g, device=dev)
+    A2 = torch.rand((16, 8192, 2), generator=g, device=dev)
+    cases.update({
+        "rows_dot_d512": (lambda: ops.rows_dot(Xc, V1), M * 512 * 2, 0),
+        "wrowsum_d512": (lambda: ops.weighted_rowsum(Xc, A1), M * 512 * 2, 0),
+        "gated_score_fwd": (lambda: ops.gated_score_fwd(X, wc, bc1), M * 512 * 2, 0),
+        "rows_dot_d1024": (lambda: ops.rows_dot(Xd, V2), Xd.numel() * 2, 0),
+        "wrowsum_d1024": (lambda: ops.weighted_rowsum(Xd, A2), Xd.numel() * 2, 0),
+        "rows_dot_wsum_d1024": (lambda: ops.rows_dot_wsum(Xd, V2, A2), Xd.numel() * 2, 0),
+    })
+    Xf = torch.randn((16, 8192, 1024), generator=g, device=dev).abs() * 0.5                # DSMIL C5 share in f32
+    cases.update({
+        "rows_dot_f32_d1024": (lambda: ops.rows_dot(Xf, V2), Xf.numel() * 4, 0),
+        "wrowsum_f32_d1024": (lambda: ops.weighted_rowsum(Xf, A2), Xf.numel() * 4, 0),
+        "rows_dot_wsum_f32_d1024": (lambda: ops.rows_dot_wsum(Xf, V2, A2), Xf.numel() * 4, 0),
+    })
     for name, (fn, nbytes, flops) in cases.items():
         if a.only and not any(tok in name for tok in a.only.split(",")):
             continue
