@@ -206,10 +206,13 @@ __global__ __launch_bounds__(256) void gated_score_reduce_kernel(const float* __
         else if (dbab) dbab[c - D - 1] = t;
     }
 }
+#ifndef GS_WGS
+#define GS_WGS 4096
+#endif
 static bool gs_shape_ok(int D) { return D >= 8 && D <= 2048 && D % 8 == 0; }
 static int gs_rows_per_block(long rows, int D) {
     const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
-    long rpb = (rows + 4095) / 4096;                       // ~4096 workgroups
+    long rpb = (rows + GS_WGS - 1) / GS_WGS;               // ~GS_WGS workgroups
     rpb = ((rpb + RL - 1) / RL) * RL;
     if (rpb < 4 * RL) rpb = 4 * RL;
     return (int)rpb;
