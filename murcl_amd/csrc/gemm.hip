@@ -1295,10 +1295,17 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         // bag-level layers: the whole reduction fits the four-slot ring (one memory round trip per workgroup), and every
         // extra M-split would add N1*N2*4 bytes of float atomics (dW_ih: 6.3 MB each, ~5 us at the memory side)
         splits = 1;
-    } else if (splits <= 0) {                // fill the chip: two 64 KiB-LDS workgroups per CU, splits % 8 == 0
-        splits = (512 + t1 * t2 - 1) / (t1 * t2);
-        splits = ((splits + 7) / 8) * 8;
+    } else if (splits <= 0) {
+        // ONE workgroup per CU (then the four-slot ring: three slabs in flight), not two: measured per shape with
+        // tools/_tn128.py - dWa [262144 x 128]^T [. x 512] bf16 78 -> 67 us (64 splits instead of 128), DSMIL's dWq
+        // [131072 x 128]^T [. x 1024] 71 -> 63 us (32 instead of 64), the deferred head gradients [768 x 3072]^T [. x 512]
+        // f32 56 -> 40 us (3 instead of 8) and [. x 1024] 99 -> 62 us (2 instead of 8); the exact-f32 dWq [131072 x 128]^T [. x 1024] is MFMA-bound
+        // (313 against 289 us with two workgroups per CU: long f32 reductions keep the 512-workgroup target)
+        const int target = (dtype == MURCL_DTYPE_F32 && M >= 16384) ? 512 : 256;
+        splits = (target + t1 * t2 - 1) / (t1 * t2);
+        if (splits >= 8) splits = ((splits + 7) / 8) * 8;                       // multiples of 8: the XCD-aware work map
         while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
+        while (splits > 1 && splits < 8 && (long)(splits - 1) * rows * 4 >= M) --splits;
     }
     int mps = (M + splits - 1) / splits;
     mps = ((mps + rows - 1) / rows) * rows;
