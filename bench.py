@@ -331,10 +331,6 @@ def main():
     gc.freeze()
     for _ in range(max(0, args.warmup - 1)):
         step()
-    # settle: at least SETTLE_STEPS untimed steps back to back right before the timed region, whatever --warmup says
-    warmup_extra = max(0, SETTLE_STEPS - args.warmup - 2)
-    for _ in range(warmup_extra):
-        step()
 
     # -- breakdown pass (untimed): find the kernel that dominates the step
     ops.TIMERS = ops.KernelTimers()
@@ -348,6 +344,13 @@ def main():
 
     # -- timed region: exactly K steps; only the dominant kernel and K2 carry HIP events, on every third launch
     ops.TIMERS = ops.KernelTimers(only={dominant, k2_key}, every=3)
+    # settle: untimed steps (in the timed region's configuration) back to back right up to the barrier that opens it, so
+    # that at least SETTLE_STEPS steps precede the timed ones whatever --warmup says and the few milliseconds of host work
+    # above (reading the breakdown events) are not the last thing the GPU saw
+    warmup_extra = max(10, SETTLE_STEPS - args.warmup - 2)
+    for _ in range(warmup_extra):
+        step()
+    ops.TIMERS.reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -404,7 +407,8 @@ def main():
         "value": round(value, 2), "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "warmup_extra": warmup_extra + 2,
         "warmup_note": f"W={args.warmup} warm-up steps as asked, then {warmup_extra + 2} more untimed steps (2 of them the per-kernel breakdown "
-                       f"pass) so that >= {SETTLE_STEPS} steps run back to back before the timed region: the first ~10 steps after an idle GPU run 14 % slower",
+                       f"pass, the rest right up to the barrier that opens the timed region) so that >= {SETTLE_STEPS} steps precede the timed ones: "
+                       "the first ~10 steps after an idle GPU run 14 % slower",
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"ABMIL+Full_layer+NT-Xent view-pair pretrain step (fwd+bwd+Adam), {B} bags x {N} x {D} "

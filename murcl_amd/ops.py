@@ -34,6 +34,10 @@ class KernelTimers:
         self._seen[key] = n + 1
         return _Span(self, key, work) if n % self.every == 0 else _NULL
 
+    def reset(self):
+        """Forget what has been recorded so far (bench.py: the settle steps before the timed region)."""
+        self.records, self._seen = {}, {}
+
     def summary(self):
         """key -> dict(calls, ms_total, ms_avg, flops, bytes)   (call after a device synchronize)"""
         out = {}
