@@ -353,10 +353,13 @@ def main():
     ops.TIMERS.reset()
     barrier()
     t0 = time.perf_counter()
+    host_t = [t0]
     for _ in range(args.steps):
         loss = step()
+        host_t.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    host_ms = [(host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps)]
     live = ops.TIMERS.summary()
     ops.TIMERS = None
     # -- statistics pass (outside the timed region): per-step HIP-event durations on the launch stream, no kernel timers,
@@ -373,7 +376,7 @@ def main():
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.stat_steps))
         q = lambda f: per[min(len(per) - 1, int(f * len(per)))]  # noqa: E731
         stats = dict(steps=args.stat_steps, median_ms=round(q(0.5), 4), p10_ms=round(q(0.1), 4), p90_ms=round(q(0.9), 4),
-                     min_ms=round(per[0], 4), timing="HIP events on the launch stream, one per step")
+                     min_ms=round(per[0], 4), max_ms=round(per[-1], 4), timing="HIP events on the launch stream, one per step")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -419,6 +422,8 @@ def main():
         "roofline_k2": roof(k2_key),
         "loss": round(float(loss.item()), 6),
         "step_stats": stats,
+        "timed_region_host_enqueue_ms": {"median": round(sorted(host_ms)[len(host_ms) // 2], 3), "max": round(max(host_ms), 3),
+                                         "drain_after_last_enqueue": round((elapsed - (host_t[-1] - t0)) * 1e3, 3)},
         "bags_per_s_at_median": round(B * world / (stats["median_ms"] * 1e-3), 1) if stats else None,
         "kernel_ms_per_step_note": "untimed 2-step pass with EVERY launch bracketed by HIP events (~2-3 us each): sums above ms_per_step",
         "kernel_ms_per_step": {k: round(v["ms_total"] / 2, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
