@@ -416,6 +416,11 @@ def run(args):
     criterion = NT_Xent(args.batch_size, args.temperature)
     optimizer = get_optimizer(args, model, fc)
     scheduler = get_scheduler(args, optimizer)
+    if world > 1:
+        # parameters (and the dataset order) come from the common seed above, so the replicas start identical; the SAMPLING
+        # streams - window positions, mix-up draws, the sampler's noise - must differ per rank, or every rank would draw the
+        # same numbers for its bags where the reference (one process, B_global bags) draws independent ones
+        torch.manual_seed(args.seed + 7919 * (rank + 1))
     tb_writer = None
     if rank == 0:
         G.dump_args(args, args.save_dir)
