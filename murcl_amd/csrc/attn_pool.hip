@@ -385,11 +385,14 @@ __global__ __launch_bounds__(256) void abmil_pool_combine_kernel(const float* __
     for (int n = tid; n < N; n += 256) A[(size_t)bag * N + n] = expf(scores[(size_t)bag * N + n] - m) * inv;
 }
 
+#ifndef K2_ITEMS_PER_WG
+#define K2_ITEMS_PER_WG 2
+#endif
 static int pick_chunk(int B, int N, int tr, int n_wg) {
     // rows per item: multiple of the tile height, <= K2_MAX_CHUNK, small enough to give every workgroup >= 2 items
     int chunk = ((N + tr - 1) / tr) * tr;
     if (chunk > K2_MAX_CHUNK) chunk = K2_MAX_CHUNK;
-    while (chunk > 4 * tr && (long)B * ((N + chunk - 1) / chunk) < 2L * n_wg) {
+    while (chunk > 4 * tr && (long)B * ((N + chunk - 1) / chunk) < (long)K2_ITEMS_PER_WG * n_wg) {
         int c2 = ((chunk / 2 + tr - 1) / tr) * tr;
         if (c2 == chunk) break;
         chunk = c2;
