@@ -400,10 +400,15 @@ def main():
             ach, peak, unit, bound = r["bytes"] / sec / 1e9, PEAK["hbm_GBps"], "GB/s", "hbm"
         else:
             ach, peak, unit, bound = r["flops"] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
-        return dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
-                    traffic=_pmc_traffic(key), launches=r["calls"], avg_launch_ms=round(r["ms_avg"], 4),
-                    algorithmic_bytes_per_launch=int(r["bytes"] / r["calls"]),
-                    algorithmic_flops_per_launch=int(r["flops"] / r["calls"]))
+        out = dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                   traffic=_pmc_traffic(key), launches=r["calls"], avg_launch_ms=round(r["ms_avg"], 4),
+                   algorithmic_bytes_per_launch=int(r["bytes"] / r["calls"]),
+                   algorithmic_flops_per_launch=int(r["flops"] / r["calls"]))
+        if key.startswith("gemm_tn_sq"):
+            out["note"] = ("one weight gradient = gemm_tn_sq_kernel (256x256 tiles, partial sums to a workspace) + tn_reduce_kernel (adds them "
+                           "to the gradient): avg_launch_ms and traffic cover BOTH launches plus ~2-3 us of event records; rocprofv3 lists "
+                           "them separately (profiles/r02_z_kernel_stats.csv: ~135 + ~12 us)")
+        return out
 
     out = {
         "metric": "WSI-bags/sec pretrain step (ABMIL+NT-Xent) at N=2048,d=512",
