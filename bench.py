@@ -437,12 +437,19 @@ def main():
         del model, fc, opt, views, step                    # free the headline step's activations before the second workload
         gc.collect()
         torch.cuda.empty_cache()
-        out["m_full"] = m_full(device, dtype)
-        torch.cuda.empty_cache()
-        out["rows"] = other_rows(device)
-        gc.collect()
-        torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(B, N, D)
+        # the extras run after the headline has been measured: a failure in one of them is recorded, it must not take the
+        # contract's JSON line with it
+        def extra(name, fn):
+            try:
+                out[name] = fn()
+            except Exception as e:                                   # noqa: BLE001
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                print(f"bench.py: extra '{name}' failed: {e!r}", file=sys.stderr, flush=True)
+            gc.collect()
+            torch.cuda.empty_cache()
+        extra("m_full", lambda: m_full(device, dtype))
+        extra("rows", lambda: other_rows(device))
+        extra("cpu_baseline", lambda: cpu_baseline(B, N, D))
     if args.breakdown:
         for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"]):
             print(f"{k:44s} calls/step {v['calls'] // 2:3d}  ms/step {v['ms_total'] / 2:8.4f}", file=sys.stderr)
