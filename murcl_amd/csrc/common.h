@@ -134,9 +134,12 @@ __device__ __forceinline__ void glds16_u(const void* sbase, unsigned voff, unsig
 }
 // the same with the non-temporal cache policy: a stream that is read once should not displace what the NEXT kernel will
 // read from the 256 MiB Infinity Cache (e.g. the activations this kernel is writing)
+#ifndef GLDS_STREAM_POLICY
+#define GLDS_STREAM_POLICY " nt"        // cache-policy suffix of the streaming LDS-DMA load (A/B: " sc1", " sc0 sc1", " nt sc1" ...)
+#endif
 __device__ __forceinline__ void glds16_u_nt(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" GLDS_STREAM_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
