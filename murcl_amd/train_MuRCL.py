@@ -273,6 +273,7 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
         if rank == 0:
             print(f"resident slide store: {len(store)} slides, {store.bytes() / 2 ** 30:.2f} GiB on {device}", flush=True)
     steps_per_epoch = len(mine) * args.data_repeat // args.batch_size          # identical on every rank by construction
+    writer = C.CheckpointWriter() if rank == 0 else None                      # the per-epoch files are written off this thread
     gc.collect()
     gc.freeze()          # models/optimizer state are long-lived: keep full collections (tens of ms) out of the step loop
     for epoch in range(args.epochs):
@@ -305,7 +306,7 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
             tb_writer.add_scalar("train/1.train_loss", train_loss, epoch)
         if rank == 0:
             is_best = best.compare(train_loss, epoch + 1, inplace=True)
-            C.save_checkpoint(C.make_state(epoch + 1, model, fc, optimizer, ppo), is_best, str(save_dir))      # :322-330
+            writer.submit(C.make_state(epoch + 1, model, fc, optimizer, ppo), is_best, str(save_dir))           # :322-330
             losses_csv.write_row([epoch + 1, train_loss, best.epoch, best.best])
             results_csv.write_row([epoch + 1, best.epoch, best.best])
             print(f"Loss: {train_loss:.4f}, Best: {best.best:.4f}, Epoch: {best.epoch:2}\n", flush=True)
@@ -315,6 +316,8 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
             early_stop.update(best.best)
             if early_stop.is_stop():
                 break
+    if writer is not None:
+        writer.close()                                                         # every file is complete when train() returns
     if tb_writer is not None:
         tb_writer.close()
 

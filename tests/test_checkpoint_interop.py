@@ -83,3 +83,27 @@ def test_checkpoint_round_trip_and_policies(tmp_path):
 def test_generator_exchanged_real_files_with_the_reference():
     assert _manifest()["exchange"] == {"reference_loaded_product_file_strict": True, "product_loaded_reference_file_strict": True,
                                        "finetune_strip_identical": True}
+
+
+def test_checkpoint_writer_writes_in_order_off_thread_and_reports_failures(tmp_path):
+    """utils.checkpoint.CheckpointWriter: the per-epoch files of the training loop, written by a background thread - same files
+    as save_checkpoint, in submission order, complete after close(); a failure surfaces in the training thread."""
+    import torch
+    from murcl_amd.utils import checkpoint as C
+    w = C.CheckpointWriter()
+    d = tmp_path / "run"
+    for epoch in range(1, 6):
+        state = {"epoch": epoch, "model_state_dict": {"w": torch.full((256, 256), float(epoch))}, "fc": {}, "optimizer": None,
+                 "ppo_optimizer": None, "policy": None}
+        w.submit(state, epoch in (2, 4), str(d))
+    w.close()
+    last, best = torch.load(d / "checkpoint.pth.tar"), torch.load(d / "model_best.pth.tar")
+    assert last["epoch"] == 5 and float(last["model_state_dict"]["w"][0, 0]) == 5.0
+    assert best["epoch"] == 4 and set(last) == set(C.CHECKPOINT_KEYS)
+    w.close()                                                          # idempotent
+    bad = C.CheckpointWriter()
+    blocker = tmp_path / "file_not_dir"
+    blocker.write_text("x")
+    bad.submit({"epoch": 1}, False, str(blocker / "sub"))               # makedirs under a regular file fails in the thread
+    with pytest.raises(RuntimeError, match="writing a checkpoint failed"):
+        bad.close()
