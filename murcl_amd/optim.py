@@ -102,10 +102,13 @@ class _FlatOptimizer:
             self._maybe_dirty = False
 
     # -- checkpointing (the reference stores optimizer.state_dict() under 'optimizer' / 'ppo_optimizer', train_MuRCL.py:326-327)
-    def state_dict(self):
+    def state_dict(self, on_device=False):
+        """``on_device``: the state tensors as device clones made in stream order (no host synchronisation) - for
+        ``utils.checkpoint.EpochSnapshots``, which moves them to the host on a side stream."""
+        take = (lambda t: t.detach().clone()) if on_device else (lambda t: t.detach().cpu())
         return {"kind": type(self).__name__, "step_count": self.step_count,
                 "groups": [dict(lr=g["lr"], initial_lr=g["initial_lr"], steps=[self._pstep.get(pid, 0) for pid, _, _ in g["segs"]],
-                                **{name: g[name].detach().cpu() for name in self.STATE}) for g in self.groups]}
+                                **{name: take(g[name]) for name in self.STATE}) for g in self.groups]}
 
     def load_state_dict(self, sd):
         if sd.get("kind") != type(self).__name__ or len(sd["groups"]) != len(self.groups):

@@ -274,6 +274,36 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
             print(f"resident slide store: {len(store)} slides, {store.bytes() / 2 ** 30:.2f} GiB on {device}", flush=True)
     steps_per_epoch = len(mine) * args.data_repeat // args.batch_size          # identical on every rank by construction
     writer = C.CheckpointWriter() if rank == 0 else None                      # the per-epoch files are written off this thread
+    # Epoch boundaries without a queue drain (utils.checkpoint.EpochSnapshots): state and loss are captured in stream order and
+    # reach the host behind the next epoch's first steps; the bookkeeping below then runs a few steps late.  Early stopping
+    # (--patience, as runs/pretrain.sh uses it) is decided from the same late loss: the steps of the following epoch that were
+    # already taken are discarded - nothing of that epoch is logged or saved and the modules go back to the snapshot - so the
+    # files of a run are those of the synchronous loop.  Several ranks would have to agree on the step at which they stop:
+    # with --patience they keep the synchronous boundary.
+    deferred = device.type == "cuda" and os.environ.get("MURCL_SYNC_EPOCH_END") != "1" and (early_stop is None or world == 1)
+    snaps = C.EpochSnapshots(device) if (deferred and rank == 0) else None
+    stopped = []                                                              # [state of the epoch after which training stops]
+
+    def finish_epoch(ep, train_loss, state):                                  # rank 0: :315-330 for epoch `ep` (1-based)
+        if stopped:
+            return                                                            # a later epoch of a run that has already stopped
+        if tb_writer is not None:
+            tb_writer.add_scalar("train/1.train_loss", train_loss, ep - 1)
+        is_best = best.compare(train_loss, ep, inplace=True)
+        writer.submit(state, is_best, str(save_dir))                          # :322-330
+        losses_csv.write_row([ep, train_loss, best.epoch, best.best])
+        results_csv.write_row([ep, best.epoch, best.best])
+        print(f"Loss: {train_loss:.4f}, Best: {best.best:.4f}, Epoch: {best.epoch:2}\n", flush=True)
+        if early_stop is not None:
+            early_stop.update(best.best)
+            if early_stop.is_stop():
+                stopped.append(state)
+
+    def drain_snapshots(block=False):
+        if snaps is not None:
+            for done in snaps.poll(block):
+                finish_epoch(*done)
+        return bool(stopped)
     gc.collect()
     gc.freeze()          # models/optimizer state are long-lived: keep full collections (tens of ms) out of the step loop
     for epoch in range(args.epochs):
@@ -287,6 +317,8 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
                 pack = store.pack(order[np.arange(s, s + args.batch_size) % len(store)])
                 _, ls, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
                 last_step.append(ls[-1])
+                if drain_snapshots():
+                    break
         else:
             train_set.shuffle()
             feats, clusters = [], []
@@ -299,23 +331,35 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
                     _, ls, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world)
                     last_step.append(ls[-1])
                     feats, clusters = [], []
+                    if drain_snapshots():
+                        break
+        if stopped or drain_snapshots():
+            break                                   # decided from an earlier epoch's loss: this epoch's steps are discarded
         if scheduler is not None and epoch >= args.warmup:
             scheduler.step()                                                   # :312-313
+        if deferred and last_step:
+            if snaps is not None:                                              # losses[-1].avg (:315), read back later
+                snaps.capture(epoch + 1, torch.stack(last_step).mean(), model, fc, optimizer, ppo)
+            continue                                # (other ranks: nothing needs the loss on the host without early stopping)
         train_loss = torch.stack(last_step).mean().item() if last_step else float("nan")   # losses[-1].avg (:315)
-        if tb_writer is not None:
-            tb_writer.add_scalar("train/1.train_loss", train_loss, epoch)
         if rank == 0:
-            is_best = best.compare(train_loss, epoch + 1, inplace=True)
-            writer.submit(C.make_state(epoch + 1, model, fc, optimizer, ppo), is_best, str(save_dir))           # :322-330
-            losses_csv.write_row([epoch + 1, train_loss, best.epoch, best.best])
-            results_csv.write_row([epoch + 1, best.epoch, best.best])
-            print(f"Loss: {train_loss:.4f}, Best: {best.best:.4f}, Epoch: {best.epoch:2}\n", flush=True)
+            finish_epoch(epoch + 1, train_loss, C.make_state(epoch + 1, model, fc, optimizer, ppo))
+            if stopped:
+                break
         else:
             best.compare(train_loss, epoch + 1, inplace=True)                  # every rank sees the same (global) loss
-        if early_stop is not None:
-            early_stop.update(best.best)
-            if early_stop.is_stop():
-                break
+            if early_stop is not None:
+                early_stop.update(best.best)
+                if early_stop.is_stop():
+                    break
+    drain_snapshots(block=True)
+    if stopped and deferred:                        # the modules as they were at the end of the last epoch that counts
+        st = stopped[0]
+        model.load_state_dict(st["model_state_dict"])
+        fc.load_state_dict(st["fc"])
+        if ppo is not None and st.get("policy") is not None:
+            ppo.policy.load_state_dict(st["policy"])
+            ppo.policy_old.load_state_dict(st["policy"])
     if writer is not None:
         writer.close()                                                         # every file is complete when train() returns
     if tb_writer is not None:

@@ -291,3 +291,59 @@ def test_pretrain_script_three_stages_like_runs_pretrain_sh(tmp_path, arch, caps
     assert not torch.equal(ck[1]["model_state_dict"][key], ck[2]["model_state_dict"][key])     # stage 3 trains the aggregator again
     assert all(torch.equal(ck[1]["policy"][k], ck[2]["policy"][k]) for k in ck[1]["policy"])   # ... and only samples with the policy
     assert all(torch.isfinite(v).all() for c in ck for v in c["model_state_dict"].values())
+
+
+def _run_pretrain(tmp, sync, extra=()):
+    import os
+    from murcl_amd import train_MuRCL
+    argv = ["--synthetic", "8,320", "--num_clusters", "4", "--feat_size", "64", "--T", "2", "--batch_size", "4", "--data_repeat", "2",
+            "--arch", "ABMIL", "--device", "0", "--exist_ok", "--dtype", "f32", "--base_save_dir", str(tmp), "--dataset", "Synth",
+            "--train_stage", "1", "--epochs", "5", *extra]
+    old = os.environ.get("MURCL_SYNC_EPOCH_END")
+    os.environ["MURCL_SYNC_EPOCH_END"] = "1" if sync else "0"
+    try:
+        train_MuRCL.main(argv)
+    finally:
+        if old is None:
+            os.environ.pop("MURCL_SYNC_EPOCH_END", None)
+        else:
+            os.environ["MURCL_SYNC_EPOCH_END"] = old
+    run = next(p for p in tmp.rglob("stage_1") if p.is_dir())
+    return run, torch.load(run / "checkpoint.pth.tar", map_location="cpu"), torch.load(run / "model_best.pth.tar", map_location="cpu")
+
+
+def test_epoch_boundaries_without_a_queue_drain_write_the_same_run(tmp_path, capsys):
+    """EpochSnapshots (state and loss captured in stream order, read back behind the next epoch's steps) against the synchronous
+    boundary of the reference loop: same epochs logged, same csv rows, the same parameters in checkpoint.pth.tar / model_best
+    (up to the order of float atomics between two runs of the same step sequence)."""
+    import csv
+    d_run, d_last, d_best = _run_pretrain(tmp_path / "deferred", sync=False)
+    s_run, s_last, s_best = _run_pretrain(tmp_path / "sync", sync=True)
+    assert capsys.readouterr().out.count("Loss: ") == 10
+    assert d_last["epoch"] == s_last["epoch"] == 5 and d_best["epoch"] == s_best["epoch"]
+    rows_d = list(csv.reader(open(d_run / "losses.csv")))
+    rows_s = list(csv.reader(open(s_run / "losses.csv")))
+    assert len(rows_d) == len(rows_s) == 6 and [r[0] for r in rows_d] == [r[0] for r in rows_s]
+    for a, b in zip(rows_d[1:], rows_s[1:]):
+        assert abs(float(a[1]) - float(b[1])) <= 1e-4 * max(1.0, abs(float(b[1])))
+    for key in ("model_state_dict", "fc"):
+        for k, v in s_last[key].items():
+            torch.testing.assert_close(d_last[key][k], v, rtol=1e-3, atol=1e-4, msg=lambda m: f"{key}.{k}: {m}")
+    for g_d, g_s in zip(d_last["optimizer"]["groups"], s_last["optimizer"]["groups"]):
+        assert g_d["steps"] == g_s["steps"] and g_d["lr"] == g_s["lr"]
+        torch.testing.assert_close(g_d["m"], g_s["m"], rtol=1e-2, atol=1e-5)
+    # epoch k's snapshot was taken at the end of epoch k, not when it was read back: it differs from the final state
+    first = next(iter(d_last["model_state_dict"]))
+    assert d_best["epoch"] == 5 or not torch.equal(d_best["model_state_dict"][first], d_last["model_state_dict"][first])
+
+
+def test_early_stop_with_deferred_boundaries_discards_the_extra_steps(tmp_path, capsys):
+    """--patience (runs/pretrain.sh): the stop decision arrives a few steps into the next epoch; nothing of that epoch is
+    logged or saved.  A learning rate of 0 makes the loss constant, so both loops stop after `patience` epochs."""
+    import csv
+    extra = ("--patience", "2", "--backbone_lr", "0", "--fc_lr", "0", "--epochs", "6")
+    d_run, d_last, _ = _run_pretrain(tmp_path / "deferred", sync=False, extra=extra)
+    s_run, s_last, _ = _run_pretrain(tmp_path / "sync", sync=True, extra=extra)
+    assert d_last["epoch"] == s_last["epoch"] == 2
+    assert len(list(csv.reader(open(d_run / "losses.csv")))) == len(list(csv.reader(open(s_run / "losses.csv")))) == 3
+    assert capsys.readouterr().out.count("Loss: ") == 4
