@@ -672,6 +672,23 @@ class PPOLossFn(torch.autograd.Function):
         return dlogp * g, None, dvalue * g, None, None, None, None
 
 
+class GroupedCrossEntropyFn(torch.autograd.Function):
+    """Mean CE of every group of ``group`` consecutive rows of [R,C] logits -> [R/group] losses, one launch: the T per-patch-step
+    ``nn.CrossEntropyLoss()`` values of a step whose T x B head rows were computed together (train_RLMIL.py:316,502,709)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, group):
+        loss, dl, _ = ops.cross_entropy(logits.float().contiguous(), targets.to(torch.int64).contiguous(), int(group))
+        ctx.save_for_backward(dl)
+        ctx.group = int(group)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g.reshape(-1, 1).repeat_interleave(ctx.group, 0), None, None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """nn.CrossEntropyLoss() (mean) over [R,C] logits (train_RLMIL.py:316,502,709)."""
 

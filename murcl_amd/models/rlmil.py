@@ -80,6 +80,18 @@ class Full_layer(nn.Module):
         return LinearFn.apply(self.hidden, head.weight, head.bias, False)
 
 
+    def forward_sequence(self, x):
+        """x [T,B,F]: ``[self(x[t], restart=(t == 0)) for t in range(T)]`` as ONE recurrent node and one classifier product over
+        the T*B rows -> logits [T*B, class_num]; ``self.hidden`` ends as after the loop.  (The supervised step computes all T
+        sub-bags of a stage-1 step before the head runs, so the head needs no per-step launches from Python.)"""
+        if not self.fc_rnn:
+            return torch.cat([self(x[t], restart=(t == 0)) for t in range(x.shape[0])], 0)
+        from ..functional import GRUSeqFn
+        r = self.rnn
+        hs = GRUSeqFn.apply(x.float(), r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        self.hidden = hs[-1].unsqueeze(0)
+        return LinearFn.apply(hs.reshape(x.shape[0] * x.shape[1], -1), self.fc.weight, self.fc.bias, False)
+
     def forward_views(self, xs, restart=False):
         """``[self(x, restart) for x in xs]`` - the per-view loop of the training scripts (train_MuRCL.py:243,272).
 

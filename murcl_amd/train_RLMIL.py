@@ -11,7 +11,7 @@ import os
 import torch
 
 from murcl_amd import functional
-from murcl_amd.functional import CrossEntropyFn
+from murcl_amd.functional import CrossEntropyFn, GroupedCrossEntropyFn
 from murcl_amd.models import abmil, clam, dsmil, rlmil
 from murcl_amd.utils.datasets import subbag_views
 from murcl_amd.utils.views import as_one
@@ -34,6 +34,9 @@ def create_model(arch, dim_patch, num_classes, device, model_dim=512, D=128, siz
     model.compute_dtype = dtype
     fc = rlmil.Full_layer(feat, fc_hidden_dim, True, num_classes)
     return model.to(device), fc.to(device)
+
+
+_BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/B switch
 
 
 def _confidence(logits, labels):
@@ -88,7 +91,7 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     logits with ``return_logits``)."""
     B, K, dev = pack.B, pack.K, pack.feats.device
     train_enc = train_stage != 2
-    losses, rewards, conf_last, states = [], [], None, None
+    losses, rewards, conf_last, states, loss_total = [], [], None, None, None
     # stage 1 (and injected actions): no patch step depends on the states of the one before, so the sub-bags of all T
     # steps go through the aggregator as ONE batch of T*B bags (cf. train_MuRCL._pretrain_step_all_patch_steps_at_once);
     # the recurrent head and the losses stay per step
@@ -100,7 +103,26 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
             acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
         views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)
         at_once = _aggregate(arch, model, as_one(views), labels.repeat(T))
-    for t in range(T):
+    if at_once is not None and getattr(fc, "fc_rnn", False) and _BATCHED_HEAD:
+        # ... and the head as well: the T GRU steps as one recurrent node, one classifier product and ONE grouped cross-entropy
+        # over the T*B rows (loss_t = mean over the B rows of step t, exactly the per-step values) - at the reference scripts'
+        # --batch_size 1 the step is bound by the number of launches issued from Python, and the per-step head was 2/3 of them
+        lab_all = labels.repeat(T)
+        logits_all = fc.forward_sequence(at_once[0].view(T, B, -1))
+        ce = GroupedCrossEntropyFn.apply(logits_all, lab_all, B)
+        if arch == "ABMIL":
+            loss_t = ce                                                                        # :727
+        elif arch == "CLAM_SB":
+            loss_t = bag_weight * ce + (1 - bag_weight) * at_once[2].view(T, B).mean(1)        # :336
+        else:
+            loss_t = 0.5 * ce + 0.5 * GroupedCrossEntropyFn.apply(at_once[2], lab_all, B)      # :527-529
+        conf = torch.softmax(logits_all.detach(), 1).gather(1, lab_all.view(-1, 1)).view(T, 1, B)      # :345,537,735
+        loss_total = loss_t.sum() / T
+        losses = list(loss_t.detach().unbind(0))
+        rewards = list((conf[1:] - conf[:-1]).unbind(0))                                       # :369-371,569-571
+        memory.rewards.extend(rewards)
+        logits = logits_all[-B:]
+    for t in range(T if not losses else 0):
         if at_once is not None:
             sl = slice(t * B, (t + 1) * B)
             loss, logits = _head_loss(arch, fc, at_once[0][sl], None if at_once[2] is None else at_once[2][sl], labels, t, bag_weight)
@@ -121,7 +143,7 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
             rewards.append(conf - conf_last)                                                   # :369-371,569-571
             memory.rewards.append(rewards[-1])
         conf_last = conf
-    loss = sum(losses) / T
+    loss = loss_total if loss_total is not None else sum(losses) / T
     if train_enc:
         optimizer.zero_grad()
         with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each
