@@ -85,6 +85,27 @@ def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
     return ppo.select_action(states, memory, restart_batch=(t == 1))
 
 
+def _head_all_steps(arch, fc, head_in_all, extra_all, labels, T, B, bag_weight, memory):
+    """The recurrent head, the losses and the rewards of all T patch steps at once: head_in_all [T*B,F] (step-major) -> the T GRU
+    steps as one recurrent node, one classifier product and ONE grouped cross-entropy over the T*B rows (loss_t = mean over the B
+    rows of step t, exactly the per-step values).  At the reference scripts' --batch_size 1 the step is bound by the number of
+    launches issued from Python, and the per-step head was two thirds of them.
+    -> (sum_t loss_t / T, [loss_t] detached, rewards [T-1] of [1,B] (also appended to ``memory``), logits of the last step)."""
+    lab_all = labels.repeat(T)
+    logits_all = fc.forward_sequence(head_in_all.view(T, B, -1))
+    ce = GroupedCrossEntropyFn.apply(logits_all, lab_all, B)
+    if arch == "ABMIL":
+        loss_t = ce                                                                        # :727
+    elif arch == "CLAM_SB":
+        loss_t = bag_weight * ce + (1 - bag_weight) * extra_all.view(T, B).mean(1)         # :336
+    else:
+        loss_t = 0.5 * ce + 0.5 * GroupedCrossEntropyFn.apply(extra_all, lab_all, B)       # :527-529
+    conf = torch.softmax(logits_all.detach(), 1).gather(1, lab_all.view(-1, 1)).view(T, 1, B)      # :345,537,735
+    rewards = list((conf[1:] - conf[:-1]).unbind(0))                                       # :369-371,569-571
+    memory.rewards.extend(rewards)
+    return loss_t.sum() / T, list(loss_t.detach().unbind(0)), rewards, logits_all[-B:]
+
+
 def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, feat_size=1024, train_stage=1,
                     bag_weight=0.7, actions=None, return_logits=False, batch_patch_steps=True):
     """One step on a BagPack with int64 labels [B].  Returns (loss, losses[T], rewards[T-1]) (+ the last patch step's
@@ -103,25 +124,10 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
             acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
         views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)
         at_once = _aggregate(arch, model, as_one(views), labels.repeat(T))
-    if at_once is not None and getattr(fc, "fc_rnn", False) and _BATCHED_HEAD:
-        # ... and the head as well: the T GRU steps as one recurrent node, one classifier product and ONE grouped cross-entropy
-        # over the T*B rows (loss_t = mean over the B rows of step t, exactly the per-step values) - at the reference scripts'
-        # --batch_size 1 the step is bound by the number of launches issued from Python, and the per-step head was 2/3 of them
-        lab_all = labels.repeat(T)
-        logits_all = fc.forward_sequence(at_once[0].view(T, B, -1))
-        ce = GroupedCrossEntropyFn.apply(logits_all, lab_all, B)
-        if arch == "ABMIL":
-            loss_t = ce                                                                        # :727
-        elif arch == "CLAM_SB":
-            loss_t = bag_weight * ce + (1 - bag_weight) * at_once[2].view(T, B).mean(1)        # :336
-        else:
-            loss_t = 0.5 * ce + 0.5 * GroupedCrossEntropyFn.apply(at_once[2], lab_all, B)      # :527-529
-        conf = torch.softmax(logits_all.detach(), 1).gather(1, lab_all.view(-1, 1)).view(T, 1, B)      # :345,537,735
-        loss_total = loss_t.sum() / T
-        losses = list(loss_t.detach().unbind(0))
-        rewards = list((conf[1:] - conf[:-1]).unbind(0))                                       # :369-371,569-571
-        memory.rewards.extend(rewards)
-        logits = logits_all[-B:]
+    batched_head = getattr(fc, "fc_rnn", False) and _BATCHED_HEAD
+    if at_once is not None and batched_head:
+        loss_total, losses, rewards, logits = _head_all_steps(arch, fc, at_once[0], at_once[2], labels, T, B, bag_weight, memory)
+    head_ins, extras = [], []
     for t in range(T if not losses else 0):
         if at_once is not None:
             sl = slice(t * B, (t + 1) * B)
@@ -136,6 +142,13 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
         act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions)
         (feats,), _ = subbag_views(pack, [act], feat_size, out_dtype=model.compute_dtype)
         with torch.set_grad_enabled(train_enc):
+            if batched_head:
+                # the sampler picks step t+1's windows from the AGGREGATOR's states; the head's outputs are only needed for the
+                # loss and the rewards, so the head waits until all T aggregator outputs exist and then runs once (below)
+                head_in, states, extra = _aggregate(arch, model, feats, labels)
+                head_ins.append(head_in)
+                extras.append(extra)
+                continue
             loss, logits, states = _forward_loss(arch, model, fc, feats, labels, t, bag_weight)
         losses.append(loss)
         conf = _confidence(logits, labels)
@@ -143,6 +156,11 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
             rewards.append(conf - conf_last)                                                   # :369-371,569-571
             memory.rewards.append(rewards[-1])
         conf_last = conf
+    if head_ins:
+        with torch.set_grad_enabled(train_enc):
+            loss_total, losses, rewards, logits = _head_all_steps(arch, fc, torch.cat(head_ins, 0),
+                                                                  None if extras[0] is None else torch.cat(extras, 0),
+                                                                  labels, T, B, bag_weight, memory)
     loss = loss_total if loss_total is not None else sum(losses) / T
     if train_enc:
         optimizer.zero_grad()
