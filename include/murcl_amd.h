@@ -116,15 +116,18 @@ int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float*
  * size_j = rint(float(n_j)*ratio[b]), l_j = floor(actions[b][j]*float(n_j-size_j)), ids cluster_j[l_j : l_j+size_j]
  * (Python slice semantics), all clusters merged, sorted ascending, truncated to feat_size.  ratio[b] must be
  * float32(feat_size / N_b) computed in double on the host, as the reference does.  cluster_ids holds the K id
- * lists of every bag back to back; cluster_off [B][K+1] indexes into it.  idx_out [B][feat_size] (-1 = padding). */
+ * lists of every bag back to back; cluster_off [B][K+1] indexes into it.  idx_out [B][feat_size] (-1 = padding).
+ * `views` sub-bags of the SAME B bags in one launch (the T patch steps x 2 views of a step, train_MuRCL.py:237-239,266-269):
+ * actions [views][B][K], idx_out [views][B][feat_size], count_out [views][B]. */
 int murcl_subbag_select(const int* cluster_ids, const int* cluster_off, const int* n_patches, const float* ratio,
-                        const float* actions, int B, int K, int feat_size, int max_patches, int* idx_out,
+                        const float* actions, int views, int B, int K, int feat_size, int max_patches, int* idx_out,
                         int* count_out, murcl_stream_t stream);
 /* K12+K13 -- gather the selected rows (zero padding) and, when lam/perm are given, apply mixup
  * (utils/datasets.py:263-271): out[b] = lam[b]*sub_bag[b] + (1-lam[b])*sub_bag[perm[b]].  feats: all bags' rows
- * back to back ([sum N_b, d]); bag_row_off [B] (int64 row offsets). */
+ * back to back ([sum N_b, d]); bag_row_off [B] (int64 row offsets).  `views` as above: idx [views][B][feat_size], lam and
+ * perm [views][B] (perm[v][b] = the partner bag's index 0..B-1 inside view v), out [views][B][feat_size][d]. */
 int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
-                            const int* perm, void* out, int B, int feat_size, int d, int dtype_in, int dtype_out,
+                            const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in, int dtype_out,
                             murcl_stream_t stream);
 /* K13 -- mixup on an already built batch x [B, per_bag]. */
 int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int B, long per_bag, int dtype,

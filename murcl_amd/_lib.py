@@ -34,8 +34,8 @@ SIGNATURES = {
     "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
-    "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
-    "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_mixup": [_P, _P, _P, _P, _I, _L, _I, _P],
     "murcl_dsmil_argmax": [_P, _I, _I, _I, _I, _P, _P],
     "murcl_gather_rows": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],

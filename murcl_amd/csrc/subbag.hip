@@ -31,12 +31,13 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
                                                             const int* __restrict__ cluster_off,   // [B][K+1] into cluster_ids
                                                             const int* __restrict__ n_patches,     // [B]
                                                             const float* __restrict__ ratio,       // [B] float32(feat_size / N_b)
-                                                            const float* __restrict__ actions,     // [B][K]
-                                                            int K, int feat_size, int* __restrict__ idx_out,
+                                                            const float* __restrict__ actions,     // [V][B][K]
+                                                            int B, int K, int feat_size, int* __restrict__ idx_out,
                                                             int* __restrict__ count_out) {
     __shared__ unsigned bitmap[SB_MAX_WORDS];
     __shared__ int wsum[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // one workgroup per (view, bag): the bag's tables by b, its actions / outputs by vb = view * B + b
+    const int vb = blockIdx.x, b = vb % B, tid = threadIdx.x;
     const int N = n_patches[b];
     const int words = (N + 31) >> 5;
     for (int w = tid; w < words; w += 256) bitmap[w] = 0u;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
     for (int j = 0; j < K; ++j) {
         const int beg = off[j], n = off[j + 1] - beg;
         const int size = (int)rintf((float)n * rt);                                      // single f32 products:
-        const int l = (int)floorf(actions[(size_t)b * K + j] * (float)(n - size));       // nothing to contract
+        const int l = (int)floorf(actions[(size_t)vb * K + j] * (float)(n - size));      // nothing to contract
         int lo, hi;
         py_slice(n, l, l + size, lo, hi);
         for (int t = lo + tid; t < hi; t += 256) {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
     }
     int pos = wsum[tid] - cnt;
     const int total = wsum[255];
-    int* out = idx_out + (size_t)b * feat_size;
+    int* out = idx_out + (size_t)vb * feat_size;
     for (int w = w0; w < w1 && pos < feat_size; ++w) {
         unsigned m = bitmap[w];
         while (m && pos < feat_size) {
@@ -81,16 +82,16 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
     }
     const int kept = min(total, feat_size);
     for (int r = kept + tid; r < feat_size; r += 256) out[r] = -1;      // zero-padded rows
-    if (tid == 0) count_out[b] = kept;
+    if (tid == 0) count_out[vb] = kept;
 }
 
 extern "C" int murcl_subbag_select(const int* cluster_ids, const int* cluster_off, const int* n_patches,
-                                   const float* ratio, const float* actions, int B, int K, int feat_size,
+                                   const float* ratio, const float* actions, int views, int B, int K, int feat_size,
                                    int max_patches, int* idx_out, int* count_out, hipStream_t stream) {
-    if (B <= 0) return 0;
+    if (B <= 0 || views <= 0) return 0;
     if (K <= 0 || feat_size <= 0 || max_patches > SB_MAX_WORDS * 32) return -1;
-    hipLaunchKernelGGL(subbag_select_kernel, dim3(B), dim3(256), 0, stream, cluster_ids, cluster_off, n_patches, ratio,
-                       actions, K, feat_size, idx_out, count_out);
+    hipLaunchKernelGGL(subbag_select_kernel, dim3(views * B), dim3(256), 0, stream, cluster_ids, cluster_off, n_patches, ratio,
+                       actions, B, K, feat_size, idx_out, count_out);
     return MURCL_CHECK_LAUNCH();
 }
 
@@ -101,16 +102,17 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
                                                                 const int* __restrict__ idx,
                                                                 const float* __restrict__ lam,
                                                                 const int* __restrict__ perm, TO* __restrict__ out,
-                                                                int B, int feat_size, int d) {
+                                                                int VB, int B, int feat_size, int d) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;                   // output row b*feat_size + r
-    if (row >= (long)B * feat_size) return;
-    const int b = (int)(row / feat_size), r = (int)(row - (long)b * feat_size);
-    const int i0 = idx[(size_t)b * feat_size + r];
+    const long row = (long)blockIdx.x * 4 + wave;                   // output row (view * B + b) * feat_size + r
+    if (row >= (long)VB * feat_size) return;
+    const int vb = (int)(row / feat_size), r = (int)(row - (long)vb * feat_size);
+    const int b = vb % B, v0 = vb - b;                              // the bag's rows by b; its view's block of idx / lam / perm by v0
+    const int i0 = idx[(size_t)vb * feat_size + r];
     const bool mix = lam != nullptr;
-    const int pb = mix ? perm[b] : b;
-    const int i1 = mix ? idx[(size_t)pb * feat_size + r] : -1;
-    const float l0 = mix ? lam[b] : 1.f, l1 = 1.f - l0;
+    const int pb = mix ? perm[vb] : b;                              // mix-up partner: a bag of the same view
+    const int i1 = mix ? idx[(size_t)(v0 + pb) * feat_size + r] : -1;
+    const float l0 = mix ? lam[vb] : 1.f, l1 = 1.f - l0;
     const TI* s0 = feats + (bag_row_off[b] + (i0 < 0 ? 0 : i0)) * d;
     const TI* s1 = feats + (bag_row_off[pb] + (i1 < 0 ? 0 : i1)) * d;
     TO* o = out + row * d;
@@ -136,15 +138,15 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
 }
 
 extern "C" int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
-                                       const int* perm, void* out, int B, int feat_size, int d, int dtype_in,
+                                       const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in,
                                        int dtype_out, hipStream_t stream) {
-    if (B <= 0 || feat_size <= 0) return 0;
+    if (B <= 0 || feat_size <= 0 || views <= 0) return 0;
     if (d % 8) return -1;
     if ((lam == nullptr) != (perm == nullptr)) return -1;
-    const long rows = (long)B * feat_size;
+    const long rows = (long)views * B * feat_size;
     dim3 grid((unsigned)((rows + 3) / 4));
 #define GM(TI, TO) hipLaunchKernelGGL((subbag_gather_mix_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)feats, \
-                                      bag_row_off, idx, lam, perm, (TO*)out, B, feat_size, d)
+                                      bag_row_off, idx, lam, perm, (TO*)out, views * B, B, feat_size, d)
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32) GM(float, float);
     else if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_BF16) GM(float, bf16_t);
     else if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16) GM(bf16_t, bf16_t);

@@ -107,7 +107,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         noise = torch.randn((args.T - 1, 2, B, K), device=dev) if rl and args.T > 1 else None    # rlmil.py:85-86
     for t in range(args.T):
         if t == 0 or args.train_stage == 1:
-            acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else [acts_u[t, 0], acts_u[t, 1]]
+            acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else acts_u[t]      # [2,B,K]: one launch each
         else:
             eps = [noise[t - 1, 0], noise[t - 1, 1]] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
             acts = [ppo.select_action(s, m, restart_batch=(t == 1), eps=e)
@@ -163,7 +163,7 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
             acts += [a.to(dev) for a in injected["actions"][t]]
             draws += list(injected["draws"][t])
     else:
-        acts = list(torch.rand((2 * T_, B, K), device=dev).unbind(0))                        # :235,256-258
+        acts = torch.rand((2 * T_, B, K), device=dev)                                        # :235,256-258
         draws = draw_mixups(2 * T_, B, args.alpha, dev)                                      # datasets.py:265-267
     views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch

@@ -119,7 +119,7 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     at_once = None
     if (train_stage == 1 or actions is not None) and train_enc and T > 1 and batch_patch_steps:
         if actions is None:
-            acts = list(torch.rand((T, B, K), device=dev).unbind(0))         # all T uniform draws in one launch (:345,539,735)
+            acts = torch.rand((T, B, K), device=dev)                         # all T uniform draws in one launch (:345,539,735)
         else:
             acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
         views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)

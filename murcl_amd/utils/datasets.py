@@ -128,22 +128,27 @@ class DeviceSlideStore:
 
 
 def select_indices(pack, action_sequence, feat_size):
-    """-> idx [B, feat_size] int32 (ascending patch ids, -1 padded), count [B] int32."""
+    """-> idx [B, feat_size] int32 (ascending patch ids, -1 padded), count [B] int32.  action_sequence [B,K]; or [V,B,K] for V
+    sub-bags of the same bags in one launch -> idx [V,B,feat_size], count [V,B]."""
     a = action_sequence.to(torch.float32).contiguous()
-    assert a.shape == (pack.B, pack.K), f"actions {tuple(a.shape)} vs {(pack.B, pack.K)}"
+    V = a.shape[0] if a.dim() == 3 else 1
+    assert tuple(a.shape[-2:]) == (pack.B, pack.K), f"actions {tuple(a.shape)} vs {(pack.B, pack.K)}"
     dev = pack.feats.device
-    idx = torch.empty((pack.B, feat_size), dtype=torch.int32, device=dev)
-    cnt = torch.empty((pack.B,), dtype=torch.int32, device=dev)
+    idx = torch.empty((V * pack.B, feat_size), dtype=torch.int32, device=dev)
+    cnt = torch.empty((V * pack.B,), dtype=torch.int32, device=dev)
     check(_lib.lib().murcl_subbag_select(ptr(pack.cluster_ids), ptr(pack.cluster_off), ptr(pack.n_patches),
-                                         ptr(pack.ratio(feat_size)), ptr(a), pack.B, pack.K, feat_size,
+                                         ptr(pack.ratio(feat_size)), ptr(a), V, pack.B, pack.K, feat_size,
                                          int(pack.n_host.max()), ptr(idx), ptr(cnt), stream()), "subbag_select")
+    if a.dim() == 3:
+        return idx.view(V, pack.B, feat_size), cnt.view(V, pack.B)
     return idx, cnt
 
 
-def _gather(pack, idx, feat_size, out, lam=None, perm=None):
+def _gather(pack, idx, feat_size, out, lam=None, perm=None, views=1):
+    """idx [views*B, feat_size], lam / perm [views*B] (perm: partner bag 0..B-1 inside the view), out [views*B, feat_size, d]."""
     d = pack.feats.shape[1]
     check(_lib.lib().murcl_subbag_gather_mix(ptr(pack.feats), ptr(pack.row_off), ptr(idx), ptr(lam), ptr(perm),
-                                             ptr(out), pack.B, feat_size, d, dt(pack.feats), dt(out), stream()),
+                                             ptr(out), views, pack.B, feat_size, d, dt(pack.feats), dt(out), stream()),
           "subbag_gather_mix")
     return out
 
@@ -205,7 +210,21 @@ def draw_mixups(n_views, B, alpha, device):
     u = torch.rand((2, n_views, B), device=device)
     lam = u[0].mul(1 - alpha).add_(alpha).unsqueeze(-1)
     perm = u[1].argsort(dim=1).to(torch.int32)
-    return [(lam[v], perm[v]) for v in range(n_views)]
+    return MixDraws(lam, perm)
+
+
+class MixDraws(list):
+    """[(lambda [B,1], perm [B])] per view, as slices of whole tensors ``lam`` [n,B,1] f32 / ``perm`` [n,B] int32 that
+    ``subbag_views`` hands to ONE gather launch; a slice of it is again a MixDraws over the corresponding rows."""
+
+    def __init__(self, lam, perm):
+        super().__init__((lam[v], perm[v]) for v in range(lam.shape[0]))
+        self.lam, self.perm = lam, perm
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return MixDraws(self.lam[i], self.perm[i])
+        return super().__getitem__(i)
 
 
 def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None):
@@ -213,21 +232,27 @@ def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, 
 
     ``draws`` = list of (lambda_ [B,1], rand_idx [B]) per view (generated like ``mixup`` when None and
     alpha is given; alpha None disables mix-up)."""
-    V, dev = len(action_sequences), pack.feats.device
+    dev, B = pack.feats.device, pack.B
     d = pack.feats.shape[1]
-    buf = torch.empty((V * pack.B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
-    used = []
-    for v, a in enumerate(action_sequences):
-        idx, _ = select_indices(pack, a, feat_size)
-        lam = perm = None
-        if alpha is not None or draws is not None:
-            if draws is not None:
-                lambda_, rand_idx = draws[v]
-            else:
-                lambda_ = alpha + torch.rand(size=(pack.B, 1), device=dev) * (1 - alpha)
-                rand_idx = torch.randperm(pack.B, device=dev)
-            used.append((lambda_, rand_idx))
-            lam = lambda_.reshape(-1).to(torch.float32).contiguous()
-            perm = rand_idx.to(torch.int32).contiguous()
-        _gather(pack, idx, feat_size, buf[v * pack.B:(v + 1) * pack.B], lam, perm)
-    return [buf[v * pack.B:(v + 1) * pack.B] for v in range(V)], used
+    # all V views through ONE selection launch and ONE gather (+ mix-up) launch: the views differ only in their rows of
+    # actions / lambda / perm (12 views per stage-1 step: 24 launches before)
+    if torch.is_tensor(action_sequences):
+        acts, V = action_sequences, action_sequences.shape[0]
+    else:
+        V = len(action_sequences)
+        acts = action_sequences[0].unsqueeze(0) if V == 1 else torch.stack([a.to(torch.float32) for a in action_sequences], 0)
+    buf = torch.empty((V * B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
+    idx, _ = select_indices(pack, acts.reshape(V, B, pack.K), feat_size)
+    used, lam, perm = [], None, None
+    if alpha is not None or draws is not None:
+        if draws is None:
+            draws = draw_mixups(V, B, alpha, dev)
+        if isinstance(draws, MixDraws) and draws.lam.shape[0] == V and draws.lam.is_contiguous() and draws.perm.is_contiguous():
+            lam, perm = draws.lam.reshape(-1), draws.perm.reshape(-1)
+        else:                                                       # separate tensors per view (injected draws of the parity tests)
+            lam = torch.stack([dr[0].reshape(-1).to(torch.float32) for dr in draws[:V]], 0).reshape(-1)
+            perm = torch.stack([dr[1].to(torch.int32) for dr in draws[:V]], 0).reshape(-1)
+        used = [(draws[v][0], draws[v][1]) for v in range(V)]
+        lam, perm = lam.to(torch.float32).contiguous(), perm.to(torch.int32).contiguous()
+    _gather(pack, idx.view(V * B, feat_size), feat_size, buf, lam, perm, views=V)
+    return [buf[v * B:(v + 1) * B] for v in range(V)], used
