@@ -149,7 +149,7 @@ def cpu_baseline(bags, n, d, budget_s=14.0):
                                           f"reference's torch.set_num_threads(1)), {dt_one * 1e3:.0f} ms/step"))
 
 
-def m_full(device, dtype, bags=64, raw=8192, steps=10):
+def m_full(device, dtype, bags=64, raw=8192, steps=30):
     """SURVEY 8(d) "M-full": the reference's whole stage-1 step (train_MuRCL.py:233-304) - T = 6 patch steps x 2 views of
     1024 patches drawn from raw bags of 8192 by the cluster-window sampler + mix-up, aggregator, head, NT-Xent, one
     backward, Adam - reported beside the headline (outside its timed region; tools/bench_full.py has stages 2 and 3)."""
@@ -176,7 +176,7 @@ def m_full(device, dtype, bags=64, raw=8192, steps=10):
     crit, mem = NT_Xent(bags, 1.0), [rlmil.Memory(), rlmil.Memory()]
 
     def run():
-        for _ in range(3):
+        for _ in range(5):
             pretrain_step(args, model, fc, ppo, crit, opt, pack, mem)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
