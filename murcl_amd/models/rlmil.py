@@ -92,6 +92,29 @@ class Full_layer(nn.Module):
         self.hidden = hs[-1].unsqueeze(0)
         return LinearFn.apply(hs.reshape(x.shape[0] * x.shape[1], -1), self.fc.weight, self.fc.bias, False)
 
+    def forward_view_sequence(self, xs):
+        """The head over ALL patch steps of a contrastive step: ``xs`` = the aggregator outputs [x_t0, x_t1 for t in range(T)]
+        (2T tensors [B,F]) -> z [2T*B, class_num] in the same order, as if
+        ``forward_views([x_t0, x_t1], restart=(t == 0))`` had been called step by step (train_MuRCL.py:243,272).  With the one
+        shared hidden state of the reference that loop is ONE chain: both views of step 0 start from zero, then
+        h(0,1) -> h(1,0) -> h(1,1) -> h(2,0) -> ...; so x_01, x_10, x_11, ... run as one recurrent node from a zero state and
+        x_00 as a single step beside it, and the classifier is one product over the 2T*B rows."""
+        if not self.fc_rnn:
+            raise RuntimeError("forward_view_sequence needs the recurrent head (fc_rnn=True)")
+        from ..functional import GRUSeqFn
+        xs = list(xs)
+        n2, B = len(xs), xs[0].shape[0]
+        x = _whole(xs) if n2 > 1 else xs[0]
+        if x is None:
+            x = torch.cat(xs, 0)
+        r = self.rnn
+        x = x.float()
+        h00 = GRUStepFn.apply(x[:B], None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        hs = GRUSeqFn.apply(x[B:].view(n2 - 1, B, -1), r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        self.hidden = hs[-1].unsqueeze(0)
+        h_all = torch.cat([h00, hs.reshape((n2 - 1) * B, -1)], 0)
+        return LinearFn.apply(h_all, self.fc.weight, self.fc.bias, False)
+
     def forward_views(self, xs, restart=False):
         """``[self(x, restart) for x in xs]`` - the per-view loop of the training scripts (train_MuRCL.py:243,272).
 

@@ -83,6 +83,9 @@ def get_scheduler(args, optimizer):
     return make_scheduler(optimizer, args.scheduler, args.epochs, args.warmup)
 
 
+_BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/B switch: the recurrent head over all patch steps at once
+
+
 # ------------------------------------------------------------------------------------------------ the hot step
 def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world=1, injected=None):
     """One optimizer step on a batch of raw bags (train_MuRCL.py:233-304).
@@ -98,6 +101,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
     losses, rewards, sim_last, states = [], [], None, None
+    late_head, agg_outs = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), []
     if injected is None:
         # every random number of the step in four launches (uniform window positions, mix-up draws, the sampler's Gaussian
         # noise) instead of ~10 tiny launches per view and patch step; none of them depends on anything computed in the step
@@ -118,6 +122,11 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                                 draws=mix[2 * t:2 * t + 2] if injected is None else injected["draws"][t])   # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
             outputs, states = model(views)                                                   # :242,271
+            if late_head:
+                # the sampler picks the next windows from the aggregator's states; what the head and the loss produce (the
+                # loss itself, the rewards) is needed after the last patch step only: they run once, below
+                agg_outs += list(outputs)
+                continue
             outputs = fc.forward_views(outputs, restart=(t == 0))                            # :243,272
             if world > 1:
                 loss, sim = mdist.gathered_nt_xent(outputs[0], outputs[1], args.temperature)
@@ -131,6 +140,22 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
             for m in memory_list:
                 m.rewards.append(reward)
         sim_last = sim
+    if late_head:
+        with torch.set_grad_enabled(train_enc):
+            z_all = fc.forward_view_sequence(agg_outs).view(args.T, 2, B, -1)                # :243,272 for every step at once
+            for t in range(args.T):
+                if world > 1:
+                    loss, sim = mdist.gathered_nt_xent(z_all[t, 0], z_all[t, 1], args.temperature)
+                else:
+                    loss = criterion.forward_stacked(z_all[t].reshape(2 * B, -1))            # :249,277
+                    sim = criterion.last_similarity
+                losses.append(loss)
+                if t > 0:
+                    reward = (sim_last - sim).view(1, -1)                                    # :282-283
+                    rewards.append(reward)
+                    for m in memory_list:
+                        m.rewards.append(reward)
+                sim_last = sim
     loss = sum(losses) / args.T                                                              # :291
     if train_enc:
         optimizer.zero_grad()
@@ -168,13 +193,15 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
     views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch
     losses, rewards, sim_last = [], [], None
+    z_all = fc.forward_view_sequence(outputs).view(T_, 2, B, -1) if _BATCHED_HEAD and fc.fc_rnn else None   # :243,272, all steps
     for t in range(T_):
-        z = fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))                      # :243,272
+        z = (z_all[t, 0], z_all[t, 1]) if z_all is not None else fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))
         if world > 1:
             loss_t, sim = mdist.gathered_nt_xent(z[0], z[1], args.temperature)               # global denominator (dist.py)
             losses.append(loss_t)
         else:
-            losses.append(criterion(z[0], z[1]))                                             # :249,277
+            losses.append(criterion.forward_stacked(z_all[t].reshape(2 * B, -1)) if z_all is not None
+                          else criterion(z[0], z[1]))                                        # :249,277
             sim = criterion.last_similarity
         if t > 0:
             rewards.append((sim_last - sim).view(1, -1))                                     # :282-283

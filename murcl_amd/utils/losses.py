@@ -23,12 +23,20 @@ class NT_Xent(nn.Module):
     def set_shard(self, lo, hi):
         self._shard = (int(lo), int(hi))
 
+    def forward_stacked(self, z):
+        """``forward(z[:B], z[B:])`` for a contiguous [2B,P] float32 tensor that already holds view 0's rows, then view 1's
+        (e.g. one patch step's block of ``Full_layer.forward_view_sequence``): nothing is concatenated."""
+        return self._run(z, None, z.shape[0] // 2)
+
     def forward(self, z_i, z_j):
-        lo, hi = self._shard if self._shard is not None else (0, z_i.shape[0])
         zi, zj = z_i, z_j
         base = whole([z_i, z_j]) if z_i.shape == z_j.shape and z_i.dtype == torch.float32 else None
         if base is not None:
             zi, zj = base, None          # the two views are the halves of one tensor (Full_layer.forward_views): no cat
+        return self._run(zi, zj, z_i.shape[0])
+
+    def _run(self, zi, zj, B):
+        lo, hi = self._shard if self._shard is not None else (0, B)
         if not torch.is_grad_enabled() or not zi.requires_grad:
             # nobody will differentiate this loss (frozen-encoder stage 2, validation): skip the gradient half of the kernel
             from .. import ops
