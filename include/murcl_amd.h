@@ -111,6 +111,10 @@ int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const f
 long murcl_ntxent_workspace_bytes(int n);
 int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz, float* sim,
                          int grad_lo, int grad_hi, int pair_stride, void* workspace, murcl_stream_t stream);
+/* `batches` independent problems of n <= 128 rows (cat(view 0, view 1)) in one launch - the T patch steps of a training
+ * step (train_MuRCL.py:249,277): z [batches][n][P] -> loss [batches], dz [batches][n][P] (may be NULL), sim [batches][n/2]. */
+int murcl_ntxent_fwd_bwd_batched(const float* z, int batches, int n, int P, float temperature, float* loss, float* dz,
+                                 float* sim, murcl_stream_t stream);
 
 /* K12 -- get_feats (utils/datasets.py:274-308): per bag b and cluster j (ascending id list of length n_j):
  * size_j = rint(float(n_j)*ratio[b]), l_j = floor(actions[b][j]*float(n_j-size_j)), ids cluster_j[l_j : l_j+size_j]

@@ -34,6 +34,7 @@ SIGNATURES = {
     "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
+    "murcl_ntxent_fwd_bwd_batched": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
     "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_mixup": [_P, _P, _P, _P, _I, _L, _I, _P],

@@ -301,6 +301,11 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
                                                             float* __restrict__ dz, float* __restrict__ sim,
                                                             float* __restrict__ loss_out, int grad_lo, int grad_hi) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    // blockIdx.y: one of several independent batches of the same size (the T patch steps of a training step), back to back
+    z += (size_t)blockIdx.y * n * NX_P;
+    if (dz) dz += (size_t)blockIdx.y * n * NX_P;
+    if (sim) sim += (size_t)blockIdx.y * (n / 2);
+    loss_out += blockIdx.y;
     float* zh = sm;                                   // [128][NXS_LD]
     float* S = sm + 128 * NXS_LD;                     // [128][NXS_LD] logits, then gradient weights
     float* lse = S + 128 * NXS_LD;                    // [128]
@@ -460,23 +465,15 @@ extern "C" long murcl_ntxent_workspace_bytes(int n) {
 }
 
 // C-ABI: see include/murcl_amd.h
+static int nx_small_launch(const float* z, int n, int ps, float temperature, float* loss, float* dz, float* sim, int grad_lo,
+                           int grad_hi, int batches, hipStream_t stream);
 extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float* loss, float* dz,
                                     float* sim, int grad_lo, int grad_hi, int pair_stride, void* workspace,
                                     hipStream_t stream) {
     if (P != NX_P || n <= 0 || (n & 1)) return -1;
     const int ps = pair_stride > 0 ? pair_stride : n / 2;
     if (n % (2 * ps)) return -1;
-    if (n <= 128) {
-        constexpr int LDS = (2 * 128 * NXS_LD + 128 * 5) * 4;
-        static MurclOncePerDevice once;      
-        if (once.first()) {
-            hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-                           
-        }
-        hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz, sim,
-                           loss, grad_lo, grad_hi);
-        return MURCL_CHECK_LAUNCH();
-    }
+    if (n <= 128) return nx_small_launch(z, n, ps, temperature, loss, dz, sim, grad_lo, grad_hi, 1, stream);
     static_assert(NXT_LDS <= 160 * 1024, "LDS budget");
     static MurclOncePerDevice once_t;      
     if (once_t.first()) {
@@ -496,4 +493,21 @@ extern "C" int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperat
     hipLaunchKernelGGL(ntxent_grad_kernel, dim3(dz ? nblk : 1), dim3(1024), NXT_LDS, stream, n, ps, 1.0f / temperature,
                        (const float*)zh, (const float*)inv, (const float*)stats, ntile, dz, loss, grad_lo, grad_hi);
     return MURCL_CHECK_LAUNCH();
+}
+
+static int nx_small_launch(const float* z, int n, int ps, float temperature, float* loss, float* dz, float* sim, int grad_lo,
+                           int grad_hi, int batches, hipStream_t stream) {
+    constexpr int LDS = (2 * 128 * NXS_LD + 128 * 5) * 4;
+    static MurclOncePerDevice once;
+    if (once.first()) hipFuncSetAttribute((const void*)ntxent_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL(ntxent_small_kernel, dim3((n + 15) / 16, batches), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz,
+                       sim, loss, grad_lo, grad_hi);
+    return MURCL_CHECK_LAUNCH();
+}
+// `batches` independent NT-Xent problems of n <= 128 rows each in ONE launch: z [batches][n][P] -> loss [batches],
+// dz [batches][n][P] (may be NULL), sim [batches][n/2].  The T patch steps of a training step (train_MuRCL.py:249,277).
+extern "C" int murcl_ntxent_fwd_bwd_batched(const float* z, int batches, int n, int P, float temperature, float* loss, float* dz,
+                                            float* sim, hipStream_t stream) {
+    if (P != NX_P || n <= 0 || (n & 1) || n > 128 || batches <= 0) return -1;
+    return nx_small_launch(z, n, n / 2, temperature, loss, dz, sim, 0, n / 2, batches, stream);
 }

@@ -392,6 +392,26 @@ class GRUSeqFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, _bgrad(dgi2, b_ih), _bgrad(dgh2, b_hh)
 
 
+class NTXentSeqFn(torch.autograd.Function):
+    """NT_Xent of T independent (view 0, view 1) batches at once: z [T,2B,P] -> (loss [T], cos(z_i, z_j) [T,B]); one launch
+    computes all losses, gradients and cosines (the T patch steps of a pre-training step, train_MuRCL.py:249,277)."""
+
+    @staticmethod
+    def forward(ctx, z, temperature):
+        loss, dz, sim = ops.ntxent_batched(z, temperature, want_grad=True)
+        ctx.save_for_backward(dz)
+        ctx.mark_non_differentiable(sim)
+        ctx.set_materialize_grads(False)
+        return loss, sim
+
+    @staticmethod
+    def backward(ctx, dloss, _dsim):
+        (dz,) = ctx.saved_tensors
+        if dloss is None:
+            return None, None
+        return dz * dloss.view(-1, 1, 1), None
+
+
 class NTXentFn(torch.autograd.Function):
     """NT_Xent.forward (utils/losses.py:24-41); gradient comes out of the same launch."""
 

@@ -302,6 +302,21 @@ def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None, pair_stride=
     return loss, dz, sim
 
 
+def ntxent_batched(z, temperature, want_grad=True):
+    """z [T,2B,128] f32 (2B <= 128): T independent NT-Xent problems in one launch -> (loss [T], dz [T,2B,128] or None, sim [T,B])."""
+    _need_cuda(z)
+    z = _c(z.float())
+    T_, n, P = z.shape
+    dev = z.device
+    loss = torch.empty((T_,), dtype=torch.float32, device=dev)
+    dz = torch.empty_like(z) if want_grad else None
+    sim = torch.empty((T_, n // 2), dtype=torch.float32, device=dev)
+    with _span(lambda: ("ntxent", dict(flops=6.0 * T_ * n * n * P, bytes=2 * T_ * n * P * 4))):
+        check(_lib.lib().murcl_ntxent_fwd_bwd_batched(ptr(z), T_, n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), stream()),
+              "ntxent_fwd_bwd_batched")
+    return loss, dz, sim
+
+
 def cast(x, dtype):
     _need_cuda(x)
     x = _c(x)

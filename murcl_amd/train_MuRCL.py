@@ -143,7 +143,13 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     if late_head:
         with torch.set_grad_enabled(train_enc):
             z_all = fc.forward_view_sequence(agg_outs).view(args.T, 2, B, -1)                # :243,272 for every step at once
-            for t in range(args.T):
+            if world == 1 and 2 * B <= 128:
+                loss_t, sims = criterion.forward_steps(z_all.view(args.T, 2 * B, -1))        # :249,277: one launch
+                losses = list(loss_t.unbind(0))
+                rewards = list((sims[:-1] - sims[1:]).unsqueeze(1).unbind(0))                # :282-283
+                for m in memory_list:
+                    m.rewards.extend(rewards)
+            for t in range(args.T if not losses else 0):
                 if world > 1:
                     loss, sim = mdist.gathered_nt_xent(z_all[t, 0], z_all[t, 1], args.temperature)
                 else:
@@ -194,6 +200,14 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch
     losses, rewards, sim_last = [], [], None
     z_all = fc.forward_view_sequence(outputs).view(T_, 2, B, -1) if _BATCHED_HEAD and fc.fc_rnn else None   # :243,272, all steps
+    if z_all is not None and world == 1 and 2 * B <= 128:
+        loss_t, sims = criterion.forward_steps(z_all.view(T_, 2 * B, -1))                     # :249,277 for all steps: one launch
+        loss = loss_t.sum() / T_                                                              # :291
+        optimizer.zero_grad()
+        with functional.deferred_wgrads():
+            loss.backward(ops.unit_grad(loss))
+        optimizer.step()                                                                      # :293-295
+        return loss.detach(), list(loss_t.detach().unbind(0)), list((sims[:-1] - sims[1:]).unsqueeze(1).unbind(0))   # :282-283
     for t in range(T_):
         z = (z_all[t, 0], z_all[t, 1]) if z_all is not None else fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))
         if world > 1:

@@ -28,6 +28,18 @@ class NT_Xent(nn.Module):
         (e.g. one patch step's block of ``Full_layer.forward_view_sequence``): nothing is concatenated."""
         return self._run(z, None, z.shape[0] // 2)
 
+    def forward_steps(self, z):
+        """T independent batches at once: z [T,2B,P] float32 (view 0's rows, then view 1's, per step; 2B <= 128)
+        -> (losses [T], cosines [T,B]); ``last_similarity`` is the last step's."""
+        from ..functional import NTXentSeqFn
+        if not torch.is_grad_enabled() or not z.requires_grad:
+            from .. import ops
+            loss, _, sim = ops.ntxent_batched(z, float(self.temperature), want_grad=False)
+        else:
+            loss, sim = NTXentSeqFn.apply(z, float(self.temperature))
+        self.last_similarity = sim[-1]
+        return loss, sim
+
     def forward(self, z_i, z_j):
         zi, zj = z_i, z_j
         base = whole([z_i, z_j]) if z_i.shape == z_j.shape and z_i.dtype == torch.float32 else None

@@ -311,6 +311,22 @@ def test_ntxent(Bh, tau):
     _close(sim, O.row_cosine(zi.detach(), zj.detach()), rtol=1e-4, atol=1e-6, msg="sim")
 
 
+@pytest.mark.parametrize("T_,Bh", [(1, 4), (6, 64), (3, 9), (5, 33)])
+def test_ntxent_batched_equals_one_problem_at_a_time(T_, Bh):
+    """murcl_ntxent_fwd_bwd_batched: the T patch steps' NT-Xent problems (2B <= 128 rows each) in one launch - loss, gradient
+    and cosines of every problem are those of the single-problem entry point (same kernel, blockIdx.y = problem)."""
+    from murcl_amd import ops
+    dev = _dev()
+    z = _rand(21, f"z{T_}{Bh}", (T_, 2 * Bh, 128)).to(dev)
+    loss, dz, sim = ops.ntxent_batched(z, 0.5)
+    assert loss.shape == (T_,) and dz.shape == z.shape and sim.shape == (T_, Bh)
+    for t in range(T_):
+        l1, d1, s1 = ops.ntxent(z[t], 0.5)
+        assert torch.equal(loss[t], l1[0]) and torch.equal(dz[t], d1) and torch.equal(sim[t], s1)
+    l2, d2, s2 = ops.ntxent_batched(z, 0.5, want_grad=False)
+    assert d2 is None and torch.equal(l2, loss) and torch.equal(s2, sim)
+
+
 @pytest.mark.parametrize("Bh,step", [(32, 8), (256, 64), (200, 40)])
 def test_ntxent_sharded_rows_match_global(Bh, step):
     """Rank-local gradient slices assemble to the global gradient; 256 = the global batch of 4 ranks."""
