@@ -34,11 +34,13 @@ for stage in (1, 3):
                           "host_enqueue_ms": round((t1 - t0) / n * 1e3, 3)}), flush=True)
 if os.environ.get("B1_PROFILE") == "1":
     import cProfile, pstats
-    model, fc = create_model("ABMIL", 512, 2, dev, dtype=torch.bfloat16)
+    parch, pstage = os.environ.get("B1_ARCH", "ABMIL"), int(os.environ.get("B1_STAGE", "1"))
+    model, fc = create_model(parch, 512, 2, dev, dtype=torch.bfloat16)
     opt = FlatAdam([{"params": list(model.parameters()) + list(fc.parameters()), "lr": 1e-4}])
+    ppo = rlmil.PPO(512, 512, 512, False, action_size=10) if pstage == 3 else None
     mem = rlmil.Memory()
     def step():
-        supervised_step("ABMIL", model, fc, None, opt, pack, labels, mem, T=6, feat_size=1024, train_stage=1)
+        supervised_step(parch, model, fc, ppo, opt, pack, labels, mem, T=6, feat_size=1024, train_stage=pstage)
     for _ in range(5): step()
     torch.cuda.synchronize()
     pr = cProfile.Profile(); pr.enable()
