@@ -136,6 +136,10 @@ class CLAM_SB(nn.Module):
         M, A, s, il, ids, io = self._run(x, labels, instance_eval)
         if attention_only:
             return s, [{}] * x.shape[0]
+        if not instance_eval and not return_features:
+            # nothing to report per bag (the contrastive pre-training calls it this way with 2*T*B = 768 bags per step:
+            # building 768 result dicts one by one was 2.9 ms of host time per step)
+            return M, [{} for _ in range(x.shape[0])]
         host = self._host_inst(io) if instance_eval else None
         ils = il.unbind(0) if instance_eval else il          # one autograd node for all bags (its backward is one stack)
         return M, [self._results(b, M, ils, host, instance_eval, return_features) for b in range(x.shape[0])]

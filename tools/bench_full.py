@@ -30,7 +30,7 @@ if a.force_dist:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     WORLD = 2
-args = build_parser().parse_args(["--arch", "ABMIL", "--fc_lr", "5e-5"])
+args = build_parser().parse_args(["--arch", os.environ.get("BF_ARCH", "ABMIL"), "--fc_lr", "5e-5"])
 args.T, args.feat_size, args.batch_size, args.dtype, args.train_stage, args.num_clusters = a.T, a.feat_size, a.bags, a.dtype, 1, 10
 torch.manual_seed(985)
 model, fc, ppo = create_model(args, 512, dev)          # stage-1 construction (no checkpoint needed) ...
