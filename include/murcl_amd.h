@@ -248,6 +248,12 @@ int murcl_ppo_epoch(const float* const* params, float* const* grads, int S, int 
 /* 1-bit ReLU' mask (x > 0) of an activation tensor x [M,N] in murcl_panel_gemm's bit-mask layout (M*N/8 bytes;
  * M % 32 == 0, N % 32 == 0), for layers whose forward did not emit it (clam.py:69 with a 1024-wide input). */
 int murcl_relu_bitmask(const void* x, void* bits, int M, int N, int ld, int dtype, murcl_stream_t stream);
+/* nn.Dropout applied in place to x [M,N] (contiguous; M % 32 == 0, N % 128 == 0) with the counter-based keep mask of
+ * murcl_dropout_mask for the same seed - the mask is never materialised - and, in the same pass, the 1-bit mask of the
+ * surviving positive entries in the layout above (bits may be NULL).  CLAM's Dropout(0.25) after the first layer's ReLU
+ * (models/clam.py:69-72). */
+int murcl_dropout_relu_bitmask(void* x, void* bits, int M, int N, float keep_p, float scale, unsigned long long seed, int dtype,
+                               murcl_stream_t stream);
 
 /* Compute-dtype copies / transposes of several f32 weight matrices in one launch.  jobs_dev: n_jobs records of
  * { const float* src; void* dst; int rows, cols, transpose, dtype_out; } (32 bytes each) in device memory; max_tiles =

@@ -483,18 +483,12 @@ __global__ void mul_kernel(const T* __restrict__ x, const T* __restrict__ k, T* 
 // Dropout keep mask in the compute dtype: out[i] = scale with probability keep_p (quantised to 1/256), else 0.
 // Counter-based: element i takes byte (i & 7) of splitmix64(seed + i / 8), so a mask is a pure function of (seed, i) -
 // one write pass instead of torch's uniform draw + compare + cast + scale (four passes over an f32 tensor twice the size).
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_mask_kernel(T* __restrict__ out, long n8, long n, unsigned thresh, float scale,
                                                            unsigned long long seed) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride) {
-        const unsigned long long r = splitmix64(seed + (unsigned long long)g * 0xD1342543DE82EF95ull);
+        const unsigned long long r = murcl_drop_word(seed, g);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ((unsigned)(r >> (8 * e)) & 255u) < thresh ? scale : 0.f;

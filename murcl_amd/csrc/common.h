@@ -64,6 +64,18 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
     *(u32x2*)p = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
 }
 
+// Counter-based dropout keep mask (csrc/clam.hip, csrc/elementwise.hip): element i takes byte (i & 7) of
+// splitmix64(seed + (i / 8) * C): kept (value `scale`) when the byte is below `thresh` = keep probability in 1/256ths.
+__device__ __forceinline__ unsigned long long murcl_splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long murcl_drop_word(unsigned long long seed, long group8) {
+    return murcl_splitmix64(seed + (unsigned long long)group8 * 0xD1342543DE82EF95ull);
+}
+
 // 8 consecutive elements <-> float[8] (16-byte accesses for bf16, two for f32)
 template <typename T> __device__ __forceinline__ void load8(const T* p, float* v);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {

@@ -215,6 +215,81 @@ extern "C" int murcl_relu_bitmask(const void* x, void* bits, int M, int N, int l
     return MURCL_CHECK_LAUNCH();
 }
 
+// Dropout applied in place + the 1-bit mask of what survives, one pass: x[i] *= keep(i) with the counter-based keep mask of
+// murcl_dropout_mask (same seed -> the same mask, never materialised), bits = (x > 0) afterwards in the panel layout above.
+// CLAM's Dropout(0.25) after the first layer's ReLU (clam.py:69-72): replaces mask generation (one 805 MB write at 786 k rows)
+// + an elementwise multiply (two reads, one write) + the mask pass (one read) by one read and one write.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_relu_bitmask_kernel(T* __restrict__ x, uint8_t* __restrict__ bits, int M, int N,
+                                                                   unsigned thresh, float scale, unsigned long long seed) {
+    // A wave owns a 32-row x 128-column strip (four 32-column mask blocks).  Rows are read and written in whole 256-byte (bf16)
+    // pieces, 16 lanes x 8 consecutive elements - the mask layout's own access pattern (8 bytes per lane over 16 rows) moves
+    // 512 bytes per instruction over sixteen cache lines and is bound by the address path (519 us for 1.6 GB at 786 k rows).
+    // The 1-bit flags are assembled in LDS: element (row, col) of a block belongs to word 16*((col & 15) >> 2) + (row & 15),
+    // bit idx = 8*(row >> 4) + 4*(col >> 4) + (col & 3) -> position (7 - idx/2) + 8*(idx & 1).
+    __shared__ unsigned words[4][4][64];                              // [wave][block of the strip][mask lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strips = N >> 7;
+    const long wb = (long)blockIdx.x * 4 + wave;
+    const bool live = wb < (long)(M >> 5) * strips;
+    for (int k = lane; k < 4 * 64; k += 64) words[wave][k >> 6][k & 63] = 0u;
+    __syncthreads();
+    if (live) {
+        const long tile = wb / strips;
+        const int c0 = (int)(wb - tile * strips) * 128;
+        const int rsub = lane >> 4, cl = (lane & 15) * 8;              // row within a 4-row set, first of this lane's 8 columns
+        const int blk = cl >> 5, cb = cl & 31;                         // mask block of the strip, column inside it (0, 8, 16, 24)
+#pragma unroll
+        for (int rs = 0; rs < 8; ++rs) {
+            const int row = 4 * rs + rsub;                             // 0..31 inside the tile
+            const long e0 = (long)(32 * tile + row) * N + c0 + cl;     // flat index, multiple of 8: one random word per lane
+            float v[8];
+            load8<T>(x + e0, v);
+            const unsigned long long rw = murcl_drop_word(seed, e0 >> 3);
+            unsigned nib[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float kp = ((unsigned)(rw >> (8 * e)) & 255u) < thresh ? scale : 0.f;
+                v[e] *= kp;
+                const int col = cb + e;                                // column inside the 32-column block
+                const int idx = 8 * (row >> 4) + 4 * (col >> 4) + (col & 3);
+                nib[e >> 2] |= (v[e] > 0.f ? 1u : 0u) << ((7 - (idx >> 1)) + 8 * (idx & 1));
+            }
+            store8<T>(x + e0, v);
+            if (bits) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int col = cb + 4 * h;
+                    atomicOr(&words[wave][blk][16 * ((col & 15) >> 2) + (row & 15)], nib[h]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (live && bits) {
+        const long tile = wb / strips;
+        const int g0 = (int)(wb - tile * strips) * 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            *(uint16_t*)(bits + (tile * (N >> 5) + g0 + b) * 128 + lane * 2) = (uint16_t)words[wave][b][lane];
+    }
+}
+extern "C" int murcl_dropout_relu_bitmask(void* x, void* bits, int M, int N, float keep_p, float scale, unsigned long long seed,
+                                          int dtype, hipStream_t s) {
+    if (M <= 0 || N <= 0) return 0;
+    if (M % 32 || N % 128 || !(keep_p >= 0.f && keep_p <= 1.f)) return -1;
+    const unsigned thresh = (unsigned)(keep_p * 256.f + 0.5f);
+    const long blocks = (long)(M / 32) * (N / 128);
+    dim3 grid((unsigned)((blocks + 3) / 4));
+    if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL(dropout_relu_bitmask_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)x, (uint8_t*)bits, M, N, thresh, scale, seed);
+    else if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL(dropout_relu_bitmask_kernel<float>, grid, dim3(256), 0, s, (float*)x, (uint8_t*)bits, M, N, thresh, scale, seed);
+    else
+        return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- ReLU backward: dx = dy * (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

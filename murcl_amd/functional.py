@@ -555,7 +555,15 @@ class CLAMFn(torch.autograd.Function):
         k1 = ka = kb = None
         if keeps is not None:
             k1, ka, kb = keeps
-            ops.mul(h, k1)                                                             # Dropout(0.25) after ReLU
+            if isinstance(k1, ops.DropSeed):                                           # Dropout(0.25) after ReLU (clam.py:69-72)
+                if (B * N) % 32 == 0 and L % 128 == 0:
+                    # the mask is generated inside the pass that applies it, which also leaves the 1-bit mask of the
+                    # surviving positive entries for the backward pass (bf16 panel dgrad)
+                    m1 = ops.dropout_relu_bitmask(h, k1, want_bits=(T == torch.bfloat16))
+                else:
+                    ops.mul(h, ops.dropout_mask(h.shape, T, k1.keep_p, h.device, seed=k1.seed))
+            else:
+                ops.mul(h, k1)                                                         # an injected keep mask (parity tests)
         gated = wb is not None                   # False: the plain Attn_Net (CLAM_SB(gate=False), clam.py:18-34,80-81)
         wab = torch.cat([wa, wb], 0) if gated else wa
         bab = torch.cat([ba, bb], 0) if gated else ba
@@ -654,7 +662,8 @@ class CLAMFn(torch.autograd.Function):
         if db1 is None:
             db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
-            dw1, db1 = dw1 / 0.75, db1 / 0.75
+            kp = k1.keep_p if isinstance(k1, ops.DropSeed) else 0.75
+            dw1, db1 = dw1 / kp, db1 / kp
         if not gated:
             return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),

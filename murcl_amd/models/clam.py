@@ -86,7 +86,8 @@ class CLAM_SB(nn.Module):
             # keep with probability 0.75, survivors scaled by 1/0.75 (nn.Dropout(0.25), clam.py:71-72,47-48): one write pass
             # per mask (ops.dropout_mask) instead of uniform draw + compare + cast + scale
             draw = lambda w: ops.dropout_mask((BN, w), T, 0.75, x.device)   # noqa: E731
-            keeps = (draw(L), draw(D), draw(D) if self.gate else None)
+            # (the first layer's mask is not materialised: CLAMFn generates it inside the pass that applies it)
+            keeps = (ops.DropSeed(0.75), draw(D), draw(D) if self.gate else None)
         inst_w = inst_b = cfg = None
         if instance_eval:
             inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)

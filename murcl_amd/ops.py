@@ -674,12 +674,38 @@ def cross_entropy(logits, targets, group):
 _DROP_COUNTER = 0
 
 
-def dropout_mask(shape, dtype, keep_p, device):
-    """Keep mask of ``nn.Dropout(1 - keep_p)``: ``1/keep_p`` where kept, 0 where dropped.  Seeded from torch's global
-    seed and a call counter (no device synchronisation; ``torch.manual_seed`` makes a run reproducible)."""
+class DropSeed:
+    """A dropout keep mask that is never materialised: the (seed, keep probability) its elements are a pure function of."""
+    __slots__ = ("seed", "keep_p")
+
+    def __init__(self, keep_p, seed=None):
+        self.keep_p, self.seed = float(keep_p), dropout_seed() if seed is None else int(seed)
+
+
+def dropout_seed():
+    """Seed of the next counter-based dropout mask: torch's global seed and a call counter (no device synchronisation;
+    ``torch.manual_seed`` makes a run reproducible)."""
     global _DROP_COUNTER
     _DROP_COUNTER += 1
-    seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_COUNTER * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_COUNTER * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout_relu_bitmask(x, drop, want_bits=True):
+    """x [M,N] (contiguous, M % 32 == 0, N % 128 == 0): ``x *= keep`` in place for the mask of ``drop`` (a DropSeed) and, in the
+    same pass, the panel GEMM's 1-bit mask of x > 0 afterwards -> bits [M, N/8] uint8 (None without ``want_bits``)."""
+    _need_cuda(x)
+    assert x.is_contiguous() and x.dim() == 2
+    M, N = x.shape
+    bits = torch.empty((M, N // 8), dtype=torch.uint8, device=x.device) if want_bits else None
+    check(_lib.lib().murcl_dropout_relu_bitmask(ptr(x), ptr(bits), M, N, drop.keep_p, 1.0 / drop.keep_p, drop.seed, dt(x), stream()),
+          "dropout_relu_bitmask")
+    return bits
+
+
+def dropout_mask(shape, dtype, keep_p, device, seed=None):
+    """Keep mask of ``nn.Dropout(1 - keep_p)``: ``1/keep_p`` where kept, 0 where dropped.  Seeded from torch's global
+    seed and a call counter (no device synchronisation; ``torch.manual_seed`` makes a run reproducible)."""
+    seed = dropout_seed() if seed is None else int(seed)
     out = torch.empty(shape, dtype=dtype, device=device)
     check(_lib.lib().murcl_dropout_mask(ptr(out), out.numel(), float(keep_p), 1.0 / float(keep_p), seed, dt(out), stream()),
           "dropout_mask")

@@ -207,6 +207,28 @@ def test_panel_dgrad_partial_bias_rows_fold_into_the_weight_gradient(M):
     _close(gb, b0.double() + cs_ref.double().cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(M), msg="db")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(32, 128), (4096, 512), (96, 1024)])
+def test_dropout_applied_in_place_with_the_mask_never_materialised(dtype, M, N):
+    """murcl_dropout_relu_bitmask: x *= keep with the counter-based mask of murcl_dropout_mask for the same seed (bit-identical to
+    multiplying by the materialised mask), and the panel layout's 1-bit mask of the surviving positive entries from the same pass."""
+    from murcl_amd import ops
+    dev = _dev()
+    x0 = _rand(31, f"x{M}{N}", (M, N)).to(dtype).to(dev)
+    drop = ops.DropSeed(0.75, seed=0x1234_5678_9ABC_DEF0 + M)
+    mask = ops.dropout_mask((M, N), torch.float32, 0.75, dev, seed=drop.seed)      # the same keep pattern, scale 1/0.75 in f32
+    assert torch.equal(mask != 0, ops.dropout_mask((M, N), dtype, 0.75, dev, seed=drop.seed) != 0)
+    kept = float((mask != 0).float().mean())
+    assert abs(kept - 0.75) < 0.05 and set(mask.unique().tolist()) <= {0.0, float(torch.tensor(1 / 0.75, dtype=torch.float32))}
+    want = (x0.float() * mask).to(dtype)
+    x = x0.clone()
+    bits = ops.dropout_relu_bitmask(x, drop)
+    assert torch.equal(x, want)
+    assert torch.equal(bits, ops.relu_bitmask(want))
+    x2 = x0.clone()
+    assert ops.dropout_relu_bitmask(x2, drop, want_bits=False) is None and torch.equal(x2, want)
+
+
 # ------------------------------------------------------------------ K2 attention pool
 def _k2_inputs(seed, B, N):
     H = torch.relu(_rand(seed, "H", (B, N, 512)))

@@ -14,9 +14,10 @@ for f in glob.glob("$OUT/trace/*/*kernel_trace.csv"):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 # one step = from one subbag-selection burst to the next: use the T-th-from-last .. last 'ntxent' launches (T=6 per step)
+import os
 idx = [i for i, r in enumerate(rows) if r[2].startswith("ntxent")]
-idx = idx[:-0 or None]
-a, b = idx[-13], idx[-7]          # spans exactly one step (6 ntxent launches), away from the trailing subbag timing loop
+per = int(os.environ.get("NTX_PER_STEP", "1"))      # NT-Xent launches per step: 1 (all patch steps in one launch), T with MURCL_BATCHED_HEAD=0
+a, b = idx[-2 * per - 1], idx[-per - 1]             # spans exactly one step, away from the trailing subbag timing loop
 seq = rows[a:b]
 t0 = seq[0][0]
 busy = 0
