@@ -170,12 +170,16 @@ int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float* Q, int ld
  * under the ReLU mask.  cross_entropy: mean CE over R rows + gradient + arg-max predictions (clam.py:116-118). */
 /* gated != 0: U [rows, 2D] = (tanh branch | sigmoid branch) of Attn_Net_Gated (clam.py:37-60); gated == 0: U [rows, D], the
  * plain Attn_Net (clam.py:18-34): s = tanh(U) . wc + bc (keep_b unused; dbab then holds D column sums followed by D zeros) */
+/* keep_a / keep_b NULL and 0 < keep_p < 1: the same Dropout with masks that are never materialised - the counter-based masks
+ * murcl_dropout_mask would produce for seed_a / seed_b over [rows, D] (scale 1/keep_p), regenerated identically by _bwd. */
 int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a, const void* keep_b,
-                          float* s, long rows, int D, int dtype, int gated, murcl_stream_t stream);
+                          float* s, long rows, int D, int dtype, int gated, float keep_p, unsigned long long seed_a,
+                          unsigned long long seed_b, murcl_stream_t stream);
 /* dbab (may be NULL) [2D] receives the column sums of dU - the bias gradients of the two gate Linears - from the same pass */
 int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b, const float* ds,
                           void* dU, float* dwc, float* dbc, float* dbab, float* part_ws /* [1024*(3D+1)] */, long rows, int D,
-                          int dtype, int gated, murcl_stream_t stream);
+                          int dtype, int gated, float keep_p, unsigned long long seed_a, unsigned long long seed_b,
+                          murcl_stream_t stream);
 int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t stream);
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);

@@ -20,6 +20,14 @@ template <> __device__ __forceinline__ float gs_sigmoid<bf16_t>(float x) {
 // Streaming kernels over U [rows, 2D]: a thread owns 8 consecutive columns of both gate halves (16-byte loads for
 // bf16), G = D/8 column groups, 256/G rows in flight per workgroup pass, a workgroup walks `rows_per_block` rows.
 // GATED = false: the plain attention net (clam.py:18-34): U has D columns, s_n = sum_d tanh(U[n,d]) wc[d] + bc.
+// Gate dropout without materialised masks: 8 consecutive keep values of row n, columns 8cg.. of a [rows, D] mask = the 8 bytes of
+// one counter-based word (murcl_dropout_mask's generator, flat index n*D + 8cg).
+struct GsDrop { unsigned long long seed_a, seed_b; unsigned thresh; float scale; };
+__device__ __forceinline__ void gs_keep8(unsigned long long seed, long flat8, unsigned thresh, float scale, float* k) {
+    const unsigned long long rw = murcl_drop_word(seed, flat8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k[e] = ((unsigned)(rw >> (8 * e)) & 255u) < thresh ? scale : 0.f;
+}
 #ifndef GS_UR_BF16
 #define GS_UR_BF16 4
 #endif
@@ -27,7 +35,7 @@ template <typename T, bool GATED>
 __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const float* __restrict__ bc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
-                                                              float* __restrict__ s, long rows, int D, int rows_per_block) {
+                                                              float* __restrict__ s, long rows, int D, int rows_per_block, GsDrop drop) {
     __shared__ float red[256];
     const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
     const int cg = tid % G, rl = tid / G;
@@ -56,19 +64,25 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
             const long n = base + u * RL + rl;
             if (live[u]) {
                 if (!GATED) {
-                    if (keep_a) {
+                    if (keep_a || drop.thresh) {
                         float ka[8];
-                        load8<T>(keep_a + n * D + 8 * cg, ka);
+                        if (keep_a) load8<T>(keep_a + n * D + 8 * cg, ka);
+                        else gs_keep8(drop.seed_a, (n * D + 8 * cg) >> 3, drop.thresh, drop.scale, ka);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[u] += gs_tanh<T>(ua[u][e]) * ka[e] * w[e];
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[u] += gs_tanh<T>(ua[u][e]) * w[e];
                     }
-                } else if (keep_a) {
+                } else if (keep_a || drop.thresh) {
                     float ka[8], kb[8];
-                    load8<T>(keep_a + n * D + 8 * cg, ka);
-                    load8<T>(keep_b + n * D + 8 * cg, kb);
+                    if (keep_a) {
+                        load8<T>(keep_a + n * D + 8 * cg, ka);
+                        load8<T>(keep_b + n * D + 8 * cg, kb);
+                    } else {
+                        gs_keep8(drop.seed_a, (n * D + 8 * cg) >> 3, drop.thresh, drop.scale, ka);
+                        gs_keep8(drop.seed_b, (n * D + 8 * cg) >> 3, drop.thresh, drop.scale, kb);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) acc[u] += (gs_tanh<T>(ua[u][e]) * ka[e]) * (gs_sigmoid<T>(ub[u][e]) * kb[e]) * w[e];
                 } else {
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
                                                               const float* __restrict__ ds, T* __restrict__ dU,
                                                               float* __restrict__ part,
-                                                              long rows, int D, int rows_per_block) {
+                                                              long rows, int D, int rows_per_block, GsDrop drop) {
     __shared__ float red[256][25];
     const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
     const int cg = tid % G, rl = tid / G;
@@ -131,10 +145,15 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                 float da[8], db[8], k[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) k[e] = 1.f;
-                if (keep_a) {
+                if (keep_a || drop.thresh) {
                     float ka[8], kb[8];
-                    load8<T>(keep_a + n * D + 8 * cg, ka);
-                    if (GATED) load8<T>(keep_b + n * D + 8 * cg, kb);
+                    if (keep_a) {
+                        load8<T>(keep_a + n * D + 8 * cg, ka);
+                        if (GATED) load8<T>(keep_b + n * D + 8 * cg, kb);
+                    } else {
+                        gs_keep8(drop.seed_a, (n * D + 8 * cg) >> 3, drop.thresh, drop.scale, ka);
+                        if (GATED) gs_keep8(drop.seed_b, (n * D + 8 * cg) >> 3, drop.thresh, drop.scale, kb);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) k[e] = GATED ? ka[e] * kb[e] : ka[e];
                 }
@@ -217,13 +236,20 @@ static int gs_rows_per_block(long rows, int D) {
     if (rpb < 4 * RL) rpb = 4 * RL;
     return (int)rpb;
 }
+static GsDrop gs_drop(float keep_p, unsigned long long seed_a, unsigned long long seed_b) {
+    GsDrop d{seed_a, seed_b, 0u, 1.f};
+    if (keep_p > 0.f && keep_p < 1.f) { d.thresh = (unsigned)(keep_p * 256.f + 0.5f); d.scale = 1.f / keep_p; }
+    return d;
+}
 extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a,
-                                     const void* keep_b, float* s, long rows, int D, int dtype, int gated, hipStream_t st) {
+                                     const void* keep_b, float* s, long rows, int D, int dtype, int gated, float keep_p,
+                                     unsigned long long seed_a, unsigned long long seed_b, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D)) return -1;
+    const GsDrop drop = gs_drop(keep_a ? 0.f : keep_p, seed_a, seed_b);
     const int rpb = gs_rows_per_block(rows, D);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-#define GS_FWD(T, G) hipLaunchKernelGGL((gated_score_fwd_kernel<T, G>), grid, dim3(256), 0, st, (const T*)U, wc, bc, (const T*)keep_a, (const T*)keep_b, s, rows, D, rpb)
+#define GS_FWD(T, G) hipLaunchKernelGGL((gated_score_fwd_kernel<T, G>), grid, dim3(256), 0, st, (const T*)U, wc, bc, (const T*)keep_a, (const T*)keep_b, s, rows, D, rpb, drop)
     if (dtype == MURCL_DTYPE_F32) { if (gated) GS_FWD(float, true); else GS_FWD(float, false); }
     else if (dtype == MURCL_DTYPE_BF16) { if (gated) GS_FWD(bf16_t, true); else GS_FWD(bf16_t, false); }
     else return -1;
@@ -232,15 +258,17 @@ extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float
 }
 extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
                                      const float* ds, void* dU, float* dwc, float* dbc, float* dbab, float* part_ws,
-                                     long rows, int D, int dtype, int gated, hipStream_t st) {
+                                     long rows, int D, int dtype, int gated, float keep_p, unsigned long long seed_a,
+                                     unsigned long long seed_b, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D) || !part_ws) return -1;
+    const GsDrop drop = gs_drop(keep_a ? 0.f : keep_p, seed_a, seed_b);
     const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
     long rpb = (rows + 1023) / 1024;                       // <= 1024 workgroups = rows of part_ws [1024][3D+1]
     rpb = ((rpb + RL - 1) / RL) * RL;
     if (rpb < 4 * RL) rpb = 4 * RL;
     const int grid = (int)((rows + rpb - 1) / rpb);
-#define GS_BWD(T, G) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb)
+#define GS_BWD(T, G) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb, drop)
     if (dtype == MURCL_DTYPE_F32) { if (gated) GS_BWD(float, true); else GS_BWD(float, false); }
     else if (dtype == MURCL_DTYPE_BF16) { if (gated) GS_BWD(bf16_t, true); else GS_BWD(bf16_t, false); }
     else return -1;

@@ -85,9 +85,9 @@ class CLAM_SB(nn.Module):
             L, D = net[0].out_features, wc.shape[1]
             # keep with probability 0.75, survivors scaled by 1/0.75 (nn.Dropout(0.25), clam.py:71-72,47-48): one write pass
             # per mask (ops.dropout_mask) instead of uniform draw + compare + cast + scale
-            draw = lambda w: ops.dropout_mask((BN, w), T, 0.75, x.device)   # noqa: E731
-            # (the first layer's mask is not materialised: CLAMFn generates it inside the pass that applies it)
-            keeps = (ops.DropSeed(0.75), draw(D), draw(D) if self.gate else None)
+            # none of the three masks is materialised: each is a pure function of (seed, element index) and is generated inside the
+            # passes that apply it (forward and backward regenerate the same values)
+            keeps = (ops.DropSeed(0.75), ops.DropSeed(0.75), ops.DropSeed(0.75) if self.gate else None)
         inst_w = inst_b = cfg = None
         if instance_eval:
             inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)

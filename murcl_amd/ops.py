@@ -601,9 +601,18 @@ def gated_score_fwd(U, wc, bc, keep_a=None, keep_b=None, gated=True):
     M, W = U.shape
     D = W // 2 if gated else W
     s = torch.empty((M,), dtype=torch.float32, device=U.device)
-    check(_lib.lib().murcl_gated_score_fwd(ptr(U), ptr(wc), ptr(bc), ptr(keep_a), ptr(keep_b), ptr(s), M, D, dt(U), int(gated),
-                                           stream()), "gated_score_fwd")
+    ka, kb, kp, sa, sb = _gate_drops(keep_a, keep_b)
+    check(_lib.lib().murcl_gated_score_fwd(ptr(U), ptr(wc), ptr(bc), ptr(ka), ptr(kb), ptr(s), M, D, dt(U), int(gated),
+                                           kp, sa, sb, stream()), "gated_score_fwd")
     return s
+
+
+def _gate_drops(keep_a, keep_b):
+    """keep_a / keep_b: materialised masks (tensors) or DropSeed specs (masks generated inside the kernels) -> kernel arguments."""
+    if isinstance(keep_a, DropSeed):
+        assert keep_b is None or isinstance(keep_b, DropSeed)
+        return None, None, keep_a.keep_p, keep_a.seed, keep_b.seed if keep_b is not None else 0
+    return keep_a, keep_b, 0.0, 0, 0
 
 
 def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None, gated=True):
@@ -616,8 +625,9 @@ def gated_score_bwd(U, wc, ds, keep_a=None, keep_b=None, gated=True):
     dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
     dbab = torch.empty((2 * D,), dtype=torch.float32, device=U.device)                    # column sums of dU, same pass
     part = torch.empty((1024 * (3 * D + 1),), dtype=torch.float32, device=U.device)       # per-workgroup partial rows
-    check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(keep_a), ptr(keep_b), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
-                                           ptr(dbab), ptr(part), M, D, dt(U), int(gated), stream()), "gated_score_bwd")
+    ka, kb, kp, sa, sb = _gate_drops(keep_a, keep_b)
+    check(_lib.lib().murcl_gated_score_bwd(ptr(U), ptr(wc), ptr(ka), ptr(kb), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc),
+                                           ptr(dbab), ptr(part), M, D, dt(U), int(gated), kp, sa, sb, stream()), "gated_score_bwd")
     return dU, dwc, dbc, dbab[:W]
 
 

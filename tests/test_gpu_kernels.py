@@ -229,6 +229,30 @@ def test_dropout_applied_in_place_with_the_mask_never_materialised(dtype, M, N):
     assert ops.dropout_relu_bitmask(x2, drop, want_bits=False) is None and torch.equal(x2, want)
 
 
+@pytest.mark.parametrize("gated", [True, False])
+def test_gate_dropout_masks_generated_inside_the_score_kernels(gated):
+    """gated_score_fwd / _bwd with DropSeed specs (masks never materialised) == the same kernels fed the materialised counter-based
+    masks of the same seeds (f32: bit-identical keep values)."""
+    from murcl_amd import ops
+    dev = _dev()
+    M, D = 4096, 256
+    U = _rand(33, f"U{gated}", (M, 2 * D if gated else D)).to(dev)
+    wc, bc = _rand(33, "wc", (D,)).to(dev), torch.zeros(1, device=dev)
+    ds = _rand(33, "ds", (M,)).to(dev)
+    da, db = ops.DropSeed(0.75, seed=1234567), (ops.DropSeed(0.75, seed=7654321) if gated else None)
+    ka = ops.dropout_mask((M, D), torch.float32, 0.75, dev, seed=da.seed)
+    kb = ops.dropout_mask((M, D), torch.float32, 0.75, dev, seed=db.seed) if gated else None
+    s_seed = ops.gated_score_fwd(U, wc, bc, da, db, gated=gated)
+    s_mask = ops.gated_score_fwd(U, wc, bc, ka, kb, gated=gated)
+    assert torch.equal(s_seed, s_mask)
+    assert not torch.equal(s_seed, ops.gated_score_fwd(U, wc, bc, gated=gated))
+    outs_seed = ops.gated_score_bwd(U, wc, ds, da, db, gated=gated)
+    outs_mask = ops.gated_score_bwd(U, wc, ds, ka, kb, gated=gated)
+    assert torch.equal(outs_seed[0], outs_mask[0])
+    for a, b in zip(outs_seed[1:], outs_mask[1:]):
+        _close(a, b, rtol=1e-6, atol=1e-5)
+
+
 # ------------------------------------------------------------------ K2 attention pool
 def _k2_inputs(seed, B, N):
     H = torch.relu(_rand(seed, "H", (B, N, 512)))
