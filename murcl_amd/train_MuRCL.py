@@ -6,7 +6,8 @@ Keeps the reference's flags, three-stage schedule (1: contrastive warm-up with r
 the per-batch hot step (train_MuRCL.py:233-304) is ``pretrain_step`` below and runs entirely on the HIP kernels:
 device-side sub-bag selection + fused gather/mix-up, one batched aggregator call for both views, the recurrent
 head, single-launch NT-Xent, PPO act/update.  One process per GPU: launch with
-``python -m torch.distributed.run --nproc-per-node N -m murcl_amd.train_MuRCL ...`` (instead of DataParallel).
+``python -m torch.distributed.run --nproc-per-node N -m murcl_amd.train_MuRCL --device 0,1,..,N-1 ...`` (instead of
+DataParallel; a ``--device`` list shorter than N makes rank r take cuda:r).
 
 Data: ``--data_csv`` in the reference's WSIWithCluster format (csv + npz ``img_features`` + json cluster lists),
 or ``--synthetic B,N`` for random bags.

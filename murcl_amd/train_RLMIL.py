@@ -77,12 +77,12 @@ def _forward_loss(arch, model, fc, feats, labels, t, bag_weight):
     return loss, logits, states
 
 
-def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions):
-    if actions is not None:
+def _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions, eps=None):
+    if actions is not None and t < len(actions):
         return actions[t].to(dev)
     if t == 0 or train_stage == 1:
         return torch.rand((B, K), device=dev)
-    return ppo.select_action(states, memory, restart_batch=(t == 1))
+    return ppo.select_action(states, memory, restart_batch=(t == 1), eps=None if eps is None else eps[t - 1].to(dev))
 
 
 def _head_all_steps(arch, fc, head_in_all, extra_all, labels, T, B, bag_weight, memory):
@@ -107,9 +107,12 @@ def _head_all_steps(arch, fc, head_in_all, extra_all, labels, T, B, bag_weight, 
 
 
 def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, feat_size=1024, train_stage=1,
-                    bag_weight=0.7, actions=None, return_logits=False, batch_patch_steps=True):
+                    bag_weight=0.7, actions=None, return_logits=False, batch_patch_steps=True, eps=None, trace=None):
     """One step on a BagPack with int64 labels [B].  Returns (loss, losses[T], rewards[T-1]) (+ the last patch step's
-    logits with ``return_logits``)."""
+    logits with ``return_logits``).
+    Tests inject the draws: ``actions`` [<=T][B,K] replaces the uniform window positions (and, given for all T steps, the
+    sampler), ``eps`` [T-1][B,K] the sampler's Gaussian noise; ``trace`` (a list) receives every step's action tensor and,
+    at stages 2 / 3, ``{'logprobs': [T-1,B]}``."""
     B, K, dev = pack.B, pack.K, pack.feats.device
     train_enc = train_stage != 2
     losses, rewards, conf_last, states, loss_total = [], [], None, None, None
@@ -117,11 +120,14 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
     # steps go through the aggregator as ONE batch of T*B bags (cf. train_MuRCL._pretrain_step_all_patch_steps_at_once);
     # the recurrent head and the losses stay per step
     at_once = None
-    if (train_stage == 1 or actions is not None) and train_enc and T > 1 and batch_patch_steps:
+    all_given = actions is not None and len(actions) >= T
+    if (train_stage == 1 or all_given) and train_enc and T > 1 and batch_patch_steps:
         if actions is None:
             acts = torch.rand((T, B, K), device=dev)                         # all T uniform draws in one launch (:345,539,735)
         else:
             acts = [_next_action(t, 1, None, None, memory, B, K, dev, actions) for t in range(T)]
+        if trace is not None:
+            trace.extend(a.detach().clone() for a in acts)
         views, _ = subbag_views(pack, acts, feat_size, out_dtype=model.compute_dtype)
         at_once = _aggregate(arch, model, as_one(views), labels.repeat(T))
     batched_head = getattr(fc, "fc_rnn", False) and _BATCHED_HEAD
@@ -139,7 +145,9 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
                 memory.rewards.append(rewards[-1])
             conf_last = conf
             continue
-        act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions)
+        act = _next_action(t, train_stage, ppo, states, memory, B, K, dev, actions, eps)
+        if trace is not None:
+            trace.append(act.detach().clone())
         (feats,), _ = subbag_views(pack, [act], feat_size, out_dtype=model.compute_dtype)
         with torch.set_grad_enabled(train_enc):
             if batched_head:
@@ -169,6 +177,8 @@ def supervised_step(arch, model, fc, ppo, optimizer, pack, labels, memory, T=6, 
         optimizer.step()
     else:
         ppo.update(memory)
+    if trace is not None and memory.logprobs:
+        trace.append({"logprobs": torch.stack(memory.logprobs, 0)})
     memory.clear_memory()
     out = (loss.detach(), [l.detach() for l in losses], rewards)
     return out + (logits.detach(),) if return_logits else out
@@ -273,6 +283,9 @@ def fit(arch, model, fc, ppo, optimizer, stores, epochs, batch_size, T=6, feat_s
     bests = {k: [G.Best("min" if k == "losses" else "max") for _ in range(3)] for k in ("losses", "accs", "aucs")}
     early_stop = G.EarlyStop(patience) if patience is not None else None
     for epoch in range(epochs):
+        # train_RLMIL.py:299-304,484-489,691-696: the PPO-only stage scores the sampler with the aggregator and the head in
+        # eval mode (CLAM's Dropout(0.25) off); evaluate_split below restores whatever mode it finds
+        (model.eval(), fc.eval()) if train_stage == 2 else (model.train(), fc.train())
         order, tl, outs, ys = rng.permutation(len(train)), [], [], []
         for s in range(0, len(order) - batch_size + 1, batch_size):
             sel = order[s:s + batch_size]

@@ -87,7 +87,15 @@ def pick_device(device_flag, local_rank=0):
     if flag == "cpu":
         raise RuntimeError("--device cpu: murcl_amd runs on MI355X only (no CPU path for its kernels)")
     ids = [int(v) for v in flag.split(",") if v.strip() != ""] or [local_rank]
-    want = ids[local_rank % len(ids)]
+    local_world = max(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))), local_rank + 1)
+    if len(ids) >= local_world:
+        want = ids[local_rank]
+    else:
+        # fewer listed devices than local ranks (e.g. the inherited default --device "3" under a launcher of N ranks):
+        # wrapping around would seat several ranks on one GPU, which RCCL refuses - every rank takes its own ordinal
+        if local_rank == 0:
+            print(f"--device {flag}: lists {len(ids)} device(s) for {local_world} local ranks; rank r uses cuda:r", flush=True)
+        want = local_rank
     n = torch.cuda.device_count()
     if want >= n:
         print(f"--device {flag}: cuda:{want} does not exist here ({n} device(s)); using cuda:{local_rank}", flush=True)

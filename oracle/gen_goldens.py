@@ -525,6 +525,146 @@ def g12_rl_step():
 
 
 
+def g15_supervised_steps():
+    """Row a21 / BASELINE config 5's path: batches through the reference's own ``train_ABMIL`` / ``train_CLAM`` /
+    ``train_DSMIL`` (train_RLMIL.py:715-781, 323-392, 508-590) at train_stage 1, 2 and 3, T = 3, with torch.rand and
+    MultivariateNormal.sample replaced by the injected draws and Dropout switched off (its Philox stream cannot be matched).
+    Runs (oracle/recipes.py G15_RUNS): two consecutive optimizer steps at the scripts' own batch size 1; four batch-size-1
+    bodies at frozen parameters (= the per-slide terms of the product's batched step); for ABMIL - the one body the
+    reference can batch (CLAM's result dict and DSMIL's instance scores are lists for B > 1, :335,516) - two steps of four.
+    ``args.train_model_prime`` (:719) is read by train_ABMIL but defined by no parser: True here (the t = 0 term trains,
+    as in the two other bodies).
+    Stored per (arch, stage, run): per-step losses [steps,T], rewards [steps,T-1,B], the last patch step's logits, at
+    stages 2 / 3 the sampler's actions / log-probs / selected patch ids, and the post-update fingerprints of the aggregator
+    + head (stages 1, 3) or the sampler (stage 2)."""
+    import argparse
+    from oracle import select_oracle as S
+    from oracle.recipes import G15, G15_RUNS, g15_inputs, g15_params, window_margin
+    r_train, _ = _ref_train_rlmil()
+    c = G15
+    K, fs, Tn, C, std = c["K"], c["fs"], c["T"], c["C"], c["std"]
+    Ns, feats, cls, labels, u, eps = g15_inputs()
+    MVN = torch.distributions.multivariate_normal.MultivariateNormal
+    res, margin = {}, 1.0
+    for arch in ("ABMIL", "CLAM_SB", "DSMIL"):
+        mp, fp, pp = (P.to_torch(d) for d in g15_params(arch))
+        for stage in (1, 2, 3):
+            for run, (B, steps, lr_on) in G15_RUNS.items():
+                if B > 1 and arch != "ABMIL":
+                    continue
+                tag = f"{arch}.s{stage}.{run}"
+                if arch == "ABMIL":
+                    model = r_abmil.ABMIL(c["d"], L=512, D=128, dim_out=C, dropout=0.0)
+                elif arch == "CLAM_SB":
+                    model = r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=c["k_sample"], n_classes=C,
+                                           subtyping=True, in_dim=c["d"])                         # train_RLMIL.py:102-110
+                else:
+                    model = r_dsmil.build_dsmil(c["d"], C)
+                model.load_state_dict(mp)
+                model = torch.nn.DataParallel(model)                                             # :234 (no GPU: pass-through)
+                fc = r_rlmil.Full_layer(512, 1024, True, C)
+                fc.load_state_dict(fp)
+                ppo = None
+                if stage != 1:
+                    ppo = r_rlmil.PPO(c["d"], 512, 512, False, action_std=std, lr=c["ppo_lr"] if lr_on else 0.0, gamma=c["gamma"],
+                                      K_epochs=c["K_epochs"], action_size=K)                     # :206-211
+                    ppo.policy.load_state_dict(pp)
+                    ppo.policy_old.load_state_dict(pp)
+                optimizer = None if stage == 2 else torch.optim.Adam(
+                    [{"params": model.parameters(), "lr": c["lr"] if lr_on else 0.0},
+                     {"params": fc.parameters(), "lr": c["fc_lr"] if lr_on else 0.0}], betas=(0.9, 0.999), weight_decay=c["wd"])   # :257-267
+                n_data = B * steps
+                args = argparse.Namespace(T=Tn, device="cpu", num_clusters=K, feat_size=fs, train_stage=stage, batch_size=B,
+                                          num_data=n_data, bag_weight=c["bag_weight"], epochs=1, eval_step=steps, warmup=0,
+                                          train_model_prime=True)
+
+                class _Set:
+                    def shuffle(self):
+                        pass
+
+                    def __len__(self):
+                        return n_data
+
+                    def __getitem__(self, i):
+                        return T(feats[i]), cls[i], torch.tensor(int(labels[i])), f"case{i}"
+
+                # draws in consumption order: per optimizer step, torch.rand at t = 0 (and at every t at stage 1), the
+                # sampler's noise at t >= 1 otherwise
+                rand_q, eps_q = [], []
+                for st in range(steps):
+                    sl = range(st * B, (st + 1) * B)
+                    for t in range(Tn if stage == 1 else 1):
+                        rand_q.append(T(np.stack([u[s][t] for s in sl])))
+                    if stage != 1:
+                        for t in range(Tn - 1):
+                            eps_q.append(T(np.stack([eps[s][t] for s in sl])))
+                rand_it, eps_it = iter(rand_q), iter(eps_q)
+                meters, snaps = [], []
+
+                class _Meter:                                        # stands in for utils.general.AverageMeter: records
+                    def __init__(self):
+                        self.vals, self.avg = [], 0.0
+                        meters.append(self)
+
+                    def update(self, val, n=1):
+                        self.vals.append(float(val))
+                        self.avg = float(np.mean(self.vals))
+
+                def snap_clear(self):
+                    snaps.append({f: [x.detach().clone() for x in getattr(self, f)] for f in ("actions", "states", "logprobs", "rewards")})
+                    for f in ("actions", "states", "logprobs", "rewards", "is_terminals", "hidden"):
+                        del getattr(self, f)[:]
+
+                real_to = torch.Tensor.to
+
+                def to_ignoring_ordinals(self, *a, **k):              # `states.to(0)` (:352,354): device 0 == here
+                    return self if (a and isinstance(a[0], int)) else real_to(self, *a, **k)
+
+                fn = {"ABMIL": r_train.train_ABMIL, "CLAM_SB": r_train.train_CLAM, "DSMIL": r_train.train_DSMIL}[arch]
+                with mock.patch("torch.rand", lambda *a, **k: next(rand_it)), \
+                        mock.patch.object(MVN, "sample", lambda self, *a, **k: self.loc + std * next(eps_it)), \
+                        mock.patch("torch.nn.functional.dropout", lambda x, *a, **k: x), \
+                        mock.patch.object(r_train, "AverageMeter", _Meter), \
+                        mock.patch.object(r_rlmil.Memory, "clear_memory", snap_clear), \
+                        mock.patch.object(torch.Tensor, "to", to_ignoring_ordinals):
+                    out = fn(args, 0, _Set(), model, fc, ppo, r_rlmil.Memory(), torch.nn.CrossEntropyLoss(), optimizer, None)
+                assert next(rand_it, None) is None and next(eps_it, None) is None, "an injected draw was not consumed"
+                assert len(snaps) == steps and len(meters) == 3 * Tn - 1
+                res[f"{tag}.losses"] = np.array([m.vals for m in meters[:Tn]]).T                  # [steps, T]
+                res[f"{tag}.rewards"] = np.stack([torch.cat(sn["rewards"], 0).numpy() for sn in snaps])   # [steps, T-1, B]
+                res[f"{tag}.last_loss_avg"] = np.float64(out[0])
+                if stage != 1:
+                    res[f"{tag}.actions"] = np.stack([torch.stack(sn["actions"], 0).numpy() for sn in snaps])   # [steps,T-1,B,K]
+                    res[f"{tag}.logp"] = np.stack([torch.stack(sn["logprobs"], 0).numpy() for sn in snaps])
+                    res[f"{tag}.states"] = np.stack([np.stack([_summ(x) for x in sn["states"]]) for sn in snaps])
+                    for st, sn in enumerate(snaps):
+                        sl = list(range(st * B, (st + 1) * B))
+                        for t in range(Tn - 1):
+                            a_t = sn["actions"][t].numpy()
+                            _, ids = S.get_feats([feats[s] for s in sl], [cls[s] for s in sl], a_t, fs)
+                            res[f"{tag}.ids.{st}.{t + 1}"] = np.array([i + [-1] * (fs - len(i)) for i in ids], dtype=np.int32)
+                            margin = min(margin, min(window_margin(Ns[s], cls[s], a_t[b], fs) for b, s in enumerate(sl)))
+                if lr_on:
+                    if stage == 2:
+                        for k, v in ppo.policy.state_dict().items():
+                            res[f"{tag}.policy.{k}"] = _summ(v)
+                            res[f"{tag}.policy_delta.{k}"] = _summ(v - pp[k])
+                        assert all(torch.equal(v, mp[k]) for k, v in model.module.state_dict().items())   # aggregator frozen
+                    else:
+                        for k, v in model.module.state_dict().items():
+                            res[f"{tag}.model.{k}"] = _summ(v)
+                            res[f"{tag}.model_delta.{k}"] = _summ(v - mp[k])
+                        for k, v in fc.state_dict().items():
+                            res[f"{tag}.fc.{k}"] = _summ(v)
+                            res[f"{tag}.fc_delta.{k}"] = _summ(v - fp[k])
+                else:
+                    assert all(torch.equal(v, mp[k]) for k, v in model.module.state_dict().items())
+                    assert ppo is None or all(torch.equal(v, pp[k]) for k, v in ppo.policy.state_dict().items())
+    assert margin > 1e-3, f"golden window margin too small ({margin}): pick another seed"
+    res["window_margin"] = np.float64(margin)
+    np.savez(os.path.join(OUT, "g15_supervised_steps.npz"), **res)
+
+
 def _reference_parser(mod, globals_needed):
     """The ArgumentParser that the reference's ``main()`` builds (it is local to main): run main() with parse_args
     replaced by a hook that keeps the parser and stops."""
@@ -640,7 +780,7 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

@@ -41,6 +41,38 @@ def window_margin(n_patches, clusters, actions, feat_size):
 
 
 
+# ------------------------------------------------------------------ G15: the supervised step bodies of train_RLMIL.py
+G15 = dict(seed=86, S=8, K=10, fs=64, d=512, C=2, T=3, std=0.5, gamma=0.1, K_epochs=3, ppo_lr=1e-5, lr=1e-4, fc_lr=1e-4,
+           wd=1e-5, bag_weight=0.7, k_sample=8, labels=[0, 1, 1, 0, 1, 0, 0, 1])
+# run name -> (bags per optimizer step, optimizer steps, learning rates on?)
+#   b1x2:  the reference scripts' own --batch_size 1, two consecutive optimizer steps (slides 0, 1)
+#   b1lr0: four batch-size-1 bodies at FROZEN parameters (lr = 0) = the per-slide terms of one batched step over slides 0..3
+#   b4x2:  ABMIL only (the one body the reference can batch): two optimizer steps of four slides
+G15_RUNS = {"b1x2": (1, 2, True), "b1lr0": (1, 4, False), "b4x2": (4, 2, True)}
+
+
+def g15_inputs():
+    """Slides, labels and the per-SLIDE draws of G15: u[s][t] [K] uniform window positions (every patch step at stage 1,
+    t = 0 only at stages 2 / 3) and eps[s][t-1] [K] ~ N(0,1), the sampler's noise at stages 2 / 3."""
+    c = G15
+    seed, S, K, T_ = c["seed"], c["S"], c["K"], c["T"]
+    Ns = [300 + 29 * s for s in range(S)]
+    feats = [P.bags(seed, f"g15.f{s}", 1, Ns[s], c["d"])[0] for s in range(S)]
+    cls = [P.cluster_lists(seed, f"g15.c{s}", Ns[s], K) for s in range(S)]
+    u = [[detrand.uniform(seed, f"g15.u{s}.{t}", (K,)).astype(np.float32) for t in range(T_)] for s in range(S)]
+    eps = [[detrand.normal(seed, f"g15.e{s}.{t}", (K,)).astype(np.float32) for t in range(T_ - 1)] for s in range(S)]
+    return Ns, feats, cls, np.array(c["labels"], dtype=np.int64), u, eps
+
+
+def g15_params(arch):
+    """(aggregator, head, sampler) parameter dicts of G15."""
+    c = G15
+    seed = c["seed"]
+    mp = P.abmil(seed, dim_out=c["C"]) if arch == "ABMIL" else {"CLAM_SB": P.clam_sb, "DSMIL": P.dsmil}[arch](seed)
+    return mp, P.full_layer(seed, 512, 1024, c["C"]), P.actor_critic(seed, 512, 512, c["K"])
+
+
+
 
 # ------------------------------------------------------------------ launch-script argument vectors (runs/*.sh)
 def _murcl_argv(stage, backbone_lr, fc_lr):

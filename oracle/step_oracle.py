@@ -106,3 +106,80 @@ def pretrain_step_rl(model_p, fc_p, policy_p, feats, clusters, inj, *, T, feat_s
             policy_p = ppo_update(policy_p, st, m, gamma, K_epochs, action_std, ppo_lr)
         res["policy"] = policy_p
     return res
+
+
+def supervised_step_rl(arch, model_p, fc_p, policy_p, feats, clusters, labels, u, eps, *, T, feat_size, stage,
+                       bag_weight=0.7, k_sample=8, action_std=0.5, gamma=0.1, K_epochs=3, ppo_lr=1e-5, lr=1e-4, fc_lr=1e-4,
+                       wd=1e-5, adam_state=None):
+    """One batch of the supervised bodies train_ABMIL / train_CLAM / train_DSMIL (train_RLMIL.py:715-781, 323-392, 508-590),
+    batched over the B slides of ``feats`` (the reference's CLAM / DSMIL bodies only run at B = 1; every term below is a
+    mean over bags, so B = 1 reproduces them and B > 1 is their per-bag average).
+
+    u: [T][B,K] uniform window positions (t >= 1 used at stage 1 only, :347-348); eps: [T-1][B,K] sampler noise (stages 2, 3).
+    adam_state: dict carried between calls ({'model': {}, 'fc': {}, 'ppo': {}}).
+    Returns dict(loss, losses[T], rewards [T-1,B], actions [T][B,K], logp [T-1,B], ids[T], logits (last step), model, fc,
+    policy = post-update parameter dicts)."""
+    import torch.nn.functional as F
+    B = len(feats)
+    y = torch.as_tensor(np.asarray(labels)).long()
+    C = fc_p["fc.weight"].shape[0]
+    grad_on = stage != 2
+    mp = {k: v.detach().clone().requires_grad_(grad_on) for k, v in model_p.items()}
+    fp = {k: v.detach().clone().requires_grad_(grad_on) for k, v in fc_p.items()}
+    mem = dict(states=[], actions=[], logprobs=[], rewards=[])
+    hidden = pol_hidden = states = conf_last = None
+    losses, rewards, actions_all, ids_all = [], [], [], []
+    for t in range(T):
+        if t == 0 or stage == 1:
+            a = torch.as_tensor(np.asarray(u[t], np.float32))                            # :331,347-348
+        else:
+            if t == 1:                                                                   # restart_batch=True (:351-352)
+                pol_hidden = torch.zeros(B, policy_p["gru.weight_hh_l0"].shape[1])
+            with torch.no_grad():
+                a, logp, pol_hidden = O.ppo_act(policy_p, states, pol_hidden, torch.as_tensor(np.asarray(eps[t - 1], np.float32)),
+                                                action_std)
+            mem["states"].append(states)
+            mem["actions"].append(a)
+            mem["logprobs"].append(logp)
+        actions_all.append(a.clone())
+        sub, ids = S.get_feats(feats, clusters, a.numpy(), feat_size)                    # :332,355
+        ids_all.append(ids)
+        x = torch.from_numpy(sub)
+        with torch.set_grad_enabled(grad_on):
+            if arch == "ABMIL":
+                out = O.abmil_forward(mp, x)[0]
+                states = out.detach()
+                logits, hidden = O.full_layer_step(fp, out, None if t == 0 else hidden)
+                loss = F.cross_entropy(logits, y)                                        # :727,750
+            elif arch == "CLAM_SB":
+                M, A, _, h = O.clam_sb_forward(mp, x)
+                states = M.detach()
+                inst = torch.stack([O.clam_instance_eval(mp, A[b], h[b], int(y[b]), C, k_sample, True)[0] for b in range(B)]).mean()
+                logits, hidden = O.full_layer_step(fp, M, None if t == 0 else hidden)
+                loss = bag_weight * F.cross_entropy(logits, y) + (1 - bag_weight) * inst  # :336,364
+            else:
+                c, bag, _, _ = O.dsmil_forward(mp, x)
+                states = bag.detach().mean(1)                                             # :516,549
+                logits, hidden = O.full_layer_step(fp, bag.mean(1), None if t == 0 else hidden)   # :518-519
+                loss = 0.5 * F.cross_entropy(logits, y) + 0.5 * F.cross_entropy(c.max(1)[0], y)   # :527-529
+        losses.append(loss)
+        conf = torch.softmax(logits.detach(), 1).gather(1, y.view(-1, 1)).view(1, -1)     # :345,367
+        if t > 0:
+            rewards.append(conf - conf_last)                                              # :368
+            mem["rewards"].append(rewards[-1])
+        conf_last = conf
+    total = sum(losses) / T                                                               # :374
+    adam_state = adam_state if adam_state is not None else {}
+    res = dict(loss=total.detach(), losses=[l.detach() for l in losses], rewards=torch.cat(rewards, 0), actions=actions_all,
+               ids=ids_all, logits=logits.detach(), logp=torch.stack(mem["logprobs"], 0) if mem["logprobs"] else None,
+               model=model_p, fc=fc_p, policy=policy_p)
+    if stage != 2:
+        total.backward()                                                                  # :375-378
+        for name, p, rate in (("model", mp, lr), ("fc", fp, fc_lr)):
+            live = {k: v for k, v in p.items() if v.grad is not None}                     # torch's Adam skips grad-less params
+            new = O.adam_step({k: v.detach() for k, v in live.items()}, {k: v.grad for k, v in live.items()},
+                              adam_state.setdefault(name, {}), rate, weight_decay=wd)
+            res[name] = {k: new.get(k, v.detach()) for k, v in p.items()}
+    else:
+        res["policy"] = ppo_update(policy_p, adam_state.setdefault("ppo", {}), mem, gamma, K_epochs, action_std, ppo_lr)   # :380
+    return res

@@ -127,3 +127,16 @@ def test_device_flag_rejects_cpu():
     from murcl_amd.utils import general as G
     with pytest.raises(RuntimeError, match="no CPU path"):
         G.pick_device("cpu")
+
+
+def test_device_flag_never_seats_two_local_ranks_on_one_gpu(monkeypatch):
+    """A --device list shorter than the local world (the inherited default "3" under an N-rank launcher) must not wrap around:
+    rank r takes cuda:r; a full list is indexed by the local rank."""
+    import torch
+    from murcl_amd.utils import general as G
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert [G.pick_device("3", r).index for r in range(4)] == [0, 1, 2, 3]
+    assert [G.pick_device("4,5,6,7", r).index for r in range(4)] == [4, 5, 6, 7]
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert G.pick_device("3", 0).index == 3

@@ -302,3 +302,74 @@ def test_g14_clam_plain_attention_net(golden):
         tot = tot + M[b].sum() + loss
     tot.backward()
     _check_grads(g, "grad.", p)
+
+
+# ------------------------------------------------------------------------------------------------ G15 (row a21)
+def _g15_batch(sl, u, eps, Tn):
+    """Per-slide draws of oracle/recipes.py -> the [T][B,K] / [T-1][B,K] batch form."""
+    return [np.stack([u[s][t] for s in sl]) for t in range(Tn)], [np.stack([eps[s][t] for s in sl]) for t in range(Tn - 1)]
+
+
+@pytest.mark.parametrize("arch", ["ABMIL", "CLAM_SB", "DSMIL"])
+@pytest.mark.parametrize("stage", [1, 2, 3])
+def test_g15_supervised_step_oracle_vs_reference_train_bodies(golden, arch, stage):
+    """oracle/step_oracle.supervised_step_rl == the reference's own train_ABMIL / train_CLAM / train_DSMIL bodies
+    (train_RLMIL.py:715-781, 323-392, 508-590): per-step losses, confidence rewards, sampler actions / log-probs / selected
+    patch ids and post-update parameters after TWO optimizer steps at batch size 1 (and 4 for ABMIL), and - batched over four
+    slides at frozen parameters - the mean of the reference's four batch-size-1 bodies."""
+    from oracle import step_oracle as SO
+    from oracle.recipes import G15, G15_RUNS, g15_inputs, g15_params
+    g, c = golden("g15_supervised_steps"), G15
+    Tn, fs = c["T"], c["fs"]
+    Ns, feats, cls, labels, u, eps = g15_inputs()
+    mp0, fp0, pp0 = (P.to_torch(d) for d in g15_params(arch))
+    kw = dict(T=Tn, feat_size=fs, stage=stage, bag_weight=c["bag_weight"], k_sample=c["k_sample"], action_std=c["std"],
+              gamma=c["gamma"], K_epochs=c["K_epochs"], ppo_lr=c["ppo_lr"], lr=c["lr"], fc_lr=c["fc_lr"], wd=c["wd"])
+    for run, (B, steps, lr_on) in G15_RUNS.items():
+        tag = f"{arch}.s{stage}.{run}"
+        if f"{tag}.losses" not in g.files:
+            assert B > 1 and arch != "ABMIL"
+            continue
+        if not lr_on:
+            # ONE batched step over the four slides at the initial parameters == the mean of the four B = 1 bodies
+            sl = list(range(steps))
+            ub, eb = _g15_batch(sl, u, eps, Tn)
+            r = SO.supervised_step_rl(arch, mp0, fp0, pp0, [feats[s] for s in sl], [cls[s] for s in sl], labels[sl], ub, eb, **kw)
+            np.testing.assert_allclose([l.item() for l in r["losses"]], g[f"{tag}.losses"].mean(0), rtol=2e-5)
+            np.testing.assert_allclose(r["rewards"].numpy(), g[f"{tag}.rewards"][:, :, 0].T, rtol=1e-3, atol=1e-6)
+            if stage != 1:
+                acts = torch.stack(r["actions"][1:]).numpy()                               # [T-1, 4, K]
+                np.testing.assert_allclose(acts, g[f"{tag}.actions"][:, :, 0].transpose(1, 0, 2), rtol=1e-5, atol=1e-6)
+                for t in range(1, Tn):
+                    ids = np.array([i + [-1] * (fs - len(i)) for i in r["ids"][t]], dtype=np.int32)
+                    want = np.concatenate([g[f"{tag}.ids.{s}.{t}"] for s in sl])
+                    assert np.array_equal(ids, want), (tag, t)
+            continue
+        mp, fp, pp, st = mp0, fp0, pp0, {}
+        for it in range(steps):
+            sl = list(range(it * B, (it + 1) * B))
+            ub, eb = _g15_batch(sl, u, eps, Tn)
+            r = SO.supervised_step_rl(arch, mp, fp, pp, [feats[s] for s in sl], [cls[s] for s in sl], labels[sl], ub, eb,
+                                      adam_state=st, **kw)
+            mp, fp, pp = r["model"], r["fc"], r["policy"]
+            np.testing.assert_allclose([l.item() for l in r["losses"]], g[f"{tag}.losses"][it], rtol=1e-4 if it else 2e-5,
+                                       err_msg=f"{tag} step {it}")
+            np.testing.assert_allclose(r["rewards"].numpy(), g[f"{tag}.rewards"][it], rtol=2e-3, atol=2e-6)
+            if stage != 1:
+                np.testing.assert_allclose(torch.stack(r["actions"][1:]).numpy(), g[f"{tag}.actions"][it], rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(r["logp"].numpy(), g[f"{tag}.logp"][it], rtol=1e-4, atol=1e-4)
+                for t in range(1, Tn):
+                    ids = np.array([i + [-1] * (fs - len(i)) for i in r["ids"][t]], dtype=np.int32)
+                    assert np.array_equal(ids, g[f"{tag}.ids.{it}.{t}"]), (tag, it, t)
+        for name, new, base in (("model", mp, mp0), ("fc", fp, fp0), ("policy", pp, pp0)):
+            for k, v in new.items():
+                key = f"{tag}.{name}_delta.{k}"
+                if key not in g.files:
+                    assert torch.equal(v, base[k]), (tag, name, k)         # frozen at this stage
+                    continue
+                want = g[key]
+                if want[0] == 0.0:                                           # never applied by the reference: Adam skips it
+                    assert torch.equal(v, base[k]), key
+                    continue
+                _close_summ(_fp(v - base[k]), want, 3e-2, msg=key)
+                _close_summ(_fp(v), g[f"{tag}.{name}.{k}"], 1e-4, msg=key)
