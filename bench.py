@@ -275,6 +275,28 @@ def other_rows(device):
     return out
 
 
+def launch_argv(gpus, argv, port=None):
+    """The command line ``python bench.py --gpus N ...`` turns itself into when no launcher started it: the driver's own form
+    (one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1)."""
+    port = port or int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def self_launch(gpus, argv):
+    """``python bench.py --gpus N`` without a launcher (the reference needs none: one process, nn.DataParallel,
+    train_MuRCL.py:145): this parent - which has made NO GPU call, so nothing is re-executed over an initialised device -
+    starts the N ranks as CHILD processes, lets rank 0's JSON line through on its stdout and returns the children's exit code."""
+    import subprocess
+    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    if have < gpus:
+        print(f"bench.py: --gpus {gpus} but this node has {have} GPU(s)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MASTER_PORT", None)
+    return subprocess.run(launch_argv(gpus, argv), env=env, cwd=ROOT).returncode
+
+
 SETTLE_STEPS = 30          # untimed steps (warm-up + breakdown pass + extra) that precede the timed region at the least
 
 
@@ -291,6 +313,8 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or os.environ.get("MURCL_BENCH_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
