@@ -29,8 +29,33 @@
 #ifndef K2_GK
 #define K2_GK 4                  // k-steps per LDS prefetch group in the score MFMA loop
 #endif
+#ifndef K2_SPREAD_DMA
+#define K2_SPREAD_DMA 0          // 1: the next pair's LDS-DMA pieces go out one per k-group of the score MFMA loop (measured r03: neutral, 62.9 vs 62.3 us)
+#endif
 #ifndef K2_PAIR
 #define K2_PAIR 1                // bf16 forward: two 16-row tiles per iteration (see the paired loop)
+#endif
+
+// In-kernel stamps (diagnostic builds only, -DK2_STAMPS; tools/stamps_k2.py): waves 0 and 2 of the first K2_STAMP_WG workgroups
+// note s_memtime at fixed points of each pair iteration into the (unused in the paired loop) sbuf region of LDS and copy it
+// out at the end.  No output value depends on a stamp.
+#ifdef K2_STAMPS
+#define K2_STAMP_WG 16
+#define K2_STAMP_IT 16
+#define K2_STAMP_EV 10
+__device__ unsigned g_k2_stamps[K2_STAMP_WG][2][K2_STAMP_IT][K2_STAMP_EV];
+extern "C" int murcl_debug_k2_stamps(void* host, long bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k2_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#define K2_STAMP(ev)                                                                                              \
+    do {                                                                                                          \
+        if (stamp_w >= 0 && pr < K2_STAMP_IT) {                                                                   \
+            const unsigned long long t_ = ((ev) == 8) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+            if (lane == 0) ((unsigned*)sbuf)[(stamp_w * K2_STAMP_IT + pr) * K2_STAMP_EV + (ev)] = (unsigned)t_;   \
+        }                                                                                                         \
+    } while (0)
+#else
+#define K2_STAMP(ev)
 #endif
 
 template <typename T, bool EXACT_TANH>
@@ -116,11 +141,35 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
         // two workgroups; the LDS-DMA skeleton of that shape still streams 6.1 TB/s, tools/stream_probe.py).
         float* spart1 = spart + C_::NW * 16;
         const int npair = my_tiles >> 1;
+#ifdef K2_STAMPS
+        const int stamp_w = (blockIdx.x < K2_STAMP_WG) ? (wave == 0 ? 0 : (wave == 2 ? 1 : -1)) : -1;
+        for (int i = tid; i < 2 * K2_STAMP_IT * K2_STAMP_EV; i += 64 * C_::NW) ((unsigned*)sbuf)[i] = 0u;
+#endif
         for (int pr = 0; pr < npair; ++pr) {
             const int seq = 2 * pr;
+            K2_STAMP(0);
+            K2_STAMP(8);
             if (pr == 0 && my_tiles > 2) { K2_WAIT(2 * C_::GT); } else { K2_WAIT(0); }
+            K2_STAMP(1);
             LDS_BARRIER();                     // both tiles of this pair landed; the slots of the previous pair are free
-            if (pr >= 1 && seq + 2 < my_tiles) { issue(seq + 2); issue(seq + 3); }
+            K2_STAMP(2);
+            // the next pair's 2 x GT LDS-DMA pieces: issued in one burst here they queue on the CU's address unit with the other
+            // waves' (~0.7 k cycles per pair with this wave's matrix pipe idle, profiles/r03_b_inkernel_stamps_panel_k2_before.txt);
+            // K2_SPREAD_DMA hands them out one per k-group of the score MFMA loop below
+            const bool more = pr >= 1 && seq + 2 < my_tiles;
+            const T* nb_base[2] = {H, H};
+            int nb_row0[2] = {0, 0};
+            if (K2_SPREAD_DMA) {
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        nb_base[u] = H + (size_t)ip.bag * N * K2_L;
+                        nb_row0[u] = ip.ch * chunk_rows + ip.tin * C_::TR;
+                        ip.next(tiles_per_item, gridDim.x, S);
+                    }
+                }
+            } else if (more) { issue(seq + 2); issue(seq + 3); }
+            K2_STAMP(3);
             const int tin = cp.tin;
             const int row0 = cp.ch * chunk_rows + tin * C_::TR;
             const char* tile0 = smem + (seq & (K2_NSLOT - 1)) * C_::SLOT;
@@ -152,9 +201,16 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                             acc0[j] = k2_mma<T>(wa[j][g * GK + k2], hq0[g & 1][k2], acc0[j]);
                             acc1[j] = k2_mma<T>(wa[j][g * GK + k2], hq1[g & 1][k2], acc1[j]);
                         }
+                    if (K2_SPREAD_DMA && more) {
+                        static_assert(!K2_SPREAD_DMA || NG == 2 * C_::GT, "one LDS-DMA piece per k-group");
+                        const int u = g / C_::GT;
+                        k2_issue_piece<T, K2F_NWO(T)>(nb_base[u], nb_row0[u], N, lds0 + ((seq + 2 + u) & (K2_NSLOT - 1)) * C_::SLOT,
+                                                      wave, lane, g % C_::GT);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            K2_STAMP(4);
             float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int j = 0; j < C_::NJ; ++j)
@@ -166,7 +222,9 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
             ps0 = quarters_sum(ps0);
             ps1 = quarters_sum(ps1);
             if (q4 == 0) { spart[wave * 16 + r16] = ps0; spart1[wave * 16 + r16] = ps1; }
+            K2_STAMP(5);
             LDS_BARRIER();
+            K2_STAMP(6);
 
             // phase B (every wave redundantly): lanes 0..15 <-> rows of tile 0, lanes 16..31 <-> rows of tile 1
             float s = -INFINITY;
@@ -231,7 +289,14 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
             }
             cp.next(tiles_per_item, gridDim.x, S);
             cp.next(tiles_per_item, gridDim.x, S);
+            K2_STAMP(7);
         }
+#ifdef K2_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blockIdx.x < K2_STAMP_WG)
+            for (int i = tid; i < 2 * K2_STAMP_IT * K2_STAMP_EV; i += 64 * C_::NW) (&g_k2_stamps[blockIdx.x][0][0][0])[i] = ((unsigned*)sbuf)[i];
+#endif
         return;
     }
     for (int seq = 0; seq < my_tiles; ++seq) {

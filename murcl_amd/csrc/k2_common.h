@@ -81,6 +81,17 @@ __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N
     }
 }
 
+// One LDS-DMA piece (j of GT) of a tile: the loops that spread a tile's issue over their MFMA k-groups use this form.
+template <typename T, int NWO = 0>
+__device__ __forceinline__ void k2_issue_piece(const T* bag_base, int row0, int N, unsigned slot_lds, int wave, int lane, int j) {
+    typedef K2<T, NWO> C_;
+    const int ii = j * C_::NW + wave;
+    const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
+    const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
+    const int grow = min(row0 + row, N - 1);                      // rows past N: clamped, masked by the caller
+    glds16_u((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, lane * 16, slot_lds + row * C_::PADB + half * 1024);
+}
+
 // Walks a workgroup's tile sequence without integer division in the loop: item = blockIdx + k*gridDim,
 // tile-in-item `tin`; (bag, chunk) are re-derived only when the item changes.
 struct K2Pos {

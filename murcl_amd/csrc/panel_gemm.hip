@@ -42,11 +42,50 @@
 #ifndef PG_FUSE
 #define PG_FUSE 1         // bit 0: forward epilogues (bias / bias+ReLU), bit 1: the masked dgrad - every wave runs the epilogue of
 #endif                    // tile t-1 INSIDE the MFMA loop of tile t (see the tile loop).  Forward 147 -> 142 us; dgrad neutral, so off there
+#ifndef PG_SPREAD_DMA
+#define PG_SPREAD_DMA 0   // 1: the LDS-DMA pieces of tile t+3 are issued one per k-group inside the MFMA phase of tile t (measured r03: neutral at K = 512, +10 % time at K = 128)
+#endif
+#ifndef PG_DMA_SKEW
+#define PG_DMA_SKEW 0     // 1: the upper half of the workgroup issues each LDS-DMA piece one k-group earlier than its SIMD partners
+#endif
+#ifndef PG_PRIO
+#define PG_PRIO 0         // 1: s_setprio 1 around the MFMAs of a k-group (T5); 2: the two halves of the workgroup (= the two waves of
+#endif                    // a SIMD) take priority 1 in alternate k-groups, so neither is the arbitration loser for a whole tile
+#ifndef PG_DMA_HALF
+#define PG_DMA_HALF 0     // 1: waves 0..NW/2-1 issue ALL LDS-DMA pieces of a tile (two A pieces each per slot), the upper half none;
+#endif                    // 2: the upper half issues them all.  K = 512 variants only.
+#ifndef PG_ABL
+#define PG_ABL 0          // diagnostic ablations (wrong results): 1 no LDS fragment reads, 2 no LDS-DMA in the loop, 4 no stores, 8 no MFMAs, 16 no epilogue
+#endif
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
 enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3 };
+
+// In-kernel stamps (diagnostic builds only, -DPG_STAMPS; tools/stamps_panel.py): waves 0 and 4 of the first PG_STAMP_WG
+// workgroups note s_memtime at fixed points of each tile iteration into a spare LDS region (a global store would join the
+// hand-counted vmcnt queue) and copy it out after the last tile.  No output value depends on a stamp.
+#ifdef PG_STAMPS
+#define PG_STAMP_WG 16
+#define PG_STAMP_IT 16            // every 4th tile iteration is recorded (LDS has ~1 KiB to spare)
+#define PG_STAMP_EV 8
+#define PG_STAMP_BYTES (2 * PG_STAMP_IT * PG_STAMP_EV * 4)
+__device__ unsigned g_pg_stamps[PG_STAMP_WG][2][PG_STAMP_IT][PG_STAMP_EV];
+extern "C" int murcl_debug_pg_stamps(void* host, long bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pg_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+#define PG_STAMP(ev)                                                                                              \
+    do {                                                                                                          \
+        if (stamp_w >= 0 && (seq & 3) == 0 && (seq >> 2) < PG_STAMP_IT) {                                                                  \
+            const unsigned long long t_ = ((ev) == 6) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+            if (lane == 0) stamp_lds[(stamp_w * PG_STAMP_IT + (seq >> 2)) * PG_STAMP_EV + (ev)] = (unsigned)t_;          \
+        }                                                                                                         \
+    } while (0)
+#else
+#define PG_STAMP_BYTES 0
+#define PG_STAMP(ev)
+#endif
 
 #define PG_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -54,9 +93,11 @@ enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3 };
 #define PG_STORE_POLICY ""        // cache-policy suffix of the output stores: "" | " nt" | " sc0 sc1" (A/B: tools/ab_build.sh)
 #endif
 __device__ __forceinline__ void pg_store16(void* p, u32x4 v) {
+    if (PG_ABL & 4) { asm volatile("" ::"v"(p), "v"(v)); return; }
     asm volatile("global_store_dwordx4 %0, %1, off" PG_STORE_POLICY "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void pg_store2(void* p, unsigned v) {
+    if (PG_ABL & 4) { asm volatile("" ::"v"(p), "v"(v)); return; }
     asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
@@ -105,14 +146,21 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr bool BIASED = (EPI == PG_BIAS_RELU || EPI == PG_BIAS);
     constexpr int NB = MASKED ? 1 : 0;                              // mask LDS-DMA op (128 or 256 B per wave)
     constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
-    constexpr int G = GT + NB + NR;             // counted loads per tile per wave
+    constexpr bool DMAH = PAD && PG_DMA_HALF != 0;                 // one half of the workgroup issues every A piece
+    constexpr int GA = DMAH ? 2 * GT : GT;      // A pieces per tile of an issuing wave
+    constexpr int G = GA + NB + NR;             // counted loads per tile per (issuing) wave
     constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
-    constexpr int S = NS + NMS;                 // counted stores per tile per wave
+    constexpr int S = (PG_ABL & 4) ? 0 : NS + NMS;   // counted stores per tile per wave
     // LDS carve
     constexpr int OFF_STG = PG_NSLOT * SLOT;
     constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
     constexpr int OFF_RS = OFF_BM + (NB ? PG_NSLOT * PG_NW * 256 : 0);          // [slot][64 f32]: every wave copies the same 32 row scales
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PG_STAMPS
+    unsigned* stamp_lds = (unsigned*)(smem + OFF_RS + (NR ? PG_NSLOT * 256 : 0));
+    const int stamp_w = (blockIdx.x < PG_STAMP_WG) ? ((threadIdx.x >> 6) == 0 ? 0 : ((threadIdx.x >> 6) == 4 ? 1 : -1)) : -1;
+    for (int i = threadIdx.x; i < PG_STAMP_BYTES / 4; i += 64 * PG_NW) stamp_lds[i] = 0u;
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,16 +186,19 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
     const int n0 = panel * NP + wave * WN;          // first column of this wave
 
-    auto issue = [&](int seq) {
+    // LDS-DMA piece p of tile seq's loads: p < GT a 1 KiB piece of the A tile, then (MASKED) this wave's mask blocks, then
+    // (RANK1) the tile's row scales.  One instruction each; the loop spreads them over the k-groups of the MFMA phase.
+    auto issue_piece = [&](int seq, int p) {
         const int tix = tile0 + seq * tstep;
         const bool rev = ((walk_reverse & 1) != 0) != ((PG_FLIP >> EPI) & 1);       // PG_FLIP: A/B bit mask per epilogue
         const int row0 = (rev ? n_tiles - 1 - tix : tix) * PG_TR;
         const int sl = seq % PG_NSLOT;
-        const char* base = (const char*)(A + (size_t)row0 * K);
-#pragma unroll
-        for (int j = 0; j < GT; ++j) {
+        if (p < GA) {
+            const int j = p;
+            const char* base = (const char*)(A + (size_t)row0 * K);
             if (PAD) {
-                const int row = j * PG_NW + wave;                       // wave-uniform: scalar base, lane offset lane*16
+                // wave-uniform row: scalar base, lane offset lane*16.  DMAH: the issuing half covers the tile in pieces of NW/2 rows
+                const int row = DMAH ? j * (PG_NW / 2) + (wave & (PG_NW / 2 - 1)) : j * PG_NW + wave;
                 if (walk_reverse & 2) glds16_u_nt(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
                 else glds16_u(base + (size_t)row * ROWB, lane * 16, lds0 + sl * SLOT + row * PADB);
             } else {
@@ -156,16 +207,22 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                 glds16(base + (size_t)row * ROWB + ((pos ^ (row & 15)) << 4),
                        lds0 + sl * SLOT + (j * PG_NW + wave) * 1024);
             }
-        }
-        if (MASKED) {
+        } else if (MASKED && p == GA) {
             // this wave's mask blocks of the tile (WN/32 blocks of 128 B, contiguous): one 4-byte piece per lane
             const int nbytes = (WN / 32) * 128;
             const int off = min(lane * 4, nbytes - 4);
             glds4(bm_in + ((size_t)(row0 / PG_TR) * (N / 32) + (n0 >> 5)) * 128 + off,
                   lds0 + OFF_BM + (sl * PG_NW + wave) * 256);
-        }
-        if (EPI == PG_RANK1_MASK)
+        } else if (EPI == PG_RANK1_MASK && p == GA + NB) {
             glds4(rowscale + row0 + (lane & 31), lds0 + OFF_RS + sl * 256);
+        }
+    };
+    // does this wave issue A pieces?  (the side pieces - mask words, row scales - are per wave either way)
+    const bool dma_wave = !DMAH || ((wave < PG_NW / 2) == (PG_DMA_HALF == 1));
+    auto issue = [&](int seq) {
+#pragma unroll
+        for (int p = 0; p < G; ++p)
+            if (p >= GA || dma_wave) issue_piece(seq, p);
     };
 
     const int pre = min(3, my_tiles);
@@ -251,6 +308,13 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             constexpr int GK = PG_GK, NG = NKK / GK, D = PG_PF, NBUF = D + 1;
             bf16x8 hq[NBUF][GK][2];
             auto load_grp = [&](int g, int buf) {
+                if ((PG_ABL & 1) && g > 0) {
+#pragma unroll
+                    for (int k2 = 0; k2 < GK; ++k2)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) hq[buf][k2][i] = hq[0][k2][i];
+                    return;
+                }
 #pragma unroll
                 for (int k2 = 0; k2 < GK; ++k2)
 #pragma unroll
@@ -262,13 +326,18 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             for (int g = 0; g < NG; ++g) {
                 if (g + D < NG) load_grp(g + D, (g + D) % NBUF);
                 __builtin_amdgcn_sched_barrier(0);
+                if (PG_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                if (PG_PRIO == 2) { if (((g & 1) != 0) == (wave >= PG_NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
                 for (int k2 = 0; k2 < GK; ++k2)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][g * GK + k2], hq[g % NBUF][k2][i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) {
+                            if (PG_ABL & 8) asm volatile("" : "+v"(acc[i][j]) : "v"(hq[g % NBUF][k2][i]));
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][g * GK + k2], hq[g % NBUF][k2][i], acc[i][j], 0, 0, 0);
+                        }
+                if (PG_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                 hook(g);                         // same scheduling region as the MFMAs above: VALU / LDS work rides under them
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -282,12 +351,20 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][kk], h, acc[i][j], 0, 0, 0);
                 }
+                hook(kk);
             }
         }
     };
     // part: -1 = everything; 0 / 1 = accumulator math + staging writes of row half i = part (1 also stores the mask
     // words); 2 + g = row-wise store g.  The fused schedule runs the parts of tile t-1 between the k-groups of tile t.
     auto epilogue = [&](int seq, f32x4 (&acc)[2][NJ], unsigned (&mw)[NJ / 2], float (&am)[2], int part = -1) {
+        if (PG_ABL & 16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
         const int row0 = row0_of(seq);
         unsigned ones = 0x00010001u;
         asm volatile("" : "+v"(ones));
@@ -370,16 +447,50 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     float am[2];
     // (measured in round 2: a static s_setprio(1) for the second-dispatched half of the workgroup changes nothing here)
     for (int seq = 0; seq < my_tiles; ++seq) {
+        PG_STAMP(0);
+        PG_STAMP(6);
         // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between (the late
         // half issues the stores of a tile one iteration later: its counts lag by one)
         if (seq + 2 < my_tiles) {
             const int sq = late ? seq - 1 : seq;
-            if (sq <= 0) { PG_WAIT(2 * G); } else if (sq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
+            if (dma_wave) {
+                if (sq <= 0) { PG_WAIT(2 * G); } else if (sq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
+            } else {          // (DMAH) this wave's queue holds only its side pieces and stores
+                constexpr int G0 = G - GA;
+                if (sq <= 0) { PG_WAIT(2 * G0); } else if (sq == 1) { PG_WAIT(2 * G0 + S); } else { PG_WAIT(2 * G0 + 2 * S); }
+            }
         } else {
             PG_WAIT(0);
         }
+        PG_STAMP(1);
         LDS_BARRIER();
-        if (seq + 3 < my_tiles) issue(seq + 3);
+        PG_STAMP(2);
+        // The loads of tile seq+3 (its ring slot is free since the barrier above) are NOT issued here in one burst: 8 waves x
+        // G pieces of 1 KiB queue on the CU's one address unit (64 B/clk: ~0.5 k cycles per tile with every matrix pipe idle,
+        // profiles/r03_b_inkernel_stamps_panel_k2_before.txt).  Each wave issues one piece per k-group of its MFMA phase
+        // instead; the LAST A piece stays the last VMEM operation of the iteration's loads, so the hand counts of
+        // s_waitcnt vmcnt above are unchanged (stores of the fused epilogue that precede it in program order are older ops).
+        const bool more = !(PG_ABL & 2) && seq + 3 < my_tiles;
+#if PG_SPREAD_DMA
+        constexpr int NGRP_ = PAD ? NKK / PG_GK : NKK;
+        auto dma = [&](int g) {
+            if (!more) return;
+            // piece q of G goes with k-group NGRP_-1 - (G-1-q)*NGRP_/G: spread over the tile's k-groups, right-aligned; side
+            // pieces (mask, row scales) first, then the A pieces, the last A piece in the last k-group (after every store the
+            // fused epilogue issues)
+            const int gg = (PG_DMA_SKEW && wave >= PG_NW / 2) ? g + 1 : g;
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                if (NGRP_ - 1 - ((G - 1 - q) * NGRP_) / G != gg) continue;
+                const int pc = q < G - GA ? GA + q : q - (G - GA);
+                if (pc >= GA || dma_wave) issue_piece(seq + 3, pc);
+            }
+        };
+#else
+        if (more) issue(seq + 3);
+        auto dma = [](int) {};
+#endif
+        PG_STAMP(3);
         if (FUSE) {
             // acc/mw/am still hold tile seq-1; the new tile accumulates into accn and is handed over at the end
             f32x4 accn[2][NJ];
@@ -388,6 +499,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             load_side(seq, mwn, amn);
             const bool prev = seq > 0;
             mfma_phase(seq, accn, [&](int g) {
+                dma(g);
                 if (!prev) return;
                 // 8 k-groups per tile: math of row half 0, its store, math of row half 1 (+ mask words), its store(s)
                 constexpr int NGRP = NKK / PG_GK;
@@ -412,6 +524,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                     if (NS > 2 && g == 6) { epilogue(seq - 1, acc, mw, am, 4); epilogue(seq - 1, acc, mw, am, 5); }
                 }
             });
+            PG_STAMP(4);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -422,15 +535,24 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             am[1] = amn[1];
         } else if (!late) {
             load_side(seq, mw, am);          // requested ahead of the MFMA loop
-            mfma_phase(seq, acc, [](int) {});
+            mfma_phase(seq, acc, dma);
+            PG_STAMP(4);
             epilogue(seq, acc, mw, am);
         } else {
             if (seq > 0) epilogue(seq - 1, acc, mw, am);
+            PG_STAMP(4);
             load_side(seq, mw, am);
-            mfma_phase(seq, acc, [](int) {});
+            mfma_phase(seq, acc, dma);
         }
+        PG_STAMP(5);
     }
     if (late) epilogue(my_tiles - 1, acc, mw, am);
+#ifdef PG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (blockIdx.x < PG_STAMP_WG)
+        for (int i = threadIdx.x; i < PG_STAMP_BYTES / 4; i += 64 * PG_NW) (&g_pg_stamps[blockIdx.x][0][0][0])[i] = stamp_lds[i];
+#endif
 
     if (MASKED && colsum_part) {
         // the 16 lanes of a quarter hold the same columns for different rows: reduce over them and publish this
@@ -463,7 +585,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     constexpr int STG_LD = WN * 2 + 16;
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD +
                         ((EPI == PG_MASK || EPI == PG_RANK1_MASK) ? PG_NSLOT * PG_NW * 256 : 0) +
-                        (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0);
+                        (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0) + PG_STAMP_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
     static MurclOncePerDevice once;      
