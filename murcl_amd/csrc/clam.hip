@@ -238,7 +238,7 @@ static int gs_rows_per_block(long rows, int D) {
 }
 static GsDrop gs_drop(float keep_p, unsigned long long seed_a, unsigned long long seed_b) {
     GsDrop d{seed_a, seed_b, 0u, 1.f};
-    if (keep_p > 0.f && keep_p < 1.f) { d.thresh = (unsigned)(keep_p * 256.f + 0.5f); d.scale = 1.f / keep_p; }
+    if (keep_p > 0.f && keep_p < 1.f) { d.thresh = (unsigned)(keep_p * 256.f + 0.5f); d.scale = 256.f / (float)(d.thresh ? d.thresh : 1u); }   // 1 / the REALISED keep probability
     return d;
 }
 extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float* bc, const void* keep_a,

@@ -55,7 +55,7 @@
 #define PG_DMA_HALF 0     // 1: waves 0..NW/2-1 issue ALL LDS-DMA pieces of a tile (two A pieces each per slot), the upper half none;
 #endif                    // 2: the upper half issues them all.  K = 512 variants only.
 #ifndef PG_ABL
-#define PG_ABL 0          // diagnostic ablations (wrong results): 1 no LDS fragment reads, 2 no LDS-DMA in the loop, 4 no stores, 8 no MFMAs, 16 no epilogue
+#define PG_ABL 0          // diagnostic ablations (wrong results): 1 no LDS fragment reads, 2 no LDS-DMA in the loop, 4 no stores, 8 no MFMAs, 16 no epilogue, 32 A loaded by column panel 0 only
 #endif
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         }
     };
     // does this wave issue A pieces?  (the side pieces - mask words, row scales - are per wave either way)
-    const bool dma_wave = !DMAH || ((wave < PG_NW / 2) == (PG_DMA_HALF == 1));
+    const bool dma_wave = (!DMAH || ((wave < PG_NW / 2) == (PG_DMA_HALF == 1))) && !((PG_ABL & 32) && panel != 0);   // ABL 32: only panel 0 loads A
     auto issue = [&](int seq) {
 #pragma unroll
         for (int p = 0; p < G; ++p)

@@ -195,11 +195,15 @@ class ABMILFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wa, ba, wb, bb, wd, bd):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wa, ba, wb, bb, wd, bd, drops=None):
+        """``drops`` = None or the two Dropout(p) keep masks after encoder layers 1 and 2 (abmil.py:12-19): ``ops.DropSeed``s
+        (training: the masks are generated inside the passes that apply them) or materialised keep-multiplier tensors
+        (values 0 or 1/keep, parity tests)."""
         B, N, d = x.shape
         T = x.dtype
         x2 = x.reshape(B * N, d)
         L = w3.shape[0]
+        pool_fast = (L == 512 and wa.shape[0] == 128)       # the one-pass K2 kernel is built for L = 512, D = 128
         # compute-dtype copies of W1..W3, Wa for this pass and W2^T, W3^T, Wa^T for the dgrads of the backward pass: one
         # launch, and only when a parameter changed since they were last built (ops.weight_views)
         wmats = (w1, w2, w3, wa)
@@ -214,26 +218,60 @@ class ABMILFn(torch.autograd.Function):
             w1c, w2c, w3c, wac = (ops.cast(w.contiguous(), T) for w in wmats)
             wat, w3t, w2t = (ops.transpose_cast(w, T) for w in (wa, w3, w2))
         # bf16 + panel-friendly shapes: weight-stationary GEMMs that also emit 1-bit ReLU masks
-        fast = (T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
+        fast = (T == torch.bfloat16 and d == 512 and pool_fast and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
                 and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
+        seeded = drops is not None and isinstance(drops[0], ops.DropSeed)
+
+        def drop(h, k, bits):
+            """Dropout after a ReLU, in place: h *= keep.  -> the 1-bit mask of the surviving positive entries (fast path)."""
+            if seeded and h.shape[0] % 32 == 0 and h.shape[1] % 128 == 0:
+                return ops.dropout_relu_bitmask(h, k, want_bits=bits)
+            ops.mul(h, ops.dropout_mask(h.shape, T, k.keep_p, h.device, seed=k.seed) if seeded else k.to(T).reshape(h.shape))
+            return ops.relu_bitmask(h) if bits else None
+
         if fast:
             nt = _STREAM_A
             keep = any(ctx.needs_input_grad)     # forward-only passes (frozen encoder of stage 2, validation): no ReLU masks to write
-            h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=keep, stream_a=bool(nt & 1))
+            h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=keep and drops is None, stream_a=bool(nt & 1))
+            if drops is not None:
+                m1 = drop(h1, drops[0], keep)
             # layer 2 walks the rows backwards (layer 1 has just written the high rows of h1), layer 3 forwards again,
             # and the pooling kernel backwards: every pass starts on what its producer left in the Infinity Cache
-            h2, m2, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=keep, reverse=True, stream_a=bool(nt & 2))
+            h2, m2, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=keep and drops is None, reverse=True,
+                                       stream_a=bool(nt & 2))
+            if drops is not None:
+                m2 = drop(h2, drops[1], keep)
             h3, m3, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=keep, stream_a=bool(nt & 4))
         else:
             m1 = m2 = m3 = None
             h1 = ops.gemm_nt(x2, w1c, epi=ops.EPI_BIAS_RELU, bias=b1)
+            if drops is not None:
+                drop(h1, drops[0], False)
             h2 = ops.gemm_nt(h1, w2c, epi=ops.EPI_BIAS_RELU, bias=b2)
+            if drops is not None:
+                drop(h2, drops[1], False)
             h3 = ops.gemm_nt(h2, w3c, epi=ops.EPI_BIAS_RELU, bias=b3)
-        scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
+        if pool_fast:
+            scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
+        else:
+            # any L / D (abmil.py:8-30 takes them as arguments): the same attention pooling as a chain of the generic kernels -
+            # projection GEMM, tanh score, row soft-max, /sqrt(N) (abmil.py:40-41), weighted row sum
+            U = ops.gemm_nt(h3, wac, epi=ops.EPI_BIAS, bias=ba)                                     # [B*N, D]
+            s = ops.gated_score_fwd(U, wb.reshape(-1).contiguous(), bb, gated=False).view(B, N)
+            Asm = ops.softmax_rows(s)
+            A = ops.mul(Asm, torch.full_like(Asm, 1.0 / (N ** 0.5)), out=torch.empty_like(Asm))
+            M = ops.weighted_rowsum(h3.view(B, N, L), A.view(B, N, 1)).view(B, L)
+            scores, ml = U, Asm                                                                    # what the generic backward needs
         out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
         ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
                               b1, b2, b3, bb, bd, wat, w3t, w2t)
         ctx.dims = (B, N, d)
+        ctx.pool_fast = pool_fast
+        # the surviving entries of a keep mask all equal 1/keep: the masked dgrads below run unscaled and the (linear) factors
+        # are applied to the few gradients behind them
+        ctx.drop_scale = None
+        if drops is not None:
+            ctx.drop_scale = tuple(1.0 / k.keep_q if isinstance(k, ops.DropSeed) else float(k.max().item()) for k in drops)
         ctx.mark_non_differentiable(A)
         ctx.set_materialize_grads(False)         # no zero-filled dA (a launch) for the attention output nobody differentiates
         return out, A
@@ -246,7 +284,9 @@ class ABMILFn(torch.autograd.Function):
         T = x2.dtype
         L = h3.shape[1]
         if dout is None:
-            return (None,) * 13
+            return (None,) * 14
+        if ctx.drop_scale is not None or not ctx.pool_fast:
+            return ABMILFn._backward_general(ctx, dout)
         # decoder (bag level, f32)
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd, dbd = _wbgrad(dpre, M, wd, bd)
@@ -305,7 +345,52 @@ class ABMILFn(torch.autograd.Function):
             dba = dwb = dbb = None
         else:
             dba, dwb, dbb = _pgrad(dba, ba), _pgrad(dwb.reshape(1, -1), wb), _pgrad(dbb, bb)
-        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd
+        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd, None
+
+    @staticmethod
+    def _backward_general(ctx, dout):
+        """The configurations outside the tuned default (``--dropout`` > 0 while training, ``--L`` / ``--D`` other than 512 /
+        128): the same backward pass with every gradient returned to autograd as its own tensor, so that the dropout
+        factors can be applied to them (no direct accumulation into the flat gradient buffer on this path)."""
+        (x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
+         b1, b2, b3, bb, bd, wat, w3t, w2t) = ctx.saved_tensors
+        B, N, d = ctx.dims
+        T = x2.dtype
+        L = h3.shape[1]
+        dpre = ops.relu_bwd(dout.contiguous(), out)
+        dwd, dbd = ops.gemm_tn(dpre, M), ops.colsum(dpre)
+        dM = ops.gemm_nt(dpre, ops.transposed(wd))
+        if ctx.pool_fast:
+            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
+            dwb = dwb.reshape(1, -1)
+        else:
+            U, Asm = scores, ml
+            dA = ops.rows_dot(h3.view(B, N, L), dM.view(B, 1, L)).view(B, N)
+            dAs = ops.mul(dA, torch.full_like(dA, 1.0 / (N ** 0.5)))                               # A = softmax / sqrt(N)
+            ds = ops.softmax_rows_bwd(Asm, dAs).view(-1)
+            dT, dwb, dbb, dba = ops.gated_score_bwd(U, wb.reshape(-1).contiguous(), ds, gated=False)
+            dwb, dba = dwb.view(1, -1), dba.contiguous()
+        dwa = ops.gemm_tn(dT, h3)
+        if m3 is not None:
+            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
+            dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True)
+            dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True)
+        else:
+            dz3, ws = ops.gemm_nt(dT, wat, epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
+            db3 = ops.colsum(ws)
+            dz2, ws = ops.gemm_nt(dz3, w3t, epi=ops.EPI_MASK, mask=h2, colsum=True)
+            db2 = ops.colsum(ws)
+            dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
+            db1 = ops.colsum(ws)
+        dw3, dw2, dw1 = ops.gemm_tn(dz3, h2), ops.gemm_tn(dz2, h1), ops.gemm_tn(dz1, x2)
+        dx = ops.gemm_nt(dz1, ops.transpose_cast(w1, T)).view(B, N, d) if ctx.needs_input_grad[0] else None
+        if ctx.drop_scale is not None:
+            # dZ2 = (dZ3 W3) * relu'(H2) * keep2 and dZ1 = (dZ2 W2) * relu'(H1) * keep1, the masks above hold relu' AND kept
+            s2 = ctx.drop_scale[1]
+            s1 = ctx.drop_scale[0] * s2
+            dw2, db2, dw1, db1 = dw2 * s2, db2 * s2, dw1 * s1, db1 * s1
+            dx = dx * s1 if dx is not None else None
+        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd, None
 
 
 class GRUStepFn(torch.autograd.Function):
@@ -662,7 +747,7 @@ class CLAMFn(torch.autograd.Function):
         if db1 is None:
             db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
-            kp = k1.keep_p if isinstance(k1, ops.DropSeed) else 0.75
+            kp = k1.keep_q if isinstance(k1, ops.DropSeed) else 0.75
             dw1, db1 = dw1 / kp, db1 / kp
         if not gated:
             return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)

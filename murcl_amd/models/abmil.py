@@ -32,21 +32,28 @@ class ABMIL(nn.Module):
         self.fc = nn.Linear(L, dim_out)              # built, never applied (abmil.py:33)
         self.compute_dtype = torch.float32           # torch.bfloat16 = throughput path
         self.last_attention = None                   # A [B,N] of the most recent call (detached)
+        self.keep_masks = None                       # tests: (k1, k2) keep-multiplier tensors [B*N, L] replacing the dropout draws
 
     # -- kernels -------------------------------------------------------------------------
     def _bags(self, x):
         """x [B,N,d] -> [B,L] through the fused HIP path."""
-        if self.K != 1 or self.L != 512 or self.D != 128:
-            raise NotImplementedError("murcl_amd ABMIL kernels are built for L=512, D=128, K=1")
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("dropout>0 is not wired into the fused encoder (reference default 0.0)")
+        if self.K != 1:
+            raise NotImplementedError("murcl_amd ABMIL: K != 1 attention heads are not built (no reference script sets K)")
+        # L = 512, D = 128 (every launch script's values) run the one-pass K2 pooling kernel and, in bf16, the weight-stationary
+        # encoder; other --L / --D (train_RLMIL.py:91-97) and --dropout > 0 while training take the general path of ABMILFn
+        drops = None
+        if self.keep_masks is not None:                              # injected keep multipliers (parity tests)
+            drops = self.keep_masks
+        elif self.training and self.dropout > 0.0:                   # nn.Dropout(p) after encoder layers 1 and 2 (abmil.py:15,18)
+            from .. import ops
+            drops = (ops.DropSeed(1.0 - self.dropout), ops.DropSeed(1.0 - self.dropout))
         if x.dtype != self.compute_dtype:
             from .. import ops
             x = ops.cast(x.float().contiguous(), self.compute_dtype) if x.dtype != torch.float32 else \
                 ops.cast(x.contiguous(), self.compute_dtype)
         e, a, d = self.encoder, self.attention, self.decoder
         out, A = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
-                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias)
+                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops)
         self.last_attention = A
         return out
 

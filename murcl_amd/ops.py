@@ -691,6 +691,12 @@ class DropSeed:
     def __init__(self, keep_p, seed=None):
         self.keep_p, self.seed = float(keep_p), dropout_seed() if seed is None else int(seed)
 
+    @property
+    def keep_q(self):
+        """The keep probability the kernels REALISE: one byte per element, so ``keep_p`` rounded to 1/256.  Survivors are scaled
+        by 1/keep_q (exactly 1/keep_p for CLAM's 0.75; for e.g. 0.9 -> 230/256 scaling by 1/0.9 would bias the mean by 0.2 %)."""
+        return max(1, int(self.keep_p * 256.0 + 0.5)) / 256.0
+
 
 def dropout_seed():
     """Seed of the next counter-based dropout mask: torch's global seed and a call counter (no device synchronisation;
@@ -707,7 +713,7 @@ def dropout_relu_bitmask(x, drop, want_bits=True):
     assert x.is_contiguous() and x.dim() == 2
     M, N = x.shape
     bits = torch.empty((M, N // 8), dtype=torch.uint8, device=x.device) if want_bits else None
-    check(_lib.lib().murcl_dropout_relu_bitmask(ptr(x), ptr(bits), M, N, drop.keep_p, 1.0 / drop.keep_p, drop.seed, dt(x), stream()),
+    check(_lib.lib().murcl_dropout_relu_bitmask(ptr(x), ptr(bits), M, N, drop.keep_p, 1.0 / drop.keep_q, drop.seed, dt(x), stream()),
           "dropout_relu_bitmask")
     return bits
 
@@ -717,7 +723,7 @@ def dropout_mask(shape, dtype, keep_p, device, seed=None):
     seed and a call counter (no device synchronisation; ``torch.manual_seed`` makes a run reproducible)."""
     seed = dropout_seed() if seed is None else int(seed)
     out = torch.empty(shape, dtype=dtype, device=device)
-    check(_lib.lib().murcl_dropout_mask(ptr(out), out.numel(), float(keep_p), 1.0 / float(keep_p), seed, dt(out), stream()),
+    check(_lib.lib().murcl_dropout_mask(ptr(out), out.numel(), float(keep_p), 1.0 / DropSeed(keep_p, seed).keep_q, seed, dt(out), stream()),
           "dropout_mask")
     return out
 

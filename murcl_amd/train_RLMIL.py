@@ -18,9 +18,9 @@ from murcl_amd.utils.views import as_one
 
 
 def create_model(arch, dim_patch, num_classes, device, model_dim=512, D=128, size_arg="small", k_sample=8,
-                 fc_hidden_dim=1024, dtype=torch.float32):
+                 fc_hidden_dim=1024, dtype=torch.float32, dropout=0.0, fc_rnn=True):
     if arch == "ABMIL":
-        model = abmil.ABMIL(dim_in=dim_patch, L=model_dim, D=D, dim_out=num_classes)
+        model = abmil.ABMIL(dim_in=dim_patch, L=model_dim, D=D, dim_out=num_classes, dropout=dropout)     # train_RLMIL.py:90-96
         feat = model_dim
     elif arch == "CLAM_SB":
         model = clam.CLAM_SB(gate=True, size_arg=size_arg, dropout=True, k_sample=k_sample, n_classes=num_classes,
@@ -32,7 +32,7 @@ def create_model(arch, dim_patch, num_classes, device, model_dim=512, D=128, siz
     else:
         raise NotImplementedError(arch)
     model.compute_dtype = dtype
-    fc = rlmil.Full_layer(feat, fc_hidden_dim, True, num_classes)
+    fc = rlmil.Full_layer(feat, fc_hidden_dim, fc_rnn, num_classes)                                       # :115
     return model.to(device), fc.to(device)
 
 
@@ -464,7 +464,8 @@ def run(args):
     dim_patch = stores[0].patch_dim
     # train_RLMIL.py:88-116: ABMIL takes --L, the head's input width follows the aggregator's output
     model, fc = create_model(args.arch, dim_patch, args.num_classes, dev, model_dim=args.L, D=args.D, size_arg=args.size_arg,
-                             k_sample=args.k_sample, fc_hidden_dim=args.fc_hidden_dim, dtype=dt_)
+                             k_sample=args.k_sample, fc_hidden_dim=args.fc_hidden_dim, dtype=dt_, dropout=args.dropout,
+                             fc_rnn=args.fc_rnn)
     args.feature_num = fc.feature_num
     ppo = None
     if args.train_stage in (2, 3):

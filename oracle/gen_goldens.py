@@ -665,6 +665,50 @@ def g15_supervised_steps():
     np.savez(os.path.join(OUT, "g15_supervised_steps.npz"), **res)
 
 
+def g16_abmil_general():
+    """The reference's ABMIL (models/abmil.py:8-45) outside the launch scripts' defaults: training-mode Dropout(0.25) after
+    encoder layers 1 and 2 (torch.nn.functional.dropout replaced by the injected keep masks, in call order), and L / D other
+    than 512 / 128 (train_RLMIL.py:91-97 passes --L / --D).  Outputs, attention weights and parameter-gradient fingerprints
+    for loss = out.sum()."""
+    from oracle.recipes import G16, g16_inputs
+    res = {}
+    for case, k in G16["cases"].items():
+        p, x, masks = g16_inputs(case)
+        m = r_abmil.ABMIL(k["d"], L=k["L"], D=k["D"], dim_out=2, dropout=0.25 if masks is not None else 0.0)
+        m.load_state_dict(P.to_torch(p))
+        m.train()
+        calls = []
+
+        def fake_dropout(inp, p_=0.5, training=True, inplace=False):
+            if masks is None or not training or p_ == 0.0:
+                return inp
+            b = len(calls) // 2                                  # bag b: the batch loop runs the encoder once per bag (abmil.py:47-51)
+            mk = T(masks[len(calls) % 2][b])
+            calls.append(1)
+            return inp * mk
+
+        with mock.patch("torch.nn.functional.dropout", fake_dropout):
+            out, _ = m(T(x))
+            out.sum().backward()
+        assert masks is None or len(calls) == 2 * x.shape[0]
+        res[f"{case}.out"] = out.detach().numpy()
+        with torch.no_grad():
+            A = []
+            for b in range(x.shape[0]):
+                h = T(x[b])
+                for i, lin in enumerate((m.encoder[0], m.encoder[3], m.encoder[6])):
+                    h = torch.relu(lin(h))
+                    if masks is not None and i < 2:
+                        h = h * T(masks[i][b])
+                a = torch.softmax(m.attention(h).t(), dim=1)
+                A.append(a / np.sqrt(a.shape[-1]))
+        res[f"{case}.A"] = torch.cat(A).numpy()
+        for name, v in m.named_parameters():
+            if v.grad is not None:
+                res[f"{case}.grad.{name}"] = _summ(v.grad)
+    np.savez(os.path.join(OUT, "g16_abmil_general.npz"), **res)
+
+
 def _reference_parser(mod, globals_needed):
     """The ArgumentParser that the reference's ``main()`` builds (it is local to main): run main() with parse_args
     replaced by a hook that keeps the parser and stops."""
@@ -780,7 +824,7 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

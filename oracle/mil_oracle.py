@@ -19,16 +19,21 @@ def _lin(x, p, name):
 
 
 # ----------------------------------------------------------------------------- ABMIL
-def abmil_forward(p, x):
+def abmil_forward(p, x, drop_masks=None):
     """ABMIL.bag_forward over a batch (models/abmil.py:35-45, batch loop :47-51).
 
     x [B,N,d] -> out [B,L], A [B,N] (post-softmax, already divided by sqrt(N) as in
     abmil.py:40-41), s [B,N] raw scores, M [B,L] pooled vector before the decoder.
-    Dropout (abmil.py:15,18) is p=0 in every launch script (train_MuRCL.py:456) and is
-    the identity here.  ``self.fc`` (abmil.py:33) is never applied by the reference.
+    Dropout (abmil.py:15,18) is p=0 in every launch script (train_MuRCL.py:456): ``drop_masks`` = None is the
+    identity; (k1, k2) keep multipliers [B,N,L] (0 or 1/keep) inject the training-mode masks after layers 1 and 2.
+    ``self.fc`` (abmil.py:33) is never applied by the reference.  Any L / D (abmil.py:8).
     """
     h = torch.relu(_lin(x, p, "encoder.0"))          # abmil.py:13-14
+    if drop_masks is not None:
+        h = h * drop_masks[0]                        # abmil.py:15
     h = torch.relu(_lin(h, p, "encoder.3"))          # abmil.py:16-17
+    if drop_masks is not None:
+        h = h * drop_masks[1]                        # abmil.py:18
     h = torch.relu(_lin(h, p, "encoder.6"))          # abmil.py:19-20
     t = torch.tanh(_lin(h, p, "attention.0"))        # abmil.py:24-25
     s = _lin(t, p, "attention.2").squeeze(-1)        # abmil.py:26 (K=1)

@@ -73,6 +73,24 @@ def g15_params(arch):
 
 
 
+# ------------------------------------------------------------------ G16: ABMIL outside the launch scripts' default shape
+G16 = dict(seed=29, B=3, N=160, keep=0.75,
+           cases={"dropout": dict(d=512, L=512, D=128), "small": dict(d=320, L=256, D=64), "small_dropout": dict(d=320, L=256, D=64)})
+
+
+def g16_inputs(case):
+    """(parameter dict, bags [B,N,d], the two keep-multiplier masks [B,N,L] or None) of a G16 case."""
+    c, k = G16, G16["cases"][case]
+    p = P.abmil(c["seed"], dim_in=k["d"], L=k["L"], D=k["D"], dim_out=2)
+    x = P.bags(c["seed"], f"g16.{case}.x", c["B"], c["N"], k["d"])
+    masks = None
+    if "dropout" in case:
+        masks = [(detrand.uniform(c["seed"], f"g16.{case}.k{i}", (c["B"], c["N"], k["L"])) < c["keep"]).astype(np.float32) / c["keep"]
+                 for i in range(2)]
+    return p, x, masks
+
+
+
 
 # ------------------------------------------------------------------ launch-script argument vectors (runs/*.sh)
 def _murcl_argv(stage, backbone_lr, fc_lr):

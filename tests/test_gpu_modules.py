@@ -550,3 +550,99 @@ def test_clam_plain_attention_net_gate_false(golden, dtype):
         assert (M.detach().cpu() - T(g["M_batch"])).abs().max().item() < 3e-2 * float(np.abs(g["M_batch"]).max())
         (M.sum() + il.sum()).backward()
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+# ---------------------------------------------------------------- ABMIL outside the launch scripts' default shape (G16)
+def _abmil_general(case, dtype=torch.float32):
+    from murcl_amd.models.abmil import ABMIL
+    from oracle.recipes import G16, g16_inputs
+    k = G16["cases"][case]
+    pd, x, masks = g16_inputs(case)
+    m = ABMIL(k["d"], L=k["L"], D=k["D"], dim_out=2, dropout=0.25 if masks is not None else 0.0)
+    m.load_state_dict(P.to_torch(pd))
+    m.compute_dtype = dtype
+    m = m.to(_dev()).train()
+    if masks is not None:
+        m.keep_masks = tuple(T(mk).reshape(-1, k["L"]).to(_dev()) for mk in masks)
+    return m, T(x).to(_dev())
+
+
+@pytest.mark.parametrize("case", ["dropout", "small", "small_dropout"])
+def test_abmil_dropout_and_other_L_D_vs_reference_golden(golden, case):
+    """VERDICT r2 missing 5: ``--dropout`` > 0 in training mode and ``--L`` / ``--D`` other than 512 / 128 (abmil.py:8-33,
+    train_RLMIL.py:91-97) run on the kernels and match the reference module (G16: out, attention, every parameter gradient)."""
+    g = golden("g16_abmil_general")
+    m, x = _abmil_general(case)
+    out, det = m(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"{case}.out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), g[f"{case}.A"], rtol=1e-4, atol=1e-9)
+    out.sum().backward()
+    n = 0
+    for k, v in m.named_parameters():
+        key = f"{case}.grad.{k}"
+        if key not in g.files:
+            continue
+        if k == "attention.2.bias":
+            assert v.grad.abs().max().item() < 1e-4 * m.attention[2].weight.grad.norm().item()
+            continue
+        _check_summ(_summ(v.grad), g[key], 5e-4, key)
+        n += 1
+    assert n >= 11 and m.fc.weight.grad is None
+
+
+def test_abmil_dropout_bf16_fast_path_close_to_fp32_and_seeded_masks_equal_materialised_ones():
+    """The bf16 weight-stationary path with Dropout: (a) injected masks - close to the f32 kernels; (b) masks generated inside
+    the passes from DropSeeds == the same masks materialised and injected (outputs and gradients bit for bit: same kernels,
+    same multipliers), so training-mode dropout back-propagates through exactly the mask the forward applied."""
+    from murcl_amd import ops
+    m32, x = _abmil_general("dropout")
+    m16, _ = _abmil_general("dropout", torch.bfloat16)
+    o32, _ = m32(x)
+    o16, _ = m16(x)
+    assert (o16 - o32).abs().max().item() <= 3e-2 * o32.abs().max().item()
+    o32.sum().backward(), o16.sum().backward()
+    for (k, a), (_, b) in zip(m32.named_parameters(), m16.named_parameters()):
+        if a.grad is not None and k != "attention.2.bias":
+            assert ((a.grad - b.grad).norm() / a.grad.norm()).item() < 6e-2, k
+    # (b) seeds vs materialised masks, bf16 fast path and f32 general path
+    for dtype in (torch.bfloat16, torch.float32):
+        seeds = (ops.DropSeed(0.75, seed=1234567), ops.DropSeed(0.75, seed=7654321))
+        ma, _ = _abmil_general("dropout", dtype)
+        mb, _ = _abmil_general("dropout", dtype)
+        ma.keep_masks = seeds
+        mb.keep_masks = tuple(ops.dropout_mask((x.shape[0] * x.shape[1], 512), dtype, 0.75, x.device, seed=s.seed) for s in seeds)
+        frac = (mb.keep_masks[0] != 0).float().mean().item()
+        assert abs(frac - 0.75) < 5e-3
+        oa, _ = ma(x)
+        ob, _ = mb(x)
+        assert torch.equal(oa, ob)
+        oa.sum().backward(), ob.sum().backward()
+        for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+            if a.grad is not None:
+                assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), k
+
+
+def test_abmil_training_mode_dropout_draws_fresh_masks_and_eval_is_deterministic():
+    m, x = _abmil_general("dropout")
+    m.keep_masks = None                                   # the module's own draws
+    torch.manual_seed(11)
+    a, _ = m(x)
+    b, _ = m(x)
+    assert not torch.equal(a, b)                           # two calls, two masks
+    m.eval()
+    c, _ = m(x)
+    d, _ = m(x)
+    assert torch.equal(c, d)
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_dropout_scale_is_the_realised_keep_probability():
+    """survivors are scaled by 1 / (the keep probability the kernels realise), e.g. 230/256 for keep 0.9."""
+    from murcl_amd import ops
+    k = ops.dropout_mask((1 << 16, 64), torch.float32, 0.9, _dev(), seed=99)
+    kept = k[k != 0]
+    assert torch.all(kept == kept[0]) and abs(kept[0].item() - 256.0 / 230.0) < 1e-6
+    assert abs(k.mean().item() - 1.0) < 2e-3                # unbiased: E[keep multiplier] = 1
+    k75 = ops.dropout_mask((1 << 12, 64), torch.float32, 0.75, _dev(), seed=5)
+    assert abs(k75[k75 != 0][0].item() - 1.0 / 0.75) < 1e-6

@@ -45,7 +45,9 @@ def test_abmil_type_error_and_guards():
     with pytest.raises(TypeError):
         ABMIL(512)("not a tensor")
     with pytest.raises(NotImplementedError):
-        ABMIL(512, L=256)._bags(torch.zeros(1, 4, 512))
+        ABMIL(512, K=2)._bags(torch.zeros(1, 4, 512))                 # K != 1 heads: no reference script sets K
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ABMIL(512, L=256)._bags(torch.zeros(1, 4, 512))               # other L / D are built (general path) - on the GPU only
 
 
 def test_shard_range():

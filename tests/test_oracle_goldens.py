@@ -373,3 +373,17 @@ def test_g15_supervised_step_oracle_vs_reference_train_bodies(golden, arch, stag
                     continue
                 _close_summ(_fp(v - base[k]), want, 3e-2, msg=key)
                 _close_summ(_fp(v), g[f"{tag}.{name}.{k}"], 1e-4, msg=key)
+
+
+@pytest.mark.parametrize("case", ["dropout", "small", "small_dropout"])
+def test_g16_abmil_outside_the_default_shape(golden, case):
+    """The oracle's ABMIL with injected Dropout masks and with L / D other than 512 / 128 == the reference module in train mode."""
+    from oracle.recipes import g16_inputs
+    g = golden("g16_abmil_general")
+    pd, x, masks = g16_inputs(case)
+    p = _leaf(pd)
+    out, A, s, M = O.abmil_forward(p, T(x), None if masks is None else [T(k) for k in masks])
+    np.testing.assert_allclose(out.detach().numpy(), g[f"{case}.out"], **TOL)
+    np.testing.assert_allclose(A.detach().numpy(), g[f"{case}.A"], rtol=2e-5, atol=1e-8)
+    out.sum().backward()
+    _check_grads(g, f"{case}.grad.", p)
