@@ -34,7 +34,7 @@ __device__ __forceinline__ u32x4 fe_load16(const void* p) {
 template <int NSLOT>
 __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                        const float* __restrict__ bias, bf16_t* __restrict__ Hout,
-                                                                       int M, int layers, int store_all, int no_mfma) {
+                                                                       int M, int layers, int store_all, int no_mfma, int rotate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int OFF_BIAS = NSLOT * FE_SLOT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // The 16 slots of a layer are independent (disjoint output features), so every workgroup may walk them from its own start:
+    // in lockstep all 32 CUs of an XCD would pull the SAME 33 KiB of W through the same few L2 channels at the same time.
+    const int rot = rotate ? (int)(blockIdx.x >> 3) & 15 : 0;
     // slot g = ((tile * layers) + layer) * 16 + jj: LDS row p = 16b + i  <-  W_layer row 32jj + 8(i/4) + 4b + (i%4)
     auto issue = [&](int g) {
-        const int jj = g & 15, layer = (g >> 4) % layers;
+        const int jj = ((g & 15) + rot) & 15, layer = (g >> 4) % layers;
         const char* wl = (const char*)(W + (size_t)layer * 512 * 512);
         const unsigned dst = lds0 + (g % NSLOT) * FE_SLOT;
 #pragma unroll
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk)
-                    raw[h][kk] = fe_load16((const char*)X + (size_t)(row0 + 16 * h + m16) * 1024 + 64 * kk + 16 * q);
+                    raw[h][kk] = fe_load16((const char*)X + (size_t)(row0 + 16 * h + m16) * 1024 + 64 * ((kk + rot) & 15) + 16 * q);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -105,8 +108,11 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
                     for (int b = 0; b < 2; ++b) acc[h][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
-                    const bf16x8 a0 = *(const bf16x8*)(fb + 64 * kk);
-                    const bf16x8 a1 = *(const bf16x8*)(fb + 16 * FE_STRIDE + 64 * kk);
+                    // register position kk holds k block (kk + rot) & 15 (X is loaded, and every layer's output is produced, in
+                    // this workgroup's rotated block order)
+                    const int kb = rotate ? 64 * ((kk + rot) & 15) : 64 * kk;
+                    const bf16x8 a0 = *(const bf16x8*)(fb + kb);
+                    const bf16x8 a1 = *(const bf16x8*)(fb + 16 * FE_STRIDE + kb);
                     if (!no_mfma) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -118,8 +124,9 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
                     }
                 }
                 // bias + ReLU, 8 consecutive features 32jj + 8q .. +7 of rows 16h + m16 -> next layer's k-step jj
-                const f32x4 b0 = *(const f32x4*)(lbias + layer * 512 + 32 * jj + 8 * q);
-                const f32x4 b1 = *(const f32x4*)(lbias + layer * 512 + 32 * jj + 8 * q + 4);
+                const int jf = (jj + rot) & 15;                  // the feature block this slot produced
+                const f32x4 b0 = *(const f32x4*)(lbias + layer * 512 + 32 * jf + 8 * q);
+                const f32x4 b1 = *(const f32x4*)(lbias + layer * 512 + 32 * jf + 8 * q + 4);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x4 v0 = acc[h][0] + b0, v1 = acc[h][1] + b1;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
                     out_[h][jj] = __builtin_bit_cast(bf16x8, w);
                     if (store) {
                         bf16_t* dst = Hout + (size_t)(store_all ? layer : 0) * M * 512;
-                        fe_store16(dst + (size_t)(row0 + 16 * h + m16) * 512 + 32 * jj + 8 * q, w);
+                        fe_store16(dst + (size_t)(row0 + 16 * h + m16) * 512 + 32 * jf + 8 * q, w);
                     }
                 }
             }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void fused_encoder_probe_kernel(const bf16_
 }
 
 extern "C" int murcl_debug_fused_encoder(const void* X, const void* W, const float* bias, void* Hout, int M, int layers,
-                                         int store_all, int nslot, int no_mfma, hipStream_t stream) {
+                                         int store_all, int nslot, int no_mfma, int rotate, hipStream_t stream) {
     if (M <= 0 || M % 128 || layers < 1 || layers > 3) return -1;
     const int grid = M / 128 < 256 ? M / 128 : 256;
 #define FE(NS)                                                                                                  \
@@ -153,7 +160,7 @@ extern "C" int murcl_debug_fused_encoder(const void* X, const void* W, const flo
         const int lds = NS * FE_SLOT + 3 * 512 * 4;                                                             \
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                   \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, stream, (const bf16_t*)X, (const bf16_t*)W, bias,     \
-                           (bf16_t*)Hout, M, layers, store_all, no_mfma);                                       \
+                           (bf16_t*)Hout, M, layers, store_all, no_mfma, rotate);                               \
         return MURCL_CHECK_LAUNCH();                                                                            \
     }
     FE(3) FE(4)

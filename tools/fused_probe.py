@@ -15,12 +15,12 @@ from murcl_amd import _lib  # noqa: E402
 
 L = ctypes.CDLL(_lib.LIB_PATH)
 f = L.murcl_debug_fused_encoder
-f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 f.restype = ctypes.c_int
 
 
-def run(X, W, b, out, layers, store_all=0, nslot=4, no_mfma=0):
-    rc = f(X.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), X.shape[0], layers, store_all, nslot, no_mfma,
+def run(X, W, b, out, layers, store_all=0, nslot=4, no_mfma=0, rotate=1):
+    rc = f(X.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), X.shape[0], layers, store_all, nslot, no_mfma, rotate,
            torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 
@@ -48,29 +48,29 @@ def main():
     W = (torch.randn((3, 512, 512), generator=g, device=dev) / math.sqrt(512) * 1.4).bfloat16()
     b = torch.randn((3, 512), generator=g, device=dev) * 0.1
     # ---- correctness at a small M (ragged workgroup shares: 5 tiles)
-    M = 640
+    M = 128 * 300                       # more tiles than CUs: ragged shares, every rotation
     X = (torch.randn((M, 512), generator=g, device=dev).abs() * 0.5).bfloat16()
     for layers in (1, 2, 3):
-        for nslot in (3, 4):
+        for nslot, rotate in ((3, 0), (4, 1)):
             out = torch.zeros((3, M, 512), dtype=torch.bfloat16, device=dev)
-            run(X, W, b, out, layers, store_all=1, nslot=nslot)
+            run(X, W, b, out, layers, store_all=1, nslot=nslot, rotate=rotate)
             h = X.float()
             for l in range(layers):
                 h = torch.relu(h @ W[l].float().t() + b[l]).bfloat16().float()
                 err = (out[l].float() - h).abs().max().item() / h.abs().max().item()
                 assert err < 2e-2, (layers, nslot, l, err)
-            print(f"layers {layers} nslot {nslot}: max rel err {err:.2e}  ok")
+            print(f"layers {layers} nslot {nslot} rotate {rotate}: max rel err {err:.2e}  ok")
     # ---- timing at the C2 shape
     M = 128 * 2048
     X = (torch.randn((M, 512), generator=g, device=dev).abs() * 0.5).bfloat16()
     out = torch.empty((3, M, 512), dtype=torch.bfloat16, device=dev)
     gflop = 2.0 * M * 512 * 512 / 1e9           # per layer; / us / 1e3 = PFLOP/s
     for layers in (1, 3):
-        for store_all in (0, 1):
-            for nslot in (3, 4):
-                for no_mfma in (0, 1):
-                    med, mn = timed(lambda: run(X, W, b, out, layers, store_all, nslot, no_mfma))
-                    print(f"M {M} layers {layers} store_all {store_all} nslot {nslot} no_mfma {no_mfma}: median {med:7.1f} us  min {mn:7.1f} us"
+        for store_all, nslot, no_mfma, rotate in ((0, 4, 0, 0), (0, 4, 1, 0), (0, 4, 0, 1), (0, 4, 1, 1), (1, 4, 0, 1), (1, 3, 0, 1), (1, 4, 1, 1)):
+            if True:
+                if True:
+                    med, mn = timed(lambda: run(X, W, b, out, layers, store_all, nslot, no_mfma, rotate))
+                    print(f"M {M} layers {layers} store_all {store_all} nslot {nslot} no_mfma {no_mfma} rotate {rotate}: median {med:7.1f} us  min {mn:7.1f} us"
                           f"  = {med / layers:6.1f} us per layer, {gflop * layers / med / 1e3:6.3f} PFLOP/s", flush=True)
 
 
