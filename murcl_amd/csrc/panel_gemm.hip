@@ -24,6 +24,7 @@
 // exactly what "shift left, OR in the packed pair's >0 flags" leaves behind (2 VALU ops per bf16 pair), and
 // the consumer applies it with one v_bfe_i32 + v_and per accumulator value.
 #include "common.h"
+#include <type_traits>
 
 #define PG_TR 32
 #define PG_NSLOT 4
@@ -57,6 +58,9 @@
 #ifndef PG_ABL
 #define PG_ABL 0          // diagnostic ablations (wrong results): 1 no LDS fragment reads, 2 no LDS-DMA in the loop, 4 no stores, 8 no MFMAs, 16 no epilogue, 32 A loaded by column panel 0 only
 #endif
+#ifndef PG_REGSTAGE
+#define PG_REGSTAGE 0     // 1: forward variants (K = 512, bias epilogues): A tiles travel global -> VGPRs -> LDS (plain 16-byte loads two
+#endif                    // tiles ahead into two register sets, ds_write_b128 one tile ahead) instead of LDS-DMA (see the tile loop)
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
@@ -99,6 +103,19 @@ __device__ __forceinline__ void pg_store16(void* p, u32x4 v) {
 __device__ __forceinline__ void pg_store2(void* p, unsigned v) {
     if (PG_ABL & 4) { asm volatile("" ::"v"(p), "v"(v)); return; }
     asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// plain global load of 16 bytes per lane, wave-uniform base + per-lane offset; hipcc does not track it: the caller waits by
+// hand (s_waitcnt vmcnt) before the first use of the result
+__device__ __forceinline__ u32x4 pg_gload16(const void* sbase, unsigned voff) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4 pg_gload16_nt(const void* sbase, unsigned voff) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" GLDS_STREAM_POLICY : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    return v;
 }
 
 // per bf16 half of w: 1 if > 0 (signed 16-bit compare: -0.0 and negatives give 0), else 0.  Inline asm because hipcc
@@ -225,8 +242,39 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             if (p >= GA || dma_wave) issue_piece(seq, p);
     };
 
-    const int pre = min(3, my_tiles);
+    // Register staging (PG_REGSTAGE, forward variants): an LDS-DMA instruction holds the issuing wave for 100-190 cycles (480-640
+    // per tile and wave, in-kernel stamps of round 3) wherever it is placed; a plain global_load_dwordx4 issues in a few cycles and
+    // a ds_write_b128 in ~13.  Tile t+3's rows are loaded into one of two register sets at the top of iteration t, written to
+    // LDS slot (t+1) % NSLOT... one tile ahead at the top of iteration t (tile t+1), so three tiles are on their way as before.
+    auto row0_of_early = [&](int seq) {
+        const int tix = tile0 + seq * tstep;
+        const bool rev = ((walk_reverse & 1) != 0) != ((PG_FLIP >> EPI) & 1);
+        return (rev ? n_tiles - 1 - tix : tix) * PG_TR;
+    };
+    constexpr bool RS = PG_REGSTAGE != 0 && PAD && BIASED;
+    u32x4 rs_reg[2][RS ? GT : 1];
+    auto rs_load = [&](auto par, int seq) {
+        constexpr int P = decltype(par)::value;
+        const char* base = (const char*)(A + (size_t)row0_of_early(seq) * K);
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+            const int row = j * PG_NW + wave;
+            rs_reg[P][j] = (walk_reverse & 2) ? pg_gload16_nt(base + (size_t)row * ROWB, lane * 16) : pg_gload16(base + (size_t)row * ROWB, lane * 16);
+        }
+    };
+    auto rs_write = [&](auto par, int seq) {
+        constexpr int P = decltype(par)::value;
+        char* slot = smem + (seq % PG_NSLOT) * SLOT;
+#pragma unroll
+        for (int j = 0; j < GT; ++j) {
+            const int row = j * PG_NW + wave;
+            asm volatile("" : "+v"(rs_reg[P][j]));
+            *(u32x4*)(slot + row * PADB + lane * 16) = rs_reg[P][j];
+        }
+    };
+    const int pre = RS ? 0 : min(3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
+    if (RS) rs_load(std::integral_constant<int, 0>{}, 0);
 
     // ---- W slice: MFMA "a" operands, rows n = n0 + 16j + r16
     bf16x8 wf[NJ][NKK];
@@ -263,6 +311,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RS) {
+        rs_write(std::integral_constant<int, 0>{}, 0);
+        if (my_tiles > 1) rs_load(std::integral_constant<int, 1>{}, 1);
+        if (my_tiles > 2) rs_load(std::integral_constant<int, 0>{}, 2);
+    }
 
     char* stg = smem + OFF_STG + wave * (PG_TR * STG_LD);        // wave-private staging patch
     const int crow = lane / CPW, cchunk = lane % CPW;            // row-wise phase: row RPI*g + crow, chunk cchunk
@@ -446,9 +499,25 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     unsigned mw[NJ / 2];
     float am[2];
     // (measured in round 2: a static s_setprio(1) for the second-dispatched half of the workgroup changes nothing here)
-    for (int seq = 0; seq < my_tiles; ++seq) {
+    static_assert(!RS || FUSE, "register staging is counted for the fused forward schedule");
+    auto iteration = [&](auto par, int seq) {
         PG_STAMP(0);
         PG_STAMP(6);
+        if (RS) {
+            // tile seq+1 sits in register set !par (loaded two iterations ago): wait for it, hand it to LDS slot (seq+1) % NSLOT (the
+            // tile read there, seq-3, is long done), and send the same registers for tile seq+3.  Operations younger than tile
+            // seq+1's loads: the stores of iteration seq-2 (tile seq-3's epilogue), the loads and stores of iteration seq-1.
+            constexpr int Q = 1 - decltype(par)::value;
+            if (seq + 1 < my_tiles) {
+                if (seq + 3 < my_tiles) {
+                    if (seq <= 1) { PG_WAIT(GT); } else if (seq == 2) { PG_WAIT(GT + S); } else { PG_WAIT(GT + 2 * S); }
+                } else {
+                    PG_WAIT(0);
+                }
+                rs_write(std::integral_constant<int, Q>{}, seq + 1);
+                if (seq + 3 < my_tiles) rs_load(std::integral_constant<int, Q>{}, seq + 3);
+            }
+        } else
         // ops issued after tile seq's loads: 2 more tiles' loads plus the stores of the iterations in between (the late
         // half issues the stores of a tile one iteration later: its counts lag by one)
         if (seq + 2 < my_tiles) {
@@ -470,7 +539,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         // profiles/r03_b_inkernel_stamps_panel_k2_before.txt).  Each wave issues one piece per k-group of its MFMA phase
         // instead; the LAST A piece stays the last VMEM operation of the iteration's loads, so the hand counts of
         // s_waitcnt vmcnt above are unchanged (stores of the fused epilogue that precede it in program order are older ops).
-        const bool more = !(PG_ABL & 2) && seq + 3 < my_tiles;
+        const bool more = !RS && !(PG_ABL & 2) && seq + 3 < my_tiles;
 #if PG_SPREAD_DMA
         constexpr int NGRP_ = PAD ? NKK / PG_GK : NKK;
         auto dma = [&](int g) {
@@ -545,6 +614,14 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             mfma_phase(seq, acc, dma);
         }
         PG_STAMP(5);
+    };
+    if (RS) {
+        for (int seq = 0; seq < my_tiles; seq += 2) {
+            iteration(std::integral_constant<int, 0>{}, seq);
+            if (seq + 1 < my_tiles) iteration(std::integral_constant<int, 1>{}, seq + 1);
+        }
+    } else {
+        for (int seq = 0; seq < my_tiles; ++seq) iteration(std::integral_constant<int, 0>{}, seq);
     }
     if (late) epilogue(my_tiles - 1, acc, mw, am);
 #ifdef PG_STAMPS
