@@ -622,7 +622,7 @@ def test_abmil_dropout_bf16_fast_path_close_to_fp32_and_seeded_masks_equal_mater
         oa.sum().backward(), ob.sum().backward()
         for (k, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
             if a.grad is not None and k != "attention.2.bias":
-                assert ((a.grad - b.grad).norm() / b.grad.norm()).item() < (1e-5 if dtype == torch.float32 else 2e-2), k
+                assert ((a.grad - b.grad).norm() / b.grad.norm()).item() < (1e-5 if dtype == torch.float32 else 5e-2), k
 
 
 def test_abmil_training_mode_dropout_draws_fresh_masks_and_eval_is_deterministic():
