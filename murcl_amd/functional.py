@@ -278,15 +278,21 @@ class ABMILFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dA):
-        (x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
-         b1, b2, b3, bb, bd, wat, w3t, w2t) = ctx.saved_tensors
-        B, N, d = ctx.dims
-        T = x2.dtype
-        L = h3.shape[1]
         if dout is None:
             return (None,) * 14
         if ctx.drop_scale is not None or not ctx.pool_fast:
             return ABMILFn._backward_general(ctx, dout)
+        return ABMILFn._backward_default(ctx.saved_tensors, ctx.dims, dout, ctx.needs_input_grad[0]) + (None,)
+
+    @staticmethod
+    def _backward_default(saved, dims, dout, need_dx):
+        """The backward pass of the default configuration on explicit tensors (``ABMILFn.backward`` hands it one call's saved
+        tensors, ``EncoderSession`` the activations of all patch steps of a training step as one batch)."""
+        (x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
+         b1, b2, b3, bb, bd, wat, w3t, w2t) = saved
+        B, N, d = dims
+        T = x2.dtype
+        L = h3.shape[1]
         # decoder (bag level, f32)
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd, dbd = _wbgrad(dpre, M, wd, bd)
@@ -339,13 +345,13 @@ class ABMILFn(torch.autograd.Function):
         else:
             dw1 = _wgrad(dz1, x2, w1)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             dx = ops.gemm_nt(dz1, ops.transpose_cast(w1, T)).view(B, N, d)
         if direct_k2:
             dba = dwb = dbb = None
         else:
             dba, dwb, dbb = _pgrad(dba, ba), _pgrad(dwb.reshape(1, -1), wb), _pgrad(dbb, bb)
-        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd, None
+        return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd
 
     @staticmethod
     def _backward_general(ctx, dout):
@@ -391,6 +397,93 @@ class ABMILFn(torch.autograd.Function):
             dw2, db2, dw1, db1 = dw2 * s2, db2 * s2, dw1 * s1, db1 * s1
             dx = dx * s1 if dx is not None else None
         return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd, None
+
+
+def abmil_fast_path(rows, N, d, L, D, dtype):
+    """Does an ABMIL call of this shape take the bf16 weight-stationary encoder + one-pass pooling kernels?"""
+    return (dtype == torch.bfloat16 and d == 512 and L == 512 and D == 128 and ops.panel_supported(rows, L, 512, ops.PG_BIAS_RELU)
+            and ops.panel_supported(rows, L, 128, ops.PG_RANK1_MASK, N))
+
+
+class EncoderSession:
+    """ONE aggregator backward for the T patch steps of a sequential training step (train_MuRCL.py:233-304 at train_stage 3).
+
+    The PPO sampler picks step t+1's windows from step t's aggregator states, so the T forward passes cannot be batched -
+    but their backward passes can: every step's sub-bags and activations are written into row blocks of ONE set of buffers
+    (``x``, ``h1..h3``, ReLU bit masks, scores, pooled vectors), the per-step autograd nodes (``ABMILStepFn``) only collect their
+    upstream gradients, and the node autograd reaches last runs the backward kernels once over all T * bags bags: each dgrad /
+    wgrad / pooling-backward kernel once at full size instead of T times at 1/T of it (a launch costs ~15 us before its first tile
+    and the weight gradients re-reduce their partial tiles per launch)."""
+
+    def __init__(self, steps, bags, N, d, L, dtype, device):
+        self.steps, self.bags, self.N, self.d, self.L = steps, bags, N, d, L
+        R, Bt = steps * bags * N, steps * bags
+        e = lambda shape, dt: torch.empty(shape, dtype=dt, device=device)      # noqa: E731
+        self.x = e((steps, bags, N, d), dtype)
+        self.h1, self.h2, self.h3 = e((R, L), dtype), e((R, L), dtype), e((R, L), dtype)
+        self.m1, self.m2, self.m3 = (e((R, L // 8), torch.uint8) for _ in range(3))
+        self.scores, self.A = e((Bt, N), torch.float32), e((Bt, N), torch.float32)
+        self.M, self.ml, self.out = e((Bt, L), torch.float32), e((Bt, 2), torch.float32), e((Bt, L), torch.float32)
+        self.t, self.pending, self.dout, self.weights = 0, 0, [None] * steps, None
+
+    def views(self, t):
+        """The [bags, N, d] block step t's sub-bags are gathered into (``subbag_views(out=...)``)."""
+        return self.x[t]
+
+    def rows(self, buf, t, per=None):
+        per = self.bags * self.N if per is None else per
+        return buf[t * per:(t + 1) * per]
+
+
+class ABMILStepFn(torch.autograd.Function):
+    """One patch step's ABMIL forward inside an ``EncoderSession`` (default shape, bf16): same kernels as ``ABMILFn``, results in
+    the session's row blocks; the backward only files its upstream gradient until the session's last node runs them all."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wa, ba, wb, bb, wd, bd, session):
+        s, t = session, session.t
+        B, N, d = x.shape
+        T = x.dtype
+        assert t < s.steps and (B, N, d) == (s.bags, s.N, s.d), "EncoderSession: shape / step count differ from what it was built for"
+        x2 = s.x[t].view(B * N, d)
+        if x.data_ptr() != x2.data_ptr():
+            x2.copy_(x.reshape(B * N, d))
+        w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views([(w, False, T) for w in (w1, w2, w3, wa)] +
+                                                              [(wa, True, T), (w3, True, T), (w2, True, T)])
+        nt = _STREAM_A
+        h1, _, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=True, stream_a=bool(nt & 1),
+                                  out=s.rows(s.h1, t), bitmask_out=s.rows(s.m1, t))
+        h2, _, _ = ops.panel_gemm(h1, w2c, ops.PG_BIAS_RELU, bias=b2, want_bitmask=True, reverse=True, stream_a=bool(nt & 2),
+                                  out=s.rows(s.h2, t), bitmask_out=s.rows(s.m2, t))
+        h3, _, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=True, stream_a=bool(nt & 4),
+                                  out=s.rows(s.h3, t), bitmask_out=s.rows(s.m3, t))
+        blk = lambda buf: s.rows(buf, t, B)                                          # noqa: E731
+        _, A, M, _ = ops.abmil_pool_fwd(h3.view(B, N, s.L), wac, ba, wb, bb, out=(blk(s.scores), blk(s.A), blk(s.M), blk(s.ml)))
+        out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd, out=blk(s.out))
+        s.weights = (w1, w2, w3, wa, ba, wb, wd, wac, b1, b2, b3, bb, bd, wat, w3t, w2t)
+        s.t, s.pending = t + 1, s.pending + 1
+        ctx.session, ctx.t = s, t
+        ctx.mark_non_differentiable(A)
+        ctx.set_materialize_grads(False)
+        return out, A
+
+    @staticmethod
+    def backward(ctx, dout, _dA):
+        s = ctx.session
+        s.dout[ctx.t] = dout
+        s.pending -= 1
+        if s.pending > 0:
+            return (None,) * 14
+        n = s.t                                                                      # steps that ran
+        if all(g is None for g in s.dout[:n]):
+            return (None,) * 14
+        like = next(g for g in s.dout[:n] if g is not None)
+        dout_all = torch.cat([g.contiguous() if g is not None else torch.zeros_like(like) for g in s.dout[:n]], 0)
+        (w1, w2, w3, wa, ba, wb, wd, wac, b1, b2, b3, bb, bd, wat, w3t, w2t) = s.weights
+        R, Bt = n * s.bags * s.N, n * s.bags
+        saved = (s.x.view(-1, s.d)[:R], s.h1[:R], s.h2[:R], s.h3[:R], s.scores[:Bt], s.A[:Bt], s.M[:Bt], s.ml[:Bt], s.out[:Bt],
+                 w1, w2, w3, wa, ba, wb, wd, wac, s.m1[:R], s.m2[:R], s.m3[:R], b1, b2, b3, bb, bd, wat, w3t, w2t)
+        return ABMILFn._backward_default(saved, (Bt, s.N, s.d), dout_all, False) + (None,)
 
 
 class GRUStepFn(torch.autograd.Function):

@@ -10,7 +10,7 @@ for all bags of a batch at once instead of the reference's per-bag Python loop (
 import torch
 from torch import nn
 
-from ..functional import ABMILFn
+from ..functional import ABMILFn, ABMILStepFn
 
 
 def _stack(spec):
@@ -33,6 +33,7 @@ class ABMIL(nn.Module):
         self.compute_dtype = torch.float32           # torch.bfloat16 = throughput path
         self.last_attention = None                   # A [B,N] of the most recent call (detached)
         self.keep_masks = None                       # tests: (k1, k2) keep-multiplier tensors [B*N, L] replacing the dropout draws
+        self.session = None                          # functional.EncoderSession of the training step in progress (deferred backward)
 
     # -- kernels -------------------------------------------------------------------------
     def _bags(self, x):
@@ -52,6 +53,12 @@ class ABMIL(nn.Module):
             x = ops.cast(x.float().contiguous(), self.compute_dtype) if x.dtype != torch.float32 else \
                 ops.cast(x.contiguous(), self.compute_dtype)
         e, a, d = self.encoder, self.attention, self.decoder
+        if self.session is not None and drops is None and torch.is_grad_enabled():
+            # a sequential training step keeps all its patch steps' activations in one set of buffers and runs ONE backward
+            out, A = ABMILStepFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
+                                       a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, self.session)
+            self.last_attention = A
+            return out
         out, A = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
                                a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops)
         self.last_attention = A

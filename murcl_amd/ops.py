@@ -129,7 +129,7 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False, colsum_into=None, colsum_defer=False, reverse=False, stream_a=False):
+               colsum=False, colsum_into=None, colsum_defer=False, reverse=False, stream_a=False, out=None, bitmask_out=None):
     """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
     ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None.
     ``colsum_defer``: no second launch - the third result is (partial rows [R,N] f32, R) for ``gemm_tn(colsum_parts=...)``,
@@ -142,8 +142,13 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     M, K = A.shape
     N = W.shape[0]
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
-    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
-    bm = torch.empty((M, N // 8), dtype=torch.uint8, device=A.device) if want_bitmask else None
+    # ``out`` / ``bitmask_out``: caller-owned result buffers (row blocks of a larger tensor: functional.EncoderSession)
+    C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device) if out is None else out
+    assert C.is_contiguous() and C.dtype == torch.bfloat16 and tuple(C.shape) == (M, N)
+    bm = None
+    if want_bitmask:
+        bm = torch.empty((M, N // 8), dtype=torch.uint8, device=A.device) if bitmask_out is None else bitmask_out
+        assert bm.is_contiguous() and bm.dtype == torch.uint8 and bm.numel() == M * N // 8
     cs = torch.empty((N,), dtype=torch.float32, device=A.device) if (colsum and colsum_into is None and not colsum_defer) else None
     if colsum_into is not None:
         assert not colsum_defer
@@ -223,8 +228,9 @@ def pool_chunks(B, N, dtype_code):
     return cr.value, nc.value
 
 
-def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
-    """H [B,N,512], Wa [128,512] (same dtype) -> scores [B,N], A [B,N], M [B,512], ml [B,2] (all f32)."""
+def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
+    """H [B,N,512], Wa [128,512] (same dtype) -> scores [B,N], A [B,N], M [B,512], ml [B,2] (all f32).
+    ``out`` = (scores, A, M, ml) caller-owned contiguous buffers of those shapes."""
     _need_cuda(H, Wa)
     H, Wa = _c(H), _c(Wa)
     B, N, L = H.shape
@@ -233,10 +239,15 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None):
         exact_tanh = H.dtype == torch.float32
     dev = H.device
     _, S = pool_chunks(B, N, dt(H))
-    scores = torch.empty((B, N), dtype=torch.float32, device=dev)
-    A = torch.empty((B, N), dtype=torch.float32, device=dev)
-    M = torch.empty((B, L), dtype=torch.float32, device=dev)
-    ml = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    if out is None:
+        scores = torch.empty((B, N), dtype=torch.float32, device=dev)
+        A = torch.empty((B, N), dtype=torch.float32, device=dev)
+        M = torch.empty((B, L), dtype=torch.float32, device=dev)
+        ml = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    else:
+        scores, A, M, ml = out
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in out)
+        assert tuple(scores.shape) == (B, N) and tuple(A.shape) == (B, N) and tuple(M.shape) == (B, L) and tuple(ml.shape) == (B, 2)
     part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
     es = H.element_size()
     # algorithmic bytes per bag: H once + scores out + pooled M out; Wa amortised over the launch

@@ -84,6 +84,7 @@ def get_scheduler(args, optimizer):
     return make_scheduler(optimizer, args.scheduler, args.epochs, args.warmup)
 
 
+_DEFERRED_ENCODER = os.environ.get("MURCL_DEFERRED_ENCODER", "1") == "1"     # dev A/B switch: one aggregator backward per sequential step
 _BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/B switch: the recurrent head over all patch steps at once
 
 
@@ -103,6 +104,13 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
     losses, rewards, sim_last, states = [], [], None, None
     late_head, agg_outs = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), []
+    # stage 3: the T aggregator passes stay sequential (the sampler needs step t's states for step t+1's windows) but share ONE
+    # backward over all T * 2B bags (functional.EncoderSession); ABMIL's default shape in bf16 only
+    enc, session = model.encoder, None
+    d_feat = pack.feats.shape[1]
+    if (_DEFERRED_ENCODER and train_enc and args.T > 1 and isinstance(enc, abmil.ABMIL) and enc.K == 1 and not (enc.training and enc.dropout > 0)
+            and functional.abmil_fast_path(2 * B * args.feat_size, args.feat_size, d_feat, enc.L, enc.D, dt_)):
+        session = enc.session = functional.EncoderSession(args.T, 2 * B, args.feat_size, d_feat, enc.L, dt_, dev)
     if injected is None:
         # every random number of the step in four launches (uniform window positions, mix-up draws, the sampler's Gaussian
         # noise) instead of ~10 tiny launches per view and patch step; none of them depends on anything computed in the step
@@ -120,7 +128,8 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         if injected is not None and injected.get("trace") is not None:
             injected["trace"].append([a.detach().clone() for a in acts])
         views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=dt_,
-                                draws=mix[2 * t:2 * t + 2] if injected is None else injected["draws"][t])   # :237-239,266-269
+                                draws=mix[2 * t:2 * t + 2] if injected is None else injected["draws"][t],
+                                out=None if session is None else session.views(t))                        # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
             outputs, states = model(views)                                                   # :242,271
             if late_head:
@@ -164,6 +173,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                         m.rewards.append(reward)
                 sim_last = sim
     loss = sum(losses) / args.T                                                              # :291
+    enc.session = None
     if train_enc:
         optimizer.zero_grad()
         with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each

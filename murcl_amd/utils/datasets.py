@@ -227,7 +227,7 @@ class MixDraws(list):
         return super().__getitem__(i)
 
 
-def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None):
+def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None, out=None):
     """Fused K12+K13 for V views: returns (views: list of [B,feat_size,d] slices of ONE buffer, draws).
 
     ``draws`` = list of (lambda_ [B,1], rand_idx [B]) per view (generated like ``mixup`` when None and
@@ -241,7 +241,11 @@ def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, 
     else:
         V = len(action_sequences)
         acts = action_sequences[0].unsqueeze(0) if V == 1 else torch.stack([a.to(torch.float32) for a in action_sequences], 0)
-    buf = torch.empty((V * B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
+    if out is None:
+        buf = torch.empty((V * B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
+    else:                                   # a caller-owned [V*B, feat_size, d] block (functional.EncoderSession keeps all patch steps' views)
+        buf = out
+        assert buf.is_contiguous() and tuple(buf.shape) == (V * B, feat_size, d) and buf.dtype == (out_dtype or pack.feats.dtype)
     idx, _ = select_indices(pack, acts.reshape(V, B, pack.K), feat_size)
     used, lam, perm = [], None, None
     if alpha is not None or draws is not None:

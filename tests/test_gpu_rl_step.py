@@ -25,7 +25,7 @@ def _close_summ(got, want, rtol, msg=""):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * want[1], err_msg=msg)
 
 
-def _build(tmp_path, stage, Tn, seed, K, fs, B, ppo_lr, lr, K_epochs=3):
+def _build(tmp_path, stage, Tn, seed, K, fs, B, ppo_lr, lr, K_epochs=3, dtype="f32"):
     """Stage-k objects through the product's own create_model: the previous stage's checkpoint is written from the
     deterministic parameter sets and picked up by the default ``../stage_{k-1}/model_best.pth.tar`` rule."""
     from murcl_amd.train_MuRCL import build_parser, create_model, get_optimizer
@@ -35,7 +35,7 @@ def _build(tmp_path, stage, Tn, seed, K, fs, B, ppo_lr, lr, K_epochs=3):
     torch.save({"epoch": 1, "model_state_dict": {"encoder." + k: v for k, v in P.to_torch(P.abmil(seed)).items()},
                 "fc": P.to_torch(P.full_layer(seed)), "optimizer": None, "ppo_optimizer": None, "policy": pol},
                prev / "model_best.pth.tar")
-    args = build_parser().parse_args(["--arch", "ABMIL", "--dtype", "f32", "--train_stage", str(stage), "--T", str(Tn),
+    args = build_parser().parse_args(["--arch", "ABMIL", "--dtype", dtype, "--train_stage", str(stage), "--T", str(Tn),
                                       "--feat_size", str(fs), "--batch_size", str(B), "--num_clusters", str(K),
                                       "--ppo_lr", str(ppo_lr), "--backbone_lr", str(lr), "--fc_lr", str(lr),
                                       "--K_epochs", str(K_epochs), "--save_dir", str(tmp_path / f"stage_{stage}")])
@@ -136,6 +136,51 @@ def test_rl_in_the_loop_step_vs_oracle_other_shape(tmp_path, stage):
         for k, v in ppo.policy.state_dict().items():
             want = _summ(r["policy"][k] - pp[k])
             _close_summ(_summ(v.cpu() - pre_pol[k].cpu()), want, 3e-2, k)
+
+
+def test_stage3_one_deferred_aggregator_backward_equals_the_per_step_backwards(tmp_path, monkeypatch):
+    """Stage 3 (bf16): the T sequential aggregator passes write into one EncoderSession and share ONE backward over all T * 2B
+    bags; same forward (losses, rewards, actions bit for bit) and the same update as T separate backward passes."""
+    from murcl_amd import functional, train_MuRCL as TM
+    seed, B, K, fs, Tn = 41, 4, 10, 128, 4
+    Ns = [700 + 53 * b for b in range(B)]
+    feats = [P.bags(seed, f"f{b}", 1, Ns[b], 512)[0] for b in range(B)]
+    cls = [P.cluster_lists(seed, f"c{b}", Ns[b], K) for b in range(B)]
+    inj = {"actions": [[detrand.uniform(seed, f"a{v}", (B, K)).astype(np.float32) for v in range(2)]],
+           "draws": [[(detrand.uniform(seed, f"l{t}{v}", (B, 1), 0.9, 1.0).astype(np.float32), detrand.permutation(seed, f"p{t}{v}", B))
+                      for v in range(2)] for t in range(Tn)],
+           "eps": [[detrand.normal(seed, f"e{t}{v}", (B, K)).astype(np.float32) for v in range(2)] for t in range(Tn - 1)]}
+    made = []
+    real_init = functional.EncoderSession.__init__
+    monkeypatch.setattr(functional.EncoderSession, "__init__", lambda self, *a, **k: (made.append(a), real_init(self, *a, **k))[1])
+
+    def run(deferred):
+        monkeypatch.setattr(TM, "_DEFERRED_ENCODER", deferred)
+        args, model, fc, ppo, opt, dev = _build(tmp_path / f"d{int(deferred)}", 3, Tn, seed, K, fs, B, 1e-5, 1e-3, dtype="bf16")
+        p0 = [p.detach().clone() for p in list(model.parameters()) + list(fc.parameters())]
+        loss, losses, rewards, acts, logp, ids = _run(args, model, fc, ppo, opt, dev, feats, cls, inj, B)
+        assert model.encoder.session is None
+        p1 = [p.detach().clone() for p in list(model.parameters()) + list(fc.parameters())]
+        return [l.item() for l in losses], torch.cat(rewards).cpu().numpy(), [torch.stack(a).cpu().numpy() for a in acts], p0, p1
+
+    n0 = len(made)
+    a = run(True)
+    assert len(made) == n0 + 1 and made[-1][0] == Tn and made[-1][1] == 2 * B          # one session of T steps x 2B bags
+    b = run(False)
+    assert len(made) == n0 + 1
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
+    np.testing.assert_array_equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        np.testing.assert_array_equal(x, y)
+    moved = 0
+    for p0, pa, pb in zip(a[3], a[4], b[4]):
+        step = (pb - p0).norm().item()
+        if step == 0.0:
+            assert torch.equal(pa, p0)
+            continue
+        moved += 1
+        assert ((pa - pb).norm().item() / step) < 3e-2
+    assert moved >= 10
 
 
 def test_flat_adam_skips_parameters_without_gradient_like_torch():
