@@ -32,6 +32,12 @@
 #ifndef K2_SPREAD_DMA
 #define K2_SPREAD_DMA 0          // 1: the next pair's LDS-DMA pieces go out one per k-group of the score MFMA loop (measured r03: neutral, 62.9 vs 62.3 us)
 #endif
+#ifndef K2_STAGGER
+#define K2_STAGGER 0             // 1: tile 1's score MFMAs run beside tile 0's tanh, pooling B operands requested before the barrier (measured r03: neutral, 61.3-62.3 vs 61.6-62.8 us)
+#endif                           // requested before the barrier that precedes the pooling (see the paired loop)
+#ifndef K2_WPRO
+#define K2_WPRO 1                // bf16 forward: the wave's Wa slice is fetched as whole 1 KiB rows (LDS-DMA into the not yet used ring)
+#endif                           // and read back as fragments, instead of fragment-shaped global loads (see the prologue)
 #ifndef K2_PAIR
 #define K2_PAIR 1                // bf16 forward: two 16-row tiles per iteration (see the paired loop)
 #endif
@@ -93,7 +99,13 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     };
     constexpr bool PAIR = K2_PAIR && sizeof(T) == 2 && !EXACT_TANH;
     const int pre = min(PAIR ? 4 : 3, my_tiles);
-    for (int s = 0; s < pre; ++s) issue(s);
+    // Weight prologue.  A fragment-shaped global load (16 rows x 4 pieces of 16 B, 256 B apart) touches 64 cache lines per
+    // instruction: 32 such instructions per wave pull each line of the slice through the CU's memory pipe up to eight times -
+    // about as many bytes as the workgroup's whole share of H.  WPRO: the wave's 16 rows per column block travel as 16 whole-row
+    // LDS-DMA pieces into its private quarter of the (still empty) tile ring and come back as conflict-free ds_read_b128 fragments.
+    constexpr bool WPRO = K2_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+    if (!WPRO)
+        for (int s = 0; s < pre; ++s) issue(s);
 
     // ---- this wave's DW columns of Wa as MFMA "a" operands: row d = DW*wave + 16j + r16; quarter q4 of k-step
     // kk covers the 16-byte chunk (kk + NKK*q4) of the row (any k assignment works as long as H uses the same)
@@ -102,8 +114,22 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
 #pragma unroll
     for (int j = 0; j < C_::NJ; ++j) {
         const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
+        if (WPRO) {
+            const char* wblk = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j) * K2_L);
+            const unsigned stage = lds0 + wave * 16 * C_::PADB;
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK; ++kk) {
+            for (int u = 0; u < 16; ++u) glds16_u(wblk + (size_t)u * C_::ROWB, lane * 16, stage + u * C_::PADB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* fb = smem + (wave * 16 + r16) * C_::PADB + C_::NKK * q4 * 16;
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) {
+                wa[j][kk] = *(const frag_t*)(fb + kk * 16);
+                asm volatile("" : "+v"(wa[j][kk]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next block's pieces overwrite these rows
+        }
+#pragma unroll
+        for (int kk = 0; kk < C_::NKK && !WPRO; ++kk) {
             wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
             asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
         }
@@ -121,6 +147,10 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     const bool fixed_ref = smax < 30.f;
     // retire the compiler-counted loads above; from here on the only VMEM ops in flight are LDS-DMA tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (WPRO) {
+        LDS_BARRIER();                          // every wave has read its fragments back: the ring is free for tiles
+        for (int s = 0; s < pre; ++s) issue(s);
+    }
 
     // Pooling runs on the matrix cores too: M[PC*w + 16j + c] += sum_r p_r H[r][.] as a 16x16 MFMA whose A operand
     // carries p in row 0 (bf16: p = hi + lo split over rows 0 and 1, so p keeps ~16 mantissa bits; f32: exact) and
@@ -177,6 +207,56 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
             f32x4 acc0[C_::NJ], acc1[C_::NJ];
 #pragma unroll
             for (int j = 0; j < C_::NJ; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = acc0[j]; }
+            float ps0 = 0.f, ps1 = 0.f;
+            // pooling B operands (k-major 4x16 reads of both tiles): with K2_STAGGER they are requested right after the score
+            // MFMAs - the fragment registers of the score loop are free by then - and land while the tanh of tile 1 issues
+            s16x4 pb0[C_::NPJ], pb1[C_::NPJ];
+            const int pu = lane & 15;
+            const unsigned ptoff = (4 * q4 + (pu >> 2)) * C_::PADB + (C_::PC * wave + 4 * (pu & 3)) * 2;
+            if constexpr (K2_STAGGER && C_::NJ == 2) {
+                // Staggered chains: tile 0's 32 MFMAs first; tile 1's 32 MFMAs then run with tile 0's eight tanh evaluations (one
+                // v_exp + one v_rcp each) issued between them - the VALU work of one tile rides in the shadow of the other's
+                // matrix work instead of both tiles' tanh following both tiles' MFMAs.
+                const char* h0 = tile0 + r16 * C_::PADB + C_::NKK * q4 * 16;
+                const char* h1 = tile1 + r16 * C_::PADB + C_::NKK * q4 * 16;
+                constexpr int GK = 4, NG = C_::NKK / GK;
+                frag_t hq[2][GK];
+                auto tile_mfmas = [&](const char* hb, f32x4 (&acc)[C_::NJ], auto&& hook) {
+#pragma unroll
+                    for (int k2 = 0; k2 < GK; ++k2) hq[0][k2] = *(const frag_t*)(hb + k2 * 16);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g + 1 < NG) {
+#pragma unroll
+                            for (int k2 = 0; k2 < GK; ++k2) hq[(g + 1) & 1][k2] = *(const frag_t*)(hb + ((g + 1) * GK + k2) * 16);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k2 = 0; k2 < GK; ++k2)
+#pragma unroll
+                            for (int j = 0; j < C_::NJ; ++j) acc[j] = k2_mma<T>(wa[j][g * GK + k2], hq[g & 1][k2], acc[j]);
+                        hook(g);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                tile_mfmas(h0, acc0, [](int) {});
+                tile_mfmas(h1, acc1, [&](int g) {
+                    // two of tile 0's eight values per k-group: (j, r) = (g / 2, 2 (g % 2) + {0, 1})
+                    const int j = g >> 1, r = 2 * (g & 1);
+                    ps0 += wb_r[j][r] * fast_tanh(acc0[j][r] + ba_r[j][r]);
+                    ps0 += wb_r[j][r + 1] * fast_tanh(acc0[j][r + 1] + ba_r[j][r + 1]);
+                });
+                K2_STAMP(4);
+#pragma unroll
+                for (int j = 0; j < C_::NPJ; ++j) {
+                    pb0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile0 + ptoff + j * 32));
+                    pb1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile1 + ptoff + j * 32));
+                }
+#pragma unroll
+                for (int j = 0; j < C_::NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ps1 += wb_r[j][r] * fast_tanh(acc1[j][r] + ba_r[j][r]);
+            } else {
             {
                 const char* h0 = tile0 + r16 * C_::PADB + C_::NKK * q4 * 16;
                 const char* h1 = tile1 + r16 * C_::PADB + C_::NKK * q4 * 16;
@@ -211,7 +291,6 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                 }
             }
             K2_STAMP(4);
-            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int j = 0; j < C_::NJ; ++j)
 #pragma unroll
@@ -219,6 +298,7 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                     ps0 += wb_r[j][r] * fast_tanh(acc0[j][r] + ba_r[j][r]);
                     ps1 += wb_r[j][r] * fast_tanh(acc1[j][r] + ba_r[j][r]);
                 }
+            }
             ps0 = quarters_sum(ps0);
             ps1 = quarters_sum(ps1);
             if (q4 == 0) { spart[wave * 16 + r16] = ps0; spart1[wave * 16 + r16] = ps1; }
@@ -263,14 +343,14 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                 const u32x2 w0 = u32x2{__builtin_amdgcn_perm(pa0[1], pa0[0], psel), __builtin_amdgcn_perm(pa0[3], pa0[2], psel)};
                 const u32x2 w1 = u32x2{__builtin_amdgcn_perm(pa1[1], pa1[0], psel), __builtin_amdgcn_perm(pa1[3], pa1[2], psel)};
                 const s16x4 af0 = __builtin_bit_cast(s16x4, w0), af1 = __builtin_bit_cast(s16x4, w1);
-                const int u = lane & 15, rq = u >> 2, pp4 = u & 3;
-                const unsigned toff = (4 * q4 + rq) * C_::PADB + (C_::PC * wave + 4 * pp4) * 2;
 #pragma unroll
                 for (int j = 0; j < C_::NPJ; ++j) {
-                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile0 + toff + j * 32));
-                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile1 + toff + j * 32));
-                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af0, b0, macc[j], 0, 0, 0);
-                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af1, b1, macc[j], 0, 0, 0);
+                    if (!(K2_STAGGER && C_::NJ == 2)) {
+                        pb0[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile0 + ptoff + j * 32));
+                        pb1[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile1 + ptoff + j * 32));
+                    }
+                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af0, pb0[j], macc[j], 0, 0, 0);
+                    macc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af1, pb1[j], macc[j], 0, 0, 0);
                 }
             }
             if (tin + 1 == tiles_per_item - 1) {    // ---- end of item: publish partial + raw scores
