@@ -25,6 +25,9 @@ template <typename T> struct KBLds {
     static constexpr int BYTES = OFF_SC + K2_NSLOT * K2<T>::NW * 256;
 };
 
+#ifndef K2B_WPRO
+#define K2B_WPRO 1
+#endif
 template <typename T, bool EXACT_TANH>
 __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
@@ -62,15 +65,33 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         ip.next(tiles_per_item, gridDim.x, S);
     };
     const int pre = min(3, my_tiles);
-    for (int s = 0; s < pre; ++s) issue(s);
+    // weight prologue as in the forward kernel (attn_pool.hip): whole-row LDS-DMA pieces through the still empty tile ring
+    // instead of fragment-shaped global loads that touch 64 cache lines per instruction
+    constexpr bool WPRO = K2B_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+    if (!WPRO)
+        for (int s = 0; s < pre; ++s) issue(s);
 
     frag_t wa[C_::NJ][C_::NKK];
     float ba_r[C_::NJ][4], wb_r[C_::NJ][4], dba_r[C_::NJ][4], dwb_r[C_::NJ][4];
 #pragma unroll
     for (int j = 0; j < C_::NJ; ++j) {
         const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
+        if (WPRO) {
+            const char* wblk = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j) * K2_L);
+            const unsigned stage = lds0 + wave * 16 * C_::PADB;
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK; ++kk) {
+            for (int u = 0; u < 16; ++u) glds16_u(wblk + (size_t)u * C_::ROWB, lane * 16, stage + u * C_::PADB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* fb = smem + (wave * 16 + r16) * C_::PADB + C_::NKK * q4 * 16;
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) {
+                wa[j][kk] = *(const frag_t*)(fb + kk * 16);
+                asm volatile("" : "+v"(wa[j][kk]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next block's pieces overwrite these rows
+        }
+#pragma unroll
+        for (int kk = 0; kk < C_::NKK && !WPRO; ++kk) {
             wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
             asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
         }
@@ -87,6 +108,10 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     float bag_m = 0.f, bag_invl = 0.f, bag_c = 0.f;
     int cur_bag = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (WPRO) {
+        LDS_BARRIER();                          // every wave has read its fragments back: the ring is free for tiles
+        for (int s = 0; s < pre; ++s) issue(s);
+    }
 
     for (int seq = 0; seq < my_tiles; ++seq) {
         // only the 5 LDS-DMA ops per tile are counted; the dT stores issued in between are also younger than

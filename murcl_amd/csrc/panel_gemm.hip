@@ -61,6 +61,9 @@
 #ifndef PG_REGSTAGE
 #define PG_REGSTAGE 0     // 1: forward variants (K = 512, bias epilogues): A tiles travel global -> VGPRs -> LDS (plain 16-byte loads two
 #endif                    // tiles ahead into two register sets, ds_write_b128 one tile ahead) instead of LDS-DMA (see the tile loop)
+#ifndef PG_WPRO
+#define PG_WPRO 1         // K = 512: a wave's W slice arrives as whole 1 KiB rows (LDS-DMA into the still empty tile ring) and is read
+#endif                    // back as fragments, instead of fragment-shaped global loads that touch 64 cache lines each (see the prologue)
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
@@ -272,7 +275,13 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             *(u32x4*)(slot + row * PADB + lane * 16) = rs_reg[P][j];
         }
     };
-    const int pre = RS ? 0 : min(3, my_tiles);
+    // Weight prologue (WPRO, K = 512): a fragment-shaped global load (16 rows x 4 pieces of 16 B, 256 B apart) touches 64 cache
+    // lines per instruction, and the NJ * NKK of them a wave needs pull every line of its slice through the CU's memory pipe up to
+    // eight times.  Instead each 16-row block of the slice travels as 16 whole-row LDS-DMA pieces into the wave's private 1/NW of
+    // the tile ring (not yet in use: the first tiles are requested after the fragments have been read back).  Measured on the K2
+    // forward, which has the same prologue: 62.8 -> 55.1 us per launch (profiles/r03_m).
+    constexpr bool WPRO = PG_WPRO != 0 && PAD && !RS && PG_NW * 16 * PADB <= PG_NSLOT * SLOT;
+    const int pre = (RS || WPRO) ? 0 : min(3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
     if (RS) rs_load(std::integral_constant<int, 0>{}, 0);
 
@@ -281,6 +290,21 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const bf16_t* wrow = W + (size_t)(n0 + 16 * j + r16) * K;
+        if (WPRO) {
+            const char* wblk = (const char*)(W + (size_t)(n0 + 16 * j) * K);
+            const unsigned stage = lds0 + wave * 16 * PADB;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) glds16_u(wblk + (size_t)u * ROWB, lane * 16, stage + u * PADB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* fb = smem + (wave * 16 + r16) * PADB + NKK * q4 * 16;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                wf[j][kk] = *(const bf16x8*)(fb + kk * 16);
+                asm volatile("" : "+v"(wf[j][kk]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next block's pieces overwrite these rows
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             // k assignment of lane quarter q4 in k-step kk: PAD -> 16-byte chunk (kk + NKK*q4); else chunk (4kk + q4)
@@ -311,6 +335,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (WPRO) {
+        LDS_BARRIER();                           // every wave has read its fragments back: the ring is free for tiles
+        const int pre_w = min(3, my_tiles);
+        for (int s = 0; s < pre_w; ++s) issue(s);
+    }
     if (RS) {
         rs_write(std::integral_constant<int, 0>{}, 0);
         if (my_tiles > 1) rs_load(std::integral_constant<int, 1>{}, 1);
