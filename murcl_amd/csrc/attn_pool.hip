@@ -2,13 +2,15 @@
 //
 //   s_n = wb . tanh(Wa H_n + ba) + bb ;  A = softmax_N(s) / sqrt(N) ;  M = A . H
 //
-// One pass over H.  Persistent workgroups (one per CU, 8 waves = two per SIMD, so one wave's VALU phases
-// overlap its partner's MFMAs) walk (bag, row-chunk) items; H row tiles stream HBM -> LDS by LDS-DMA
-// into a 4-slot ring with three tiles (96 KiB) in flight per CU; each wave keeps its 16-column slice of
-// Wa in registers as MFMA operands for the whole launch, so per tile the matrix cores see only LDS reads
-// of H.  Scores are reduced across waves through LDS, the soft-max is kept online (running max / sum per
-// chunk), and the weighted sum M is accumulated on the VALU from the same LDS tile.  Per-chunk partials
-// (m, l, sum p.H) are merged per bag by abmil_pool_combine_kernel.
+// One pass over H.  bf16 (throughput path): persistent 4-wave workgroups, TWO per CU - they desynchronise naturally, so one
+// workgroup's barriers and LDS latencies are covered by the other's MFMA / VALU work - walk (bag, row-chunk) items from the last
+// bag to the first (what the encoder wrote last is still in the Infinity Cache); H row tiles of 16 rows stream HBM -> LDS by
+// LDS-DMA into a 4-slot ring and are consumed two at a time (the pair in use + the next pair in flight); each wave keeps its
+// 32-column slice of Wa in registers as MFMA operands for the whole launch (fetched once as whole rows through the still empty
+// ring, K2_WPRO), so per tile the matrix cores see only LDS reads of H.  Scores are reduced across waves through LDS, the soft-max
+// uses a fixed reference (tanh bounds every score) or the online running max, and the weighted sum M = p.H runs on the matrix
+// cores too (v_mfma_f32_16x16x16_bf16, p as hi + lo bf16 rows, H read k-major by ds_read_b64_tr_b16).  Per-chunk partials
+// (m, l, sum p.H) are merged per bag by abmil_pool_combine_kernel.  f32 (parity path): one 8-wave workgroup per CU, exact tanh.
 //
 // LDS row image: rows are stored whole at a stride of ROWB+16 bytes (each LDS-DMA instruction writes
 // 1 KiB inside one row, so the pad is free): 16 lanes reading the same 16-byte chunk of 16 consecutive

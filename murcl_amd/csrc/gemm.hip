@@ -969,6 +969,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
 // 64 MB of partial tiles leave as plain 64-byte row segments (~6 TB/s) instead of 32 MB of memory-side atomics (~1.3 TB/s).
 // Eight waves as 2 (n1) x 4 (n2) wave tiles of 128 x 64; slabs of 32 patch rows x (256 + 256) columns = 32 KiB run
 // through a four-slot ring with three slabs in flight.
+#ifndef TN_SQ_ACC_LAYOUT
+#define TN_SQ_ACC_LAYOUT 0     // 1: partial tiles in accumulator layout (32 whole-KiB stores per wave instead of 128 four-byte ones) - measured r03: neutral (139-143 vs 141 us) and the reduce launch 1 us slower
+#endif
 __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                          float* __restrict__ part, int M, int N1, int N2, int lda,
                                                          int ldb, int m_per_split, int nsplit) {
@@ -1077,7 +1080,17 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
-    // ---- this split's partial tile -> part[sp][N1][N2] (plain stores; 16 lanes write 64 contiguous bytes of a row)
+    // ---- this split's partial tile -> the workspace IN ACCUMULATOR LAYOUT: part[sp][tile][wave][i][j][lane][4], one 16-byte
+    // store per lane and (i, j) = 1 KiB contiguous per instruction (32 per wave).  In the matrix's own row-major layout the
+    // same values are 128 four-byte stores per wave, each touching four 64-byte row segments: a fifth of the kernel's vector
+    // memory instructions for 1/32 of its bytes.  tn_reduce_kernel walks the workspace in this order and scatters into C once.
+#if TN_SQ_ACC_LAYOUT
+    float* pt = part + (size_t)sp * N1 * N2 + ((size_t)tile * 8 + wave) * (8 * 4 * 64 * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(pt + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+#else
     float* pt = part + (size_t)sp * N1 * N2;
     const int q4 = lane >> 4, r16 = lane & 15;
 #pragma unroll
@@ -1091,6 +1104,7 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
                 pt[(size_t)n1 * N2 + n2] = acc[i][j][r];
             }
         }
+#endif
 }
 // C[n] += sum_s part[s][n]   (n over N1*N2 elements as float4; eight splits of loads in flight per thread)
 // Blocks past the matrix part (cs_part given) add up [cs_rows][N1] partial column-sum rows into cs_out the same way: the
@@ -1143,9 +1157,20 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
     for (; s < nsplit; ++s) a0 += p[(size_t)s * n4];
     const f32x4 t = (a0 + a1) + (a2 + a3);
+#if TN_SQ_ACC_LAYOUT
+    // float4 i of the workspace = lane (i & 63) of block (ii, jj) of wave w of tile tl: rows n1 .. n1+3 of column n2
+    const int ln = (int)(i & 63), ij = (int)(i >> 6) & 31, w = (int)(i >> 11) & 7, tl = (int)(i >> 14);
+    const int T1 = N1 >> 8, t1 = tl % T1, t2 = tl / T1;
+    const int n1 = (t1 << 8) + (w >> 2) * 128 + (ij >> 2) * 16 + 4 * (ln >> 4);
+    const int n2 = (t2 << 8) + (w & 3) * 64 + (ij & 3) * 16 + (ln & 15);
+    float* c = C + (size_t)n1 * ldc + n2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[(size_t)r * ldc] += t[r];
+#else
     const long e = i * 4, row = e / N2, col = e % N2;
     f32x4* c = (f32x4*)(C + row * ldc + col);
     *c = *c + t;
+#endif
 }
 static int tn_sq_plan(int M, int N1, int N2, int* splits_out, int* mps_out) {
     const int tiles = (N1 / 256) * (N2 / 256);
