@@ -11,7 +11,9 @@
  * contiguous unless a leading dimension is given; `stream` is the hipStream_t to launch on (the
  * caller passes torch.cuda.current_stream()); nothing allocates, frees or synchronises; workspaces
  * are caller-provided.  Return 0 on success, a hipError_t (>0) if a launch failed, <0 for
- * unsupported arguments.  dtype codes: 0 = f32, 1 = bf16 (f32 accumulate everywhere).
+ * unsupported arguments.  dtype codes: 0 = f32, 1 = bf16 (f32 accumulate everywhere); murcl_gemm_nt
+ * (dtype_in) and murcl_gemm_tn / murcl_gemm_tn_ws also take 2 = f32 tensors whose products run as a 3-term bf16 split on the bf16
+ * matrix pipe (hi + mid + lo, six MFMAs per product, f32-level accuracy at 6/16 of the exact-f32 MFMA time).
  */
 #ifndef MURCL_AMD_H
 #define MURCL_AMD_H

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define MURCL_DTYPE_F32 0
 #define MURCL_DTYPE_BF16 1
+#define MURCL_DTYPE_F32X3 2      // GEMM entry points only: f32 tensors, products as a 3-term bf16 split on the bf16 matrix pipe
 
 #define MURCL_CHECK_LAUNCH() ((int)hipGetLastError())
 

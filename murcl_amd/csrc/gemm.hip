@@ -45,8 +45,41 @@ __device__ __forceinline__ f32x4 mma16<float>(f32x4 a, f32x4 b, f32x4 c) {
     return c;
 }
 
+// f32 operands on the bf16 matrix pipe (dtype code MURCL_DTYPE_F32X3): x = hi + mid + lo with three bf16 terms (8 + 8 + 8
+// significant bits, residuals exact in f32), the six products of order <= 2 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
+// v_mfma_f32_16x16x32_bf16 with f32 accumulation: each bf16 x bf16 product is exact, the dropped terms are <= 2^-26 of the
+// product - f32-level accuracy at 6/16 of the exact-f32 MFMA time (v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate).
+// Two f32x4 fragments (the lane's k values of k-groups 0 and 1 of a 32-deep slab) make one 8-deep bf16 fragment per term;
+// both operands are built the same way, so the k order is permuted identically on both sides.
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split3(f32x4 x0, f32x4 x1) {
+    u32x4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = p < 2 ? x0[2 * p] : x1[2 * p - 4], b = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
+        const uint32_t hp = pack_bf2(a, b);
+        const float ra = a - bf_lo(hp), rb = b - bf_hi(hp);
+        const uint32_t mp = pack_bf2(ra, rb);
+        const float sa = ra - bf_lo(mp), sb = rb - bf_hi(mp);
+        h[p] = hp;
+        m[p] = mp;
+        l[p] = pack_bf2(sa, sb);
+    }
+    return Split3{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
+}
+// c += a . b over the slab's 32 k values, a and b as split operands (MFMA rows <- a)
+__device__ __forceinline__ f32x4 mma_x3(const Split3& a, const Split3& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);       // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+
 // ------------------------------------------------------------------------------------- NT
-template <typename T, typename OutT, int EPI>
+template <typename T, typename OutT, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                       OutT* __restrict__ C, int M, int N, int K, int lda,
                                                       int ldb, int ldc, GemmEpi e) {
@@ -90,6 +123,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
     auto compute = [&](int buf) {
         const char* la = smem + buf * 32768;
         const char* lb = la + 16384;
+        if constexpr (X3) {
+            static_assert(!X3 || sizeof(T) == 4, "the 3-term split is for f32 operands");
+            Split3 as[4], bs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wr * 64 + i * 16 + r16;
+                as[i] = split3(*(const f32x4*)(la + row * 128 + (((q4) ^ (row & 7)) << 4)),
+                               *(const f32x4*)(la + row * 128 + (((4 + q4) ^ (row & 7)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wc * 64 + j * 16 + r16;
+                bs[j] = split3(*(const f32x4*)(lb + row * 128 + (((q4) ^ (row & 7)) << 4)),
+                               *(const f32x4*)(lb + row * 128 + (((4 + q4) ^ (row & 7)) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma_x3(bs[j], as[i], acc[i][j]);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             frag_t af[4], bfr[4];
@@ -204,13 +258,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
     }
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool X3 = false>
 static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, int lda, int ldb, int ldc, int epi,
                          const GemmEpi& e, hipStream_t s) {
     const int grid = ((M + 127) / 128) * ((N + 127) / 128);
 #define NT_CASE(E)                                                                                             \
     case E: {                                                                                                  \
-        auto k = gemm_nt_kernel<T, OutT, E>;                                                                   \
+        auto k = gemm_nt_kernel<T, OutT, E, X3>;                                                               \
         static MurclOncePerDevice once;                                                                                    \
         if (once.first()) {                                                                                           \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);            \
@@ -556,6 +610,8 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
                              int ldmask, const float* rowscale, const float* rank1, int rows_per_bag,
                              float* colsum_ws, int accumulate, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
+    const bool x3 = dtype_in == MURCL_DTYPE_F32X3;       // f32 storage, 3-term bf16 split on the bf16 matrix pipe
+    if (x3) dtype_in = MURCL_DTYPE_F32;
     const int bke = dtype_in == MURCL_DTYPE_BF16 ? 64 : 32;
     if (K <= 0 || K % bke) return -1;                    // K must be a whole number of 128-byte slabs
     if ((lda * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16 || (ldb * (dtype_in == MURCL_DTYPE_BF16 ? 2 : 4)) % 16)
@@ -574,6 +630,9 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
     if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_F32)
         return launch_nt_epi<bf16_t, float>((const bf16_t*)A, (const bf16_t*)B, (float*)C, M, N, K, lda, ldb, ldc,
                                             epilogue, e, stream);
+    if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && x3)
+        return launch_nt_epi<float, float, true>((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc,
+                                                 epilogue, e, stream);
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32)
         return launch_nt_epi<float, float>((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc,
                                            epilogue, e, stream);
@@ -617,7 +676,7 @@ __device__ __forceinline__ f32x4 tn_frag(const char* tile, int t, int kk, int la
     return v;
 }
 
-template <typename T, int NSLOT>
+template <typename T, int NSLOT, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                          float* __restrict__ C, int M, int N1, int N2, int lda, int ldb,
                                                          int ldc, int m_per_split, int nsplit,
@@ -719,6 +778,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const T* __restrict__ A
     auto compute = [&](int s) {
         const char* la = smem + (s & (NSLOT - 1)) * 32768;
         const char* lb = la + 16384;
+        if constexpr (X3) {
+            static_assert(!X3 || sizeof(T) == 4, "the 3-term split is for f32 operands");
+            Split3 as[4], bs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) as[i] = split3(tn_frag(la, wr * 4 + i, 0, lane, float()), tn_frag(la, wr * 4 + i, 1, lane, float()));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] = split3(tn_frag(lb, wc * 4 + j, 0, lane, float()), tn_frag(lb, wc * 4 + j, 1, lane, float()));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma_x3(as[i], bs[j], acc[i][j]);
+            if (do_cs) {                       // column sums of A: A^T . 1, the ones fragment is exact in bf16
+                const bf16x8 one8 = bf16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[i].l, one8, accs[i], 0, 0, 0);
+                    accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[i].m, one8, accs[i], 0, 0, 0);
+                    accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as[i].h, one8, accs[i], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             frag_t af[4], bfr[4];
@@ -1277,6 +1358,8 @@ static int tn_small_enabled() {
 extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int N1, int N2, int lda, int ldb, int ldc,
                              int dtype, int splits, float* colsum_out, hipStream_t stream) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    const bool x3 = dtype == MURCL_DTYPE_F32X3;          // f32 storage, 3-term bf16 split on the bf16 matrix pipe (gemm_nt above)
+    if (x3) dtype = MURCL_DTYPE_F32;
     const int es = dtype == MURCL_DTYPE_BF16 ? 2 : 4, epc = 16 / es;
     if (N1 < epc || N2 < epc || N1 % epc || N2 % epc || (lda * es) % 16 || (ldb * es) % 16) return -1;
     if (dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 128 == 0 && M >= 4096) {
@@ -1305,7 +1388,7 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     // one pass only: at M = 768 (the deferred head gradients of a T = 6 step) two serial passes per 32 x 32 tile take 78 us where
     // the 128 x 128 ring kernel below takes 55 us ([768 x 3072 x 512], tools/tn_trace.sh); up to 512 rows the small tiles win
     // (16.6 -> 12.2 us [128 x 3072 x 512], 7.7 -> 5.8 us [128 x 512 x 512], 23.7 -> 18.0 us [320 x 2048 x 512])
-    if (dtype == MURCL_DTYPE_F32 && splits <= 0 && M <= TS_MAXM && tn_small_enabled()) {
+    if (dtype == MURCL_DTYPE_F32 && !x3 && splits <= 0 && M <= TS_MAXM && tn_small_enabled()) {
         const int mp = ((M < TS_MAXM ? M : TS_MAXM) + 15) & ~15;
         static MurclOncePerDevice once;
         if (once.first())
@@ -1326,7 +1409,7 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         // [131072 x 128]^T [. x 1024] 71 -> 63 us (32 instead of 64), the deferred head gradients [768 x 3072]^T [. x 512]
         // f32 56 -> 40 us (3 instead of 8) and [. x 1024] 99 -> 62 us (2 instead of 8); the exact-f32 dWq [131072 x 128]^T [. x 1024] is MFMA-bound
         // (313 against 289 us with two workgroups per CU: long f32 reductions keep the 512-workgroup target)
-        const int target = (dtype == MURCL_DTYPE_F32 && M >= 16384) ? 512 : 256;
+        const int target = (dtype == MURCL_DTYPE_F32 && !x3 && M >= 16384) ? 512 : 256;
         splits = (target + t1 * t2 - 1) / (t1 * t2);
         if (splits >= 8) splits = ((splits + 7) / 8) * 8;                       // multiples of 8: the XCD-aware work map
         while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
@@ -1337,18 +1420,20 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     if ((long)mps * (splits - 1) >= M) splits = (M + mps - 1) / mps;           // tiny M: drop empty splits
     dim3 grid(t1 * t2 * splits);
     const bool deep = (t1 * t2 * splits <= 256 || splits == 1) && mps > rows;   // small grid, several slabs per workgroup
-#define TN_LAUNCH(T, NS)                                                                                            \
+#define TN_LAUNCH(T, NS, X3)                                                                                        \
     {                                                                                                               \
-        auto k = gemm_tn_kernel<T, NS>;                                                                             \
+        auto k = gemm_tn_kernel<T, NS, X3>;                                                                         \
         static MurclOncePerDevice once;                                                                                         \
         if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, NS * 32768); } \
         hipLaunchKernelGGL(k, grid, dim3(256), NS * 32768, stream, (const T*)A, (const T*)B, C, M, N1, N2, lda, ldb, ldc, mps, \
                            splits, colsum_out);                                                                     \
     }
     if (dtype == MURCL_DTYPE_BF16) {
-        if (deep) TN_LAUNCH(bf16_t, 4) else TN_LAUNCH(bf16_t, 2)
+        if (deep) TN_LAUNCH(bf16_t, 4, false) else TN_LAUNCH(bf16_t, 2, false)
+    } else if (dtype == MURCL_DTYPE_F32 && x3) {
+        if (deep) TN_LAUNCH(float, 4, true) else TN_LAUNCH(float, 2, true)
     } else if (dtype == MURCL_DTYPE_F32) {
-        if (deep) TN_LAUNCH(float, 4) else TN_LAUNCH(float, 2)
+        if (deep) TN_LAUNCH(float, 4, false) else TN_LAUNCH(float, 2, false)
     } else {
         return -1;
     }

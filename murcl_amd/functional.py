@@ -32,6 +32,7 @@ import os as _os
 # the backward pass, while its output (H3) is what the pooling kernel streams next: kept out of the Infinity Cache, H2
 # leaves more of H3 there (K2 forward 67.6 -> 62.4 us inside the step; the other layers measured neutral-to-slower).
 _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
+_DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
 
@@ -635,8 +636,11 @@ class DSMILFn(torch.autograd.Function):
         x2 = x.reshape(B * N, d)
         # queries: one 128-column GEMM.  The C (<= 4) instance-score columns are a streaming row dot product: as columns
         # 128..128+C-1 of the same GEMM they would cost a second, almost empty 128-column tile pass over X.
+        # f32 (parity path): the two GEMMs over all patches - the queries here and dWq in the backward pass - run as a 3-term bf16
+        # split on the bf16 matrix pipe (ops.gemm_nt x3: f32-level accuracy; the exact-f32 MFMA form ran them at 0.72 of the
+        # 157 TFLOP/s f32 matrix peak = 2 x 303 us of the C5 share's 1.28 ms)
         Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
-                        out_dtype=torch.float32)                                        # Q [B*N, 128]
+                        out_dtype=torch.float32, x3=_DSMIL_X3)                          # Q [B*N, 128]
         cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d)).view(B * N, C)
         cls += bc
         m = ops.dsmil_argmax(cls, B, N, C)
@@ -670,7 +674,7 @@ class DSMILFn(torch.autograd.Function):
         dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
         dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                      # written in full below
         dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
-        dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2)                # [128, d]: one tile row
+        dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2, x3=_DSMIL_X3)  # [128, d]: one tile row
         dbq = ops.colsum(dQ)
         xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
         ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)

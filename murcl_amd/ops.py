@@ -90,9 +90,14 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+F32X3 = 2          # GEMM dtype code: f32 tensors, products as a 3-term bf16 split on the bf16 matrix pipe (include/murcl_amd.h)
+
+
 def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=None, rows_per_bag=0,
-            out_dtype=None, colsum=False, out=None, accumulate=False):
-    """C[M,N] = epi(A[M,K] @ B[N,K]^T).  Returns C or (C, colsum_ws[ceil(M/128),N])."""
+            out_dtype=None, colsum=False, out=None, accumulate=False, x3=False):
+    """C[M,N] = epi(A[M,K] @ B[N,K]^T).  Returns C or (C, colsum_ws[ceil(M/128),N]).
+    ``x3`` (f32 operands, more than 1024 rows): the products run as a 3-term bf16 split on the bf16 matrix pipe - f32-level
+    accuracy (relative error ~1e-7 against the exact-f32 MFMA path) at a fraction of its time."""
     _need_cuda(A, B)
     A, B = _c(A), _c(B)
     M, K = A.shape
@@ -111,10 +116,11 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
         mask = _c(mask)
         assert mask.dtype == A.dtype and mask.shape == (M, N)
     es = A.element_size()
-    with _span(lambda: (f"gemm_nt<{_DT_NAME[A.dtype]},{_DT_NAME[C.dtype]},{_EPI_NAME[epi]}>",
+    x3 = bool(x3) and A.dtype == torch.float32 and C.dtype == torch.float32 and M > 1024
+    with _span(lambda: (f"gemm_nt<{'f32x3' if x3 else _DT_NAME[A.dtype]},{_DT_NAME[C.dtype]},{_EPI_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=(M * K + N * K) * es + M * N * C.element_size()
                     + (M * N * es if mask is not None else 0)))):
-        check(_lib.lib().murcl_gemm_nt(ptr(A), ptr(B), ptr(C), M, N, K, K, K, N, dt(A), dt(C), epi, ptr(bias),
+        check(_lib.lib().murcl_gemm_nt(ptr(A), ptr(B), ptr(C), M, N, K, K, K, N, F32X3 if x3 else dt(A), dt(C), epi, ptr(bias),
                                        ptr(mask), N, ptr(rowscale), ptr(rank1), rows_per_bag, ptr(ws), int(accumulate),
                                        stream()), "gemm_nt")
     return (C, ws) if colsum else C
@@ -180,7 +186,7 @@ import os as _os
 _TN_SQ = _os.environ.get("MURCL_TN_SQ", "1") == "1"          # dev A/B switch: 0 keeps the 256 x 128 atomics kernel
 
 
-def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None):
+def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3=False):
     """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given).  ``colsum_into`` [N1] f32: the column sums
     of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient); with
     ``colsum_parts`` = (rows [R,N1] f32, R) from ``panel_gemm(colsum_defer=True)`` those rows are summed instead."""
@@ -215,9 +221,10 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None):
     if colsum_parts is not None:                      # other paths: the partial rows get their own small launch
         colsum(colsum_parts[0].view(-1, N1)[:colsum_parts[1]], out=colsum_into, accumulate=True)
         colsum_into = None
-    with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{_DT_NAME[A.dtype]}>",
+    x3 = bool(x3) and A.dtype == torch.float32 and M >= 4096       # (``x3``: the 3-term bf16 split of gemm_nt, long f32 reductions)
+    with _span(lambda: (f"gemm_tn{'_wide' if wide else ''}<{'f32x3' if x3 else _DT_NAME[A.dtype]}>",
                dict(flops=2.0 * M * N1 * N2, bytes=M * (N1 + N2) * A.element_size() + N1 * N2 * 4))):
-        check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, dt(A), splits, ptr(colsum_into),
+        check(_lib.lib().murcl_gemm_tn(ptr(A), ptr(B), ptr(C), M, N1, N2, N1, N2, N2, F32X3 if x3 else dt(A), splits, ptr(colsum_into),
                                        stream()), "gemm_tn")
     return C
 

@@ -142,6 +142,43 @@ def test_gemm_tn(dtype, M, N1, N2):
     _close(C, ref, rtol=1e-4, atol=1e-4 * s if dtype == torch.float32 else 2e-2 * s, msg="tn")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(16384, 128, 1024, "bias"), (4096 + 64, 200, 512, "none"), (5000, 512, 256, "relu")])
+def test_gemm_nt_f32_as_three_term_bf16_split(M, N, K, epi):
+    """dtype code 2 (include/murcl_amd.h): f32 operands, six bf16 MFMAs per product.  Against float64 it must be as good as
+    the exact-f32 MFMA path (both ~1e-7 relative), so the 1e-4 parity contract of the f32 mode holds with it."""
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(8, f"A{M}{K}", (M, K))
+    B = _rand(8, f"B{N}{K}", (N, K))
+    bias = _rand(8, f"b{N}", (N,))
+    e = {"none": ops.EPI_NONE, "bias": ops.EPI_BIAS, "relu": ops.EPI_BIAS_RELU}[epi]
+    ref = A.double() @ B.double().t() + (bias.double() if epi != "none" else 0.0)
+    if epi == "relu":
+        ref = ref.clamp_min(0.0)
+    kw = dict(epi=e, bias=bias.to(dev) if epi != "none" else None)
+    exact = ops.gemm_nt(A.to(dev), B.to(dev), **kw)
+    split = ops.gemm_nt(A.to(dev), B.to(dev), x3=True, **kw)
+    r_exact, r_split = _rel_fro(exact, ref), _rel_fro(split, ref)
+    assert r_split < 2e-6 and r_split < 3 * r_exact + 1e-8, (r_exact, r_split)
+    _close(split, ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), msg="x3")
+
+
+@pytest.mark.parametrize("M,N1,N2,cs", [(131072, 128, 1024, False), (20000 + 17, 128, 512, True), (8192, 256, 256, True)])
+def test_gemm_tn_f32_as_three_term_bf16_split(M, N1, N2, cs):
+    from murcl_amd import ops
+    dev = _dev()
+    A = _rand(9, f"A{M}{N1}", (M, N1))
+    B = _rand(9, f"B{M}{N2}", (M, N2))
+    ref = A.double().t() @ B.double()
+    colsum = torch.zeros((N1,), device=dev) if cs else None
+    exact = ops.gemm_tn(A.to(dev), B.to(dev))
+    split = ops.gemm_tn(A.to(dev), B.to(dev), x3=True, colsum_into=colsum)
+    r_exact, r_split = _rel_fro(exact, ref), _rel_fro(split, ref)
+    assert r_split < 2e-6 and r_split < 3 * r_exact + 1e-8, (r_exact, r_split)
+    if cs:
+        _close(colsum, A.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(M), msg="colsum")
+
+
 @pytest.mark.parametrize("dtype,M,N1,N2", [(torch.float32, 128, 3072, 512), (torch.float32, 128, 512, 512), (torch.float32, 77, 132, 260),
                                            (torch.float32, 320, 10, 512), (torch.bfloat16, 4096, 128, 512), (torch.bfloat16, 8192, 512, 512),
                                            (torch.bfloat16, 1000, 136, 72)])
