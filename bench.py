@@ -218,8 +218,11 @@ def other_rows(device):
     """The other aggregators of SURVEY section 8 at their BASELINE shapes, beside the headline (outside its timed
     region): BASELINE configs[2] CLAM-SB + instance loss 64 x 4096 x 512 (bf16 storage) and one GPU's share of configs[4]
     DSMIL 16 x 8192 x 1024 (fp32 like the reference), forward + backward through the batched internals the training
-    steps use (train_RLMIL.supervised_step), median of 10 HIP-event timings.  `frac_of_8TBps` uses the pass counts of
-    the un-fused operator chain as the algorithmic bytes (15 passes over [B*N,512] for CLAM, 4 over X for DSMIL)."""
+    steps use (train_RLMIL.supervised_step), median of 10 HIP-event timings.  Two accountings per row: `survey_8d` = the
+    ALGORITHMIC work of SURVEY section 8(d) (FLOPs of the K4 / K6 chain forward + backward against the dense bf16 MFMA peak; X
+    once forward and twice backward against 8 TB/s), and `chain_traffic_*` = the bytes the un-fused operator chain as built
+    moves (15 passes over [B*N,512] for CLAM, 4 over X for DSMIL) - the second says how well the passes stream, not how close
+    the row is to its algorithmic floor."""
     from murcl_amd.models.clam import CLAM_SB
     from murcl_amd.models.dsmil import build_dsmil
     g = torch.Generator(device=device)
@@ -240,8 +243,15 @@ def other_rows(device):
     for name, inst in (("clam_sb_c3_fwd_bwd_instance_loss", True), ("clam_sb_c3_fwd_bwd_aggregator", False)):
         ms = _timed_ms(lambda: clam_fb(inst))
         nbytes = 15 * B * N * 512 * 2
+        # the two 512 x 512 projections dominate - fc forward + weight gradient (no dX), gate forward + dgrad + weight
+        # gradient = 5 x 2*N*512^2 FLOP per bag (10.7 GFLOP at N = 4096); bytes: X once forward, twice backward
+        flops = B * 5 * 2.0 * N * 512 * 512
+        xbytes = 3 * B * N * 512 * 2
         out[name] = dict(workload=f"CLAM_SB {B} bags x {N} x 512 bf16", ms=round(ms, 4), bags_per_s=round(B / ms * 1e3, 1),
-                         algorithmic_GB=round(nbytes / 1e9, 3), frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+                         survey_8d=dict(bound="mfma", GFLOP_fwd_bwd=round(flops / 1e9, 1),
+                                        frac_of_bf16_mfma_peak=round(flops / (ms * 1e-3) / (PEAK["mfma_bf16_TFLOPs"] * 1e12), 4),
+                                        x_bytes_GB=round(xbytes / 1e9, 3), frac_of_8TBps_on_x_bytes=round(xbytes / ms / 1e6 / 8000, 4)),
+                         chain_traffic_GB=round(nbytes / 1e9, 3), chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
     del m, x
     B, N, d = 16, 8192, 1024
     md = build_dsmil(d, 2).to(device)
@@ -258,20 +268,25 @@ def other_rows(device):
     # weight gradient dQ^T X (2 * B*N*d*128 FLOP each at PEAK["mfma_f32_TFLOPs"]); the other passes over X (scores + pooling
     # forward, the fused dA / dWc sweep backward) are HBM passes.  The row's floor is the sum of its kernels' own floors.
     gemm_flops = 2.0 * B * N * d * 128
-    floor_ms = 2 * gemm_flops / (PEAK["mfma_f32_TFLOPs"] * 1e12) * 1e3 + 3 * (B * N * d * 4) / (PEAK["hbm_GBps"] * 1e9) * 1e3
+    # since round 3 the two f32 GEMMs run as a 3-term bf16 split: six bf16 MFMAs per product on the 2.5 PFLOP/s pipe
+    floor_ms = 2 * 6 * gemm_flops / (PEAK["mfma_bf16_TFLOPs"] * 1e12) * 1e3 + 4 * (B * N * d * 4) / (PEAK["hbm_GBps"] * 1e9) * 1e3
     out["dsmil_c5_share_fwd_bwd"] = dict(workload=f"DSMIL {B} bags x {N} x {d} f32 (one GPU's share of 128 bags)", ms=round(ms, 4),
-                                         bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
-                                         frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4),
+                                         bags_per_s=round(B / ms * 1e3, 1),
+                                         survey_8d=dict(bound="hbm", x_bytes_GB=round(3 * B * N * d * 4 / 1e9, 3),
+                                                        frac_of_8TBps_on_x_bytes=round(3 * B * N * d * 4 / ms / 1e6 / 8000, 4),
+                                                        note="reassociated K6: X once forward (scores + pooling from one pass is the floor), twice backward"),
+                                         chain_traffic_GB=round(nbytes / 1e9, 3),
+                                         chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4),
                                          kernelwise_floor_ms=round(floor_ms, 4), frac_of_kernelwise_floor=round(floor_ms / ms, 4),
-                                         floor_note="2 f32-MFMA-bound GEMMs (query projection, its weight gradient: 34.4 GFLOP each at "
-                                                    "157 TFLOP/s) + 3 HBM passes over X at 8 TB/s")
+                                         floor_note="2 GEMMs over all patches (query projection, its weight gradient: 34.4 GFLOP each as six "
+                                                    "bf16 MFMA products at 2.5 PFLOP/s) + 4 HBM passes over X at 8 TB/s")
     md.compute_dtype = torch.bfloat16                               # patch features stored in bf16, f32 accumulation
     xd = xd.bfloat16()
     ms = _timed_ms(dsmil_fb)
     nbytes = 4 * B * N * d * 2
     out["dsmil_c5_share_fwd_bwd_bf16"] = dict(workload=f"DSMIL {B} bags x {N} x {d} bf16 storage", ms=round(ms, 4),
-                                              bags_per_s=round(B / ms * 1e3, 1), algorithmic_GB=round(nbytes / 1e9, 3),
-                                              frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+                                              bags_per_s=round(B / ms * 1e3, 1), chain_traffic_GB=round(nbytes / 1e9, 3),
+                                              chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
     return out
 
 
