@@ -709,6 +709,117 @@ def g16_abmil_general():
     np.savez(os.path.join(OUT, "g16_abmil_general.npz"), **res)
 
 
+def g17_rl_two_steps():
+    """G12 with a second optimizer step (Adam's first step is sign-like, a second one makes the comparison bite):
+    TWO consecutive batches through the reference's own ``train()`` (train_MuRCL.py:189-343) at train_stage 2 and 3, T = 3,
+    every draw injected.  Stored per stage: per-step losses, rewards, sampler actions / log-probs and selected patch ids of
+    BOTH batches, and the parameter fingerprints after the second update."""
+    import argparse
+    import tempfile
+    from oracle import select_oracle as S
+    r_tm = _ref_train_murcl()
+    c = G12
+    seed, B, K, fs, std, Tn = c["seed"], c["B"], c["K"], c["fs"], c["std"], 3
+    MVN = torch.distributions.multivariate_normal.MultivariateNormal
+    batches = [g12_inputs(Tn, b) for b in range(2)]
+    feats = batches[0][1] + batches[1][1]
+    cls = batches[0][2] + batches[1][2]
+    res, margin = {}, 1.0
+    for stage in (2, 3):
+        tag = f"s{stage}"
+        enc = r_abmil.ABMIL(c["d"], L=512, D=128, dim_out=128)
+        enc.load_state_dict(P.to_torch(P.abmil(seed)))
+        model = torch.nn.DataParallel(r_cl.CL(enc, projection_dim=128, n_features=512))
+        fc = r_rlmil.Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(seed)))
+        ppo = r_rlmil.PPO(c["d"], 512, 512, False, action_std=std, lr=c["ppo_lr"], gamma=c["gamma"], K_epochs=c["K_epochs"], action_size=K)
+        sd = P.to_torch(P.actor_critic(seed, 512, 512, K))
+        ppo.policy.load_state_dict(sd)
+        ppo.policy_old.load_state_dict(sd)
+        optimizer = None if stage == 2 else torch.optim.Adam(
+            [{"params": model.parameters(), "lr": c["lr"]}, {"params": fc.parameters(), "lr": c["lr"]}],
+            betas=(0.9, 0.999), weight_decay=c["wd"])
+        args = argparse.Namespace(T=Tn, device="cpu", num_clusters=K, feat_size=fs, train_stage=stage, batch_size=B,
+                                  epochs=1, num_data=2 * B, eval_step=2, alpha=c["alpha"], patience=None, warmup=0)
+
+        class _Set:
+            def shuffle(self):
+                pass
+
+            def __len__(self):
+                return 2 * B
+
+            def __getitem__(self, i):
+                return T(feats[i]), cls[i], 0, f"case{i}"
+
+        injs = [b[3] for b in batches]
+        act_draws = iter([T(a) for inj in injs for a in inj["actions"][0]])
+        u_draws = iter([T(inj["u"][t][v]) for inj in injs for t in range(Tn) for v in range(2)])
+        perm_draws = iter([T(inj["perm"][t][v]) for inj in injs for t in range(Tn) for v in range(2)])
+        eps_draws = iter([T(inj["eps"][t][v]) for inj in injs for t in range(Tn - 1) for v in range(2)])
+
+        def fake_rand(*a, **k):
+            size = tuple(k["size"]) if "size" in k else (tuple(a[0]) if isinstance(a[0], (tuple, list)) else tuple(a))
+            return next(act_draws) if size == (B, K) else next(u_draws)
+
+        snaps, step_losses = [], []
+        inner = r_losses.NT_Xent(B, 1.0)
+
+        class _Crit(torch.nn.Module):
+            def forward(self, zi, zj):
+                l = inner(zi, zj)
+                step_losses.append(l.item())
+                return l
+
+        def snap_clear(self):
+            snaps.append({f: [x.detach().clone() for x in getattr(self, f)] for f in ("actions", "states", "logprobs", "rewards")})
+            for f in ("actions", "states", "logprobs", "rewards", "is_terminals", "hidden"):
+                del getattr(self, f)[:]
+
+        real_to = torch.Tensor.to
+
+        def to_ignoring_ordinals(self, *a, **k):
+            return self if (a and isinstance(a[0], int)) else real_to(self, *a, **k)
+
+        with tempfile.TemporaryDirectory() as tmp, \
+                mock.patch("torch.rand", fake_rand), mock.patch("torch.randperm", lambda *a, **k: next(perm_draws)), \
+                mock.patch.object(MVN, "sample", lambda self, *a, **k: self.loc + std * next(eps_draws)), \
+                mock.patch.object(r_rlmil.Memory, "clear_memory", snap_clear), \
+                mock.patch.object(torch.Tensor, "to", to_ignoring_ordinals):
+            r_tm.train(args, _Set(), model, fc, ppo, _Crit(), optimizer, None, None, tmp)
+        assert len(snaps) == 4 and len(step_losses) == 2 * Tn
+        for it in (act_draws, u_draws, perm_draws, eps_draws):
+            assert next(it, None) is None, "an injected draw was not consumed"
+        res[f"{tag}.losses"] = np.array(step_losses).reshape(2, Tn)
+        res[f"{tag}.rewards"] = np.stack([torch.cat(snaps[2 * b]["rewards"], 0).numpy() for b in range(2)])       # [2, T-1, B]
+        for b in range(2):
+            Ns_b, feats_b, cls_b = batches[b][0], batches[b][1], batches[b][2]
+            for v in range(2):
+                sn = snaps[2 * b + v]
+                res[f"{tag}.actions.{b}.{v}"] = torch.stack(sn["actions"], 0).numpy()
+                res[f"{tag}.logp.{b}.{v}"] = torch.stack(sn["logprobs"], 0).numpy()
+                for t in range(Tn - 1):
+                    a_t = sn["actions"][t].numpy()
+                    _, ids = S.get_feats(feats_b, cls_b, a_t, fs)
+                    res[f"{tag}.ids.{b}.{t + 1}.{v}"] = np.array([i + [-1] * (fs - len(i)) for i in ids], dtype=np.int32)
+                    margin = min(margin, min(_window_margin(Ns_b[x], cls_b[x], a_t[x], fs) for x in range(B)))
+        pre = P.to_torch(P.actor_critic(seed, 512, 512, K))
+        for k, v in ppo.policy.state_dict().items():
+            res[f"{tag}.policy.{k}"] = _summ(v)
+            res[f"{tag}.policy_delta.{k}"] = _summ(v - pre[k])
+        if stage == 3:
+            pre_m, pre_f = P.to_torch(P.abmil(seed)), P.to_torch(P.full_layer(seed))
+            for k, v in model.module.encoder.state_dict().items():
+                res[f"{tag}.model.{k}"] = _summ(v)
+                res[f"{tag}.model_delta.{k}"] = _summ(v - pre_m[k])
+            for k, v in fc.state_dict().items():
+                res[f"{tag}.fc.{k}"] = _summ(v)
+                res[f"{tag}.fc_delta.{k}"] = _summ(v - pre_f[k])
+    assert margin > 1e-3, f"golden window margin too small ({margin})"
+    res["window_margin"] = np.float64(margin)
+    np.savez(os.path.join(OUT, "g17_rl_two_steps.npz"), **res)
+
+
 def _reference_parser(mod, globals_needed):
     """The ArgumentParser that the reference's ``main()`` builds (it is local to main): run main() with parse_args
     replaced by a hook that keeps the parser and stops."""
@@ -824,7 +935,7 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general, g17_rl_two_steps):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

@@ -10,17 +10,19 @@ T = torch.from_numpy
 G12 = dict(seed=77, B=4, K=10, fs=128, d=512, std=0.5, gamma=0.1, K_epochs=3, ppo_lr=1e-5, lr=1e-3, wd=1e-5, alpha=0.9)
 
 
-def g12_inputs(Tn):
-    """Inputs of the G12 step (shared with the tests through this recipe): ragged bags, cluster lists, every draw."""
+def g12_inputs(Tn, batch=0):
+    """Inputs of the G12 step (shared with the tests through this recipe): ragged bags, cluster lists, every draw.
+    ``batch`` > 0: the inputs of a further, different batch (G17 runs two consecutive optimizer steps)."""
     c = G12
     seed, B, K = c["seed"], c["B"], c["K"]
-    Ns = [640 + 37 * b for b in range(B)]
-    feats = [P.bags(seed, f"g12.f{b}", 1, Ns[b], c["d"])[0] for b in range(B)]
-    cls = [P.cluster_lists(seed, f"g12.c{b}", Ns[b], K) for b in range(B)]
-    inj = {"actions": [[detrand.uniform(seed, f"g12.a{v}", (B, K)).astype(np.float32) for v in range(2)]],
-           "u": [[detrand.uniform(seed, f"g12.u{t}{v}", (B, 1)).astype(np.float32) for v in range(2)] for t in range(Tn)],
-           "perm": [[detrand.permutation(seed, f"g12.p{t}{v}", B) for v in range(2)] for t in range(Tn)],
-           "eps": [[detrand.normal(seed, f"g12.e{t}{v}", (B, K)).astype(np.float32) for v in range(2)] for t in range(Tn - 1)]}
+    g = "g12." if batch == 0 else f"g12.b{batch}."
+    Ns = [640 + 37 * b + 19 * batch for b in range(B)]
+    feats = [P.bags(seed, f"{g}f{b}", 1, Ns[b], c["d"])[0] for b in range(B)]
+    cls = [P.cluster_lists(seed, f"{g}c{b}", Ns[b], K) for b in range(B)]
+    inj = {"actions": [[detrand.uniform(seed, f"{g}a{v}", (B, K)).astype(np.float32) for v in range(2)]],
+           "u": [[detrand.uniform(seed, f"{g}u{t}{v}", (B, 1)).astype(np.float32) for v in range(2)] for t in range(Tn)],
+           "perm": [[detrand.permutation(seed, f"{g}p{t}{v}", B) for v in range(2)] for t in range(Tn)],
+           "eps": [[detrand.normal(seed, f"{g}e{t}{v}", (B, K)).astype(np.float32) for v in range(2)] for t in range(Tn - 1)]}
     # lambda exactly as mixup forms it (datasets.py:265): alpha + U * (1 - alpha) in float32 tensor arithmetic
     inj["draws"] = [[((c["alpha"] + T(inj["u"][t][v]) * (1 - c["alpha"])).numpy(), inj["perm"][t][v]) for v in range(2)]
                     for t in range(Tn)]

@@ -47,7 +47,7 @@ def ppo_update(policy_p, adam_state, memory, gamma, K_epochs, action_std, lr, ep
 
 
 def pretrain_step_rl(model_p, fc_p, policy_p, feats, clusters, inj, *, T, feat_size, stage, temperature=1.0,
-                     action_std=0.5, gamma=0.1, K_epochs=3, ppo_lr=1e-5, arch="ABMIL"):
+                     action_std=0.5, gamma=0.1, K_epochs=3, ppo_lr=1e-5, arch="ABMIL", ppo_state=None):
     """One batch of train_MuRCL.py:233-304 at train_stage 2 or 3.
 
     feats: list of B [N_i,d] float32 arrays; clusters: B lists of K ascending id lists; ``inj``: 'actions'[0][v] [B,K],
@@ -101,7 +101,7 @@ def pretrain_step_rl(model_p, fc_p, policy_p, feats, clusters, inj, *, T, feat_s
     loss = sum(losses) / T                                                       # :291
     res = dict(loss=loss, losses=losses, rewards=rewards, actions=actions_all, ids=ids_all, memories=mem, policy=policy_p)
     if stage == 2:
-        st = {}
+        st = ppo_state if ppo_state is not None else {}          # the sampler's ONE Adam state lives across batches (rlmil.py:141)
         for m in mem:                                                            # :297-298
             policy_p = ppo_update(policy_p, st, m, gamma, K_epochs, action_std, ppo_lr)
         res["policy"] = policy_p

@@ -105,6 +105,39 @@ def test_rl_in_the_loop_step_vs_reference_train_loop(golden, tmp_path, Tn, stage
 
 
 @pytest.mark.parametrize("stage", [2, 3])
+def test_two_optimizer_steps_vs_reference_train_loop(golden, tmp_path, stage):
+    """G17: TWO consecutive batches through the reference's own train(); the second batch's losses, rewards, actions and patch
+    ids depend on the first update (policy at stage 2, aggregator + head at stage 3), and the fingerprints are taken after both."""
+    g, c, Tn = golden("g17_rl_two_steps"), G12, 3
+    tag = f"s{stage}"
+    seed, B, K, fs = c["seed"], c["B"], c["K"], c["fs"]
+    args, model, fc, ppo, opt, dev = _build(tmp_path, stage, Tn, seed, K, fs, B, c["ppo_lr"], c["lr"], c["K_epochs"])
+    pre = {"policy": {k: v.detach().clone() for k, v in ppo.policy.state_dict().items()},
+           "model": {k: v.detach().clone() for k, v in model.encoder.state_dict().items()},
+           "fc": {k: v.detach().clone() for k, v in fc.state_dict().items()}}
+    for b in range(2):
+        Ns, feats, cls, inj = g12_inputs(Tn, b)
+        loss, losses, rewards, acts, logp, ids = _run(args, model, fc, ppo, opt, dev, feats, cls, inj, B)
+        np.testing.assert_allclose([l.item() for l in losses], g[f"{tag}.losses"][b], rtol=1e-4 if b == 0 else 3e-4, err_msg=f"batch {b}")
+        np.testing.assert_allclose(torch.cat(rewards).cpu().numpy(), g[f"{tag}.rewards"][b], rtol=1e-2, atol=5e-6)
+        for v in range(2):
+            got = torch.stack([acts[t][v] for t in range(1, Tn)]).cpu().numpy()
+            np.testing.assert_allclose(got, g[f"{tag}.actions.{b}.{v}"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(logp[v].cpu().numpy(), g[f"{tag}.logp.{b}.{v}"], rtol=1e-4, atol=1e-4)
+            for t in range(1, Tn):
+                assert np.array_equal(ids[t][v], g[f"{tag}.ids.{b}.{t}.{v}"]), f"patch ids differ: batch {b}, step {t}, view {v}"
+    now = {"policy": ppo.policy.state_dict(), "model": model.encoder.state_dict(), "fc": fc.state_dict()}
+    for name in ("policy", "model", "fc"):
+        for k, v in now[name].items():
+            key = f"{tag}.{name}_delta.{k}"
+            if key not in g.files or g[key][0] == 0.0:
+                assert torch.equal(v, pre[name][k]), key
+                continue
+            _close_summ(_summ(v - pre[name][k]), g[key], 3e-2, key)
+            _close_summ(_summ(v), g[f"{tag}.{name}.{k}"], 1e-4, key)
+
+
+@pytest.mark.parametrize("stage", [2, 3])
 def test_rl_in_the_loop_step_vs_oracle_other_shape(tmp_path, stage):
     """Same comparison against the oracle composition at another size (B = 6 ragged bags, K = 6 clusters, T = 4)."""
     seed, B, K, fs, Tn = 31, 6, 6, 96, 4

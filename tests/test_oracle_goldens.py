@@ -287,6 +287,53 @@ def test_g12_rl_step_oracle_vs_reference_train_loop(golden, Tn, stage):
                 _close_summ(_fp(new[k] - base[k]), want, 3e-2, msg=k)
 
 
+@pytest.mark.parametrize("stage", [2, 3])
+def test_g17_two_optimizer_steps_oracle_vs_reference_train_loop(golden, stage):
+    """Two consecutive batches through the reference's own train() (G17): the second batch runs on the parameters the first
+    update left behind, so a wrong update direction or Adam state shows in its losses and actions, not only in fingerprints."""
+    from oracle import step_oracle as SO
+    from oracle.recipes import G12, g12_inputs
+    g, c, Tn = golden("g17_rl_two_steps"), G12, 3
+    tag = f"s{stage}"
+    mp, fp = P.to_torch(P.abmil(c["seed"])), P.to_torch(P.full_layer(c["seed"]))
+    pp = P.to_torch(P.actor_critic(c["seed"], 512, 512, c["K"]))
+    pp0, mp0, fp0 = dict(pp), dict(mp), dict(fp)
+    ppo_state, adam = {}, {"model": {}, "fc": {}}
+    for b in range(2):
+        Ns, feats, cls, inj = g12_inputs(Tn, b)
+        mpl, fpl = ({k: v.clone().requires_grad_() for k, v in d.items()} for d in (mp, fp))
+        r = SO.pretrain_step_rl(mpl, fpl, pp, feats, cls, inj, T=Tn, feat_size=c["fs"], stage=stage, action_std=c["std"],
+                                gamma=c["gamma"], K_epochs=c["K_epochs"], ppo_lr=c["ppo_lr"], ppo_state=ppo_state)
+        np.testing.assert_allclose([l.item() for l in r["losses"]], g[f"{tag}.losses"][b], rtol=2e-5 if b else 2e-6, err_msg=f"batch {b}")
+        np.testing.assert_allclose(torch.stack(r["rewards"]).numpy(), g[f"{tag}.rewards"][b], rtol=2e-3, atol=2e-7)
+        for v in range(2):
+            acts = torch.stack([r["actions"][t][v] for t in range(1, Tn)]).numpy()
+            # (batch 1 runs on parameters that Adam's sign-like first steps produced: last-bit differences in those gradients
+            #  show up at the 1e-5 level)
+            np.testing.assert_allclose(acts, g[f"{tag}.actions.{b}.{v}"], rtol=1e-4 if b else 1e-5, atol=1e-5 if b else 1e-6)
+            np.testing.assert_allclose(torch.stack(r["memories"][v]["logprobs"]).numpy(), g[f"{tag}.logp.{b}.{v}"], rtol=1e-4 if b else 1e-5,
+                                       atol=1e-4 if b else 1e-5)
+            for t in range(1, Tn):
+                ids = np.array([i + [-1] * (c["fs"] - len(i)) for i in r["ids"][t][v]], dtype=np.int32)
+                assert np.array_equal(ids, g[f"{tag}.ids.{b}.{t}.{v}"]), (b, t, v)
+        pp = r["policy"]
+        if stage == 3:
+            r["loss"].backward()
+            for name, live in (("model", mpl), ("fc", fpl)):
+                used = {k: v for k, v in live.items() if v.grad is not None}
+                new = O.adam_step({k: v.detach() for k, v in used.items()}, {k: v.grad for k, v in used.items()}, adam[name], c["lr"],
+                                  weight_decay=c["wd"])
+                (mp if name == "model" else fp).update({k: new[k] for k in used})
+    for name, now, base in (("policy", pp, pp0), ("model", mp, mp0), ("fc", fp, fp0)):
+        for k, v in now.items():
+            key = f"{tag}.{name}_delta.{k}"
+            if key not in g.files or g[key][0] == 0.0:
+                assert torch.equal(v.detach(), base[k]), key
+                continue
+            _close_summ(_fp(v.detach() - base[k]), g[key], 3e-2, msg=key)
+            _close_summ(_fp(v.detach()), g[f"{tag}.{name}.{k}"], 1e-4, msg=key)
+
+
 def test_g14_clam_plain_attention_net(golden):
     """CLAM_SB(gate=False): the oracle's Attn_Net branch vs the reference (scores, soft-max, pooled vector, gradients)."""
     g = golden("g14_clam_plain")
