@@ -65,7 +65,11 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * ReLU' taken from a 1-bit-per-element mask ([M,N/8] bytes; bit e of byte c <=> column 8c+e of the forward
  * output was > 0) that the forward epilogue (epilogue 0) can emit through bitmask_out.
  * epilogue: 0 = relu(.+bias) (K=512), 1 = . * mask (K=512), 2 = (. + rowscale[m]*rank1[m/rows_per_bag][n]) * mask
- * (K=128 with N=512, or K=512), 3 = . + bias (K=512).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
+ * (K=128 with N=512, or K=512), 3 = . + bias (K=512), 4 = CLAM's gated attention score without the pre-activations
+ * (clam.py:55-60; K=512, forward-only calls): W / bias hold attention_a and attention_b interleaved in 16-row blocks (rows
+ * 32g..32g+15 = attention_a[16g..], rows 32g+16..32g+31 = attention_b[16g..]), rank1 = attention_c's weight at the a-rows ([N]
+ * f32), and the ONLY output is colsum_ws = [N/32][M] f32 partial scores, partial[g][m] = sum over d in 16g..16g+15 of
+ * tanh(a_d) sigmoid(b_d) c_d for row m (C may be NULL; colsum_out must be NULL).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
  * when colsum_accumulate != 0 (accumulation straight into a gradient buffer); the workgroups' partial sums pass through
  * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.  walk_reverse bit 0: the
  * row tiles are visited from the last to the first (same result; use it when the kernel that has just produced A

@@ -68,7 +68,7 @@
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
-enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3 };
+enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3, PG_GATE = 4 };
 
 // In-kernel stamps (diagnostic builds only, -DPG_STAMPS; tools/stamps_panel.py): waves 0 and 4 of the first PG_STAMP_WG
 // workgroups note s_memtime at fixed points of each tile iteration into a spare LDS region (a global store would join the
@@ -102,6 +102,9 @@ extern "C" int murcl_debug_pg_stamps(void* host, long bytes) {
 __device__ __forceinline__ void pg_store16(void* p, u32x4 v) {
     if (PG_ABL & 4) { asm volatile("" ::"v"(p), "v"(v)); return; }
     asm volatile("global_store_dwordx4 %0, %1, off" PG_STORE_POLICY "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void pg_store4(void* p, float v) {
+    asm volatile("global_store_dword %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void pg_store2(void* p, unsigned v) {
     if (PG_ABL & 4) { asm volatile("" ::"v"(p), "v"(v)); return; }
@@ -163,14 +166,19 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr int NS = PG_TR / RPI;             // store instructions per tile: 2 / 4
     constexpr int STG_LD = WN * 2 + 16;         // staging row stride (bytes), 16-B aligned, breaks the pow-2 stride
     constexpr bool MASKED = (EPI == PG_MASK || EPI == PG_RANK1_MASK);
-    constexpr bool BIASED = (EPI == PG_BIAS_RELU || EPI == PG_BIAS);
+    // PG_GATE (CLAM's gated attention score, clam.py:55-60, forward-only calls): W holds the two gate branches interleaved so that a
+    // wave's first 16-column block is attention_a[d .. d+15] and its second block attention_b of the SAME d: the lane that holds
+    // a_d also holds b_d, and the epilogue emits sum_d tanh(a_d) sigmoid(b_d) wc_d over the wave's 16 pairs per row - one f32 per
+    // row and wave ([N/32][M] partial scores) instead of the [M, 2D] gate pre-activations (no 268 MB written and read back at C3).
+    constexpr bool GATE = (EPI == PG_GATE);
+    constexpr bool BIASED = (EPI == PG_BIAS_RELU || EPI == PG_BIAS || GATE);
     constexpr int NB = MASKED ? 1 : 0;                              // mask LDS-DMA op (128 or 256 B per wave)
     constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
     constexpr bool DMAH = PAD && PG_DMA_HALF != 0;                 // one half of the workgroup issues every A piece
     constexpr int GA = DMAH ? 2 * GT : GT;      // A pieces per tile of an issuing wave
     constexpr int G = GA + NB + NR;             // counted loads per tile per (issuing) wave
     constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
-    constexpr int S = (PG_ABL & 4) ? 0 : NS + NMS;   // counted stores per tile per wave
+    constexpr int S = (PG_ABL & 4) ? 0 : (EPI == PG_GATE ? 2 : NS + NMS);   // counted stores per tile per wave
     // LDS carve
     constexpr int OFF_STG = PG_NSLOT * SLOT;
     constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const int tile0 = CONTIG ? stream * per : stream, tstep = CONTIG ? 1 : streams;
     const int my_tiles = CONTIG ? min(per, n_tiles - tile0) : (n_tiles - stream + streams - 1) / streams;
     if (stream >= streams || my_tiles <= 0) {
-        if (colsum_part && stream < streams)                 // no tiles: this workgroup's row of partial sums is zero
+        if (EPI != PG_GATE && colsum_part && stream < streams)   // no tiles: this workgroup's row of partial sums is zero
             for (int c = threadIdx.x; c < NP; c += 64 * PG_NW) colsum_part[(size_t)stream * N + panel * NP + c] = 0.f;
         return;
     }
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         const bool rev = ((walk_reverse & 1) != 0) != ((PG_FLIP >> EPI) & 1);
         return (rev ? n_tiles - 1 - tix : tix) * PG_TR;
     };
-    constexpr bool RS = PG_REGSTAGE != 0 && PAD && BIASED;
+    constexpr bool RS = PG_REGSTAGE != 0 && PAD && (EPI == PG_BIAS_RELU || EPI == PG_BIAS);
     u32x4 rs_reg[2][RS ? GT : 1];
     auto rs_load = [&](auto par, int seq) {
         constexpr int P = decltype(par)::value;
@@ -326,6 +334,14 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                 // the first use, inside the tile loop, where it drains the LDS-DMA ring on every tile
                 asm volatile("" : "+v"(bias_r[j][r]));
             }
+    }
+    float gw[4] = {0.f, 0.f, 0.f, 0.f};              // PG_GATE: wc of this lane's four (a_d, b_d) pairs
+    if (GATE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gw[r] = rank1[n0 + 4 * q4 + r];
+            asm volatile("" : "+v"(gw[r]));
+        }
     }
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
     int cur_bag = -1;
@@ -448,6 +464,23 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             return;
         }
         const int row0 = row0_of(seq);
+        if constexpr (GATE) {
+            static_assert(!GATE || NJ == 2, "PG_GATE pairs the wave's two 16-column blocks");
+            float* sp = colsum_part + (size_t)(n0 >> 5) * M + row0;       // partial scores [N/32][M]
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * acc[i][1][r]));
+                    t += fast_tanh(acc[i][0][r]) * sg * gw[r];
+                }
+                t = quarters_sum(t);
+                // 16 consecutive floats per instruction (lanes of quarter 0; the other quarters carry the same sums)
+                if (q4 == 0) pg_store4(sp + 16 * i + r16, t);
+            }
+            return;
+        }
         unsigned ones = 0x00010001u;
         asm volatile("" : "+v"(ones));
         // ---- accumulator-layout math: lane holds row 16i+r16, columns 16j+4q4+r
@@ -521,7 +554,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // Fused schedule (PG_FUSE, K = 512): every wave keeps the accumulators of tile t-1 and runs its epilogue in pieces
     // between the k-groups of tile t, so VALU / LDS-staging / store work issues in the shadow of the MFMAs instead
     // of after them with the matrix pipe idle.  Store counts lag by one tile, exactly like the rotated half.
-    constexpr bool FUSE = PAD && (((PG_FUSE & 1) && BIASED) || ((PG_FUSE & 2) && EPI == PG_MASK));   // (the K = 512 rank-1 variant would spill)
+    constexpr bool FUSE = PAD && (((PG_FUSE & 1) && (EPI == PG_BIAS_RELU || EPI == PG_BIAS)) || ((PG_FUSE & 2) && EPI == PG_MASK));   // (the K = 512 rank-1 variant would spill)
     constexpr bool ROT = PG_ROTATE != 0 && !FUSE;
     const bool late = FUSE || (ROT && wave >= PG_NW / 2);
     f32x4 acc[2][NJ];
@@ -713,7 +746,7 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
 extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag) {
     if (M <= 0 || M % PG_TR) return 0;
     if (K == 512)
-        return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK || epilogue == PG_BIAS ||
+        return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK || epilogue == PG_BIAS || epilogue == PG_GATE ||
                                   (epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0));
     if (K == 128) return N == 512 && epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0;
     return 0;
@@ -750,6 +783,10 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     } else if (K == 512 && epilogue == PG_BIAS) {
         if (!bias) return -1;
         rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
+    } else if (K == 512 && epilogue == PG_GATE) {
+        // rank1 = wc per interleaved column [N] f32, colsum_ws = the partial scores [N/32][M] f32 (the only output: C may be NULL)
+        if (!bias || !rank1 || !colsum_ws || colsum_out) return -1;
+        rc = pg_launch<512, 32, 8, PG_GATE, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_RANK1_MASK) {
         if (!bi || !rowscale || !rank1) return -1;
         rc = pg_launch<512, 32, 8, PG_RANK1_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);

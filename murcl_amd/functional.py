@@ -32,6 +32,7 @@ import os as _os
 # the backward pass, while its output (H3) is what the pooling kernel streams next: kept out of the Infinity Cache, H2
 # leaves more of H3 there (K2 forward 67.6 -> 62.4 us inside the step; the other layers measured neutral-to-slower).
 _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
+_FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B switch: CLAM's gate score from the gate GEMM's epilogue (forward-only)
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
@@ -196,10 +197,12 @@ class ABMILFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wa, ba, wb, bb, wd, bd, drops=None):
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, wa, ba, wb, bb, wd, bd, drops=None, grad_on=True):
         """``drops`` = None or the two Dropout(p) keep masks after encoder layers 1 and 2 (abmil.py:12-19): ``ops.DropSeed``s
         (training: the masks are generated inside the passes that apply them) or materialised keep-multiplier tensors
-        (values 0 or 1/keep, parity tests)."""
+        (values 0 or 1/keep, parity tests).  ``grad_on``: the caller's ``torch.is_grad_enabled()`` - inside ``forward`` autograd
+        is always off and ``ctx.needs_input_grad`` stays True for parameters under ``torch.no_grad()``, so only the caller knows
+        that no backward pass can follow (frozen encoder of stage 2, validation): then no ReLU masks are written."""
         B, N, d = x.shape
         T = x.dtype
         x2 = x.reshape(B * N, d)
@@ -232,7 +235,7 @@ class ABMILFn(torch.autograd.Function):
 
         if fast:
             nt = _STREAM_A
-            keep = any(ctx.needs_input_grad)     # forward-only passes (frozen encoder of stage 2, validation): no ReLU masks to write
+            keep = bool(grad_on) and any(ctx.needs_input_grad)     # forward-only passes: no ReLU masks to write
             h1, m1, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=keep and drops is None, stream_a=bool(nt & 1))
             if drops is not None:
                 m1 = drop(h1, drops[0], keep)
@@ -280,10 +283,10 @@ class ABMILFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dA):
         if dout is None:
-            return (None,) * 14
+            return (None,) * 15
         if ctx.drop_scale is not None or not ctx.pool_fast:
-            return ABMILFn._backward_general(ctx, dout)
-        return ABMILFn._backward_default(ctx.saved_tensors, ctx.dims, dout, ctx.needs_input_grad[0]) + (None,)
+            return ABMILFn._backward_general(ctx, dout) + (None,)
+        return ABMILFn._backward_default(ctx.saved_tensors, ctx.dims, dout, ctx.needs_input_grad[0]) + (None, None)
 
     @staticmethod
     def _backward_default(saved, dims, dout, need_dx):
@@ -721,7 +724,7 @@ class CLAMFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w1, b1, wa, ba, wb, bb, wc, bc, inst_w, inst_b, keeps, inst_cfg):
+    def forward(ctx, x, w1, b1, wa, ba, wb, bb, wc, bc, inst_w, inst_b, keeps, inst_cfg, grad_on=True):
         B, N, d = x.shape
         T = x.dtype
         f32 = T == torch.float32
@@ -731,7 +734,7 @@ class CLAMFn(torch.autograd.Function):
         m1 = None
         if T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU):
             # weight-stationary panel kernel; without dropout its 1-bit ReLU mask also serves the backward pass
-            h, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=keeps is None)
+            h, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=keeps is None and bool(grad_on))
         else:
             h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                # clam.py:69
         k1 = ka = kb = None
@@ -752,11 +755,20 @@ class CLAMFn(torch.autograd.Function):
         GW = wab.shape[0]                        # gate columns: 2D / D
         # bf16 with 512-wide h and gates: the weight-stationary panel kernel (same GEMM, half the time of the tile kernel)
         panel = (T == torch.bfloat16 and L == 512 and ops.panel_supported(B * N, GW, 512, ops.PG_BIAS))
-        if panel:
+        # (``grad_on`` = the caller's torch.is_grad_enabled(): see ABMILFn.forward)
+        fused_gate = (_FUSED_GATE and panel and gated and keeps is None and GW == 512 and not (grad_on and any(ctx.needs_input_grad))
+                      and ops.panel_supported(B * N, GW, 512, ops.PG_GATE))
+        if fused_gate:
+            # forward-only calls (validation, heat-map scoring, the frozen aggregator of stage 2): the score comes out of the gate
+            # GEMM's epilogue - tanh(a_d) sigmoid(b_d) c_d summed per wave - and the [B*N, 2D] pre-activations are never written
+            U = None
+            s = ops.panel_gate_score(h, *ops.gate_interleave(wa, ba, wb, bb, wc, T), bc).view(B, N)
+        elif panel:
             U, _, _ = ops.panel_gemm(h, c(wab), ops.PG_BIAS, bias=bab)                  # both gate branches, one pass
         else:
             U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
-        s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
+        if not fused_gate:
+            s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
         A = ops.softmax_rows(s)                                                        # clam.py:144
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
         dev = x.device
@@ -788,7 +800,8 @@ class CLAMFn(torch.autograd.Function):
             inst_loss = loss_g.view(B, n_cls).sum(1) * scale
             inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
             saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
-        ctx.save_for_backward(x2, h, U, A, M, w1, wa, wb, wc, inst_w if inst_w is not None else x2.new_zeros(1), m1)
+        ctx.save_for_backward(x2, h, U if U is not None else x2.new_zeros(1), A, M, w1, wa, wb, wc,
+                              inst_w if inst_w is not None else x2.new_zeros(1), m1)
         ctx.gated = gated
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
@@ -847,9 +860,9 @@ class CLAMFn(torch.autograd.Function):
             kp = k1.keep_q if isinstance(k1, ops.DropSeed) else 0.75
             dw1, db1 = dw1 / kp, db1 / kp
         if not gated:
-            return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
+            return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None, None)
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),
-                dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None)
+                dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None, None)
 
 
 class PolicyHeadFn(torch.autograd.Function):

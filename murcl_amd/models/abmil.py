@@ -60,7 +60,7 @@ class ABMIL(nn.Module):
             self.last_attention = A
             return out
         out, A = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
-                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops)
+                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops, torch.is_grad_enabled())
         self.last_attention = A
         return out
 

@@ -62,6 +62,7 @@ class CLAM_SB(nn.Module):
         self.instance_loss_fn = instance_loss_fn          # kept for API compat; CE is evaluated by the HIP kernel
         self.compute_dtype = torch.float32
         self.last_attention = None
+        self._empty_results = None                   # cached per-bag result dicts of calls that report nothing (batch_forward)
         initialize_weights(self)
 
     def relocate(self):
@@ -97,7 +98,7 @@ class CLAM_SB(nn.Module):
             lab = labels.reshape(-1) if isinstance(labels, torch.Tensor) else [int(l) for l in labels]
             cfg = (lab, self.k_sample, self.subtyping)
         M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias, wa, ba, wb, bb, wc, bc,
-                                                         inst_w, inst_b, keeps, cfg)
+                                                         inst_w, inst_b, keeps, cfg, torch.is_grad_enabled())
         self.last_attention = A
         return M, A, s, inst_loss, ids, inst_out
 
@@ -140,7 +141,13 @@ class CLAM_SB(nn.Module):
         if not instance_eval and not return_features:
             # nothing to report per bag (the contrastive pre-training calls it this way with 2*T*B = 768 bags per step:
             # building 768 result dicts one by one was 2.9 ms of host time per step)
-            return M, [{} for _ in range(x.shape[0])]
+            # ONE cached list of empty dicts per batch size: 768 fresh containers per call push CPython's cyclic collector
+            # over its allocation threshold in this very line, and a full collection (tens of ms with a model alive) then lands
+            # inside the step every few steps (10.2 vs 6.1 ms per stage-1 step measured)
+            n = x.shape[0]
+            if self._empty_results is None or len(self._empty_results) != n:
+                self._empty_results = [{} for _ in range(n)]
+            return M, self._empty_results
         host = self._host_inst(io) if instance_eval else None
         ils = il.unbind(0) if instance_eval else il          # one autograd node for all bags (its backward is one stack)
         return M, [self._results(b, M, ils, host, instance_eval, return_features) for b in range(x.shape[0])]

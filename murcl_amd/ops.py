@@ -126,8 +126,43 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     return (C, ws) if colsum else C
 
 
-PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK, PG_BIAS = 0, 1, 2, 3
-_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK", 3: "BIAS"}
+PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK, PG_BIAS, PG_GATE = 0, 1, 2, 3, 4
+_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK", 3: "BIAS", 4: "GATE"}
+
+
+_GATE_IDX = {}
+
+
+def gate_interleave(wa, ba, wb, bb, wc, dtype):
+    """CLAM's gate weights in the layout of ``panel_gate_score``: rows 32g .. 32g+15 = attention_a[16g ..], rows 32g+16 .. 32g+31 =
+    attention_b[16g ..] (so that one wave of the panel GEMM holds matching (a_d, b_d) pairs) -> (W [2D,L] in ``dtype``, bias [2D]
+    f32, wc per interleaved row [2D] f32: attention_c's weight at the a-rows, 0 at the b-rows)."""
+    D = wa.shape[0]
+    key = (D, wa.device)
+    idx = _GATE_IDX.get(key)
+    if idx is None:
+        n = torch.arange(2 * D)
+        g, j, i = n // 32, (n % 32) // 16, n % 16
+        idx = _GATE_IDX[key] = ((16 * g + i) + D * j).to(wa.device)
+    W = torch.cat([wa, wb], 0).index_select(0, idx)
+    b = torch.cat([ba, bb], 0).index_select(0, idx).contiguous()
+    c = torch.cat([wc.reshape(-1), torch.zeros_like(wc.reshape(-1))], 0).index_select(0, idx).contiguous()
+    return (W.contiguous() if dtype == torch.float32 else cast(W.contiguous(), dtype)), b, c
+
+
+def panel_gate_score(h, W_il, b_il, c_il, bc):
+    """CLAM's gated attention score straight from the gate GEMM's epilogue (``murcl_panel_gemm`` epilogue 4): h [M,512] bf16 ->
+    raw scores s [M] f32 = sum_d tanh(a_d) sigmoid(b_d) wc_d + bc, without materialising the [M, 2D] gate pre-activations."""
+    _need_cuda(h, W_il)
+    h = _c(h)
+    M, K = h.shape
+    N = W_il.shape[0]
+    part = torch.empty((N // 32, M), dtype=torch.float32, device=h.device)
+    with _span(lambda: (f"panel_gemm<K{K},GATE>", dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + (N // 32) * M * 4))):
+        check(_lib.lib().murcl_panel_gemm(ptr(h), ptr(W_il), None, M, N, K, PG_GATE, ptr(b_il), None, None, None, ptr(c_il), 0,
+                                          None, 0, ptr(part), 0, stream()), "panel_gemm(gate)")
+    s = bc.reshape(1).to(torch.float32).expand(M).contiguous()           # (a fill: the partial rows are ADDED to it)
+    return colsum(part, out=s, accumulate=True)
 
 
 def panel_supported(M, N, K, epi, rows_per_bag=0):

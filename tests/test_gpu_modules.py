@@ -415,6 +415,44 @@ def test_clam_bf16_path_and_cl_wrapper():
         assert a.shape == (4, 512) and (a - b).abs().max().item() <= 3e-2 * b.abs().max().item()
 
 
+def test_clam_fused_gate_score_forward_only_matches_the_unfused_chain_and_the_oracle(monkeypatch):
+    """in forward-only calls (validation, heat-map scoring, stage 2) the gated attention score comes out of
+    the gate GEMM's epilogue (murcl_panel_gemm epilogue 4) without materialising the [B*N, 2D] pre-activations: raw scores,
+    soft-max, pooled vector and top-k ids against the un-fused bf16 chain and against the f32 oracle."""
+    from murcl_amd import functional, ops
+    dev = _dev()
+    B, N = 3, 2048
+    x = T(P.bags(15, "fg.x", B, N, 512)).to(dev)
+    m16 = _clam(15, True, torch.bfloat16).eval()
+    seen = []
+    real = ops.panel_gate_score
+    monkeypatch.setattr(ops, "panel_gate_score", lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        raw_f = m16.bag_forward(x[0], attention_only=True)                       # fused (no grad)
+        M_f, A_f, s_f, _, ids_f, _ = m16._run(x, torch.tensor([1, 0, 1], device=dev), True)
+    assert len(seen) == 2
+    monkeypatch.setattr(functional, "_FUSED_GATE", False)
+    with torch.no_grad():
+        raw_u = m16.bag_forward(x[0], attention_only=True)
+        M_u, A_u, s_u, _, ids_u, _ = m16._run(x, torch.tensor([1, 0, 1], device=dev), True)
+    assert len(seen) == 2
+    sc = s_u.abs().max().item()
+    assert (s_f - s_u).abs().max().item() <= 2e-2 * sc and (raw_f - raw_u).abs().max().item() <= 2e-2 * sc
+    assert (M_f - M_u).abs().max().item() <= 2e-2 * M_u.abs().max().item()
+    # against the f32 oracle the fused path (f32 accumulators into tanh / sigmoid) must be no worse than the un-fused one
+    # (which rounds the pre-activations to bf16 first)
+    p = P.to_torch(P.clam_sb(15))
+    Mo, Ao, so, _ = O.clam_sb_forward(p, x.cpu())
+    e_f, e_u = (s_f.cpu() - so).abs().max().item(), (s_u.cpu() - so).abs().max().item()
+    assert e_f <= 1.5 * e_u + 1e-3 * so.abs().max().item(), (e_f, e_u)
+    # a call that needs gradients keeps the un-fused chain (the backward pass reads the pre-activations)
+    monkeypatch.setattr(functional, "_FUSED_GATE", True)
+    m16.train()
+    out = m16._run(x, None, False)[0]
+    out.sum().backward()
+    assert len(seen) == 2 and m16.attention_net[0].weight.grad is not None
+
+
 # ------------------------------------------------------------------ PPO (K10/K11)
 def test_ppo_act_evaluate_update_vs_reference_golden(golden):
     """G8: act (injected eps) -> actions/logp/hidden; evaluate; one update (K_epochs=1, Adam lr 1e-3) -> parameters."""
