@@ -69,7 +69,7 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * (clam.py:55-60; K=512, forward-only calls): W / bias hold attention_a and attention_b interleaved in 16-row blocks (rows
  * 32g..32g+15 = attention_a[16g..], rows 32g+16..32g+31 = attention_b[16g..]), rank1 = attention_c's weight at the a-rows ([N]
  * f32), and the ONLY output is colsum_ws = [N/32][M] f32 partial scores, partial[g][m] = sum over d in 16g..16g+15 of
- * tanh(a_d) sigmoid(b_d) c_d for row m (C may be NULL; colsum_out must be NULL).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
+ * tanh(a_d) sigmoid(b_d) c_d for row m, plus rowscale[0] (attention_c's bias; rowscale may be NULL) in partial[0] (C may be NULL; colsum_out must be NULL).  colsum_out ([N] f32, may be NULL) receives the column sums of the output (bias gradient): overwritten, or added to
  * when colsum_accumulate != 0 (accumulation straight into a gradient buffer); the workgroups' partial sums pass through
  * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.  walk_reverse bit 0: the
  * row tiles are visited from the last to the first (same result; use it when the kernel that has just produced A
@@ -84,6 +84,18 @@ int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K,
                      void* bitmask_out, const void* bitmask_in, const float* rowscale, const float* rank1,
                      int rows_per_bag, float* colsum_out, int colsum_accumulate, float* colsum_ws /* [256*N] */,
                      int walk_reverse, murcl_stream_t stream);
+/* The same with two more things for CLAM-SB's training forward (clam.py:69-72,40-60):
+ * epilogue 5 (K=512) = epilogue 4's partial scores AND the gate pre-activations: C [M,N] = A W^T + bias in the interleaved
+ * column order of W (what murcl_gated_score_bwd_il reads back), colsum_ws = [N/32][M] partial scores as for epilogue 4;
+ * 0 < keep_p < 1 = nn.Dropout(1 - keep_p) inside the epilogue, masks never materialised (the counter-based masks of
+ * murcl_dropout_mask: the same seed gives the same mask in every kernel): epilogue 0 with bitmask_out - the mask of seed_a over
+ * [M,N] applied behind the ReLU, bitmask_out records what survives (= murcl_dropout_relu_bitmask on the epilogue's output, without
+ * that pass); epilogue 5 - the masks of seed_a / seed_b over [M,N/2] applied to tanh(a) and sigmoid(b) inside the partial scores
+ * (murcl_gated_score_fwd's seeded form; C stays the un-dropped pre-activations).  Other epilogues: keep_p must be 0 or 1. */
+int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int M, int N, int K, int epilogue, const float* bias,
+                          void* bitmask_out, const void* bitmask_in, const float* rowscale, const float* rank1,
+                          int rows_per_bag, float* colsum_out, int colsum_accumulate, float* colsum_ws, int walk_reverse,
+                          float keep_p, unsigned long long seed_a, unsigned long long seed_b, murcl_stream_t stream);
 
 /* K2 -- ABMIL attention pooling, abmil.py:38-42:  scores[b,n] = wb.tanh(Wa H[b,n]+ba)+bb,
  * A = softmax_N(scores)/sqrt(N), M[b] = A[b].H[b];  ml[b] = (max, sum exp) of the soft-max.
@@ -186,6 +198,15 @@ int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, co
                           void* dU, float* dwc, float* dbc, float* dbab, float* part_ws /* [1024*(3D+1)] */, long rows, int D,
                           int dtype, int gated, float keep_p, unsigned long long seed_a, unsigned long long seed_b,
                           murcl_stream_t stream);
+/* The CLAM-SB training chain's form (gated, U / dU [rows,2D] in the interleaved column order of murcl_panel_gemm_drop's epilogue
+ * 5; dwc, dbab in natural order; seeded masks only).  ds given - or ds NULL and the pooling + soft-max backward
+ * (clam.py:144,170) taken in the same pass: ds_n = A_n (h_n . dM_bag - Mp_bag . dM_bag) from h [rows,L] (dtype of U, bf16),
+ * the pooled vectors Mp [rows/rows_per_bag, L], their upstream gradient dM (same shape) and the attention A [rows], all f32;
+ * L = 8 c D/8 with c in {1,2,4}, D/8 a power of two <= 64. */
+int murcl_gated_score_bwd_il(const void* U, const float* wc, const float* ds, void* dU, float* dwc, float* dbc, float* dbab,
+                             float* part_ws /* [1024*(3D+1)] */, long rows, int D, int dtype, float keep_p,
+                             unsigned long long seed_a, unsigned long long seed_b, const void* h, const float* dM,
+                             const float* Mp, const float* A, int L, int rows_per_bag, murcl_stream_t stream);
 int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t stream);
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);
@@ -268,7 +289,9 @@ int murcl_dropout_relu_bitmask(void* x, void* bits, int M, int N, float keep_p, 
 /* Compute-dtype copies / transposes of several f32 weight matrices in one launch.  jobs_dev: n_jobs records of
  * { const float* src; void* dst; int rows, cols, transpose, dtype_out; } (32 bytes each) in device memory; max_tiles =
  * the largest ceil(rows/32)*ceil(cols/32) among them.  Replaces the per-tensor `.to(dtype)` / `.t()` copies that the
- * reference's nn.Linear calls imply (abmil.py:12-21). */
+ * reference's nn.Linear calls imply (abmil.py:12-21).  `transpose`: bit 0 = transpose; bits 8.. = the leading dimension of dst in
+ * elements (0: the job's own width), so that a job can fill a row or column block of a larger matrix - CLAM's two gate Linears
+ * interleaved in 16-row blocks for murcl_panel_gemm epilogues 4 / 5 (clam.py:40-48) are 2 x D/16 such jobs. */
 int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stream_t stream);
 
 /* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g

@@ -25,6 +25,7 @@ SIGNATURES = {
     "murcl_panel_gemm_colsum_rows": [_I, _I, _I, _I],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
+    "murcl_panel_gemm_drop": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_dropout_mask": [_P, _L, _F, _F, ctypes.c_ulonglong, _I, _P],
@@ -48,6 +49,7 @@ SIGNATURES = {
     "murcl_dsmil_attn_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P],
     "murcl_gated_score_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
     "murcl_gated_score_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
+    "murcl_gated_score_bwd_il": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, _P, _P, _P, _I, _I, _P],
     "murcl_softmax_rows": [_P, _P, _I, _I, _P],
     "murcl_softmax_rows_bwd": [_P, _P, _P, _I, _I, _P],
     "murcl_topk_ids": [_P, _I, _I, _I, _P, _P],

@@ -111,31 +111,79 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
 // dU[n,d] = ds_n wc_d g (1-a^2) ka kb ; dU[n,D+d] = ds_n wc_d a g (1-g) ka kb ; dwc_d += ds_n a g ka kb ; dbc += ds_n
 // and, from the same pass, the column sums of dU (the bias gradients of the two gate Linears: a separate column-sum
 // launch re-read all of dU, 54 us at the C3 shape)
-template <typename T, bool GATED>
+// IL: U / dU in the interleaved column order of the panel GEMM's PG_GATE_U epilogue (16 a-columns, then the 16 b-columns of the
+//     same d, per 32-column block); dwc / the column sums stay in natural order.
+// HC > 0: ds is not an input - the pooling and soft-max backward (clam.py:144,170) are taken in this pass:
+//     ds_n = A_n (h_n . dM_bag - M_bag . dM_bag)     (sum_m A_m (h_m . dM) = M . dM: no reduction over the bag is needed)
+//     with h [rows, L], L = 8 HC G: a thread takes HC 16-byte pieces of the row, the G threads of a row add up by lane shuffles
+//     (G a power of two <= 64), and a workgroup's rows lie in one bag (rows_per_bag % rows_per_block == 0).
+#ifndef GSB_UR
+#define GSB_UR (HC > 0 ? 2 : 4)      // rows in flight per thread (measured r03: one-pass form 161 / 171 us at 2 / 4, ds-given form 119 / 111)
+#endif
+template <typename T, bool GATED, bool IL, int HC>
 __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restrict__ U, const float* __restrict__ wc,
                                                               const T* __restrict__ keep_a, const T* __restrict__ keep_b,
                                                               const float* __restrict__ ds, T* __restrict__ dU,
                                                               float* __restrict__ part,
-                                                              long rows, int D, int rows_per_block, GsDrop drop) {
+                                                              long rows, int D, int rows_per_block, GsDrop drop,
+                                                              const T* __restrict__ h, const float* __restrict__ dM,
+                                                              const float* __restrict__ Mp, const float* __restrict__ Asm,
+                                                              int rows_per_bag) {
     __shared__ float red[256][25];
     const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
     const int cg = tid % G, rl = tid / G;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const int W = (GATED ? 2 : 1) * D;
+    const int off_a = IL ? 32 * (cg >> 1) + 8 * (cg & 1) : 8 * cg;
+    const int off_b = IL ? off_a + 16 : D + 8 * cg;
     float w[8], wacc[8], csa[8], csb[8], dbc_acc = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = csa[e] = csb[e] = 0.f; }
+    const int L = 8 * HC * G;
+    float dm[HC > 0 ? 8 * HC : 1], mdm = 0.f;
+    if (HC > 0 && rl < RL) {
+        const long bag = r0 / rows_per_bag;
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            float mp[8];
+            load8<float>(dM + bag * L + 8 * (c * G + cg), dm + 8 * c);
+            load8<float>(Mp + bag * L + 8 * (c * G + cg), mp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mdm += mp[e] * dm[8 * c + e];
+        }
+        for (int o = 1; o < G; o <<= 1) mdm += __shfl_xor(mdm, o, 64);
+    }
     if (rl < RL) {
-        constexpr int UR = 2;                             // rows in flight per thread
+        constexpr int UR = GSB_UR;                        // rows in flight per thread
         for (long n0 = r0 + rl; n0 < r1; n0 += UR * RL) {
             float ua[UR][8], ub[UR][8], dsn[UR];
+            float hv[HC > 0 ? UR : 1][HC > 0 ? 8 * HC : 1], an[UR];
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const long n = n0 + u * RL;
-                dsn[u] = 0.f;
+                dsn[u] = an[u] = 0.f;
                 if (n < r1) {
-                    load8<T>(U + n * (GATED ? 2 : 1) * D + 8 * cg, ua[u]);
-                    if (GATED) load8<T>(U + n * 2 * D + D + 8 * cg, ub[u]);
-                    dsn[u] = ds[n];
+                    load8<T>(U + n * W + off_a, ua[u]);
+                    if (GATED) load8<T>(U + n * W + off_b, ub[u]);
+                    if (HC == 0) dsn[u] = ds[n];
+                    if (HC > 0) {
+                        an[u] = Asm[n];
+#pragma unroll
+                        for (int c = 0; c < HC; ++c) load8<T>(h + n * L + 8 * (c * G + cg), hv[u] + 8 * c);
+                    }
+                }
+            }
+            if (HC > 0) {
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const long n = n0 + u * RL;          // (n < r1 is uniform over the G lanes of a row: the shuffles below are safe)
+                    float t = 0.f;
+                    if (n < r1) {
+#pragma unroll
+                        for (int e = 0; e < 8 * HC; ++e) t += hv[u][e] * dm[e];
+                    }
+                    for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o, 64);
+                    dsn[u] = an[u] * (t - mdm);
                 }
             }
 #pragma unroll
@@ -167,8 +215,8 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
                     csa[e] += da[e];
                     csb[e] += db[e];
                 }
-                store8<T>(dU + n * (GATED ? 2 : 1) * D + 8 * cg, da);
-                if (GATED) store8<T>(dU + n * 2 * D + D + 8 * cg, db);
+                store8<T>(dU + n * W + off_a, da);
+                if (GATED) store8<T>(dU + n * W + off_b, db);
             }
         }
     }
@@ -256,27 +304,61 @@ extern "C" int murcl_gated_score_fwd(const void* U, const float* wc, const float
 #undef GS_FWD
     return MURCL_CHECK_LAUNCH();
 }
-extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
-                                     const float* ds, void* dU, float* dwc, float* dbc, float* dbab, float* part_ws,
-                                     long rows, int D, int dtype, int gated, float keep_p, unsigned long long seed_a,
-                                     unsigned long long seed_b, hipStream_t st) {
+static int gs_bwd_launch(const void* U, const float* wc, const void* keep_a, const void* keep_b, const float* ds, void* dU,
+                         float* dwc, float* dbc, float* dbab, float* part_ws, long rows, int D, int dtype, int gated, float keep_p,
+                         unsigned long long seed_a, unsigned long long seed_b, int interleaved, const void* h, const float* dM,
+                         const float* Mp, const float* Asm, int L, int rows_per_bag, hipStream_t st) {
     if (rows <= 0) return 0;
     if (!gs_shape_ok(D) || !part_ws) return -1;
     const GsDrop drop = gs_drop(keep_a ? 0.f : keep_p, seed_a, seed_b);
-    const int RL = 256 / (D / 8) > 0 ? 256 / (D / 8) : 1;
+    const int G = D / 8, RL = 256 / G > 0 ? 256 / G : 1;
     long rpb = (rows + 1023) / 1024;                       // <= 1024 workgroups = rows of part_ws [1024][3D+1]
     rpb = ((rpb + RL - 1) / RL) * RL;
     if (rpb < 4 * RL) rpb = 4 * RL;
+    int hc = 0;
+    if (h) {
+        // fused pooling / soft-max backward: bf16, gated, interleaved only (the CLAM-SB training chain), see the kernel
+        if (!dM || !Mp || !Asm || ds || dtype != MURCL_DTYPE_BF16 || !gated || !interleaved || G > 64 || (G & (G - 1)) || L % (8 * G) ||
+            rows_per_bag <= 0 || rows % rows_per_bag)
+            return -1;
+        hc = L / (8 * G);
+        if (hc != 1 && hc != 2 && hc != 4) return -1;
+        while (rows_per_bag % rpb) rpb += RL;              // a workgroup's rows lie in one bag
+        if ((rows + rpb - 1) / rpb > 1024) return -1;
+    } else if (!ds) {
+        return -1;
+    }
+    if (interleaved && (!gated || D % 16)) return -1;
     const int grid = (int)((rows + rpb - 1) / rpb);
-#define GS_BWD(T, G) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb, drop)
-    if (dtype == MURCL_DTYPE_F32) { if (gated) GS_BWD(float, true); else GS_BWD(float, false); }
-    else if (dtype == MURCL_DTYPE_BF16) { if (gated) GS_BWD(bf16_t, true); else GS_BWD(bf16_t, false); }
+#define GS_BWD(T, G_, IL_, HC_) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G_, IL_, HC_>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb, drop, (const T*)h, dM, Mp, Asm, rows_per_bag)
+    if (hc == 1) GS_BWD(bf16_t, true, true, 1);
+    else if (hc == 2) GS_BWD(bf16_t, true, true, 2);
+    else if (hc == 4) GS_BWD(bf16_t, true, true, 4);
+    else if (dtype == MURCL_DTYPE_F32) { if (interleaved) GS_BWD(float, true, true, 0); else if (gated) GS_BWD(float, true, false, 0); else GS_BWD(float, false, false, 0); }
+    else if (dtype == MURCL_DTYPE_BF16) { if (interleaved) GS_BWD(bf16_t, true, true, 0); else if (gated) GS_BWD(bf16_t, true, false, 0); else GS_BWD(bf16_t, false, false, 0); }
     else return -1;
 #undef GS_BWD
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
     hipLaunchKernelGGL(gated_score_reduce_kernel, dim3((3 * D + 1 + 15) / 16), dim3(256), 0, st, part_ws, grid, D, dwc, dbc, dbab);
     return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_gated_score_bwd(const void* U, const float* wc, const void* keep_a, const void* keep_b,
+                                     const float* ds, void* dU, float* dwc, float* dbc, float* dbab, float* part_ws,
+                                     long rows, int D, int dtype, int gated, float keep_p, unsigned long long seed_a,
+                                     unsigned long long seed_b, hipStream_t st) {
+    return gs_bwd_launch(U, wc, keep_a, keep_b, ds, dU, dwc, dbc, dbab, part_ws, rows, D, dtype, gated, keep_p, seed_a, seed_b, 0,
+                         nullptr, nullptr, nullptr, nullptr, 0, 0, st);
+}
+// The CLAM-SB training chain's form (see gated_score_bwd_kernel): U / dU [rows, 2D] in the interleaved column order of
+// murcl_panel_gemm epilogue 5; ds given, or (ds NULL) derived in the same pass from h [rows, L] (dtype of U), the pooled
+// vectors Mp [bags, L], their upstream gradient dM [bags, L] and the attention A [rows] (f32).
+extern "C" int murcl_gated_score_bwd_il(const void* U, const float* wc, const float* ds, void* dU, float* dwc, float* dbc,
+                                        float* dbab, float* part_ws, long rows, int D, int dtype, float keep_p,
+                                        unsigned long long seed_a, unsigned long long seed_b, const void* h, const float* dM,
+                                        const float* Mp, const float* A, int L, int rows_per_bag, hipStream_t st) {
+    return gs_bwd_launch(U, wc, nullptr, nullptr, ds, dU, dwc, dbc, dbab, part_ws, rows, D, dtype, 1, keep_p, seed_a, seed_b, 1,
+                         h, dM, Mp, A, L, rows_per_bag, st);
 }
 
 // ---------------------------------------------------------------- soft-max over the N patches of each bag

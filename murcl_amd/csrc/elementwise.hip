@@ -57,23 +57,28 @@ extern "C" int murcl_transpose_cast(const float* x, void* y, int R, int C, int d
 struct MurclCastJob {           // 32 bytes, mirrored by murcl_amd/ops.py
     const float* src;           // [rows, cols] f32, contiguous
     void* dst;                  // [rows, cols] or (transpose) [cols, rows] in dtype_out
-    int rows, cols, transpose, dtype_out;
+    int rows, cols;
+    int transpose;              // bit 0: transpose; bits 8..: leading dimension of dst in elements (0: cols, or rows when transposed) -
+    int dtype_out;              //   a job may fill a row / column block of a larger matrix (CLAM's interleaved gate weights)
 };
 template <typename T>
 __device__ __forceinline__ void cast_job_tile(const MurclCastJob& j, int tile, float (*t)[33]) {
     const int tc = (j.cols + 31) / 32;
     const int c0 = (tile % tc) * 32, r0 = (tile / tc) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     T* y = (T*)j.dst;
-    if (j.transpose) {
+    const int ldd = j.transpose >> 8;
+    if (j.transpose & 1) {
+        const size_t ld = ldd ? ldd : j.rows;
         for (int k = ty; k < 32; k += 8)
             if (r0 + k < j.rows && c0 + tx < j.cols) t[k][tx] = j.src[(size_t)(r0 + k) * j.cols + c0 + tx];
         __syncthreads();
         for (int k = ty; k < 32; k += 8)
-            if (c0 + k < j.cols && r0 + tx < j.rows) y[(size_t)(c0 + k) * j.rows + r0 + tx] = from_f<T>(t[tx][k]);
+            if (c0 + k < j.cols && r0 + tx < j.rows) y[(size_t)(c0 + k) * ld + r0 + tx] = from_f<T>(t[tx][k]);
     } else {
+        const size_t ld = ldd ? ldd : j.cols;
         for (int k = ty; k < 32; k += 8)
             if (r0 + k < j.rows && c0 + tx < j.cols)
-                y[(size_t)(r0 + k) * j.cols + c0 + tx] = from_f<T>(j.src[(size_t)(r0 + k) * j.cols + c0 + tx]);
+                y[(size_t)(r0 + k) * ld + c0 + tx] = from_f<T>(j.src[(size_t)(r0 + k) * j.cols + c0 + tx]);
     }
 }
 __global__ __launch_bounds__(256) void cast_batch_kernel(const MurclCastJob* __restrict__ jobs) {
@@ -96,7 +101,7 @@ extern "C" int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles,
 // execute at the memory side and adders on ONE address serialise (1024 adders per column: 228 us for 134 MB).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int R, int N, int ld,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, int overwrite) {
     constexpr int CPT = 16 / (int)sizeof(T);
     __shared__ float red[16][16][CPT + 1];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -148,16 +153,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) t += red[k][cl][e];
-            if (gridDim.y == 1) out[c + e] += t; else atomicAdd(out + c + e, t);
+            if (overwrite) out[c + e] = t;                     // one row split and nothing to add to: no zero-fill before the launch
+            else if (gridDim.y == 1) out[c + e] += t;
+            else atomicAdd(out + c + e, t);
         }
     }
 }
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s) {
     if (N <= 0) return 0;
-    if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, s);
-        if (e != hipSuccess) return (int)e;
-    }
     const int bc = dtype == MURCL_DTYPE_BF16 ? 128 : 64;     // columns per block
     const int cg = (N + bc - 1) / bc;
     int splits = R > 64 ? (1024 + cg - 1) / cg : 1;        // ~1024 blocks, >= 32 rows each, <= 64 adders per column
@@ -166,10 +169,15 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
     if (splits < 1) splits = 1;
     const int rpb = (R + splits - 1) / splits;
     dim3 grid(cg, (R + rpb - 1) / rpb);
+    const int overwrite = !accumulate && grid.y == 1;
+    if (!accumulate && !overwrite) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, R, N, ld, rpb);
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, R, N, ld, rpb, overwrite);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, R, N, ld, rpb);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, R, N, ld, rpb, overwrite);
     else
         return -1;
     return MURCL_CHECK_LAUNCH();

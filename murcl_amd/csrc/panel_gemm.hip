@@ -64,11 +64,23 @@
 #ifndef PG_WPRO
 #define PG_WPRO 1         // K = 512: a wave's W slice arrives as whole 1 KiB rows (LDS-DMA into the still empty tile ring) and is read
 #endif                    // back as fragments, instead of fragment-shaped global loads that touch 64 cache lines each (see the prologue)
+#ifndef PG_GATE_U_FUSE
+#define PG_GATE_U_FUSE 1  // PG_GATE_U rides the fused forward schedule (its epilogue inside the next tile's MFMA loop) like PG_BIAS
+#endif
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
 
-enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3, PG_GATE = 4 };
+enum { PG_BIAS_RELU = 0, PG_MASK = 1, PG_RANK1_MASK = 2, PG_BIAS = 3, PG_GATE = 4, PG_GATE_U = 5 };
+
+// Dropout inside an epilogue (template flag DROP): the keep value of element `flat` of the [M, cols] mask is byte flat & 7 of
+// murcl_drop_word(seed, flat >> 3) - the generator of murcl_dropout_mask / murcl_dropout_relu_bitmask, so a mask is the same
+// whichever kernel realises it.  A lane's four accumulator values are four consecutive columns: half a word.
+struct PgDrop { unsigned long long seed_a, seed_b; unsigned thresh; float scale; };
+__device__ __forceinline__ unsigned pg_keep4(unsigned long long seed, long flat4) {
+    const unsigned long long rw = murcl_drop_word(seed, flat4 >> 3);
+    return (unsigned)(rw >> (8 * (int)(flat4 & 4)));
+}
 
 // In-kernel stamps (diagnostic builds only, -DPG_STAMPS; tools/stamps_panel.py): waves 0 and 4 of the first PG_STAMP_WG
 // workgroups note s_memtime at fixed points of each tile iteration into a spare LDS region (a global store would join the
@@ -145,12 +157,12 @@ __device__ __forceinline__ unsigned pg_pos_flags_nonneg(unsigned w, unsigned one
     return t;
 }
 
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false>
 __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
     const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
     const float* __restrict__ rowscale, const float* __restrict__ rank1, int rows_per_bag,
-    float* __restrict__ colsum_part, int walk_reverse) {
+    float* __restrict__ colsum_part, int walk_reverse, PgDrop drop) {
     constexpr int ROWB = K * 2;                 // bytes per A row
     // K = 512: one LDS-DMA instruction writes exactly one row, so rows can be stored at a padded stride (conflict-free
     // 16-row fragment reads with immediate offsets, no swizzle math).  K = 128: four rows per instruction -> XOR swizzle.
@@ -170,7 +182,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // wave's first 16-column block is attention_a[d .. d+15] and its second block attention_b of the SAME d: the lane that holds
     // a_d also holds b_d, and the epilogue emits sum_d tanh(a_d) sigmoid(b_d) wc_d over the wave's 16 pairs per row - one f32 per
     // row and wave ([N/32][M] partial scores) instead of the [M, 2D] gate pre-activations (no 268 MB written and read back at C3).
-    constexpr bool GATE = (EPI == PG_GATE);
+    // PG_GATE_U (training forward): the same scores AND the pre-activations U, bias added, in this interleaved column order (the
+    // backward pass reads them: murcl_gated_score_bwd with `interleaved`); DROP: the two gate Dropouts (clam.py:47-48) applied to
+    // tanh(a_d) / sigmoid(b_d) from the seeds, as murcl_gated_score_fwd does.
+    constexpr bool GATE = (EPI == PG_GATE || EPI == PG_GATE_U);
     constexpr bool BIASED = (EPI == PG_BIAS_RELU || EPI == PG_BIAS || GATE);
     constexpr int NB = MASKED ? 1 : 0;                              // mask LDS-DMA op (128 or 256 B per wave)
     constexpr int NR = (EPI == PG_RANK1_MASK) ? 1 : 0;              // rowscale LDS-DMA op
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     constexpr int GA = DMAH ? 2 * GT : GT;      // A pieces per tile of an issuing wave
     constexpr int G = GA + NB + NR;             // counted loads per tile per (issuing) wave
     constexpr int NMS = BM_OUT ? WN / 32 : 0;   // mask stores per tile per wave
-    constexpr int S = (PG_ABL & 4) ? 0 : (EPI == PG_GATE ? 2 : NS + NMS);   // counted stores per tile per wave
+    constexpr int S = (PG_ABL & 4) ? 0 : (EPI == PG_GATE ? 1 : NS + NMS + (EPI == PG_GATE_U ? 1 : 0));   // counted stores per tile per wave
     // LDS carve
     constexpr int OFF_STG = PG_NSLOT * SLOT;
     constexpr int OFF_BM = OFF_STG + PG_NW * PG_TR * STG_LD;                    // [slot][wave][256 B]
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const int tile0 = CONTIG ? stream * per : stream, tstep = CONTIG ? 1 : streams;
     const int my_tiles = CONTIG ? min(per, n_tiles - tile0) : (n_tiles - stream + streams - 1) / streams;
     if (stream >= streams || my_tiles <= 0) {
-        if (EPI != PG_GATE && colsum_part && stream < streams)   // no tiles: this workgroup's row of partial sums is zero
+        if (!GATE && colsum_part && stream < streams)   // no tiles: this workgroup's row of partial sums is zero
             for (int c = threadIdx.x; c < NP; c += 64 * PG_NW) colsum_part[(size_t)stream * N + panel * NP + c] = 0.f;
         return;
     }
@@ -336,13 +351,17 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
             }
     }
     float gw[4] = {0.f, 0.f, 0.f, 0.f};              // PG_GATE: wc of this lane's four (a_d, b_d) pairs
+    float gbc = 0.f;                                 // attention_c's bias, carried by the first 32-column group's partial score
     if (GATE) {
+        if (rowscale && n0 == 0) gbc = rowscale[0];
+        asm volatile("" : "+v"(gbc));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             gw[r] = rank1[n0 + 4 * q4 + r];
             asm volatile("" : "+v"(gw[r]));
         }
     }
+    float gsc[2] = {0.f, 0.f};                       // PG_GATE: the tile's two 16-row partial scores, until they are stored together
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
     int cur_bag = -1;
     float csum[NJ][4];                       // column sums in accumulator layout: column 16j + 4q4 + r, over this lane's rows
@@ -466,20 +485,37 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         const int row0 = row0_of(seq);
         if constexpr (GATE) {
             static_assert(!GATE || NJ == 2, "PG_GATE pairs the wave's two 16-column blocks");
-            float* sp = colsum_part + (size_t)(n0 >> 5) * M + row0;       // partial scores [N/32][M]
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                // (fused schedule of PG_GATE_U: with the second block of the row half)
+                if (EPI == PG_GATE_U && part >= 0 && part != 10 + NJ * i + 1) continue;
+                unsigned ka4 = 0u, kb4 = 0u;
+                if (DROP) {
+                    const long flat4 = (long)(row0 + 16 * i + r16) * (N >> 1) + 16 * (n0 >> 5) + 4 * q4;
+                    ka4 = pg_keep4(drop.seed_a, flat4);
+                    kb4 = pg_keep4(drop.seed_b, flat4);
+                }
                 float t = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * acc[i][1][r]));
-                    t += fast_tanh(acc[i][0][r]) * sg * gw[r];
+                    float u = fast_tanh(acc[i][0][r]) * sg * gw[r];
+                    if (DROP) {
+                        const bool keep = ((ka4 >> (8 * r)) & 255u) < drop.thresh && ((kb4 >> (8 * r)) & 255u) < drop.thresh;
+                        u = keep ? u * (drop.scale * drop.scale) : 0.f;
+                    }
+                    t += u;
                 }
-                t = quarters_sum(t);
-                // 16 consecutive floats per instruction (lanes of quarter 0; the other quarters carry the same sums)
-                if (q4 == 0) pg_store4(sp + 16 * i + r16, t);
+                gsc[i] = quarters_sum(t) + gbc;
             }
-            return;
+            if (part < 0 || part == 10 + NJ + 1) {
+                // ONE full-wave store per tile, no divergent branch inside the MFMA loop's scheduling region: every quarter carries
+                // both sums; even quarters write rows 0-15, odd quarters rows 16-31 (the two copies of a row hit the same address
+                // with the same value)
+                float* sp = colsum_part + (size_t)(n0 >> 5) * M + row0;       // partial scores [N/32][M]
+                pg_store4(sp + 16 * (q4 & 1) + r16, (q4 & 1) ? gsc[1] : gsc[0]);
+            }
+            if (EPI == PG_GATE) return;
         }
         unsigned ones = 0x00010001u;
         asm volatile("" : "+v"(ones));
@@ -515,6 +551,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                         const int keep = __builtin_amdgcn_sbfe((int)mw[j >> 1], (7 - (idx >> 1)) + 8 * (idx & 1), 1);   // 0 / -1
                         v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
                     }
+                }
+                if (DROP && EPI == PG_BIAS_RELU) {   // Dropout behind the ReLU (clam.py:69-72): the flags below record what survives
+                    const unsigned k4 = pg_keep4(drop.seed_a, (long)(row0 + row) * N + n0 + 16 * j + 4 * q4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ((k4 >> (8 * r)) & 255u) < drop.thresh ? v[r] * drop.scale : 0.f;
                 }
                 if (MASKED && colsum_part) {         // bias gradient from the f32 values, before they are rounded to bf16 (backward variants only)
 #pragma unroll
@@ -554,7 +595,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // Fused schedule (PG_FUSE, K = 512): every wave keeps the accumulators of tile t-1 and runs its epilogue in pieces
     // between the k-groups of tile t, so VALU / LDS-staging / store work issues in the shadow of the MFMAs instead
     // of after them with the matrix pipe idle.  Store counts lag by one tile, exactly like the rotated half.
-    constexpr bool FUSE = PAD && (((PG_FUSE & 1) && (EPI == PG_BIAS_RELU || EPI == PG_BIAS)) || ((PG_FUSE & 2) && EPI == PG_MASK));   // (the K = 512 rank-1 variant would spill)
+    constexpr bool FUSE = PAD && (((PG_FUSE & 1) && (EPI == PG_BIAS_RELU || EPI == PG_BIAS || (PG_GATE_U_FUSE && EPI == PG_GATE_U))) || ((PG_FUSE & 2) && EPI == PG_MASK));   // (the K = 512 rank-1 variant would spill)
     constexpr bool ROT = PG_ROTATE != 0 && !FUSE;
     const bool late = FUSE || (ROT && wave >= PG_NW / 2);
     f32x4 acc[2][NJ];
@@ -716,17 +757,17 @@ static int pg_grid(int M, int panels) {
     return grid;
 }
 
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT>
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
-                     float* colsum_part, int* streams_out, int walk_reverse, hipStream_t s) {
+                     float* colsum_part, int* streams_out, int walk_reverse, hipStream_t s, PgDrop drop = PgDrop{0ull, 0ull, 0u, 1.f}) {
     constexpr int SLOT = PG_TR * (K == 512 ? K * 2 + 16 : K * 2);
     constexpr int STG_LD = WN * 2 + 16;
     constexpr int LDS = PG_NSLOT * SLOT + PG_NW * PG_TR * STG_LD +
                         ((EPI == PG_MASK || EPI == PG_RANK1_MASK) ? PG_NSLOT * PG_NW * 256 : 0) +
                         (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0) + PG_STAMP_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT>;
+    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT, DROP>;
     static MurclOncePerDevice once;      
     if (once.first()) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -735,7 +776,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     const int panels = N / (PG_NW * WN);
     const int grid = pg_grid(M, panels);
     hipLaunchKernelGGL(k, dim3(grid), dim3(64 * PG_NW), LDS, s, A, W, C, M, N, bias, bm_out, bm_in, rowscale, rank1,
-                       rows_per_bag, colsum_part, walk_reverse);
+                       rows_per_bag, colsum_part, walk_reverse, drop);
     *streams_out = grid / panels;
     return MURCL_CHECK_LAUNCH();
 }
@@ -747,6 +788,7 @@ extern "C" int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int
     if (M <= 0 || M % PG_TR) return 0;
     if (K == 512)
         return (N % 256 == 0) && (epilogue == PG_BIAS_RELU || epilogue == PG_MASK || epilogue == PG_BIAS || epilogue == PG_GATE ||
+                                  epilogue == PG_GATE_U ||
                                   (epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0));
     if (K == 128) return N == 512 && epilogue == PG_RANK1_MASK && rows_per_bag > 0 && rows_per_bag % PG_TR == 0;
     return 0;
@@ -760,11 +802,34 @@ extern "C" int murcl_panel_gemm_colsum_rows(int M, int N, int K, int epilogue) {
     return pg_grid(M, panels) / panels;
 }
 
+extern "C" int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
+                                     const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
+                                     const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
+                                     float* colsum_ws, int walk_reverse, float keep_p, unsigned long long seed_a,
+                                     unsigned long long seed_b, hipStream_t stream);
 extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
                                 const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
                                 const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
                                 float* colsum_ws, int walk_reverse, hipStream_t stream) {
+    return murcl_panel_gemm_drop(A, W, C, M, N, K, epilogue, bias, bitmask_out, bitmask_in, rowscale, rank1, rows_per_bag, colsum_out,
+                                 colsum_accumulate, colsum_ws, walk_reverse, 0.f, 0ull, 0ull, stream);
+}
+// keep_p in (0, 1): Dropout(1 - keep_p) inside the epilogue - PG_BIAS_RELU (K = 512, with the bit mask): after the ReLU, mask of
+// seed_a over [M, N]; PG_GATE_U: on tanh(a) and sigmoid(b), masks of seed_a / seed_b over [M, N/2].  Survivors are scaled by
+// 256 / round(256 keep_p), as in murcl_dropout_mask.  Any other keep_p: no dropout.
+extern "C" int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int M, int N, int K, int epilogue,
+                                     const float* bias, void* bitmask_out, const void* bitmask_in, const float* rowscale,
+                                     const float* rank1, int rows_per_bag, float* colsum_out, int colsum_accumulate,
+                                     float* colsum_ws, int walk_reverse, float keep_p, unsigned long long seed_a,
+                                     unsigned long long seed_b, hipStream_t stream) {
     if (!murcl_panel_gemm_supported(M, N, K, epilogue, rows_per_bag)) return -1;
+    PgDrop drop{seed_a, seed_b, 0u, 1.f};
+    const bool dropping = keep_p > 0.f && keep_p < 1.f;
+    if (dropping) {
+        drop.thresh = (unsigned)(keep_p * 256.f + 0.5f);
+        drop.scale = 256.f / (float)(drop.thresh ? drop.thresh : 1u);
+        if (K != 512 || !((epilogue == PG_BIAS_RELU && bitmask_out) || epilogue == PG_GATE_U)) return -1;
+    }
     if (colsum_out && !colsum_ws) return -1;
     float* part = colsum_ws;                 // without colsum_out: the partial rows are the result (the caller adds them up)
     int streams = 0, rc = -1;
@@ -773,7 +838,15 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
     bf16_t* c = (bf16_t*)C;
     uint8_t* bo = (uint8_t*)bitmask_out;
     const uint8_t* bi = (const uint8_t*)bitmask_in;
-    if (K == 512 && epilogue == PG_BIAS_RELU) {
+    if (K == 512 && epilogue == PG_BIAS_RELU && dropping) {
+        if (!bias) return -1;
+        rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream, drop);
+    } else if (K == 512 && epilogue == PG_GATE_U) {
+        // C = the gate pre-activations [M, N] in the interleaved column order of W; rank1 / colsum_ws as for PG_GATE
+        if (!bias || !rank1 || !colsum_ws || colsum_out || !c) return -1;
+        rc = dropping ? pg_launch<512, 32, 8, PG_GATE_U, false, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream, drop)
+                      : pg_launch<512, 32, 8, PG_GATE_U, false, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
+    } else if (K == 512 && epilogue == PG_BIAS_RELU) {
         if (!bias) return -1;
         rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream)
                 : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
@@ -784,7 +857,8 @@ extern "C" int murcl_panel_gemm(const void* A, const void* W, void* C, int M, in
         if (!bias) return -1;
         rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_GATE) {
-        // rank1 = wc per interleaved column [N] f32, colsum_ws = the partial scores [N/32][M] f32 (the only output: C may be NULL)
+        // rank1 = wc per interleaved column [N] f32, colsum_ws = the partial scores [N/32][M] f32 (the only output: C may be NULL);
+        // rowscale (may be NULL) = one float, attention_c's bias, added to partial row 0
         if (!bias || !rank1 || !colsum_ws || colsum_out) return -1;
         rc = pg_launch<512, 32, 8, PG_GATE, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_RANK1_MASK) {

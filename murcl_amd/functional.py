@@ -33,6 +33,8 @@ import os as _os
 # leaves more of H3 there (K2 forward 67.6 -> 62.4 us inside the step; the other layers measured neutral-to-slower).
 _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
 _FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B switch: CLAM's gate score from the gate GEMM's epilogue (forward-only)
+_GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
+_FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
@@ -731,16 +733,27 @@ class CLAMFn(torch.autograd.Function):
         c = (lambda w: w) if f32 else (lambda w: ops.cast(w, T))
         x2 = x.reshape(B * N, d)
         L, D = w1.shape[0], wa.shape[0]
+        # bf16 gated chain: the compute-dtype copy of fc, the two gate Linears interleaved for the panel kernel and their transpose
+        # come out of ONE launch (none between optimizer steps) instead of a dozen cat / gather / cast launches
+        views = ops.clam_views(w1, wa, ba, wb, bb, wc, T) if (T == torch.bfloat16 and wb is not None and D % 16 == 0) else None
+        if views is not None:
+            c = lambda w: views[0] if w is w1 else ops.cast(w, T)          # noqa: E731
         m1 = None
-        if T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU):
-            # weight-stationary panel kernel; without dropout its 1-bit ReLU mask also serves the backward pass
-            h, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=keeps is None and bool(grad_on))
-        else:
-            h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                # clam.py:69
         k1 = ka = kb = None
         if keeps is not None:
             k1, ka, kb = keeps
-            if isinstance(k1, ops.DropSeed):                                           # Dropout(0.25) after ReLU (clam.py:69-72)
+        seeded = isinstance(k1, ops.DropSeed)
+        fc_drop = False
+        if T == torch.bfloat16 and d == 512 and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU):
+            # weight-stationary panel kernel; its 1-bit ReLU mask also serves the backward pass.  Seeded Dropout(0.25) behind the
+            # ReLU (clam.py:69-72) happens in the same epilogue: the mask is never materialised and the bits record what survives
+            fc_drop = _FUSED_FC_DROP and seeded
+            h, m1, _ = ops.panel_gemm(x2, c(w1), ops.PG_BIAS_RELU, bias=b1, want_bitmask=fc_drop or (keeps is None and bool(grad_on)),
+                                      drop=k1 if fc_drop else None)
+        else:
+            h = ops.gemm_nt(x2, c(w1), epi=ops.EPI_BIAS_RELU, bias=b1)                # clam.py:69
+        if keeps is not None and not fc_drop:
+            if seeded:                                                                 # Dropout(0.25) after ReLU (clam.py:69-72)
                 if (B * N) % 32 == 0 and L % 128 == 0:
                     # the mask is generated inside the pass that applies it, which also leaves the 1-bit mask of the
                     # surviving positive entries for the backward pass (bf16 panel dgrad)
@@ -750,24 +763,33 @@ class CLAMFn(torch.autograd.Function):
             else:
                 ops.mul(h, k1)                                                         # an injected keep mask (parity tests)
         gated = wb is not None                   # False: the plain Attn_Net (CLAM_SB(gate=False), clam.py:18-34,80-81)
-        wab = torch.cat([wa, wb], 0) if gated else wa
-        bab = torch.cat([ba, bb], 0) if gated else ba
-        GW = wab.shape[0]                        # gate columns: 2D / D
+        GW = 2 * D if gated else D               # gate columns
         # bf16 with 512-wide h and gates: the weight-stationary panel kernel (same GEMM, half the time of the tile kernel)
         panel = (T == torch.bfloat16 and L == 512 and ops.panel_supported(B * N, GW, 512, ops.PG_BIAS))
         # (``grad_on`` = the caller's torch.is_grad_enabled(): see ABMILFn.forward)
         fused_gate = (_FUSED_GATE and panel and gated and keeps is None and GW == 512 and not (grad_on and any(ctx.needs_input_grad))
                       and ops.panel_supported(B * N, GW, 512, ops.PG_GATE))
+        # calls a backward pass may follow: the same epilogue also leaves the pre-activations (interleaved column order) for it,
+        # and the separate score pass over U (97-120 us at C3) disappears; the gate Dropouts are applied inside from their seeds
+        gate_u = (_GATE_U and not fused_gate and panel and gated and GW == 512 and (keeps is None or seeded)
+                  and ops.panel_supported(B * N, GW, 512, ops.PG_GATE_U) and ops.gated_bwd_il_supported(B * N, D, L, N)
+                  and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N))
         if fused_gate:
             # forward-only calls (validation, heat-map scoring, the frozen aggregator of stage 2): the score comes out of the gate
             # GEMM's epilogue - tanh(a_d) sigmoid(b_d) c_d summed per wave - and the [B*N, 2D] pre-activations are never written
             U = None
-            s = ops.panel_gate_score(h, *ops.gate_interleave(wa, ba, wb, bb, wc, T), bc).view(B, N)
-        elif panel:
-            U, _, _ = ops.panel_gemm(h, c(wab), ops.PG_BIAS, bias=bab)                  # both gate branches, one pass
+            s = ops.panel_gate_score(h, views[1], views[3], views[4], bc).view(B, N)
+        elif gate_u:
+            U, s = ops.panel_gate_u(h, views[1], views[3], views[4], bc, ka, kb)
+            s = s.view(B, N)
         else:
-            U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
-        if not fused_gate:
+            wab = torch.cat([wa, wb], 0) if gated else wa
+            bab = torch.cat([ba, bb], 0) if gated else ba
+            if panel:
+                U, _, _ = ops.panel_gemm(h, c(wab), ops.PG_BIAS, bias=bab)              # both gate branches, one pass
+            else:
+                U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
+        if not fused_gate and not gate_u:
             s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
         A = ops.softmax_rows(s)                                                        # clam.py:144
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
@@ -802,7 +824,8 @@ class CLAMFn(torch.autograd.Function):
             saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
         ctx.save_for_backward(x2, h, U if U is not None else x2.new_zeros(1), A, M, w1, wa, wb, wc,
                               inst_w if inst_w is not None else x2.new_zeros(1), m1)
-        ctx.gated = gated
+        ctx.gated, ctx.gate_u = gated, gate_u
+        ctx.wab_t = views[2] if gate_u else None         # (a cached view: parameters do not change between a forward and its backward)
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
             ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
@@ -823,18 +846,27 @@ class CLAMFn(torch.autograd.Function):
         if ctx.keeps is not None:
             k1, ka, kb = ctx.keeps
         dM = dM.contiguous() if dM is not None else torch.zeros_like(M)
-        # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
-        dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
-        ds = ops.softmax_rows_bwd(A, dA).view(-1)
         gated = ctx.gated
-        dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb, gated=gated)   # dbab: column sums, same pass
-        dwab = ops.gemm_tn(dU, h)                                                     # [2D, L] (gated) / [D, L]
-        wab = torch.cat([wa, wb], 0) if gated else wa
+        if ctx.gate_u:
+            # pooling + soft-max + gate backward in ONE pass over (h, U): sum_m A_m (h_m . dM) = M . dM, so
+            # ds_n = A_n (h_n . dM - M . dM) needs no reduction over the bag; U / dU in the interleaved column order of the forward
+            dU, dwc, dbc, dbab = ops.gated_score_bwd_il(U, wc.reshape(-1).contiguous(), ka, kb, h=h, dM=dM, Mp=M, A=A.view(-1),
+                                                        rows_per_bag=N)
+            dwab = ops.gemm_tn(dU, h).view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)   # rows back in [Wa; Wb] order
+            wab_t = ctx.wab_t                                                         # [L, 2D] interleaved columns, as dU's
+        else:
+            # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
+            dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
+            ds = ops.softmax_rows_bwd(A, dA).view(-1)
+            dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb, gated=gated)   # dbab: column sums, same pass
+            dwab = ops.gemm_tn(dU, h)                                                     # [2D, L] (gated) / [D, L]
+            wab_t = None
+        wab = None if wab_t is not None else (torch.cat([wa, wb], 0) if gated else wa)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
-        if (T == torch.bfloat16 and wab.shape[0] == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
+        if (T == torch.bfloat16 and dU.shape[1] == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
             # column sums (the bias gradient) come out of the same launch; the instance branch below extends them by the
             # few rows it adds
-            dz1, _, db1 = ops.panel_gemm(dU, ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
+            dz1, _, db1 = ops.panel_gemm(dU, wab_t if wab_t is not None else ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
                                          bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
                                          rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
         else:

@@ -126,8 +126,8 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     return (C, ws) if colsum else C
 
 
-PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK, PG_BIAS, PG_GATE = 0, 1, 2, 3, 4
-_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK", 3: "BIAS", 4: "GATE"}
+PG_BIAS_RELU, PG_MASK, PG_RANK1_MASK, PG_BIAS, PG_GATE, PG_GATE_U = 0, 1, 2, 3, 4, 5
+_PG_NAME = {0: "BIAS_RELU", 1: "MASK", 2: "RANK1_MASK", 3: "BIAS", 4: "GATE", 5: "GATE_U"}
 
 
 _GATE_IDX = {}
@@ -150,6 +150,19 @@ def gate_interleave(wa, ba, wb, bb, wc, dtype):
     return (W.contiguous() if dtype == torch.float32 else cast(W.contiguous(), dtype)), b, c
 
 
+def gate_interleave_t(wa, wb, dtype):
+    """[Wa; Wb] transposed, [L, 2D] in ``dtype``, columns in the interleaved order of ``gate_interleave`` (the dgrad operand that
+    goes with an interleaved dU)."""
+    gate_interleave  # (the index table is built there)
+    D = wa.shape[0]
+    idx = _GATE_IDX.get((D, wa.device))
+    if idx is None:
+        n = torch.arange(2 * D)
+        g, j, i = n // 32, (n % 32) // 16, n % 16
+        idx = _GATE_IDX[(D, wa.device)] = ((16 * g + i) + D * j).to(wa.device)
+    return transpose_cast(torch.cat([wa, wb], 0).index_select(0, idx), dtype)
+
+
 def panel_gate_score(h, W_il, b_il, c_il, bc):
     """CLAM's gated attention score straight from the gate GEMM's epilogue (``murcl_panel_gemm`` epilogue 4): h [M,512] bf16 ->
     raw scores s [M] f32 = sum_d tanh(a_d) sigmoid(b_d) wc_d + bc, without materialising the [M, 2D] gate pre-activations."""
@@ -159,10 +172,58 @@ def panel_gate_score(h, W_il, b_il, c_il, bc):
     N = W_il.shape[0]
     part = torch.empty((N // 32, M), dtype=torch.float32, device=h.device)
     with _span(lambda: (f"panel_gemm<K{K},GATE>", dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + (N // 32) * M * 4))):
-        check(_lib.lib().murcl_panel_gemm(ptr(h), ptr(W_il), None, M, N, K, PG_GATE, ptr(b_il), None, None, None, ptr(c_il), 0,
+        check(_lib.lib().murcl_panel_gemm(ptr(h), ptr(W_il), None, M, N, K, PG_GATE, ptr(b_il), None, None, ptr(_c(bc)), ptr(c_il), 0,
                                           None, 0, ptr(part), 0, stream()), "panel_gemm(gate)")
-    s = bc.reshape(1).to(torch.float32).expand(M).contiguous()           # (a fill: the partial rows are ADDED to it)
-    return colsum(part, out=s, accumulate=True)
+    return colsum(part)                                                   # (attention_c's bias rides in partial row 0)
+
+
+def panel_gate_u(h, W_il, b_il, c_il, bc, keep_a=None, keep_b=None):
+    """CLAM's gate GEMM for a call that a backward pass may follow (``murcl_panel_gemm_drop`` epilogue 5): the raw scores as in
+    ``panel_gate_score`` AND the gate pre-activations U [M, 2D] bf16 in the interleaved column order of ``gate_interleave`` (read
+    back by ``gated_score_bwd_il``).  ``keep_a`` / ``keep_b``: DropSeed specs of the two gate Dropouts (clam.py:47-48) or None.
+    -> (U, s [M] f32)."""
+    _need_cuda(h, W_il)
+    h = _c(h)
+    M, K = h.shape
+    N = W_il.shape[0]
+    U = torch.empty((M, N), dtype=torch.bfloat16, device=h.device)
+    part = torch.empty((N // 32, M), dtype=torch.float32, device=h.device)
+    kp, sa, sb = (keep_a.keep_p, keep_a.seed, keep_b.seed) if keep_a is not None else (0.0, 0, 0)
+    with _span(lambda: (f"panel_gemm<K{K},GATE_U>", dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (N // 32) * M * 4))):
+        check(_lib.lib().murcl_panel_gemm_drop(ptr(h), ptr(W_il), ptr(U), M, N, K, PG_GATE_U, ptr(b_il), None, None, ptr(_c(bc)), ptr(c_il), 0,
+                                               None, 0, ptr(part), 0, kp, sa, sb, stream()), "panel_gemm(gate_u)")
+    return U, colsum(part)                                                # (attention_c's bias rides in partial row 0)
+
+
+def gated_score_bwd_il(U, wc, keep_a=None, keep_b=None, *, ds=None, h=None, dM=None, Mp=None, A=None, rows_per_bag=0):
+    """``gated_score_bwd`` for U in the interleaved layout of ``panel_gate_u`` -> (dU in the same layout, dwc [D], dbc [1], column
+    sums [2D] in NATURAL order).  ``ds`` [M] given, or None with (h [M,L], dM [B,L], Mp [B,L], A [M], rows_per_bag): the pooling and
+    soft-max backward are then taken in the same pass (ds_n = A_n (h_n . dM - Mp . dM))."""
+    U = _c(U)
+    M, W = U.shape
+    D = W // 2
+    dU = torch.empty_like(U)
+    dwc = torch.empty((D,), dtype=torch.float32, device=U.device)
+    dbc = torch.empty((1,), dtype=torch.float32, device=U.device)
+    dbab = torch.empty((2 * D,), dtype=torch.float32, device=U.device)
+    part = torch.empty((1024 * (3 * D + 1),), dtype=torch.float32, device=U.device)
+    kp, sa, sb = (keep_a.keep_p, keep_a.seed, keep_b.seed) if keep_a is not None else (0.0, 0, 0)
+    L = 0
+    if ds is None:
+        h, dM, Mp, A = _c(h), _c(dM), _c(Mp), _c(A)
+        assert h.dtype == U.dtype and dM.dtype == Mp.dtype == A.dtype == torch.float32
+        L = h.shape[1]
+    else:
+        ds = _c(ds)
+    check(_lib.lib().murcl_gated_score_bwd_il(ptr(U), ptr(wc), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc), ptr(dbab), ptr(part), M, D, dt(U),
+                                              kp, sa, sb, ptr(h), ptr(dM), ptr(Mp), ptr(A), L, rows_per_bag, stream()), "gated_score_bwd_il")
+    return dU, dwc, dbc, dbab
+
+
+def gated_bwd_il_supported(M, D, L, rows_per_bag):
+    G = D // 8
+    return (D % 16 == 0 and G <= 64 and (G & (G - 1)) == 0 and L % (8 * G) == 0 and L // (8 * G) in (1, 2, 4) and rows_per_bag > 0
+            and M % rows_per_bag == 0 and rows_per_bag % (256 // G) == 0)
 
 
 def panel_supported(M, N, K, epi, rows_per_bag=0):
@@ -170,14 +231,17 @@ def panel_supported(M, N, K, epi, rows_per_bag=0):
 
 
 def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowscale=None, rank1=None, rows_per_bag=0,
-               colsum=False, colsum_into=None, colsum_defer=False, reverse=False, stream_a=False, out=None, bitmask_out=None):
+               colsum=False, colsum_into=None, colsum_defer=False, reverse=False, stream_a=False, out=None, bitmask_out=None,
+               drop=None):
     """bf16 weight-stationary C = epi(A @ W^T).  Returns (C, bitmask_out or None, colsum or None).
     ``colsum_into`` ([N] f32): the column sums are ADDED to it (gradient accumulation) and returned as None.
     ``colsum_defer``: no second launch - the third result is (partial rows [R,N] f32, R) for ``gemm_tn(colsum_parts=...)``,
     the weight gradient of the same layer, whose reduce launch adds them up on the way.
     ``reverse``: visit the row tiles last-to-first (cache reuse after a producer that walked forward; same result).
     ``stream_a``: load A with the non-temporal policy (K = 512): it is read once and should not displace the output, which
-    the next kernel reads, from the Infinity Cache."""
+    the next kernel reads, from the Infinity Cache.
+    ``drop`` (a DropSeed; PG_BIAS_RELU with ``want_bitmask``, K = 512): Dropout behind the ReLU inside the epilogue, the mask
+    never materialised; the bit mask records what survives (= ``dropout_relu_bitmask`` on the output, without that pass)."""
     _need_cuda(A, W)
     A, W = _c(A), _c(W)
     M, K = A.shape
@@ -197,11 +261,19 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     ws = torch.empty((256 * N,), dtype=torch.float32, device=A.device) if (colsum or colsum_into is not None or colsum_defer) else None
     with _span(lambda: (f"panel_gemm<K{K},{_PG_NAME[epi]}>",
                dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (M * N // 8 if (want_bitmask or bitmask is not None) else 0)))):
-        check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
-                                          ptr(rowscale), ptr(rank1), rows_per_bag,
-                                          ptr(colsum_into if colsum_into is not None else cs),
-                                          int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0), stream()),
-              "panel_gemm")
+        if drop is not None:
+            assert epi == PG_BIAS_RELU and want_bitmask and K == 512
+            check(_lib.lib().murcl_panel_gemm_drop(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
+                                                   ptr(rowscale), ptr(rank1), rows_per_bag,
+                                                   ptr(colsum_into if colsum_into is not None else cs),
+                                                   int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0),
+                                                   drop.keep_p, drop.seed, 0, stream()), "panel_gemm(drop)")
+        else:
+            check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
+                                              ptr(rowscale), ptr(rank1), rows_per_bag,
+                                              ptr(colsum_into if colsum_into is not None else cs),
+                                              int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0), stream()),
+                  "panel_gemm")
     if colsum_defer:
         return C, bm, (ws, _lib.lib().murcl_panel_gemm_colsum_rows(M, N, K, epi))
     return C, bm, cs
@@ -434,6 +506,65 @@ def weight_views(specs):
         check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
         st["ver"] = ver
     return st["outs"]
+
+
+def _job_views(key, params, build):
+    """Shared cache of ``weight_views`` / ``clam_views``: ``build()`` -> (outs, job records, max_tiles); refreshed like weight_views."""
+    import numpy as np
+    ver = (PARAM_EPOCH, tuple(p._version for p in params))
+    st = _VIEWS.get(key)
+    if st is None:
+        if len(_VIEWS) >= 64:
+            _VIEWS.clear()
+            _MERGED.clear()
+        outs, rec, max_tiles = build()
+        jobs = np.array(rec, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
+                                             ("tr", "<i4"), ("dt", "<i4")]))
+        table = torch.from_numpy(jobs.view(np.uint8).copy()).to(params[0].device)
+        st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None, keep=list(params), managed=False)
+    st["managed"] = all(is_managed(p) for p in params)
+    if st["ver"] != ver or not st["managed"]:
+        check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
+        st["ver"] = ver
+    return st["outs"]
+
+
+def clam_views(w1, wa, ba, wb, bb, wc, dtype):
+    """Everything CLAM-SB's bf16 chain needs from its parameters, prepared by ONE launch (none while an optimizer that announces its
+    steps owns them and nothing changed): -> (w1 [L,d] in ``dtype``; W_il [2D,L] ``dtype``: attention_a / attention_b interleaved in
+    16-row blocks (``gate_interleave``); W_il^T [L,2D] ``dtype`` (the dgrad operand); b_il [2D] f32; c_il [2D] f32 = attention_c's
+    weight at the a-rows, 0 at the b-rows)."""
+    params = (w1, wa, ba, wb, bb, wc)
+    D, L = wa.shape
+    key = tuple((p.data_ptr(), "clam", i, dtype) for i, p in enumerate(params))
+
+    def build():
+        dev = w1.device
+        code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+        es = 2 if dtype == torch.bfloat16 else 4
+        for p in params:
+            _need_cuda(p)
+            assert p.dtype == torch.float32 and p.is_contiguous()
+        w1c = torch.empty(w1.shape, dtype=dtype, device=dev)
+        W_il = torch.empty((2 * D, L), dtype=dtype, device=dev)
+        W_ilT = torch.empty((L, 2 * D), dtype=dtype, device=dev)
+        b_il = torch.empty((2 * D,), dtype=torch.float32, device=dev)
+        c_il = torch.zeros((2 * D,), dtype=torch.float32, device=dev)
+        rec = []
+        R1, C1 = w1.shape
+        for r0 in range(0, R1, 32):                  # 32-row strips: every job of the table has about the same number of tiles
+            rows = min(32, R1 - r0)
+            rec.append((w1.data_ptr() + r0 * C1 * 4, w1c.data_ptr() + r0 * C1 * es, rows, C1, 0, code))
+        for g in range(D // 16):
+            for j, (w, b) in enumerate(((wa, ba), (wb, bb))):
+                r = 32 * g + 16 * j                  # destination row block / column block
+                rec.append((w.data_ptr() + 16 * g * L * 4, W_il.data_ptr() + r * L * es, 16, L, 0, code))
+                rec.append((w.data_ptr() + 16 * g * L * 4, W_ilT.data_ptr() + r * es, 16, L, 1 | ((2 * D) << 8), code))
+                rec.append((b.data_ptr() + 16 * g * 4, b_il.data_ptr() + r * 4, 1, 16, 0, _lib.F32))
+            rec.append((wc.data_ptr() + 16 * g * 4, c_il.data_ptr() + 32 * g * 4, 1, 16, 0, _lib.F32))
+        max_tiles = max(((rw + 31) // 32) * ((cl + 31) // 32) for _, _, rw, cl, _, _ in rec)
+        return [w1c, W_il, W_ilT, b_il, c_il], rec, max_tiles
+    return _job_views(key, params, build)
 
 
 _UNIT = {}

@@ -290,6 +290,129 @@ def test_gate_dropout_masks_generated_inside_the_score_kernels(gated):
         _close(a, b, rtol=1e-6, atol=1e-5)
 
 
+def _gate_inputs(seed, M, D=256, L=512):
+    h = torch.relu(_rand(seed, "h", (M, L))).bfloat16()
+    wa, wb = _rand(seed, "wa", (D, L), 1.5 / math.sqrt(L)), _rand(seed, "wb", (D, L), 1.5 / math.sqrt(L))
+    ba, bb = _rand(seed, "ba", (D,), 0.1), _rand(seed, "bb", (D,), 0.1)
+    wc, bc = _rand(seed, "wc", (D,), 2.0 / math.sqrt(D)), _rand(seed, "bc", (1,), 0.1)
+    return h, wa, ba, wb, bb, wc, bc
+
+
+def _deinterleave(U_il, D):
+    """[M, 2D] in the panel GEMM's interleaved gate order -> (a | b) natural order."""
+    M = U_il.shape[0]
+    return U_il.view(M, D // 16, 2, 16).permute(0, 2, 1, 3).reshape(M, 2 * D)
+
+
+@pytest.mark.parametrize("D,L,d", [(256, 512, 512), (128, 512, 1024), (64, 256, 320)])
+def test_clam_parameter_views_from_one_launch(D, L, d):
+    """ops.clam_views: the bf16 copy of fc, attention_a / attention_b interleaved in 16-row blocks, the transpose of that, and the
+    interleaved bias / attention_c vectors - one murcl_cast_batch launch of row / column BLOCK jobs - equal what cat + gather +
+    cast + transpose produce; they follow the parameters (rebuilt on the next call for parameters no optimizer manages)."""
+    from murcl_amd import ops
+    dev = _dev()
+    w1 = _rand(47, "w1", (L, d)).to(dev)
+    wa, wb = _rand(47, "wa", (D, L)).to(dev), _rand(47, "wb", (D, L)).to(dev)
+    ba, bb, wc = _rand(47, "ba", (D,)).to(dev), _rand(47, "bb", (D,)).to(dev), _rand(47, "wc", (1, D)).to(dev)
+    for _ in range(2):
+        w1c, W_il, W_ilT, b_il, c_il = ops.clam_views(w1, wa, ba, wb, bb, wc, torch.bfloat16)
+        W_ref, b_ref, c_ref = ops.gate_interleave(wa, ba, wb, bb, wc, torch.bfloat16)
+        assert torch.equal(w1c, w1.bfloat16()) and torch.equal(W_il, W_ref) and torch.equal(W_ilT, W_ref.t().contiguous())
+        assert torch.equal(b_il, b_ref) and torch.equal(c_il, c_ref)
+        with torch.no_grad():                                   # second round: changed parameters
+            for p in (w1, wa, wb, ba, bb, wc):
+                p.mul_(1.5).add_(0.01)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+@pytest.mark.parametrize("M", [64, 4096, 8192 + 32])
+def test_panel_gate_u_scores_and_pre_activations_from_one_gemm(M, drop):
+    """murcl_panel_gemm_drop epilogue 5 (CLAM's training forward): the pre-activations it stores, de-interleaved, are the bias
+    GEMM's (bit for bit: same MFMA chain, same rounding), and its scores are those of murcl_gated_score_fwd on the un-rounded
+    accumulators - compared with the score pass over the bf16 U (tolerance = what that rounding is worth) and, tighter, with a
+    float64 evaluation of the bf16 inputs; with seeded gate Dropout the same masks as the score kernel's."""
+    from murcl_amd import ops
+    dev = _dev()
+    h, wa, ba, wb, bb, wc, bc = [t.to(dev) for t in _gate_inputs(41, M)]
+    D = 256
+    da, db = (ops.DropSeed(0.75, seed=991), ops.DropSeed(0.75, seed=17)) if drop else (None, None)
+    W_il, b_il, c_il = ops.gate_interleave(wa, ba, wb, bb, wc, torch.bfloat16)
+    U_il, s = ops.panel_gate_u(h, W_il, b_il, c_il, bc, da, db)
+    U_ref, _, _ = ops.panel_gemm(h, torch.cat([wa, wb], 0).bfloat16(), ops.PG_BIAS, bias=torch.cat([ba, bb], 0))
+    assert torch.equal(_deinterleave(U_il, D), U_ref)
+    s_chain = ops.gated_score_fwd(U_ref, wc, bc, da, db)
+    sc = s_chain.abs().max().item()
+    assert (s - s_chain).abs().max().item() <= 2e-2 * sc
+    # float64 reference on the bf16-rounded operands
+    Ud = h.double() @ torch.cat([wa, wb], 0).bfloat16().double().t() + torch.cat([ba, bb], 0).double()
+    t = torch.tanh(Ud[:, :D]) * torch.sigmoid(Ud[:, D:])
+    if drop:
+        ka = ops.dropout_mask((M, D), torch.float32, 0.75, dev, seed=da.seed).double()
+        kb = ops.dropout_mask((M, D), torch.float32, 0.75, dev, seed=db.seed).double()
+        t = t * ka * kb
+    s64 = (t * wc.double()).sum(1) + bc.double()
+    e_new, e_chain = (s.double() - s64).abs().max().item(), (s_chain.double() - s64).abs().max().item()
+    assert e_new <= 3e-3 * sc and e_new <= 1.5 * e_chain + 1e-4 * sc, (e_new, e_chain)
+    if not drop:
+        assert torch.equal(ops.panel_gate_score(h, W_il, b_il, c_il, bc), s)       # the forward-only epilogue: the same scores
+
+
+@pytest.mark.parametrize("drop", [False, True])
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 2048), (5, 96)])
+def test_gate_backward_in_one_pass_over_interleaved_pre_activations(B, N, drop):
+    """murcl_gated_score_bwd_il: (a) with ds given = murcl_gated_score_bwd on the de-interleaved tensors, bit for bit; (b) with ds
+    derived in the pass (ds_n = A_n (h_n . dM - M . dM)) = rows_dot -> softmax_rows_bwd -> gated_score_bwd, to f32 rounding."""
+    from murcl_amd import ops
+    dev = _dev()
+    M, D, L = B * N, 256, 512
+    h, wa, ba, wb, bb, wc, bc = [t.to(dev) for t in _gate_inputs(43, M)]
+    da, db = (ops.DropSeed(0.75, seed=5), ops.DropSeed(0.75, seed=6)) if drop else (None, None)
+    W_il, b_il, c_il = ops.gate_interleave(wa, ba, wb, bb, wc, torch.bfloat16)
+    U_il, s = ops.panel_gate_u(h, W_il, b_il, c_il, bc, da, db)
+    U_nat = _deinterleave(U_il, D).contiguous()
+    A = ops.softmax_rows(s.view(B, N))
+    Mp = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)
+    dM = _rand(43, "dM", (B, L)).to(dev)
+    dA = ops.rows_dot(h.view(B, N, L), dM.view(B, 1, L)).view(B, N)
+    ds = ops.softmax_rows_bwd(A, dA).view(-1)
+    ref = ops.gated_score_bwd(U_nat, wc, ds, da, db)
+    got = ops.gated_score_bwd_il(U_il, wc, da, db, ds=ds)
+    assert torch.equal(_deinterleave(got[0], D), ref[0])
+    for a, b in zip(got[1:], ref[1:]):
+        _close(a, b.double().cpu(), rtol=1e-5, atol=1e-5 * max(1.0, b.abs().max().item()))
+    if not ops.gated_bwd_il_supported(M, D, L, N):
+        return
+    one = ops.gated_score_bwd_il(U_il, wc, da, db, h=h, dM=dM, Mp=Mp, A=A.view(-1), rows_per_bag=N)
+    scale = ref[0].float().abs().max().item()
+    assert (_deinterleave(one[0], D).float() - ref[0].float()).abs().max().item() <= 2e-2 * scale      # bf16 outputs of ds values that differ in the last f32 bits
+    for a, b, name in zip(one[1:], ref[1:], ("dwc", "dbc", "dbab")):
+        # (dbc = sum_n ds_n is zero in exact arithmetic - a soft-max gradient sums to nothing - so it is compared on the scale of its terms)
+        floor = ds.abs().sum().item() if name == "dbc" else max(1e-6, b.abs().max().item())
+        _close(a, b.double().cpu(), rtol=2e-3, atol=2e-3 * floor, msg=name)
+
+
+@pytest.mark.parametrize("M", [32, 4096, 8192 + 64])
+def test_panel_forward_with_dropout_inside_the_epilogue(M):
+    """murcl_panel_gemm_drop epilogue 0 with keep_p: relu(x W^T + b) * keep from the seed's counter-based mask - the keep pattern and the
+    1-bit mask of what survives are exactly those of murcl_dropout_relu_bitmask on the un-dropped output; the values differ from that
+    two-pass form by one bf16 rounding (the epilogue scales the f32 accumulator and rounds once)."""
+    from murcl_amd import ops
+    dev = _dev()
+    x = torch.relu(_rand(45, "x", (M, 512))).bfloat16().to(dev)
+    w, b = _rand(45, "w", (512, 512), 1.5 / math.sqrt(512)).bfloat16().to(dev), _rand(45, "b", (512,), 0.1).to(dev)
+    drop = ops.DropSeed(0.75, seed=0xABCDEF + M)
+    h, bits, _ = ops.panel_gemm(x, w, ops.PG_BIAS_RELU, bias=b, want_bitmask=True, drop=drop)
+    h2, _, _ = ops.panel_gemm(x, w, ops.PG_BIAS_RELU, bias=b, want_bitmask=True)
+    bits2 = ops.dropout_relu_bitmask(h2, drop)
+    assert torch.equal(bits, bits2)
+    assert torch.equal(h != 0, h2 != 0)
+    assert (h.float() - h2.float()).abs().max().item() <= 2 ** -7 * h2.float().abs().max().item()
+    # one rounding: closer to (or as close as) the exact product than the two-pass form
+    mask = ops.dropout_mask((M, 512), torch.float32, 0.75, dev, seed=drop.seed).double()
+    exact = torch.relu(x.double() @ w.double().t() + b.double()) * mask
+    assert (h.double() - exact).abs().max().item() <= (h2.double() - exact).abs().max().item() + 1e-6
+
+
 # ------------------------------------------------------------------ K2 attention pool
 def _k2_inputs(seed, B, N):
     H = torch.relu(_rand(seed, "H", (B, N, 512)))

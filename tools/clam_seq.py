@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""CLAM_SB aggregator forward+backward at the C3 shape (64 bags x 4096 x 512 bf16), a few passes and nothing after them:
+for tools/trace_seq.sh (kernel sequence of the last pass)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from murcl_amd.models.clam import CLAM_SB
+
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(3)
+B, N = 64, 4096
+m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512).to(dev)
+m.compute_dtype = torch.bfloat16
+x = (torch.randn((B, N, 512), generator=g, device=dev).abs() * 0.5).bfloat16()
+if len(sys.argv) > 1 and sys.argv[1] == "train":
+    m.train()
+else:
+    m.eval()
+fwd_only = len(sys.argv) > 1 and sys.argv[1] == "fwd"
+for _ in range(6):
+    if fwd_only:
+        with torch.no_grad(): m(x)
+        continue
+    for p in m.parameters(): p.grad = None
+    out = m(x)
+    out[0].sum().backward()
+torch.cuda.synchronize()

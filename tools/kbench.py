@@ -83,6 +83,31 @@ def main():
         "wrowsum_d1024": (lambda: ops.weighted_rowsum(Xd, A2), Xd.numel() * 2, 0),
         "rows_dot_wsum_d1024": (lambda: ops.rows_dot_wsum(Xd, V2, A2), Xd.numel() * 2, 0),
     })
+    # CLAM-SB's gate GEMM forms and its gate backward (C3: 262144 rows, D = 256)
+    wa_, wb_ = torch.randn((256, 512), generator=g, device=dev) / math.sqrt(512), torch.randn((256, 512), generator=g, device=dev) / math.sqrt(512)
+    ba_, bb_ = torch.randn((256,), generator=g, device=dev) * 0.1, torch.randn((256,), generator=g, device=dev) * 0.1
+    W_il, b_il, c_il = ops.gate_interleave(wa_, ba_, wb_, bb_, wc, torch.bfloat16)
+    dsa, dsb = ops.DropSeed(0.75, seed=11), ops.DropSeed(0.75, seed=12)
+    U_il, s_il = ops.panel_gate_u(H, W_il, b_il, c_il, bc1)
+    A_sm = ops.softmax_rows(s_il.view(Bc, Nc))
+    Mp_c = ops.weighted_rowsum(H.view(Bc, Nc, 512), A_sm.view(Bc, Nc, 1)).view(Bc, 512)
+    dM_c = torch.randn((Bc, 512), generator=g, device=dev)
+    ds_c = torch.randn((M,), generator=g, device=dev) * 1e-3
+    gbytes = 2 * M * 512 * 2
+    cases.update({
+        "panel_bias": (lambda: ops.panel_gemm(H, W_il, ops.PG_BIAS, bias=b_il), gbytes, 2.0 * M * 512 * 512),
+        "panel_gate_score": (lambda: ops.panel_gate_score(H, W_il, b_il, c_il, bc1), M * 512 * 2, 2.0 * M * 512 * 512),
+        "panel_gate_u": (lambda: ops.panel_gate_u(H, W_il, b_il, c_il, bc1), gbytes, 2.0 * M * 512 * 512),
+        "panel_gate_u_drop": (lambda: ops.panel_gate_u(H, W_il, b_il, c_il, bc1, dsa, dsb), gbytes, 2.0 * M * 512 * 512),
+        "panel_fwd_drop": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, drop=dsa), gbytes, 2.0 * M * 512 * 512),
+        "pair_fc_gate_u": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gate_u(H, W_il, b_il, c_il, bc1)), 2 * gbytes, 0),
+        "pair_fc_biasgate": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gemm(H, W_il, ops.PG_BIAS, bias=b_il)), 2 * gbytes, 0),
+        "pair_fc_gatescore": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gate_score(H, W_il, b_il, c_il, bc1)), 2 * gbytes, 0),
+        "gate_bwd_nat": (lambda: ops.gated_score_bwd(U_il, wc, ds_c), gbytes, 0),
+        "gate_bwd_il": (lambda: ops.gated_score_bwd_il(U_il, wc, ds=ds_c), gbytes, 0),
+        "gate_bwd_il_onepass": (lambda: ops.gated_score_bwd_il(U_il, wc, h=H, dM=dM_c, Mp=Mp_c, A=A_sm.view(-1), rows_per_bag=Nc), 3 * M * 512 * 2, 0),
+        "gate_bwd_il_onepass_drop": (lambda: ops.gated_score_bwd_il(U_il, wc, dsa, dsb, h=H, dM=dM_c, Mp=Mp_c, A=A_sm.view(-1), rows_per_bag=Nc), 3 * M * 512 * 2, 0),
+    })
     Xf = torch.randn((16, 8192, 1024), generator=g, device=dev).abs() * 0.5                # DSMIL C5 share in f32
     cases.update({
         "rows_dot_f32_d1024": (lambda: ops.rows_dot(Xf, V2), Xf.numel() * 4, 0),
