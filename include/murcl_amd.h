@@ -162,6 +162,15 @@ int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int
  * because every column of A sums to one.  rows_dot: out[b,n,c] = X[b,n,:].V[b,c,:].  attn_bwd: soft-max backward,
  * dQ written into dY[:, qcol0:qcol0+128] and dqmax[b,c,:]. */
 int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_out, murcl_stream_t stream);
+/* The same attention without the [B*N,128] queries (dsmil.py:64-78 reassociated): Q[n].qmax[c]/sqrt(128) = X[n].v[c] + const with
+ * v[c] = Wq^T qmax[c] / sqrt(128), and a soft-max over n ignores the constant - so the scores are a murcl_rows_dot of X against
+ * v (a [B*C, d] matrix from two tiny GEMMs), murcl_dsmil_softmax turns them into A in place, and in the backward pass
+ * murcl_dsmil_softmax_bwd gives dS = A * (dA - sum_n A dA) (dots_ws: B*C floats), whose weighted row sum over X
+ * (murcl_weighted_rowsum) carries everything the query projection's gradient needs:  dWq = (qmax^T R + dqmax^T X[m]) with
+ * R[c] = sum_n dS[n,c] X[n] / sqrt(128) and dqmax = R Wq^T.  No GEMM over all patches remains in K6. */
+int murcl_dsmil_softmax(float* S, int B, int N, int C, murcl_stream_t stream);
+int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,
+                            murcl_stream_t stream);
 int murcl_gather_rows(const void* src, const int* m, int B, int C, int N, int ld, int col0, int width, void* out,
                       int dtype, murcl_stream_t stream);
 int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float* qmax, int B, int N, int C, float* A,

@@ -134,6 +134,15 @@ extern "C" int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float*
     return MURCL_CHECK_LAUNCH();
 }
 
+// In-place soft-max over n of raw scores S[b, :, c] that are already scaled (the reassociated K6 path: S = X . v with
+// v = qmax Wq / sqrt(128), so that the [B*N, 128] queries are never formed - see functional.DSMILFn).
+extern "C" int murcl_dsmil_softmax(float* S, int B, int N, int C, hipStream_t s) {
+    if (B <= 0 || N <= 0) return 0;
+    if (C <= 0 || C > 4) return -1;
+    hipLaunchKernelGGL(dsmil_softmax_kernel, dim3(B, C), dim3(256), 0, s, S, N, C);
+    return MURCL_CHECK_LAUNCH();
+}
+
 #ifndef WR_UR
 #define WR_UR 4
 #endif
@@ -503,5 +512,31 @@ extern "C" int murcl_dsmil_attn_bwd(const float* A, const float* dA, const float
     if (rc) return rc;
     hipLaunchKernelGGL(dsmil_attn_bwd_kernel, dim3((N + DS_RPB - 1) / DS_RPB, B), dim3(256), 0, s, A, dA, Q, ldq, qcol0, qmax,
                        dots_ws, N, C, 1.0f / sqrtf((float)DS_Q), dY, ldy, dqmax);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// Soft-max backward alone, dS = A * (dA - sum_n A dA) per (bag, class), for the reassociated path (dS then weights the rows of X:
+// sum_n dS[n,c] X[n,:] is all the query projection's backward needs).  dots_ws: B*C floats.
+__global__ __launch_bounds__(256) void dsmil_softmax_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA,
+                                                                const float* __restrict__ dots, long total, int N, int C,
+                                                                float* __restrict__ dS) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long b = i / ((long)N * C);
+        const int c = (int)(i % C);
+        dS[i] = A[i] * (dA[i] - dots[b * C + c]);
+    }
+}
+extern "C" int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,
+                                       hipStream_t s) {
+    if (B <= 0 || N <= 0) return 0;
+    if (C <= 0 || C > 4 || !dots_ws) return -1;
+    hipLaunchKernelGGL(dsmil_attn_dots_kernel, dim3(B, C), dim3(256), 0, s, A, dA, N, C, dots_ws);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    const long total = (long)B * N * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(dsmil_softmax_bwd_kernel, dim3(grid), dim3(256), 0, s, A, dA, dots_ws, total, N, C, dS);
     return MURCL_CHECK_LAUNCH();
 }

@@ -4,6 +4,8 @@ Forward and backward are sequences of C-ABI launches (murcl_amd.ops); torch supp
 only tensor storage and the autograd graph.  No CPU / eager-PyTorch fallback exists:
 CPU tensors raise.
 """
+import math
+
 import torch
 
 from . import ops
@@ -35,6 +37,7 @@ _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
 _FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B switch: CLAM's gate score from the gate GEMM's epilogue (forward-only)
 _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
+_DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
@@ -625,9 +628,13 @@ class NTXentFn(torch.autograd.Function):
 class DSMILFn(torch.autograd.Function):
     """MILNet.forward for a batch of equal-length bags (models/dsmil.py:9-16,64-81,104-113).
 
-    One GEMM over X produces the queries Q (columns 0..127) and the instance scores (columns 128..128+C-1);
-    the value projection is applied AFTER pooling: bag = (A^T X) Wv^T + bv, identical to A^T (X Wv^T + bv)
-    because every column of the soft-max sums to one (dropout_v = 0).  Returns (classes [B,N,C], bag [B,C,d]).
+    The value projection is applied AFTER pooling: bag = (A^T X) Wv^T + bv, identical to A^T (X Wv^T + bv) because every column
+    of the soft-max sums to one (dropout_v = 0).  The query projection is reassociated the same way (round 3): the attention
+    logits Q[n] . q_c / sqrt(128) with Q = X Wq^T + bq equal X[n] . v_c + const for v_c = Wq^T q_c / sqrt(128), and the soft-max
+    over n ignores the constant - so K6 is four streaming passes over X (instance scores; attention logits; pooling; and, going
+    back, dA = X dZ^T with dWc, then R = dS^T X) and a handful of [B*C]-row GEMMs; the [B*N, 128] queries and the two GEMMs over
+    all patches (forward and dWq) are never formed.  ``_DSMIL_REASSOC = False`` keeps the literal order of the reference (queries
+    by one GEMM, 3-term bf16 split for f32).  Returns (classes [B,N,C], bag [B,C,d]).
     """
     QD = 128
 
@@ -639,31 +646,36 @@ class DSMILFn(torch.autograd.Function):
         QD = DSMILFn.QD
         LD = QD + ((C + 7) // 8) * 8
         x2 = x.reshape(B * N, d)
-        # queries: one 128-column GEMM.  The C (<= 4) instance-score columns are a streaming row dot product: as columns
-        # 128..128+C-1 of the same GEMM they would cost a second, almost empty 128-column tile pass over X.
-        # f32 (parity path): the two GEMMs over all patches - the queries here and dWq in the backward pass - run as a 3-term bf16
-        # split on the bf16 matrix pipe (ops.gemm_nt x3: f32-level accuracy; the exact-f32 MFMA form ran them at 0.72 of the
-        # 157 TFLOP/s f32 matrix peak = 2 x 303 us of the C5 share's 1.28 ms)
-        Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
-                        out_dtype=torch.float32, x3=_DSMIL_X3)                          # Q [B*N, 128]
-        cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d)).view(B * N, C)
+        cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d)).view(B * N, C)       # instance scores (dsmil.py:9-16)
         cls += bc
-        m = ops.dsmil_argmax(cls, B, N, C)
-        qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
-        A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
+        m = ops.dsmil_argmax(cls, B, N, C)                                              # critical instances (:71-73)
+        reassoc = _DSMIL_REASSOC and C <= 4
+        if reassoc:
+            xm = ops.cast(ops.gather_rows(x2, m, B, C, N, 0, d), torch.float32)         # [B*C, d]
+            qmax = ops.gemm_nt(xm, wq, epi=ops.EPI_BIAS, bias=bq)                       # q_c = Wq x_m + bq     [B*C, 128]
+            v = ops.gemm_nt(qmax, ops.transposed(wq))                                   # Wq^T q_c              [B*C, d]
+            v *= 1.0 / math.sqrt(QD)
+            A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))                    # soft-max_n(X v_c)  (:76-77)
+            Y = v
+        else:
+            # queries: one 128-column GEMM; f32: as a 3-term bf16 split on the bf16 matrix pipe (ops.gemm_nt x3)
+            Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
+                            out_dtype=torch.float32, x3=_DSMIL_X3)                      # Q [B*N, 128]
+            qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
+            A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
         Z = ops.weighted_rowsum(x, A)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
         classes = cls.view(B, N, C)
-        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv)
-        ctx.meta = (B, N, d, C, LD)
+        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq)
+        ctx.meta = (B, N, d, C, LD, reassoc)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
         return classes, bag, m
 
     @staticmethod
     def backward(ctx, dclasses, dbag, _dm):
-        x, Y, m, qmax, A, Z, wv = ctx.saved_tensors
-        B, N, d, C, LD = ctx.meta
+        x, Y, m, qmax, A, Z, wv, wq = ctx.saved_tensors
+        B, N, d, C, LD, reassoc = ctx.meta
         T, QD = x.dtype, DSMILFn.QD
         dev = x.device
         x2 = x.reshape(B * N, d)
@@ -677,12 +689,25 @@ class DSMILFn(torch.autograd.Function):
             dcls = dclasses.reshape(B, N, C).float().contiguous()
             fused = ops.rows_dot_wsum(x, dZ, dcls)
         dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
-        dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                      # written in full below
-        dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
-        dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2, x3=_DSMIL_X3)  # [128, d]: one tile row
-        dbq = ops.colsum(dQ)
         xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
-        ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
+        if reassoc:
+            # dS weights the rows of X once more: R_c = sum_n dS[n,c] X[n] / sqrt(128) is the gradient of v_c, and
+            #   sum_n dQ[n]^T X[n] = qmax^T R,   dqmax = sum_n dS[n,c] Q[n] / sqrt(128) = R Wq^T  (+ bq sum_n dS[n,c], and a soft-max
+            #   gradient sums to nothing)
+            R = ops.weighted_rowsum(x, ops.dsmil_softmax_bwd(A, dA)).view(B * C, d)
+            R *= 1.0 / math.sqrt(QD)
+            dqmax = ops.gemm_nt(R, wq)                                                      # [B*C, 128]
+            dwq = ops.gemm_tn(qmax, R)                                                      # [128, d]
+            dbq = torch.zeros((QD,), dtype=torch.float32, device=dev)
+        else:
+            dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                  # written in full below
+            dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
+            dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2, x3=_DSMIL_X3)  # [128, d]: one tile row
+            dbq = ops.colsum(dQ)
+        if reassoc:
+            ops.gemm_tn(dqmax, ops.cast(xm, torch.float32), out=dwq)
+        else:
+            ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
         ops.colsum(dqmax, out=dbq, accumulate=True)
         dwc = dbc = None
         if dclasses is not None:

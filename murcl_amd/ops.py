@@ -724,6 +724,24 @@ def dsmil_attn(Y, qcol0, qmax, B, N, C):
     return A
 
 
+def dsmil_softmax_(S):
+    """In-place soft-max over n of S [B,N,C] f32 (already scaled raw scores) -> the same tensor, now A."""
+    assert S.is_contiguous() and S.dtype == torch.float32
+    B, N, C = S.shape
+    check(_lib.lib().murcl_dsmil_softmax(ptr(S), B, N, C, stream()), "dsmil_softmax")
+    return S
+
+
+def dsmil_softmax_bwd(A, dA):
+    """dS = A * (dA - sum_n A dA) per (bag, class); A, dA [B,N,C] f32."""
+    A, dA = _c(A), _c(dA)
+    B, N, C = A.shape
+    dS = torch.empty_like(A)
+    dots = torch.empty((B * C,), dtype=torch.float32, device=A.device)
+    check(_lib.lib().murcl_dsmil_softmax_bwd(ptr(A), ptr(dA), B, N, C, ptr(dS), ptr(dots), stream()), "dsmil_softmax_bwd")
+    return dS
+
+
 def weighted_rowsum(X, A):
     """Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]   X [B,N,d] (f32/bf16), A [B,N,C] f32 -> Z [B,C,d] f32."""
     X, A = _c(X), _c(A)

@@ -54,6 +54,9 @@ if "clam" in only or not only:
         out = m(x)
         out[0].sum().backward()
     report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward, aggregator only (no instance eval)", timed(fb_agg), 15 * B * N * 512 * es, B, "bags")
+    m.train()                          # Dropout(0.25) behind fc and on both gate branches: what the training scripts run
+    report("a4-a8 CLAM_SB (K4/K5) C3", "forward+backward, aggregator only, training mode (dropout)", timed(fb_agg), 15 * B * N * 512 * es, B, "bags")
+    m.eval()
 # ---- C5 share of one GPU: DSMIL 16 bags x 8192 x 1024 f32
 if "dsmil" in only or not only:
     B, N, d = 16, 8192, 1024
@@ -61,10 +64,10 @@ if "dsmil" in only or not only:
     x = torch.randn((B, N, d), generator=g, device=dev).abs() * 0.5
     def fwd():
         with torch.no_grad(): m(x)
-    def fb():
+    def fb():                          # bag term + max-instance term (train_RLMIL.py:516-529), batched as the training step has it
         for p in m.parameters(): p.grad = None
-        c, bag, _ = m(x)
-        (bag.sum() + sum(cc.max(0)[0].sum() for cc in c)).backward()
+        classes, bag = m._run(x)
+        (bag.sum() + classes.max(1)[0].sum()).backward()
     report("a9-a11 DSMIL (K6) C5/8", "forward (2 passes over X)", timed(fwd), 2 * B * N * d * 4, B, "bags")
     report("a9-a11 DSMIL (K6) C5/8", "forward+backward (4 passes over X)", timed(fb), 4 * B * N * d * 4, B, "bags")
 # ---- C4 per-GPU share: sub-bag builder, 64 raw bags x 8192 x 512 -> 2 views x 1024
