@@ -240,7 +240,10 @@ def other_rows(device):
             p.grad = None
         M, _, _, il, _, _ = m._run(x, labels if inst else None, inst)
         (M.sum() + il.sum()).backward() if inst else M.sum().backward()
-    for name, inst in (("clam_sb_c3_fwd_bwd_instance_loss", True), ("clam_sb_c3_fwd_bwd_aggregator", False)):
+    for name, inst in (("clam_sb_c3_fwd_bwd_instance_loss", True), ("clam_sb_c3_fwd_bwd_aggregator", False),
+                       ("clam_sb_c3_fwd_bwd_aggregator_training_mode", False)):
+        # the last row: Dropout(0.25) behind fc and on both gate branches live, as the training scripts run the aggregator
+        m.train(name.endswith("training_mode"))
         ms = _timed_ms(lambda: clam_fb(inst))
         nbytes = 15 * B * N * 512 * 2
         # the two 512 x 512 projections dominate - fc forward + weight gradient (no dX), gate forward + dgrad + weight

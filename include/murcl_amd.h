@@ -169,6 +169,19 @@ int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_
  * (murcl_weighted_rowsum) carries everything the query projection's gradient needs:  dWq = (qmax^T R + dqmax^T X[m]) with
  * R[c] = sum_n dS[n,c] X[n] / sqrt(128) and dqmax = R Wq^T.  No GEMM over all patches remains in K6. */
 int murcl_dsmil_softmax(float* S, int B, int N, int C, murcl_stream_t stream);
+/* The same path with attention AND pooling in one pass over X, and their whole backward in one more (C <= 2, d <= 1024, d % 8 == 0:
+ * murcl_dsmil_stream_plan > 0 = the rows a wave takes; 0: use the separate launches above).
+ * attn_pool: A [B,N,C] receives the logits X.v and then the soft-max over n (online soft-max per wave, merged per bag); Z [B,C,d]
+ * = A^T X.  ws: (B*N/plan)*C*(d+2) + 2*B*C floats.
+ * attn_pool_bwd: R [B,C,d] = scale * sum_n A[n,c] (dA[n,c] - sum_m A[m,c] dA[m,c]) X[n] with dA = X dZ^T, taken as
+ * (sum_n A dA X[n]) - (sum_n A dA) Z[c] - Z = the forward's pooled rows - so that neither dA nor dS is stored; with dcls [B,N,C]
+ * (may be NULL) the pass also leaves the per-wave partial rows of dWc = dcls^T X in gpart [(B*N/plan)][C*d] (sum them with
+ * murcl_colsum).  ws: (B*N/plan)*C*(d+2) floats. */
+int murcl_dsmil_stream_plan(int B, int N, int d, int C);
+int murcl_dsmil_attn_pool(const void* X, const float* v, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
+                          murcl_stream_t stream);
+int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls, float scale,
+                              float* R, float* gpart, float* ws, int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,
                             murcl_stream_t stream);
 int murcl_gather_rows(const void* src, const int* m, int B, int C, int N, int ld, int col0, int width, void* out,

@@ -540,3 +540,217 @@ extern "C" int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, i
     hipLaunchKernelGGL(dsmil_softmax_bwd_kernel, dim3(grid), dim3(256), 0, s, A, dA, dots_ws, total, N, C, dS);
     return MURCL_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- reassociated K6: attention + pooling in ONE pass over X, and the
+// whole backward of (attention, pooling, query projection) in ONE more
+//
+// Forward (dsmil.py:76-78 with the logits as X . v, see murcl_dsmil_softmax): a wave walks rows_per_wave consecutive rows of one
+// bag exactly like rows_dot_wsum_kernel (four rows in flight, a lane owns 8 consecutive columns per 512-column step), takes
+// s[n,c] = X[n] . v[c] by a wave reduction, and keeps a running soft-max per class (online: maximum m, sum l, and the weighted row
+// sum Z' = sum_n e^{s[n,c] - m} X[n] in registers, rescaled when m moves).  It leaves the raw logits S[n,c], its (m, l) and Z'.
+// murcl_dsmil_attn_pool's second launch merges a bag's waves (weights e^{m_w - m}), and the third turns S into A = e^{S-m}/l.
+//
+// Backward: with dA[n,c] = X[n] . dZ[c] and w = A dA,
+//     R[c] = sum_n A[n,c] (dA[n,c] - dot_c) X[n] = (sum_n w[n,c] X[n]) - dot_c Z[c],      dot_c = sum_n w[n,c]
+// (Z = the pooled rows the forward saved), so dS never has to exist and X is read once; the same pass takes dWc = dcls^T X.
+template <typename T, int MODE>          // MODE 0: forward, 1: backward
+__global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__ X, const float* __restrict__ V,
+                                                           const float* __restrict__ Ain, const float* __restrict__ G,
+                                                           int N, int d, int C, int rows_per_wave, float* __restrict__ S,
+                                                           float* __restrict__ part, float* __restrict__ stat,
+                                                           float* __restrict__ gpart, long rows_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long row0 = wid * rows_per_wave;
+    if (row0 >= rows_total) return;
+    const long row1 = min(rows_total, row0 + rows_per_wave);
+    const float* v = V + (size_t)(row0 / N) * C * d;
+    float zacc[2][2][8], gacc[(MODE == 1) ? 2 : 1][2][8], vr[2][2][8];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};      // MODE 1: l_run = sum_n w[n,c]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int k = st * 512 + lane * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { zacc[c][st][e] = 0.f; vr[c][st][e] = 0.f; if (MODE == 1) gacc[c][st][e] = 0.f; }
+            if (c < C && k < d) load8<float>(v + (size_t)c * d + k, vr[c][st]);
+        }
+    const bool with_g = MODE == 1 && G != nullptr;
+    for (long rb = row0; rb < row1; rb += 4) {
+        float acc[4][2], xv[4][2][8], aw[4][2], gw[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long row = min(rb + u, row1 - 1);
+            const bool live = rb + u < row1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[u][c] = 0.f;
+                aw[u][c] = (MODE == 1 && live && c < C) ? Ain[row * C + c] : 0.f;
+                gw[u][c] = (with_g && live && c < C) ? G[row * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int k = st * 512 + lane * 8;
+                if (k < d) load8<T>(X + row * d + k, xv[u][st]);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[u][st][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][st][e] * vr[c][st][e];
+        float wgt[4][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float sd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? wave_sum(acc[u][c]) : 0.f;
+            if (MODE == 0) {
+                float mx = m_run[c];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rb + u < row1) mx = fmaxf(mx, sd[u]);
+                const float alpha = __expf(m_run[c] - mx);          // first batch: e^{-inf} = 0 on zero accumulators
+                float ladd = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wgt[u][c] = (rb + u < row1 && c < C) ? __expf(sd[u] - mx) : 0.f;
+                    ladd += wgt[u][c];
+                    if (lane == 0 && rb + u < row1 && c < C) S[(rb + u) * C + c] = sd[u];
+                }
+                l_run[c] = l_run[c] * alpha + ladd;
+                m_run[c] = mx;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zacc[c][st][e] *= alpha;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wgt[u][c] = aw[u][c] * sd[u];                    // (aw is 0 on dead rows / classes)
+                    l_run[c] += wgt[u][c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        zacc[c][st][e] += wgt[u][c] * xv[u][st][e];
+                        if (MODE == 1) gacc[c][st][e] += gw[u][c] * xv[u][st][e];
+                    }
+    }
+    float* pr = part + (size_t)wid * C * d;
+    float* gr = (MODE == 1 && with_g) ? gpart + (size_t)wid * C * d : nullptr;
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int k = st * 512 + lane * 8;
+            if (k < d) {
+                store8<float>(pr + (size_t)c * d + k, zacc[c][st]);
+                if (MODE == 1 && gr) store8<float>(gr + (size_t)c * d + k, gacc[c][st]);
+            }
+        }
+        if (lane == 0) { stat[(wid * C + c) * 2] = m_run[c]; stat[(wid * C + c) * 2 + 1] = l_run[c]; }
+    }
+}
+// merge the W = N / rows_per_wave waves of a bag.  grid (B*C, d/256 column blocks); MODE 0: Z = sum_w e^{m_w-m} Z'_w / l and
+// ml[b,c] = (m, l); MODE 1: R = (sum_w P_w - dot Z) * scale with dot = sum_w stat_w[1]
+template <int MODE>
+__global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restrict__ part, const float* __restrict__ stat, int W, int d,
+                                                          int C, const float* __restrict__ Zin, float scale,
+                                                          float* __restrict__ out, float* __restrict__ ml) {
+    const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+    const int k = blockIdx.y * 256 + threadIdx.x;
+    const float* st0 = stat + ((size_t)b * W * C + c) * 2;
+    float m = -INFINITY, l = 0.f;
+    if (MODE == 0) {
+        for (int w = 0; w < W; ++w) m = fmaxf(m, st0[(size_t)w * C * 2]);
+        for (int w = 0; w < W; ++w) l += st0[(size_t)w * C * 2 + 1] * __expf(st0[(size_t)w * C * 2] - m);
+    } else {
+        for (int w = 0; w < W; ++w) l += st0[(size_t)w * C * 2 + 1];
+    }
+    if (k < d) {
+        float t = 0.f;
+        const float* p0 = part + ((size_t)b * W * C + c) * d + k;
+        if (MODE == 0) {
+            for (int w = 0; w < W; ++w) t += p0[(size_t)w * C * d] * __expf(st0[(size_t)w * C * 2] - m);
+            out[(size_t)bc * d + k] = t / l;
+        } else {
+            for (int w = 0; w < W; ++w) t += p0[(size_t)w * C * d];
+            out[(size_t)bc * d + k] = (t - l * Zin[(size_t)bc * d + k]) * scale;
+        }
+    }
+    if (MODE == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ml[bc * 2] = m; ml[bc * 2 + 1] = l; }
+}
+// A = e^{S - m} / l in place, S [B,N,C]
+__global__ __launch_bounds__(256) void dsmil_normalise_kernel(float* __restrict__ S, const float* __restrict__ ml, long total, int N,
+                                                              int C) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long bc = (i / ((long)N * C)) * C + i % C;
+        S[i] = __expf(S[i] - ml[bc * 2]) / ml[bc * 2 + 1];
+    }
+}
+// plan: rows a wave takes (0: shape not covered -> rows_dot + soft-max + weighted_rowsum); the workspace holds
+// (B*N/plan) * C * (d [+ d with dcls] + 2) floats
+extern "C" int murcl_dsmil_stream_plan(int B, int N, int d, int C) { return murcl_rows_dot_wsum_plan(B, N, d, C); }
+extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float* A /* [B,N,C]: logits, then the soft-max */, float* Z,
+                                     float* ws, int B, int N, int d, int C, int dtype, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int rpw = murcl_dsmil_stream_plan(B, N, d, C);
+    if (!rpw || !ws) return -1;
+    const long rows = (long)B * N, waves = rows / rpw;
+    float* part = ws;
+    float* stat = part + waves * C * d;
+    float* ml = stat + waves * C * 2;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows);
+    else
+        return -1;
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 255) / 256), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
+    rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    const long total = rows * C;
+    int g2 = (int)((total + 255) / 256);
+    if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, A, ml, total, N, C);
+    return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls /* may be NULL */,
+                                         float scale, float* R, float* gpart /* [B*N/plan][C*d], with dcls */, float* ws, int B, int N,
+                                         int d, int C, int dtype, hipStream_t s) {
+    if (B <= 0) return 0;
+    const int rpw = murcl_dsmil_stream_plan(B, N, d, C);
+    if (!rpw || !ws || (dcls && !gpart)) return -1;
+    const long rows = (long)B * N, waves = rows / rpw;
+    float* part = ws;
+    float* stat = part + waves * C * d;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows);
+    else
+        return -1;
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 255) / 256), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr);
+    return MURCL_CHECK_LAUNCH();
+}

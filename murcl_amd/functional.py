@@ -38,6 +38,7 @@ _FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B sw
 _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
+_DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
@@ -655,15 +656,18 @@ class DSMILFn(torch.autograd.Function):
             qmax = ops.gemm_nt(xm, wq, epi=ops.EPI_BIAS, bias=bq)                       # q_c = Wq x_m + bq     [B*C, 128]
             v = ops.gemm_nt(qmax, ops.transposed(wq))                                   # Wq^T q_c              [B*C, d]
             v *= 1.0 / math.sqrt(QD)
-            A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))                    # soft-max_n(X v_c)  (:76-77)
             Y = v
+            one = ops.dsmil_attn_pool(x, v.view(B, C, d)) if _DSMIL_ONEPASS else None  # attention + pooling, one pass over X
+            if one is None:
+                A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))                # soft-max_n(X v_c)  (:76-77)
         else:
             # queries: one 128-column GEMM; f32: as a 3-term bf16 split on the bf16 matrix pipe (ops.gemm_nt x3)
             Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
                             out_dtype=torch.float32, x3=_DSMIL_X3)                      # Q [B*N, 128]
             qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
             A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
-        Z = ops.weighted_rowsum(x, A)
+            one = None
+        A, Z = one if one is not None else (A, ops.weighted_rowsum(x, A))               # Z = A^T X  (:78)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
         classes = cls.view(B, N, C)
         ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq)
@@ -683,14 +687,22 @@ class DSMILFn(torch.autograd.Function):
         dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
         dbv = ops.colsum(dbag2)
         dZ = ops.gemm_nt(dbag2, ops.transposed(wv)).view(B, C, d)
-        # dA = X dZ^T and, when the instance scores carry a gradient, dWc = dcls^T X from the SAME pass over X
-        fused = None
-        if dclasses is not None:
-            dcls = dclasses.reshape(B, N, C).float().contiguous()
-            fused = ops.rows_dot_wsum(x, dZ, dcls)
-        dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
         xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
-        if reassoc:
+        dcls = dclasses.reshape(B, N, C).float().contiguous() if dclasses is not None else None
+        # reassociated: ONE pass over X gives R (below) and dWc - neither dA nor dS is stored
+        one = ops.dsmil_attn_pool_bwd(x, dZ, A, Z, dcls, 1.0 / math.sqrt(QD)) if (reassoc and _DSMIL_ONEPASS) else None
+        # otherwise dA = X dZ^T and, when the instance scores carry a gradient, dWc = dcls^T X from the SAME pass over X
+        fused = None
+        if one is None:
+            if dclasses is not None:
+                fused = ops.rows_dot_wsum(x, dZ, dcls)
+            dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
+        if one is not None:
+            R = one[0].view(B * C, d)
+            dqmax = ops.gemm_nt(R, wq)                                                      # [B*C, 128]
+            dwq = ops.gemm_tn(qmax, R)                                                      # [128, d]
+            dbq = torch.zeros((QD,), dtype=torch.float32, device=dev)
+        elif reassoc:
             # dS weights the rows of X once more: R_c = sum_n dS[n,c] X[n] / sqrt(128) is the gradient of v_c, and
             #   sum_n dQ[n]^T X[n] = qmax^T R,   dqmax = sum_n dS[n,c] Q[n] / sqrt(128) = R Wq^T  (+ bq sum_n dS[n,c], and a soft-max
             #   gradient sums to nothing)
@@ -713,8 +725,10 @@ class DSMILFn(torch.autograd.Function):
         if dclasses is not None:
             # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile
             # for 2 columns would read X a second time through the GEMM path)
-            dcls = dclasses.reshape(1, B * N, C).float().contiguous()
-            dwc = fused[1] if fused is not None else ops.weighted_rowsum(x2.view(1, B * N, d), dcls).view(C, d)
+            if one is not None:
+                dwc = one[1]
+            else:
+                dwc = fused[1] if fused is not None else ops.weighted_rowsum(x2.view(1, B * N, d), dcls.view(1, B * N, C)).view(C, d)
             dbc = dcls.view(B * N, C).sum(0)
         return None, dwc, dbc, dwq, dbq, dwv, dbv
 

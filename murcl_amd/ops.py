@@ -732,6 +732,44 @@ def dsmil_softmax_(S):
     return S
 
 
+def dsmil_attn_pool(X, v):
+    """DSMIL's attention and pooling from ONE pass over X: A [B,N,C] = soft-max_n(X . v), Z [B,C,d] = A^T X - or None when the
+    shape is not covered (then rows_dot + dsmil_softmax_ + weighted_rowsum).  X [B,N,d] f32/bf16, v [B,C,d] f32 (already scaled)."""
+    X, v = _c(X), _c(v)
+    B, N, d = X.shape
+    C = v.shape[1]
+    rpw = _lib.lib().murcl_dsmil_stream_plan(B, N, d, C)
+    if not rpw:
+        return None
+    A = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
+    Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
+    ws = torch.empty(((B * N // rpw) * C * (d + 2) + 2 * B * C,), dtype=torch.float32, device=X.device)
+    with _span(lambda: (f"dsmil_attn_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=4.0 * B * N * d * C))):
+        check(_lib.lib().murcl_dsmil_attn_pool(ptr(X), ptr(v), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()), "dsmil_attn_pool")
+    return A, Z
+
+
+def dsmil_attn_pool_bwd(X, dZ, A, Z, dcls=None, scale=1.0):
+    """One pass over X for the backward of (attention, pooling): R [B,C,d] = scale * sum_n dS[n,c] X[n] with dS = A (dA - sum A dA),
+    dA = X dZ^T, neither stored; with ``dcls`` [B,N,C] also dWc [C,d] = dcls^T X.  None when the shape is not covered."""
+    X, dZ, A, Z = _c(X), _c(dZ), _c(A), _c(Z)
+    B, N, d = X.shape
+    C = dZ.shape[1]
+    rpw = _lib.lib().murcl_dsmil_stream_plan(B, N, d, C)
+    if not rpw:
+        return None
+    W = B * N // rpw
+    R = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
+    ws = torch.empty((W * C * (d + 2),), dtype=torch.float32, device=X.device)
+    gpart = torch.empty((W, C * d), dtype=torch.float32, device=X.device) if dcls is not None else None
+    if dcls is not None:
+        dcls = _c(dcls)
+    with _span(lambda: (f"dsmil_attn_pool_bwd<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=(4.0 if dcls is None else 6.0) * B * N * d * C))):
+        check(_lib.lib().murcl_dsmil_attn_pool_bwd(ptr(X), ptr(dZ), ptr(A), ptr(Z), ptr(dcls), float(scale), ptr(R), ptr(gpart), ptr(ws),
+                                                   B, N, d, C, dt(X), stream()), "dsmil_attn_pool_bwd")
+    return R, (colsum(gpart).view(C, d) if dcls is not None else None)
+
+
 def dsmil_softmax_bwd(A, dA):
     """dS = A * (dA - sum_n A dA) per (bag, class); A, dA [B,N,C] f32."""
     A, dA = _c(A), _c(dA)

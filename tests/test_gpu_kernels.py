@@ -413,6 +413,50 @@ def test_panel_forward_with_dropout_inside_the_epilogue(M):
     assert (h.double() - exact).abs().max().item() <= (h2.double() - exact).abs().max().item() + 1e-6
 
 
+# ------------------------------------------------------------------ K6 streaming passes (reassociated DSMIL)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,d,C", [(2, 64, 512, 2), (3, 1024, 1024, 2), (2, 96, 320, 1), (16, 8192, 1024, 2)])
+def test_dsmil_attention_and_pooling_in_one_pass_and_their_backward_in_one_more(B, N, d, C, dtype):
+    """murcl_dsmil_attn_pool (online soft-max per wave, merged per bag) against float64 soft-max_n(X v) and A^T X, and against the
+    separate launches (rows_dot -> dsmil_softmax -> weighted_rowsum); murcl_dsmil_attn_pool_bwd (R = sum A dA X - (sum A dA) Z)
+    against float64 sum_n A (dA - sum A dA) X and dcls^T X.  f32: 1e-4 of the largest entry (north_star); bf16 storage: same
+    accumulation, so the same bound against float64 of the rounded X."""
+    from murcl_amd import ops
+    dev = _dev()
+    X = torch.relu(_rand(51, f"X{N}{d}", (B, N, d))).to(dtype).to(dev)
+    v = (_rand(51, "v", (B, C, d)) * (6.0 / math.sqrt(d))).to(dev)
+    Xd, vd = X.double(), v.double()
+    S = torch.einsum("bnd,bcd->bnc", Xd, vd)
+    A64 = torch.softmax(S, 1)
+    Z64 = torch.einsum("bnc,bnd->bcd", A64, Xd)
+    one = ops.dsmil_attn_pool(X, v)
+    sep_A = ops.dsmil_softmax_(ops.rows_dot(X, v))
+    sep_Z = ops.weighted_rowsum(X, sep_A)
+    if one is None:
+        assert not ops._lib.lib().murcl_dsmil_stream_plan(B, N, d, C)
+        return
+    A, Z = one
+    _close(A, A64, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A")
+    _close(Z, Z64, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z")
+    _close(A, sep_A, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A vs separate")
+    _close(Z, sep_Z, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z vs separate")
+    np.testing.assert_allclose(A.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+    # backward
+    dZ = _rand(51, "dZ", (B, C, d)).to(dev)
+    dcls = _rand(51, "dcls", (B, N, C)).to(dev)
+    dA64 = torch.einsum("bnd,bcd->bnc", Xd, dZ.double())
+    dS64 = A64 * (dA64 - (A64 * dA64).sum(1, keepdim=True))
+    R64 = torch.einsum("bnc,bnd->bcd", dS64, Xd) * 0.25
+    dWc64 = torch.einsum("bnc,bnd->cd", dcls.double(), Xd)
+    R, dWc = ops.dsmil_attn_pool_bwd(X, dZ, A, Z, dcls, 0.25)
+    # R is a difference of two sums of the size of P = sum A dA X: the bound is on that scale (see DESIGN)
+    P64 = torch.einsum("bnc,bnd->bcd", A64 * dA64, Xd).abs().max().item() * 0.25
+    _close(R, R64, rtol=1e-4, atol=1e-4 * max(R64.abs().max().item(), 0.1 * P64), msg="R")
+    _close(dWc, dWc64, rtol=1e-4, atol=1e-4 * dWc64.abs().max().item(), msg="dWc")
+    R2, none = ops.dsmil_attn_pool_bwd(X, dZ, A, Z, None, 0.25)
+    assert none is None and torch.equal(R2, R)
+
+
 # ------------------------------------------------------------------ K2 attention pool
 def _k2_inputs(seed, B, N):
     H = torch.relu(_rand(seed, "H", (B, N, 512)))
