@@ -178,8 +178,8 @@ int murcl_dsmil_softmax(float* S, int B, int N, int C, murcl_stream_t stream);
  * (may be NULL) the pass also leaves the per-wave partial rows of dWc = dcls^T X in gpart [(B*N/plan)][C*d] (sum them with
  * murcl_colsum).  ws: (B*N/plan)*C*(d+2) floats. */
 int murcl_dsmil_stream_plan(int B, int N, int d, int C);
-int murcl_dsmil_attn_pool(const void* X, const float* v, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
-                          murcl_stream_t stream);
+int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits = vscale * X.v */, float* A, float* Z, float* ws,
+                          int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls, float scale,
                               float* R, float* gpart, float* ws, int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,

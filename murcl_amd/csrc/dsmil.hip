@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                                                            const float* __restrict__ Ain, const float* __restrict__ G,
                                                            int N, int d, int C, int rows_per_wave, float* __restrict__ S,
                                                            float* __restrict__ part, float* __restrict__ stat,
-                                                           float* __restrict__ gpart, long rows_total) {
+                                                           float* __restrict__ gpart, long rows_total, float vscale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wid = (long)blockIdx.x * 4 + wave;
     const long row0 = wid * rows_per_wave;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
         for (int c = 0; c < 2; ++c) {
             float sd[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? wave_sum(acc[u][c]) : 0.f;
+            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? wave_sum(acc[u][c]) * vscale : 0.f;
             if (MODE == 0) {
                 float mx = m_run[c];
 #pragma unroll
@@ -665,34 +665,57 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
         if (lane == 0) { stat[(wid * C + c) * 2] = m_run[c]; stat[(wid * C + c) * 2 + 1] = l_run[c]; }
     }
 }
-// merge the W = N / rows_per_wave waves of a bag.  grid (B*C, d/256 column blocks); MODE 0: Z = sum_w e^{m_w-m} Z'_w / l and
-// ml[b,c] = (m, l); MODE 1: R = (sum_w P_w - dot Z) * scale with dot = sum_w stat_w[1]
+// merge the W = N / rows_per_wave (<= 1024) waves of a bag.  grid (B*C, d/64): a workgroup first derives the bag's (m, l) and the
+// waves' weights e^{m_w - m} (in LDS), then 4 x 64 threads add W/4 partial rows each for 64 columns.
+// MODE 0: Z = sum_w e^{m_w-m} Z'_w / l and ml[b,c] = (m, l); MODE 1: R = (sum_w P_w - dot Z) * scale with dot = sum_w stat_w[1]
 template <int MODE>
 __global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restrict__ part, const float* __restrict__ stat, int W, int d,
                                                           int C, const float* __restrict__ Zin, float scale,
                                                           float* __restrict__ out, float* __restrict__ ml) {
-    const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-    const int k = blockIdx.y * 256 + threadIdx.x;
+    __shared__ float wgt[1024];
+    __shared__ float red[256];
+    __shared__ float acc[4][64];
+    const int bc = blockIdx.x, b = bc / C, c = bc - b * C, tid = threadIdx.x;
     const float* st0 = stat + ((size_t)b * W * C + c) * 2;
-    float m = -INFINITY, l = 0.f;
+    float m = 0.f;
     if (MODE == 0) {
-        for (int w = 0; w < W; ++w) m = fmaxf(m, st0[(size_t)w * C * 2]);
-        for (int w = 0; w < W; ++w) l += st0[(size_t)w * C * 2 + 1] * __expf(st0[(size_t)w * C * 2] - m);
-    } else {
-        for (int w = 0; w < W; ++w) l += st0[(size_t)w * C * 2 + 1];
+        float mx = -INFINITY;
+        for (int w = tid; w < W; w += 256) mx = fmaxf(mx, st0[(size_t)w * C * 2]);
+        red[tid] = mx;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+        m = red[0];
+        __syncthreads();
     }
+    float ls = 0.f;
+    for (int w = tid; w < W; w += 256) {
+        const float g = MODE == 0 ? __expf(st0[(size_t)w * C * 2] - m) : 1.f;
+        wgt[w] = g;
+        ls += st0[(size_t)w * C * 2 + 1] * g;
+    }
+    red[tid] = ls;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float l = red[0];
+    const int cl = tid & 63, wl = tid >> 6, k = blockIdx.y * 64 + cl;
+    float t = 0.f;
     if (k < d) {
-        float t = 0.f;
         const float* p0 = part + ((size_t)b * W * C + c) * d + k;
-        if (MODE == 0) {
-            for (int w = 0; w < W; ++w) t += p0[(size_t)w * C * d] * __expf(st0[(size_t)w * C * 2] - m);
-            out[(size_t)bc * d + k] = t / l;
-        } else {
-            for (int w = 0; w < W; ++w) t += p0[(size_t)w * C * d];
-            out[(size_t)bc * d + k] = (t - l * Zin[(size_t)bc * d + k]) * scale;
-        }
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};                     // four loads in flight per thread
+        int w = wl;
+        for (; w + 12 < W; w += 16)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t4[u] += p0[(size_t)(w + 4 * u) * C * d] * wgt[w + 4 * u];
+        for (; w < W; w += 4) t4[0] += p0[(size_t)w * C * d] * wgt[w];
+        t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
-    if (MODE == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ml[bc * 2] = m; ml[bc * 2 + 1] = l; }
+    acc[wl][cl] = t;
+    __syncthreads();
+    if (wl == 0 && k < d) {
+        t = (acc[0][cl] + acc[1][cl]) + (acc[2][cl] + acc[3][cl]);
+        out[(size_t)bc * d + k] = MODE == 0 ? t / l : (t - l * Zin[(size_t)bc * d + k]) * scale;
+    }
+    if (MODE == 0 && blockIdx.y == 0 && tid == 0) { ml[bc * 2] = m; ml[bc * 2 + 1] = l; }
 }
 // A = e^{S - m} / l in place, S [B,N,C]
 __global__ __launch_bounds__(256) void dsmil_normalise_kernel(float* __restrict__ S, const float* __restrict__ ml, long total, int N,
@@ -705,9 +728,12 @@ __global__ __launch_bounds__(256) void dsmil_normalise_kernel(float* __restrict_
 }
 // plan: rows a wave takes (0: shape not covered -> rows_dot + soft-max + weighted_rowsum); the workspace holds
 // (B*N/plan) * C * (d [+ d with dcls] + 2) floats
-extern "C" int murcl_dsmil_stream_plan(int B, int N, int d, int C) { return murcl_rows_dot_wsum_plan(B, N, d, C); }
-extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float* A /* [B,N,C]: logits, then the soft-max */, float* Z,
-                                     float* ws, int B, int N, int d, int C, int dtype, hipStream_t s) {
+extern "C" int murcl_dsmil_stream_plan(int B, int N, int d, int C) {
+    const int rpw = murcl_rows_dot_wsum_plan(B, N, d, C);
+    return (rpw && N / rpw <= 1024) ? rpw : 0;          // (the merge keeps a bag's wave weights in LDS)
+}
+extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale, float* A /* [B,N,C]: logits, then the soft-max */,
+                                     float* Z, float* ws, int B, int N, int d, int C, int dtype, hipStream_t s) {
     if (B <= 0) return 0;
     const int rpw = murcl_dsmil_stream_plan(B, N, d, C);
     if (!rpw || !ws) return -1;
@@ -717,14 +743,14 @@ extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float* A /* 
     float* ml = stat + waves * C * 2;
     dim3 grid((unsigned)((waves + 3) / 4));
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL((dsmil_stream_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows);
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows, vscale);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows);
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)X, v, nullptr, nullptr, N, d, C, rpw, A, part, stat, nullptr, rows, vscale);
     else
         return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 255) / 256), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
+    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
     rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
     const long total = rows * C;
@@ -744,13 +770,13 @@ extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const f
     float* stat = part + waves * C * d;
     dim3 grid((unsigned)((waves + 3) / 4));
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL((dsmil_stream_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows);
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows, 1.f);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows);
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)X, dZ, A, dcls, N, d, C, rpw, nullptr, part, stat, gpart, rows, 1.f);
     else
         return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 255) / 256), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr);
+    hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr);
     return MURCL_CHECK_LAUNCH();
 }

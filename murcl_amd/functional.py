@@ -655,11 +655,12 @@ class DSMILFn(torch.autograd.Function):
             xm = ops.cast(ops.gather_rows(x2, m, B, C, N, 0, d), torch.float32)         # [B*C, d]
             qmax = ops.gemm_nt(xm, wq, epi=ops.EPI_BIAS, bias=bq)                       # q_c = Wq x_m + bq     [B*C, 128]
             v = ops.gemm_nt(qmax, ops.transposed(wq))                                   # Wq^T q_c              [B*C, d]
-            v *= 1.0 / math.sqrt(QD)
             Y = v
-            one = ops.dsmil_attn_pool(x, v.view(B, C, d)) if _DSMIL_ONEPASS else None  # attention + pooling, one pass over X
+            # attention + pooling from one pass over X: A = soft-max_n(X v_c / sqrt(128)) (:76-77), Z = A^T X (:78)
+            one = ops.dsmil_attn_pool(x, v.view(B, C, d), 1.0 / math.sqrt(QD)) if _DSMIL_ONEPASS else None
             if one is None:
-                A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))                # soft-max_n(X v_c)  (:76-77)
+                v *= 1.0 / math.sqrt(QD)
+                A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))
         else:
             # queries: one 128-column GEMM; f32: as a 3-term bf16 split on the bf16 matrix pipe (ops.gemm_nt x3)
             Y = ops.gemm_nt(x2, wq if T == torch.float32 else ops.cast(wq, T), epi=ops.EPI_BIAS, bias=bq,
@@ -701,7 +702,7 @@ class DSMILFn(torch.autograd.Function):
             R = one[0].view(B * C, d)
             dqmax = ops.gemm_nt(R, wq)                                                      # [B*C, 128]
             dwq = ops.gemm_tn(qmax, R)                                                      # [128, d]
-            dbq = torch.zeros((QD,), dtype=torch.float32, device=dev)
+            dbq = None
         elif reassoc:
             # dS weights the rows of X once more: R_c = sum_n dS[n,c] X[n] / sqrt(128) is the gradient of v_c, and
             #   sum_n dQ[n]^T X[n] = qmax^T R,   dqmax = sum_n dS[n,c] Q[n] / sqrt(128) = R Wq^T  (+ bq sum_n dS[n,c], and a soft-max
@@ -710,7 +711,7 @@ class DSMILFn(torch.autograd.Function):
             R *= 1.0 / math.sqrt(QD)
             dqmax = ops.gemm_nt(R, wq)                                                      # [B*C, 128]
             dwq = ops.gemm_tn(qmax, R)                                                      # [128, d]
-            dbq = torch.zeros((QD,), dtype=torch.float32, device=dev)
+            dbq = None
         else:
             dQ = torch.empty((B * N, QD), dtype=torch.float32, device=dev)                  # written in full below
             dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
@@ -720,7 +721,7 @@ class DSMILFn(torch.autograd.Function):
             ops.gemm_tn(dqmax, ops.cast(xm, torch.float32), out=dwq)
         else:
             ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
-        ops.colsum(dqmax, out=dbq, accumulate=True)
+        dbq = ops.colsum(dqmax) if dbq is None else ops.colsum(dqmax, out=dbq, accumulate=True)
         dwc = dbc = None
         if dclasses is not None:
             # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile

@@ -732,9 +732,9 @@ def dsmil_softmax_(S):
     return S
 
 
-def dsmil_attn_pool(X, v):
-    """DSMIL's attention and pooling from ONE pass over X: A [B,N,C] = soft-max_n(X . v), Z [B,C,d] = A^T X - or None when the
-    shape is not covered (then rows_dot + dsmil_softmax_ + weighted_rowsum).  X [B,N,d] f32/bf16, v [B,C,d] f32 (already scaled)."""
+def dsmil_attn_pool(X, v, scale=1.0):
+    """DSMIL's attention and pooling from ONE pass over X: A [B,N,C] = soft-max_n(scale * X . v), Z [B,C,d] = A^T X - or None when
+    the shape is not covered (then rows_dot + dsmil_softmax_ + weighted_rowsum).  X [B,N,d] f32/bf16, v [B,C,d] f32."""
     X, v = _c(X), _c(v)
     B, N, d = X.shape
     C = v.shape[1]
@@ -745,7 +745,8 @@ def dsmil_attn_pool(X, v):
     Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
     ws = torch.empty(((B * N // rpw) * C * (d + 2) + 2 * B * C,), dtype=torch.float32, device=X.device)
     with _span(lambda: (f"dsmil_attn_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=4.0 * B * N * d * C))):
-        check(_lib.lib().murcl_dsmil_attn_pool(ptr(X), ptr(v), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()), "dsmil_attn_pool")
+        check(_lib.lib().murcl_dsmil_attn_pool(ptr(X), ptr(v), float(scale), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()),
+              "dsmil_attn_pool")
     return A, Z
 
 

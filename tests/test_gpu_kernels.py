@@ -429,7 +429,7 @@ def test_dsmil_attention_and_pooling_in_one_pass_and_their_backward_in_one_more(
     S = torch.einsum("bnd,bcd->bnc", Xd, vd)
     A64 = torch.softmax(S, 1)
     Z64 = torch.einsum("bnc,bnd->bcd", A64, Xd)
-    one = ops.dsmil_attn_pool(X, v)
+    one = ops.dsmil_attn_pool(X, v * 2.0, 0.5)
     sep_A = ops.dsmil_softmax_(ops.rows_dot(X, v))
     sep_Z = ops.weighted_rowsum(X, sep_A)
     if one is None:
