@@ -233,6 +233,19 @@ int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t st
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);
 int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d, int dtype, murcl_stream_t stream);
+/* CLAM's instance branch (clam.py:103-132,150-168) for ALL (bag, class) pairs as one launch each way.  h [B*N,L] (dtype), ids
+ * [B,2k] from murcl_topk_ids, labels [B], W [n_cls*2,L] / bias [n_cls*2] = the stacked instance classifiers (2 n_cls <= 16, k <= 32).
+ * fwd: loss[b] = scale * sum_c CE_c (class == label: targets [1]*k + [0]*k over the 2k rows, inst_eval; other classes: [0]*k over
+ * the top-k rows if subtyping, inst_eval_out, else nothing), dl [B*2k, 2 n_cls] = d loss[b] / d logits, pt [2][B][n_cls][2k] =
+ * (predictions, targets), -1 where a pair has no such row.
+ * bwd: with up[b] = dL/dloss[b]: dz[row,:] += (up dl[r,:] W) where h[row,:] > 0 for the bag's 2k rows (the first layer's ReLU
+ * mask), and part[b] = (up dl^T h_rows [2 n_cls][L] | up sum_r dl[r,:] [2 n_cls] | the column sums of what was added [L]):
+ * murcl_colsum over the B rows gives the classifiers' weight / bias gradients and the extension of the first layer's bias gradient. */
+int murcl_clam_inst_fwd(const void* h, const int* ids, const long* labels, const float* W, const float* bias, int B, int N, int L,
+                        int k, int n_cls, int subtyping, float scale, float* loss, float* dl, long* pt, int dtype,
+                        murcl_stream_t stream);
+int murcl_clam_inst_bwd(const void* h, const int* ids, const float* W, const float* dl, const float* up, int B, int N, int L, int k,
+                        int n_cls, void* dz, float* part, int dtype, murcl_stream_t stream);
 /* write_back != 0: g[r,k] is zeroed where the mask dropped it, so that on return g holds exactly what was added */
 int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, float* g, int R, int d, int dtype,
                                   int write_back, murcl_stream_t stream);

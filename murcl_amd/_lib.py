@@ -54,6 +54,8 @@ SIGNATURES = {
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_softmax_bwd": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "murcl_clam_inst_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P],
+    "murcl_clam_inst_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "murcl_gated_score_bwd_il": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, _P, _P, _P, _I, _I, _P],
     "murcl_softmax_rows": [_P, _P, _I, _I, _P],
     "murcl_softmax_rows_bwd": [_P, _P, _P, _I, _I, _P],

@@ -583,6 +583,143 @@ extern "C" int murcl_cross_entropy(const float* logits, const long* targets, int
     return MURCL_CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------- the instance branch as two launches (clam.py:103-132,150-168)
+// One workgroup per bag.  Forward: the 2k selected rows of h (top-k then bottom-k ids of the attention, murcl_topk_ids) meet ALL
+// n_cls two-way instance classifiers (W [n_cls*2, L], b [n_cls*2]) - a wave takes a row, a lane 8 columns per 512-column step, the
+// 2 n_cls dot products are wave sums - then one thread per (class, row) pair takes the cross-entropy of clam.py's targets:
+//   class == label: rows 0..k-1 -> 1, rows k..2k-1 -> 0 (inst_eval, :105-119);  class != label: rows 0..k-1 -> 0 if subtyping
+//   (inst_eval_out, :122-132), otherwise the pair is ignored;  a class's loss = the mean over its live rows.
+// Outputs: loss[b] = scale * sum_c loss_c (scale = 1/n_cls with subtyping, :167-168); dl [B*2k, 2 n_cls] = d loss[b] / d logits;
+// pt [2][B][n_cls][2k] = (prediction, target), -1 where ignored.
+// Backward (up[b] = d L / d loss[b]): g[r,:] = up sum_o dl[r,o] W[o,:] is ADDED to dz[row r] where h[row r] > 0 (the ReLU mask of
+// the first layer; the 2k rows of a bag are distinct); part[b] = ( up dl^T feats [2 n_cls][L] | up sum_r dl[r,:] [2 n_cls] |
+// sum_r of the masked g [L] ): the caller adds the B rows up (murcl_colsum) - no float atomics.
+#define CI_MAXO 16          // 2 * n_cls <= 16
+template <typename T>
+__global__ __launch_bounds__(256) void clam_inst_fwd_kernel(const T* __restrict__ h, const int* __restrict__ ids,
+                                                            const long* __restrict__ labels, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int N, int L, int k, int n_cls,
+                                                            int subtyping, float scale, float* __restrict__ loss,
+                                                            float* __restrict__ dl, long* __restrict__ pt, int B) {
+    __shared__ float lg[64][CI_MAXO];
+    __shared__ float lsum[256];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int O = 2 * n_cls, R = 2 * k;
+    for (int r = wave; r < R; r += 4) {
+        const T* row = h + ((size_t)b * N + ids[(size_t)b * R + r]) * L;
+        float acc[CI_MAXO];
+#pragma unroll
+        for (int o = 0; o < CI_MAXO; ++o) acc[o] = 0.f;
+        for (int c0 = lane * 8; c0 < L; c0 += 512) {
+            float x[8];
+            load8<T>(row + c0, x);
+#pragma unroll
+            for (int o = 0; o < CI_MAXO; ++o)
+                if (o < O) {
+                    float w[8];
+                    load8<float>(W + (size_t)o * L + c0, w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o] += x[e] * w[e];
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < CI_MAXO; ++o)
+            if (o < O) {
+                const float t = wave_sum(acc[o]);
+                if (lane == 0) lg[r][o] = t + bias[o];
+            }
+    }
+    __syncthreads();
+    const int lab = (int)labels[b];
+    float myloss = 0.f;
+    for (int p = tid; p < n_cls * R; p += 256) {
+        const int c = p / R, r = p - c * R;
+        int t;
+        float cnt;
+        if (c == lab) { t = r < k ? 1 : 0; cnt = (float)R; }
+        else { t = (subtyping && r < k) ? 0 : -1; cnt = subtyping ? (float)k : 0.f; }
+        const float x0 = lg[r][2 * c], x1 = lg[r][2 * c + 1];
+        float* d = dl + ((size_t)b * R + r) * O + 2 * c;
+        long pred = -1;
+        if (t < 0) {
+            d[0] = 0.f; d[1] = 0.f;
+        } else {
+            const float inv = 1.f / cnt;
+            const float mx = fmaxf(x0, x1);
+            const float lse = mx + logf(expf(x0 - mx) + expf(x1 - mx));
+            myloss += (lse - (t ? x1 : x0)) * inv;
+            d[0] = (expf(x0 - lse) - (t == 0 ? 1.f : 0.f)) * inv * scale;
+            d[1] = (expf(x1 - lse) - (t == 1 ? 1.f : 0.f)) * inv * scale;
+            pred = x1 > x0 ? 1 : 0;                          // first maximum, as torch.topk(logits, 1) picks it
+        }
+        pt[((size_t)b * n_cls + c) * R + r] = pred;
+        pt[(size_t)B * n_cls * R + ((size_t)b * n_cls + c) * R + r] = t;
+    }
+    lsum[tid] = myloss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) lsum[tid] += lsum[tid + o]; __syncthreads(); }
+    if (tid == 0) loss[b] = lsum[0] * scale;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void clam_inst_bwd_kernel(const T* __restrict__ h, const int* __restrict__ ids,
+                                                            const float* __restrict__ W, const float* __restrict__ dl,
+                                                            const float* __restrict__ up, int N, int L, int k, int n_cls,
+                                                            T* __restrict__ dz, float* __restrict__ part) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int O = 2 * n_cls, R = 2 * k;
+    __shared__ float sdl[64][CI_MAXO];
+    const float u = up[b];
+    for (int p = tid; p < R * O; p += 256) sdl[p / O][p % O] = dl[(size_t)b * R * O + p] * u;
+    __syncthreads();
+    float* prow = part + (size_t)b * (O * (L + 1) + L);
+    for (int c = tid; c < L; c += 256) {                    // a thread owns columns c, c + 256, ...: every row's column c is its own
+        float wcol[CI_MAXO], dw[CI_MAXO], gsum = 0.f;
+#pragma unroll
+        for (int o = 0; o < CI_MAXO; ++o) { wcol[o] = o < O ? W[(size_t)o * L + c] : 0.f; dw[o] = 0.f; }
+        for (int r = 0; r < R; ++r) {
+            const size_t row = (size_t)b * N + ids[(size_t)b * R + r];
+            const float x = to_f<T>(h[row * L + c]);
+            float g = 0.f;
+#pragma unroll
+            for (int o = 0; o < CI_MAXO; ++o)
+                if (o < O) { g += sdl[r][o] * wcol[o]; dw[o] += sdl[r][o] * x; }
+            if (x > 0.f) {
+                dz[row * L + c] = from_f<T>(to_f<T>(dz[row * L + c]) + g);
+                gsum += g;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CI_MAXO; ++o)
+            if (o < O) prow[(size_t)o * L + c] = dw[o];
+        prow[(size_t)O * (L + 1) + c] = gsum;
+    }
+    if (tid < O) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += sdl[r][tid];
+        prow[(size_t)O * L + tid] = t;
+    }
+}
+extern "C" int murcl_clam_inst_fwd(const void* h, const int* ids, const long* labels, const float* W, const float* bias, int B,
+                                   int N, int L, int k, int n_cls, int subtyping, float scale, float* loss, float* dl, long* pt,
+                                   int dtype, hipStream_t st) {
+    if (B <= 0) return 0;
+    if (k <= 0 || k > 32 || n_cls <= 0 || 2 * n_cls > CI_MAXO || L % 8) return -1;
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(clam_inst_fwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)h, ids, labels, W, bias, N, L, k, n_cls, subtyping, scale, loss, dl, pt, B);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(clam_inst_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)h, ids, labels, W, bias, N, L, k, n_cls, subtyping, scale, loss, dl, pt, B);
+    else return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_clam_inst_bwd(const void* h, const int* ids, const float* W, const float* dl, const float* up, int B, int N,
+                                   int L, int k, int n_cls, void* dz, float* part /* [B][2 n_cls (L+1) + L] */, int dtype,
+                                   hipStream_t st) {
+    if (B <= 0) return 0;
+    if (k <= 0 || k > 32 || n_cls <= 0 || 2 * n_cls > CI_MAXO) return -1;
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(clam_inst_bwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)h, ids, W, dl, up, N, L, k, n_cls, (float*)dz, part);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(clam_inst_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)h, ids, W, dl, up, N, L, k, n_cls, (bf16_t*)dz, part);
+    else return -1;
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- y *= k (dropout keep-mask multiply), y = dy * k
 template <typename T>
 __global__ void mul_kernel(const T* __restrict__ x, const T* __restrict__ k, T* __restrict__ y, long n) {

@@ -37,6 +37,7 @@ _STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
 _FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B switch: CLAM's gate score from the gate GEMM's epilogue (forward-only)
 _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
+_FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
@@ -847,21 +848,26 @@ class CLAMFn(torch.autograd.Function):
             labels, k, subtyping = inst_cfg
             n_cls = inst_w.shape[0]
             ids = ops.topk_ids(A, k)                                                   # [B, 2k]
-            base, cls_ids, t_in, t_out = _inst_constants(dev, B, N, k, n_cls, subtyping)
-            rows_all = (base + ids.to(torch.int64)).reshape(-1)                        # [B*2k] rows of h
-            feats = ops.take_rows(h, rows_all)                                         # [B*2k, L] f32
-            w_st = inst_w.reshape(n_cls * 2, -1).contiguous()
-            logits = ops.gemm_nt(feats, w_st, epi=ops.EPI_BIAS, bias=inst_b.reshape(-1).contiguous())   # [B*2k, 2 n_cls]
-            logits_g = logits.view(B, 2 * k, n_cls, 2).permute(0, 2, 1, 3).contiguous()                 # [B, n_cls, 2k, 2]
             lab = labels.to(device=dev, dtype=torch.int64) if isinstance(labels, torch.Tensor) else \
                 torch.as_tensor([int(v) for v in labels], dtype=torch.int64).to(dev)
-            same = lab.view(B, 1) == cls_ids                                                            # [B, n_cls]
-            targets = torch.where(same.unsqueeze(2), t_in, t_out).contiguous()                          # [B, n_cls, 2k]
-            loss_g, dl_g, preds_g = ops.cross_entropy(logits_g.view(-1, 2), targets.view(-1), 2 * k)
-            scale = 1.0 / n_cls if subtyping else 1.0                                  # clam.py:167-168
-            inst_loss = loss_g.view(B, n_cls).sum(1) * scale
-            inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
-            saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
+            w_st = inst_w.reshape(n_cls * 2, -1).contiguous()
+            if _FUSED_INST and 2 * n_cls <= 16 and k <= 32 and L % 8 == 0:
+                # one launch: gather the 2k rows, all 2 n_cls instance logits, the cross-entropies and their gradients
+                inst_loss, dl, inst_pt = ops.clam_inst_fwd(h, ids, lab, w_st, inst_b.reshape(-1), B, N, k, n_cls, subtyping)
+                saved_inst = ("fused", ids, dl, w_st, k, n_cls)
+            else:
+                base, cls_ids, t_in, t_out = _inst_constants(dev, B, N, k, n_cls, subtyping)
+                rows_all = (base + ids.to(torch.int64)).reshape(-1)                        # [B*2k] rows of h
+                feats = ops.take_rows(h, rows_all)                                         # [B*2k, L] f32
+                logits = ops.gemm_nt(feats, w_st, epi=ops.EPI_BIAS, bias=inst_b.reshape(-1).contiguous())   # [B*2k, 2 n_cls]
+                logits_g = logits.view(B, 2 * k, n_cls, 2).permute(0, 2, 1, 3).contiguous()                 # [B, n_cls, 2k, 2]
+                same = lab.view(B, 1) == cls_ids                                                            # [B, n_cls]
+                targets = torch.where(same.unsqueeze(2), t_in, t_out).contiguous()                          # [B, n_cls, 2k]
+                loss_g, dl_g, preds_g = ops.cross_entropy(logits_g.view(-1, 2), targets.view(-1), 2 * k)
+                scale = 1.0 / n_cls if subtyping else 1.0                                  # clam.py:167-168
+                inst_loss = loss_g.view(B, n_cls).sum(1) * scale
+                inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
+                saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
         ctx.save_for_backward(x2, h, U if U is not None else x2.new_zeros(1), A, M, w1, wa, wb, wc,
                               inst_w if inst_w is not None else x2.new_zeros(1), m1)
         ctx.gated, ctx.gate_u = gated, gate_u
@@ -915,7 +921,13 @@ class CLAMFn(torch.autograd.Function):
                               rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
         dinst_w = dinst_b = None
-        if ctx.saved_inst is not None and dinst is not None:
+        if ctx.saved_inst is not None and dinst is not None and ctx.saved_inst[0] == "fused":
+            _, ids, dl, w_st, k, n_cls = ctx.saved_inst
+            dwi, dbi, gsum = ops.clam_inst_bwd(h, ids, w_st, dl, dinst.float(), B, N, k, n_cls, dz1)
+            dinst_w, dinst_b = dwi.view(n_cls, 2, -1), dbi.view(n_cls, 2)
+            if db1 is not None:
+                db1 = db1 + gsum
+        elif ctx.saved_inst is not None and dinst is not None:
             rows_all, feats, dl_g, scale, k, n_cls = ctx.saved_inst
             up = (dinst * scale).view(B, 1, 1, 1)                                      # upstream weight per (bag, ...)
             dlog = (dl_g.view(B, n_cls, 2 * k, 2) * up).permute(0, 2, 1, 3).reshape(B * 2 * k, 2 * n_cls).contiguous()

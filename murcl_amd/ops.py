@@ -894,6 +894,35 @@ def topk_ids(A, k):
     return ids
 
 
+def clam_inst_fwd(h, ids, labels, W, bias, B, N, k, n_cls, subtyping):
+    """CLAM's instance branch for all (bag, class) pairs, one launch (``murcl_clam_inst_fwd``) -> (loss [B] f32, dl [B*2k, 2 n_cls],
+    pt [2,B,n_cls,2k] int64 = predictions / targets).  h [B*N,L], ids [B,2k] int32, labels [B] int64, W [2 n_cls, L], bias [2 n_cls]."""
+    h, W, bias = _c(h), _c(W), _c(bias)
+    L = h.shape[1]
+    dev = h.device
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    dl = torch.empty((B * 2 * k, 2 * n_cls), dtype=torch.float32, device=dev)
+    pt = torch.empty((2, B, n_cls, 2 * k), dtype=torch.int64, device=dev)
+    scale = 1.0 / n_cls if subtyping else 1.0
+    check(_lib.lib().murcl_clam_inst_fwd(ptr(h), ptr(ids), ptr(labels), ptr(W), ptr(bias), B, N, L, k, n_cls, int(bool(subtyping)), scale,
+                                         ptr(loss), ptr(dl), ptr(pt), dt(h), stream()), "clam_inst_fwd")
+    return loss, dl, pt
+
+
+def clam_inst_bwd(h, ids, W, dl, up, B, N, k, n_cls, dz):
+    """Backward of ``clam_inst_fwd``: the feature gradients are ADDED into dz [B*N,L] (in place, under h > 0) and the sums over bags of
+    ``part`` are returned: (dW [2 n_cls, L], db [2 n_cls], column sums of what was added to dz [L])."""
+    h, W = _c(h), _c(W)
+    L = h.shape[1]
+    O = 2 * n_cls
+    assert dz.is_contiguous() and dz.dtype == h.dtype
+    part = torch.empty((B, O * (L + 1) + L), dtype=torch.float32, device=h.device)
+    check(_lib.lib().murcl_clam_inst_bwd(ptr(h), ptr(ids), ptr(W), ptr(_c(dl)), ptr(_c(up)), B, N, L, k, n_cls, ptr(dz), ptr(part), dt(h),
+                                         stream()), "clam_inst_bwd")
+    sums = colsum(part)
+    return sums[:O * L].view(O, L), sums[O * L:O * L + O], sums[O * (L + 1):]
+
+
 def take_rows(src, rows):
     """src [R0,d] (f32/bf16), rows int64 [R] -> f32 [R,d]."""
     src, rows = _c(src), _c(rows)

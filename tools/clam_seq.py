@@ -17,7 +17,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "train":
 else:
     m.eval()
 fwd_only = len(sys.argv) > 1 and sys.argv[1] == "fwd"
+inst = len(sys.argv) > 1 and sys.argv[1] == "inst"          # with the instance-level loss (clam.py:103-132), batched labels
+labels = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1)).to(dev)
 for _ in range(6):
+    if inst:
+        for p in m.parameters(): p.grad = None
+        M, _, _, il, _, _ = m._run(x, labels, True)
+        (M.sum() + il.sum()).backward()
+        continue
     if fwd_only:
         with torch.no_grad(): m(x)
         continue
