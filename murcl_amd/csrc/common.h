@@ -218,6 +218,9 @@ __device__ __forceinline__ float quarters_sum(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// the whole wave's sum in every lane, VALU only (4 DPP steps inside the 16-lane rows, then the two gfx950 swaps): __shfl_xor goes
+// through the LDS crossbar (ds_bpermute) for the 16- and 32-lane steps, a dependent chain of LDS round trips per reduction
+__device__ __forceinline__ float wave_sum_valu(float v) { return quarters_sum(row16_sum(v)); }
 // reductions over lanes 0..31 (rows 0 and 1), result wave-uniform
 __device__ __forceinline__ float half_wave_sum(float v) { v = row16_sum(v); return rdlane(v, 0) + rdlane(v, 16); }
 __device__ __forceinline__ float half_wave_max(float v) { v = row16_max(v); return fmaxf(rdlane(v, 0), rdlane(v, 16)); }

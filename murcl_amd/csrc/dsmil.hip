@@ -553,6 +553,9 @@ extern "C" int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, i
 // Backward: with dA[n,c] = X[n] . dZ[c] and w = A dA,
 //     R[c] = sum_n A[n,c] (dA[n,c] - dot_c) X[n] = (sum_n w[n,c] X[n]) - dot_c Z[c],      dot_c = sum_n w[n,c]
 // (Z = the pooled rows the forward saved), so dS never has to exist and X is read once; the same pass takes dWc = dcls^T X.
+#ifndef DS_WAVE_SUM
+#define DS_WAVE_SUM wave_sum_valu
+#endif
 template <typename T, int MODE>          // MODE 0: forward, 1: backward
 __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__ X, const float* __restrict__ V,
                                                            const float* __restrict__ Ain, const float* __restrict__ G,
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
         for (int c = 0; c < 2; ++c) {
             float sd[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? wave_sum(acc[u][c]) * vscale : 0.f;
+            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? DS_WAVE_SUM(acc[u][c]) * vscale : 0.f;
             if (MODE == 0) {
                 float mx = m_run[c];
 #pragma unroll
