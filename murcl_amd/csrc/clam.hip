@@ -22,6 +22,9 @@ template <> __device__ __forceinline__ float gs_sigmoid<bf16_t>(float x) {
 // GATED = false: the plain attention net (clam.py:18-34): U has D columns, s_n = sum_d tanh(U[n,d]) wc[d] + bc.
 // Gate dropout without materialised masks: 8 consecutive keep values of row n, columns 8cg.. of a [rows, D] mask = the 8 bytes of
 // one counter-based word (murcl_dropout_mask's generator, flat index n*D + 8cg).
+#ifndef GS_GROUP_SUM
+#define GS_GROUP_SUM group_sum
+#endif
 struct GsDrop { unsigned long long seed_a, seed_b; unsigned thresh; float scale; };
 __device__ __forceinline__ void gs_keep8(unsigned long long seed, long flat8, unsigned thresh, float scale, float* k) {
     const unsigned long long rw = murcl_drop_word(seed, flat8);
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void gated_score_fwd_kernel(const T* __restric
             const long n = base + u * RL + rl;
             float t = acc[u];
             if (pow2) {
-                for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o, 64);
+                t = GS_GROUP_SUM(t, G);
             } else {
                 red[tid] = t;
                 __syncthreads();
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) mdm += mp[e] * dm[8 * c + e];
         }
-        for (int o = 1; o < G; o <<= 1) mdm += __shfl_xor(mdm, o, 64);
+        mdm = GS_GROUP_SUM(mdm, G);
     }
     if (rl < RL) {
         constexpr int UR = GSB_UR;                        // rows in flight per thread
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
 #pragma unroll
                         for (int e = 0; e < 8 * HC; ++e) t += hv[u][e] * dm[e];
                     }
-                    for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o, 64);
+                    t = GS_GROUP_SUM(t, G);
                     dsn[u] = an[u] * (t - mdm);
                 }
             }

@@ -221,6 +221,22 @@ __device__ __forceinline__ float quarters_sum(float v) {
 // the whole wave's sum in every lane, VALU only (4 DPP steps inside the 16-lane rows, then the two gfx950 swaps): __shfl_xor goes
 // through the LDS crossbar (ds_bpermute) for the 16- and 32-lane steps, a dependent chain of LDS round trips per reduction
 __device__ __forceinline__ float wave_sum_valu(float v) { return quarters_sum(row16_sum(v)); }
+// sum over aligned groups of G lanes (G a power of two, wave-uniform), every lane of a group ends with its group's sum
+__device__ __forceinline__ float group_sum(float v, int G) {
+    if (G == 64) return wave_sum_valu(v);
+    if (G == 32) {
+        v = row16_sum(v);
+        auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    if (G == 16) return row16_sum(v);
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group_sum_shfl(float v, int G) {          // the plain butterfly, for A/B builds
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 // reductions over lanes 0..31 (rows 0 and 1), result wave-uniform
 __device__ __forceinline__ float half_wave_sum(float v) { v = row16_sum(v); return rdlane(v, 0) + rdlane(v, 16); }
 __device__ __forceinline__ float half_wave_max(float v) { v = row16_max(v); return fmaxf(rdlane(v, 0), rdlane(v, 16)); }

@@ -249,6 +249,9 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
 #ifndef RD_UR_BF16
 #define RD_UR_BF16 4             // rows in flight per wave for bf16 rows (half the bytes of an f32 row)
 #endif
+#ifndef RD_WAVE_SUM
+#define RD_WAVE_SUM wave_sum_valu      // (ds_bpermute chains of __shfl_xor: rows_dot 117.5 -> 106.4 us f32, 61.9 -> 49.9 us bf16 at the C5 share)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, const float* __restrict__ V, int N, int d,
                                                        int C, float* __restrict__ out, long rows_total) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
         for (int u = 0; u < UR; ++u) {
             if (rb + u >= row1) break;
             for (int c = 0; c < C; ++c) {
-                const float s = wave_sum(acc[u][c]);
+                const float s = RD_WAVE_SUM(acc[u][c]);
                 if (lane == 0) out[(rb + u) * C + c] = s;
             }
         }
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void rows_dot_wsum_kernel(const T* __restrict_
         for (int u = 0; u < 4; ++u) {
             if (rb + u >= row1) break;
             for (int c = 0; c < C; ++c) {
-                const float sdot = wave_sum(acc[u][c]);
+                const float sdot = RD_WAVE_SUM(acc[u][c]);
                 if (lane == 0) out[(rb + u) * C + c] = sdot;
             }
         }
