@@ -453,6 +453,84 @@ def test_clam_fused_gate_score_forward_only_matches_the_unfused_chain_and_the_or
     assert len(seen) == 2 and m16.attention_net[0].weight.grad is not None
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_clam_training_chain_in_the_gemm_epilogues_matches_the_separate_passes(monkeypatch, mode):
+    """Round 3: with gradients on, the bf16 CLAM-SB chain takes the gate score (and its seeded Dropouts) from the gate GEMM's
+    epilogue, the first layer's Dropout from its epilogue, the pooling / soft-max / gate backward from one pass, the instance
+    branch from one launch each way.  Same inputs, same dropout seeds: pooled vector, attention, instance loss, top-k ids and
+    every parameter gradient against the chain of separate passes (functional switches off), to bf16 precision - and the new chain
+    must be no further from the f32 path than the old one (eval mode, where both are deterministic)."""
+    from murcl_amd import functional, ops
+    dev = _dev()
+    B, N = 4, 1024
+    x = T(P.bags(21, "tc.x", B, N, 512)).to(dev)
+    labels = torch.tensor([1, 0, 1, 1], device=dev)
+    w = T(detrand.normal(21, "tc.w", (B, 512))).to(dev)
+
+    def run(dtype):
+        m = _clam(21, True, dtype)
+        m.train(mode == "train")
+        keeps = None
+        if mode == "train":
+            keeps = (ops.DropSeed(0.75, seed=101), ops.DropSeed(0.75, seed=202), ops.DropSeed(0.75, seed=303))
+        M, A, s, il, ids, _ = m._run(x if dtype == torch.float32 else x.bfloat16(), labels, True, keeps)
+        ((M * w).sum() + il.sum()).backward()
+        return M.detach(), A.detach(), il.detach(), ids, {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    new = run(torch.bfloat16)
+    for name in ("_GATE_U", "_FUSED_FC_DROP", "_FUSED_INST"):
+        monkeypatch.setattr(functional, name, False)
+    old = run(torch.bfloat16)
+    ref = run(torch.float32) if mode == "eval" else None
+
+    def rel(a, b):
+        return (a.float() - b.float()).abs().max().item() / max(b.float().abs().max().item(), 1e-30)
+    assert rel(new[0], old[0]) <= 2e-2 and rel(new[1], old[1]) <= 5e-2 and rel(new[2], old[2]) <= 2e-2
+    assert set(new[4]) == set(old[4])
+    for k in new[4]:
+        if not k.endswith("attention_c.bias"):          # (its gradient is a sum that cancels to rounding noise)
+            assert rel(new[4][k], old[4][k]) <= 6e-2, (k, rel(new[4][k], old[4][k]))
+    if ref is not None:
+        assert torch.equal(new[3], ref[3]) or (new[3] != ref[3]).float().mean().item() <= 0.1     # ids: near-ties may flip in bf16
+        assert rel(new[0], ref[0]) <= 1.5 * rel(old[0], ref[0]) + 2e-3
+        for k in new[4]:
+            if not k.endswith("attention_c.bias"):
+                assert rel(new[4][k], ref[4][k]) <= 1.5 * rel(old[4][k], ref[4][k]) + 1e-2, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dsmil_reassociated_attention_equals_the_literal_order(monkeypatch, dtype):
+    """Round 3: K6 without the [B*N,128] queries (logits = X . Wq^T q_max / sqrt(128), one streaming pass each for attention +
+    pooling and for their backward) against the reference's literal order (queries by one GEMM over all patches): classes, bag
+    vectors, arg-max ids and every parameter gradient.  f32: 1e-4 of the largest entry (north_star); bf16 storage: 2e-2."""
+    from murcl_amd import functional
+    dev = _dev()
+    B, N, d = 3, 2048, 1024
+    x = T(P.bags(22, "dr.x", B, N, d)).to(dev).to(dtype)
+
+    def run():
+        m = _dsmil(22, d=d, dtype=dtype)
+        classes, bag = m._run(x)
+        (bag.sum() + 0.5 * (bag * bag).sum() + classes.max(1)[0].sum()).backward()
+        return classes.detach(), bag.detach(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    outs = {}
+    for name, re, one in (("onepass", True, True), ("reassoc", True, False), ("literal", False, False)):
+        monkeypatch.setattr(functional, "_DSMIL_REASSOC", re)
+        monkeypatch.setattr(functional, "_DSMIL_ONEPASS", one)
+        outs[name] = run()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    lit = outs["literal"]
+    for name in ("onepass", "reassoc"):
+        got = outs[name]
+        assert torch.equal(got[0], lit[0])                                   # the instance scores are computed identically
+        assert (got[1] - lit[1]).abs().max().item() <= tol * lit[1].abs().max().item()
+        assert set(got[2]) == set(lit[2])
+        for k in got[2]:
+            scale = max(lit[2][k].abs().max().item(), 1e-6 * max(v.abs().max().item() for v in lit[2].values()))
+            assert (got[2][k] - lit[2][k]).abs().max().item() <= tol * scale, (name, k)
+
+
 # ------------------------------------------------------------------ PPO (K10/K11)
 def test_ppo_act_evaluate_update_vs_reference_golden(golden):
     """G8: act (injected eps) -> actions/logp/hidden; evaluate; one update (K_epochs=1, Adam lr 1e-3) -> parameters."""
