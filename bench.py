@@ -214,6 +214,33 @@ def _timed_ms(fn, reps=10, warm=3):
     return ts[len(ts) // 2]
 
 
+def _kernel_table(fn, passes=3):
+    """Per-kernel HIP-event times of ``fn`` (the spans ops.py defines: the kernels that carry algorithmic bytes / FLOPs), averaged
+    over ``passes`` runs - an untimed extra pass, like the headline's breakdown.  -> {key: {us, GBps, frac_of_8TBps | TFLOPs}}"""
+    from murcl_amd import ops
+    ops.TIMERS = ops.KernelTimers()
+    try:
+        for _ in range(passes):
+            fn()
+        torch.cuda.synchronize()
+        summ = ops.TIMERS.summary()
+    finally:
+        ops.TIMERS = None
+    out = {}
+    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms_total"]):
+        if v["ms_total"] / passes < 0.02:
+            continue
+        us = v["ms_avg"] * 1e3
+        e = {"launches_per_pass": v["calls"] // passes, "us": round(us, 1)}
+        if v["bytes"]:
+            gbps = v["bytes"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e9
+            e.update(GBps=round(gbps, 1), frac_of_8TBps=round(gbps / PEAK["hbm_GBps"], 4))
+        if v["flops"]:
+            e["TFLOPs"] = round(v["flops"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e12, 1)
+        out[k] = e
+    return out
+
+
 def other_rows(device):
     """The other aggregators of SURVEY section 8 at their BASELINE shapes, beside the headline (outside its timed
     region): BASELINE configs[2] CLAM-SB + instance loss 64 x 4096 x 512 (bf16 storage) and one GPU's share of configs[4]
@@ -255,6 +282,8 @@ def other_rows(device):
                                         frac_of_bf16_mfma_peak=round(flops / (ms * 1e-3) / (PEAK["mfma_bf16_TFLOPs"] * 1e12), 4),
                                         x_bytes_GB=round(xbytes / 1e9, 3), frac_of_8TBps_on_x_bytes=round(xbytes / ms / 1e6 / 8000, 4)),
                          chain_traffic_GB=round(nbytes / 1e9, 3), chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+        if name.endswith("training_mode"):
+            out[name]["kernels"] = _kernel_table(lambda: clam_fb(False))
     del m, x
     B, N, d = 16, 8192, 1024
     md = build_dsmil(d, 2).to(device)
@@ -280,7 +309,8 @@ def other_rows(device):
                                          chain_traffic_GB=round(nbytes / 1e9, 3),
                                          chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4),
                                          kernelwise_floor_ms=round(floor_ms, 4), frac_of_kernelwise_floor=round(floor_ms / ms, 4),
-                                         floor_note="3 HBM passes over X at 8 TB/s (no GEMM over all patches remains)")
+                                         floor_note="3 HBM passes over X at 8 TB/s (no GEMM over all patches remains)",
+                                         kernels=_kernel_table(dsmil_fb))
     md.compute_dtype = torch.bfloat16                               # patch features stored in bf16, f32 accumulation
     xd = xd.bfloat16()
     ms = _timed_ms(dsmil_fb)

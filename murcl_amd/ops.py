@@ -215,8 +215,9 @@ def gated_score_bwd_il(U, wc, keep_a=None, keep_b=None, *, ds=None, h=None, dM=N
         L = h.shape[1]
     else:
         ds = _c(ds)
-    check(_lib.lib().murcl_gated_score_bwd_il(ptr(U), ptr(wc), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc), ptr(dbab), ptr(part), M, D, dt(U),
-                                              kp, sa, sb, ptr(h), ptr(dM), ptr(Mp), ptr(A), L, rows_per_bag, stream()), "gated_score_bwd_il")
+    with _span(lambda: ("gated_score_bwd_il" + ("<one pass>" if L else ""), dict(bytes=2 * U.numel() * 2 + (M * L * 2 if L else 0)))):
+        check(_lib.lib().murcl_gated_score_bwd_il(ptr(U), ptr(wc), ptr(ds), ptr(dU), ptr(dwc), ptr(dbc), ptr(dbab), ptr(part), M, D, dt(U),
+                                                  kp, sa, sb, ptr(h), ptr(dM), ptr(Mp), ptr(A), L, rows_per_bag, stream()), "gated_score_bwd_il")
     return dU, dwc, dbc, dbab
 
 
