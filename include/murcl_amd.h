@@ -177,6 +177,13 @@ int murcl_dsmil_softmax(float* S, int B, int N, int C, murcl_stream_t stream);
  * (sum_n A dA X[n]) - (sum_n A dA) Z[c] - Z = the forward's pooled rows - so that neither dA nor dS is stored; with dcls [B,N,C]
  * (may be NULL) the pass also leaves the per-wave partial rows of dWc = dcls^T X in gpart [(B*N/plan)][C*d] (sum them with
  * murcl_colsum).  ws: (B*N/plan)*C*(d+2) floats. */
+/* The [B*C]-row algebra around those passes, d % 4 == 0, d <= 2048.  qv: x_m = X[b, m[b,c]] (f32 copy xm [B*C,d]), qmax = Wq x_m + bq
+ * [B*C,128] (dsmil.py:74-75), v = Wq^T qmax [B*C,d].  qv_bwd: with R [B*C,d] = the gradient of v (murcl_dsmil_attn_pool_bwd):
+ * dq = Wq R (dq_ws [B*C,128]), dWq [128,d] = qmax^T R + dq^T xm (OVERWRITTEN), dbq [128] = sum_r dq (overwritten). */
+int murcl_dsmil_qv(const void* X, const int* m, const float* Wq, const float* bq, int B, int N, int d, int C, float* xm, float* qmax,
+                   float* v, int dtype, murcl_stream_t stream);
+int murcl_dsmil_qv_bwd(const float* R, const float* qmax, const float* xm, const float* Wq, int BC, int d, float* dq_ws, float* dWq,
+                       float* dbq, murcl_stream_t stream);
 int murcl_dsmil_stream_plan(int B, int N, int d, int C);
 int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits = vscale * X.v */, float* A, float* Z, float* ws,
                           int B, int N, int d, int C, int dtype, murcl_stream_t stream);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "murcl_gated_score_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
     "murcl_dsmil_softmax": [_P, _I, _I, _I, _P],
     "murcl_dsmil_stream_plan": [_I, _I, _I, _I],
+    "murcl_dsmil_qv": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "murcl_dsmil_qv_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_softmax_bwd": [_P, _P, _I, _I, _I, _P, _P, _P],

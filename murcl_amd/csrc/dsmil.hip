@@ -786,3 +786,119 @@ extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const f
     hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr);
     return MURCL_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- the [B*C]-row algebra of the reassociated K6 as 2 + 2 launches
+// forward, per critical instance r = (bag, class): x_m = X[bag, m[r]] (kept in f32 for the backward), q_r = Wq x_m + bq
+// (dsmil.py:74-75), v_r = Wq^T q_r (the vector the attention pass dots every patch with).  Replaces gather + cast + two GEMMs (+ a
+// transpose of Wq) on 32-row tensors.  d <= DQ_MAXD, d % 4 == 0.  (First form: one workgroup per r walking the 128 rows of Wq, 32
+// per wave, one wave reduction each: 54-62 us of pure latency - the rows are now spread over grid.y, four per wave, reduced together.)
+#define DQ_MAXD 2048
+#define DQ_OPB 16                 // outputs per workgroup of the matvec launches (grid.y = DS_Q / DQ_OPB): a wave takes 4, lanes walk k
+// out[o] = W[o,:] . xs (+ bias[o]) for this workgroup's DQ_OPB rows of W [DS_Q, d]
+__device__ __forceinline__ void dq_matvec(const float* __restrict__ W, const float* xs, const float* __restrict__ bias, int d,
+                                          float* __restrict__ gout) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o0 = blockIdx.y * DQ_OPB + wave * (DQ_OPB / 4);
+    float a[DQ_OPB / 4];
+#pragma unroll
+    for (int i = 0; i < DQ_OPB / 4; ++i) a[i] = 0.f;
+    for (int k = lane * 4; k < d; k += 256) {
+        const f32x4 x = *(const f32x4*)(xs + k);
+#pragma unroll
+        for (int i = 0; i < DQ_OPB / 4; ++i) {
+            const f32x4 w = *(const f32x4*)(W + (size_t)(o0 + i) * d + k);
+            a[i] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DQ_OPB / 4; ++i) {
+        const float t = wave_sum_valu(a[i]);
+        if (lane == 0) gout[o0 + i] = t + (bias ? bias[o0 + i] : 0.f);
+    }
+}
+// forward launch 1, grid (B*C, DS_Q / DQ_OPB): x_m (written by the y = 0 workgroups) and q_r = Wq x_m + bq
+template <typename T>
+__global__ __launch_bounds__(256) void dsmil_q_kernel(const T* __restrict__ X, const int* __restrict__ m, const float* __restrict__ Wq,
+                                                      const float* __restrict__ bq, int N, int d, int C, float* __restrict__ xm,
+                                                      float* __restrict__ qmax) {
+    __shared__ __attribute__((aligned(16))) float xs[DQ_MAXD];
+    const int r = blockIdx.x, b = r / C, tid = threadIdx.x;
+    const T* row = X + ((size_t)b * N + m[r]) * d;
+    for (int k = tid; k < d; k += 256) {
+        const float t = to_f<T>(row[k]);
+        xs[k] = t;
+        if (blockIdx.y == 0) xm[(size_t)r * d + k] = t;
+    }
+    __syncthreads();
+    dq_matvec(Wq, xs, bq, d, qmax + (size_t)r * DS_Q);
+}
+// forward launch 2, grid (B*C, ceil(d / 1024)): v_r = Wq^T q_r, a thread owns 4 columns
+__global__ __launch_bounds__(256) void dsmil_v_kernel(const float* __restrict__ qmax, const float* __restrict__ Wq, int d,
+                                                      float* __restrict__ v) {
+    __shared__ float qs[DS_Q];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (tid < DS_Q) qs[tid] = qmax[(size_t)r * DS_Q + tid];
+    __syncthreads();
+    const int k = blockIdx.y * 1024 + tid * 4;
+    if (k < d) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < DS_Q; o += 4)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += qs[o + u] * *(const f32x4*)(Wq + (size_t)(o + u) * d + k);
+        *(f32x4*)(v + (size_t)r * d + k) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+}
+// backward launch 1, grid (B*C, DS_Q / DQ_OPB): dq_r = Wq R_r     (R = the gradient of v, murcl_dsmil_attn_pool_bwd)
+__global__ __launch_bounds__(256) void dsmil_dq_kernel(const float* __restrict__ R, const float* __restrict__ Wq, int d,
+                                                       float* __restrict__ dq) {
+    __shared__ __attribute__((aligned(16))) float xs[DQ_MAXD];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < d; k += 256) xs[k] = R[(size_t)r * d + k];
+    __syncthreads();
+    dq_matvec(Wq, xs, nullptr, d, dq + (size_t)r * DS_Q);
+}
+// backward launch 2, grid (DS_Q rows o of Wq, ceil(d / 1024)): dWq[o,:] = sum_r q_r[o] R_r + dq_r[o] x_m,r ;  dbq[o] = sum_r dq_r[o]
+__global__ __launch_bounds__(256) void dsmil_dwq_kernel(const float* __restrict__ R, const float* __restrict__ qmax,
+                                                        const float* __restrict__ dq, const float* __restrict__ xm, int BC, int d,
+                                                        float* __restrict__ dWq, float* __restrict__ dbq) {
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int k = blockIdx.y * 1024 + tid * 4;
+    if (k < d) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int r = 0; r < BC; ++r) {
+            acc0 += qmax[(size_t)r * DS_Q + o] * *(const f32x4*)(R + (size_t)r * d + k);
+            acc1 += dq[(size_t)r * DS_Q + o] * *(const f32x4*)(xm + (size_t)r * d + k);
+        }
+        *(f32x4*)(dWq + (size_t)o * d + k) = acc0 + acc1;
+    }
+    if (blockIdx.y == 0 && tid == 0) {
+        float t = 0.f;
+        for (int r = 0; r < BC; ++r) t += dq[(size_t)r * DS_Q + o];
+        dbq[o] = t;
+    }
+}
+extern "C" int murcl_dsmil_qv(const void* X, const int* m, const float* Wq, const float* bq, int B, int N, int d, int C, float* xm,
+                              float* qmax, float* v, int dtype, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    if (d % 4 || d > DQ_MAXD) return -1;
+    const dim3 gq(B * C, DS_Q / DQ_OPB);
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(dsmil_q_kernel<float>, gq, dim3(256), 0, s, (const float*)X, m, Wq, bq, N, d, C, xm, qmax);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(dsmil_q_kernel<bf16_t>, gq, dim3(256), 0, s, (const bf16_t*)X, m, Wq, bq, N, d, C, xm, qmax);
+    else return -1;
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_v_kernel, dim3(B * C, (d + 1023) / 1024), dim3(256), 0, s, qmax, Wq, d, v);
+    return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_dsmil_qv_bwd(const float* R, const float* qmax, const float* xm, const float* Wq, int BC, int d, float* dq_ws,
+                                  float* dWq, float* dbq, hipStream_t s) {
+    if (BC <= 0) return 0;
+    if (d % 4 || d > DQ_MAXD || !dq_ws) return -1;
+    hipLaunchKernelGGL(dsmil_dq_kernel, dim3(BC, DS_Q / DQ_OPB), dim3(256), 0, s, R, Wq, d, dq_ws);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_dwq_kernel, dim3(DS_Q, (d + 1023) / 1024), dim3(256), 0, s, R, qmax, dq_ws, xm, BC, d, dWq, dbq);
+    return MURCL_CHECK_LAUNCH();
+}

@@ -40,6 +40,7 @@ _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B sw
 _FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
+_DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
@@ -652,10 +653,15 @@ class DSMILFn(torch.autograd.Function):
         cls += bc
         m = ops.dsmil_argmax(cls, B, N, C)                                              # critical instances (:71-73)
         reassoc = _DSMIL_REASSOC and C <= 4
-        if reassoc:
+        qv = reassoc and _DSMIL_QV and wq.shape[0] == QD and d % 4 == 0 and d <= 2048
+        xm = None
+        if qv:
+            xm, qmax, v = ops.dsmil_qv(x2, m, wq, bq, B, N, C)                          # x_m, q_c = Wq x_m + bq, Wq^T q_c: one launch
+        elif reassoc:
             xm = ops.cast(ops.gather_rows(x2, m, B, C, N, 0, d), torch.float32)         # [B*C, d]
             qmax = ops.gemm_nt(xm, wq, epi=ops.EPI_BIAS, bias=bq)                       # q_c = Wq x_m + bq     [B*C, 128]
             v = ops.gemm_nt(qmax, ops.transposed(wq))                                   # Wq^T q_c              [B*C, d]
+        if reassoc:
             Y = v
             # attention + pooling from one pass over X: A = soft-max_n(X v_c / sqrt(128)) (:76-77), Z = A^T X (:78)
             one = ops.dsmil_attn_pool(x, v.view(B, C, d), 1.0 / math.sqrt(QD)) if _DSMIL_ONEPASS else None
@@ -672,16 +678,16 @@ class DSMILFn(torch.autograd.Function):
         A, Z = one if one is not None else (A, ops.weighted_rowsum(x, A))               # Z = A^T X  (:78)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
         classes = cls.view(B, N, C)
-        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq)
-        ctx.meta = (B, N, d, C, LD, reassoc)
+        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else x.new_zeros(1))
+        ctx.meta = (B, N, d, C, LD, reassoc, qv)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
         return classes, bag, m
 
     @staticmethod
     def backward(ctx, dclasses, dbag, _dm):
-        x, Y, m, qmax, A, Z, wv, wq = ctx.saved_tensors
-        B, N, d, C, LD, reassoc = ctx.meta
+        x, Y, m, qmax, A, Z, wv, wq, xm_saved = ctx.saved_tensors
+        B, N, d, C, LD, reassoc, qv = ctx.meta
         T, QD = x.dtype, DSMILFn.QD
         dev = x.device
         x2 = x.reshape(B * N, d)
@@ -689,7 +695,7 @@ class DSMILFn(torch.autograd.Function):
         dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
         dbv = ops.colsum(dbag2)
         dZ = ops.gemm_nt(dbag2, ops.transposed(wv)).view(B, C, d)
-        xm = ops.gather_rows(x2, m, B, C, N, 0, d)                                          # critical instances
+        xm = None if qv else ops.gather_rows(x2, m, B, C, N, 0, d)                          # critical instances
         dcls = dclasses.reshape(B, N, C).float().contiguous() if dclasses is not None else None
         # reassociated: ONE pass over X gives R (below) and dWc - neither dA nor dS is stored
         one = ops.dsmil_attn_pool_bwd(x, dZ, A, Z, dcls, 1.0 / math.sqrt(QD)) if (reassoc and _DSMIL_ONEPASS) else None
@@ -699,7 +705,9 @@ class DSMILFn(torch.autograd.Function):
             if dclasses is not None:
                 fused = ops.rows_dot_wsum(x, dZ, dcls)
             dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
-        if one is not None:
+        if one is not None and qv:
+            dwq, dbq = ops.dsmil_qv_bwd(one[0].view(B * C, d), qmax, xm_saved, wq)         # dq = R Wq^T, dWq = q^T R + dq^T x_m, dbq
+        elif one is not None:
             R = one[0].view(B * C, d)
             dqmax = ops.gemm_nt(R, wq)                                                      # [B*C, 128]
             dwq = ops.gemm_tn(qmax, R)                                                      # [128, d]
@@ -718,11 +726,14 @@ class DSMILFn(torch.autograd.Function):
             dqmax = ops.dsmil_attn_bwd(A, dA, Y, 0, qmax, dQ, B, N, C)
             dwq = ops.gemm_tn(dQ if T == torch.float32 else ops.cast(dQ, T), x2, x3=_DSMIL_X3)  # [128, d]: one tile row
             dbq = ops.colsum(dQ)
-        if reassoc:
-            ops.gemm_tn(dqmax, ops.cast(xm, torch.float32), out=dwq)
+        if one is not None and qv:
+            pass
+        elif reassoc:
+            ops.gemm_tn(dqmax, xm_saved if qv else ops.cast(xm, torch.float32), out=dwq)
+            dbq = ops.colsum(dqmax) if dbq is None else ops.colsum(dqmax, out=dbq, accumulate=True)
         else:
             ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
-        dbq = ops.colsum(dqmax) if dbq is None else ops.colsum(dqmax, out=dbq, accumulate=True)
+            dbq = ops.colsum(dqmax) if dbq is None else ops.colsum(dqmax, out=dbq, accumulate=True)
         dwc = dbc = None
         if dclasses is not None:
             # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile

@@ -733,6 +733,29 @@ def dsmil_softmax_(S):
     return S
 
 
+def dsmil_qv(X, m, wq, bq, B, N, C):
+    """One launch: the critical instances' rows x_m [B*C,d] (f32), their queries q = Wq x_m + bq [B*C,128] and v = Wq^T q [B*C,d]."""
+    X, wq = _c(X), _c(wq)
+    d = X.shape[-1]
+    dev = X.device
+    xm = torch.empty((B * C, d), dtype=torch.float32, device=dev)
+    qmax = torch.empty((B * C, wq.shape[0]), dtype=torch.float32, device=dev)
+    v = torch.empty((B * C, d), dtype=torch.float32, device=dev)
+    check(_lib.lib().murcl_dsmil_qv(ptr(X), ptr(m), ptr(wq), ptr(_c(bq)), B, N, d, C, ptr(xm), ptr(qmax), ptr(v), dt(X), stream()), "dsmil_qv")
+    return xm, qmax, v
+
+
+def dsmil_qv_bwd(R, qmax, xm, wq):
+    """-> (dWq [128,d] = qmax^T R + (R Wq^T)^T xm, dbq [128]) in two launches."""
+    R, qmax, xm, wq = _c(R), _c(qmax), _c(xm), _c(wq)
+    BC, d = R.shape
+    dq = torch.empty_like(qmax)
+    dwq = torch.empty_like(wq)
+    dbq = torch.empty((wq.shape[0],), dtype=torch.float32, device=R.device)
+    check(_lib.lib().murcl_dsmil_qv_bwd(ptr(R), ptr(qmax), ptr(xm), ptr(wq), BC, d, ptr(dq), ptr(dwq), ptr(dbq), stream()), "dsmil_qv_bwd")
+    return dwq, dbq
+
+
 def dsmil_attn_pool(X, v, scale=1.0):
     """DSMIL's attention and pooling from ONE pass over X: A [B,N,C] = soft-max_n(scale * X . v), Z [B,C,d] = A^T X - or None when
     the shape is not covered (then rows_dot + dsmil_softmax_ + weighted_rowsum).  X [B,N,d] f32/bf16, v [B,C,d] f32."""
