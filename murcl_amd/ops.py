@@ -150,19 +150,6 @@ def gate_interleave(wa, ba, wb, bb, wc, dtype):
     return (W.contiguous() if dtype == torch.float32 else cast(W.contiguous(), dtype)), b, c
 
 
-def gate_interleave_t(wa, wb, dtype):
-    """[Wa; Wb] transposed, [L, 2D] in ``dtype``, columns in the interleaved order of ``gate_interleave`` (the dgrad operand that
-    goes with an interleaved dU)."""
-    gate_interleave  # (the index table is built there)
-    D = wa.shape[0]
-    idx = _GATE_IDX.get((D, wa.device))
-    if idx is None:
-        n = torch.arange(2 * D)
-        g, j, i = n // 32, (n % 32) // 16, n % 16
-        idx = _GATE_IDX[(D, wa.device)] = ((16 * g + i) + D * j).to(wa.device)
-    return transpose_cast(torch.cat([wa, wb], 0).index_select(0, idx), dtype)
-
-
 def panel_gate_score(h, W_il, b_il, c_il, bc):
     """CLAM's gated attention score straight from the gate GEMM's epilogue (``murcl_panel_gemm`` epilogue 4): h [M,512] bf16 ->
     raw scores s [M] f32 = sum_d tanh(a_d) sigmoid(b_d) wc_d + bc, without materialising the [M, 2D] gate pre-activations."""
