@@ -67,6 +67,9 @@
 #ifndef PG_GATE_U_FUSE
 #define PG_GATE_U_FUSE 1  // PG_GATE_U rides the fused forward schedule (its epilogue inside the next tile's MFMA loop) like PG_BIAS
 #endif
+#ifndef PG_EXACT_WAIT
+#define PG_EXACT_WAIT 0
+#endif
 #ifndef PG_WIDE
 #define PG_WIDE 0         // K = 512: 1 -> 4 waves x 64 columns (512 registers per wave), 0 -> 8 waves x 32 columns
 #endif
@@ -136,9 +139,21 @@ __device__ __forceinline__ u32x4 pg_gload16_nt(const void* sbase, unsigned voff)
     return v;
 }
 
-// per bf16 half of w: 1 if > 0 (signed 16-bit compare: -0.0 and negatives give 0), else 0.  Inline asm because hipcc
-// turns the min/max pair into two compares, two selects and a permute.
+// per bf16 half of w: 1 if > 0 (signed 16-bit compare: -0.0 and negatives give 0), else 0.  `ones` arrives opaque (an empty asm
+// on the register): with a literal 1 hipcc turns the min/max pair into two compares, two selects and a permute.
+// PG_NOASM (default 1, round 3): the packed 16-bit min / max go through __builtin_elementwise_min/max instead of inline asm -
+// same instructions (v_pk_min_i16 / v_pk_max_i16), but the scheduler knows them and keeps interleaving the fused epilogue's
+// VALU work with the MFMAs of the next tile (an asm statement is a black box with unknown latency in the middle of that region).
+#ifndef PG_NOASM
+#define PG_NOASM 1
+#endif
+typedef short pg_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pg_pos_flags(unsigned w, unsigned ones) {
+    if (PG_NOASM) {
+        const pg_s16x2 z = {0, 0};
+        const pg_s16x2 t = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(pg_s16x2, w), __builtin_bit_cast(pg_s16x2, ones)), z);
+        return __builtin_bit_cast(unsigned, t);
+    }
     unsigned t;
     asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=&v"(t) : "v"(w), "v"(ones));
     return t;
@@ -147,11 +162,16 @@ __device__ __forceinline__ unsigned pg_pos_flags(unsigned w, unsigned ones) {
 // max(., 0) per half IS the ReLU - after the rounding to bf16, which commutes with it (rounding is monotonic).  One VALU
 // operation per pair instead of two v_max_f32; the > 0 flags of the result are then min(., 1) per half.
 __device__ __forceinline__ unsigned pg_relu_pk(unsigned w) {
+    if (PG_NOASM) {
+        const pg_s16x2 z = {0, 0};
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(pg_s16x2, w), z));
+    }
     unsigned t;
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(t) : "v"(w));
     return t;
 }
 __device__ __forceinline__ unsigned pg_pos_flags_nonneg(unsigned w, unsigned ones) {
+    if (PG_NOASM) return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(pg_s16x2, w), __builtin_bit_cast(pg_s16x2, ones)));
     unsigned t;
     asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(w), "v"(ones));
     return t;
@@ -626,7 +646,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
         if (seq + 2 < my_tiles) {
             const int sq = late ? seq - 1 : seq;
             if (dma_wave) {
-                if (sq <= 0) { PG_WAIT(2 * G); } else if (sq == 1) { PG_WAIT(2 * G + S); } else { PG_WAIT(2 * G + 2 * S); }
+                // (from the fourth tile on, the stores issued in the iteration that requested this tile are younger than its loads
+                // too: PG_EXACT_WAIT lets them stay in flight - three tiles of stores instead of two)
+                if (sq <= 0) { PG_WAIT(2 * G); } else if (sq == 1) { PG_WAIT(2 * G + S); }
+                else if (sq == 2 || !PG_EXACT_WAIT) { PG_WAIT(2 * G + 2 * S); } else { PG_WAIT(2 * G + 3 * S); }
             } else {          // (DMAH) this wave's queue holds only its side pieces and stores
                 constexpr int G0 = G - GA;
                 if (sq <= 0) { PG_WAIT(2 * G0); } else if (sq == 1) { PG_WAIT(2 * G0 + S); } else { PG_WAIT(2 * G0 + 2 * S); }

@@ -94,12 +94,25 @@ def main():
     dM_c = torch.randn((Bc, 512), generator=g, device=dev)
     ds_c = torch.randn((M,), generator=g, device=dev) * 1e-3
     gbytes = 2 * M * 512 * 2
+    Zr = torch.zeros_like(X)
+    H2 = torch.empty_like(X)
+    Rb = (torch.randn((M, 512), generator=g, device=dev) * 0.5).bfloat16()          # both signs: more bits toggle
     cases.update({
         "panel_bias": (lambda: ops.panel_gemm(H, W_il, ops.PG_BIAS, bias=b_il), gbytes, 2.0 * M * 512 * 512),
         "panel_gate_score": (lambda: ops.panel_gate_score(H, W_il, b_il, c_il, bc1), M * 512 * 2, 2.0 * M * 512 * 512),
         "panel_gate_u": (lambda: ops.panel_gate_u(H, W_il, b_il, c_il, bc1), gbytes, 2.0 * M * 512 * 512),
         "panel_gate_u_drop": (lambda: ops.panel_gate_u(H, W_il, b_il, c_il, bc1, dsa, dsb), gbytes, 2.0 * M * 512 * 512),
         "panel_fwd_drop": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, drop=dsa), gbytes, 2.0 * M * 512 * 512),
+        "datadep_fwd_zeros": (lambda: ops.panel_gemm(Zr, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), gbytes, 2.0 * M * 512 * 512),
+        "datadep_fwd_half_zero": (lambda: ops.panel_gemm(H, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), gbytes, 2.0 * M * 512 * 512),
+        "datadep_fwd_dense": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), gbytes, 2.0 * M * 512 * 512),
+        "datadep_fwd_randbits": (lambda: ops.panel_gemm(Rb, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), gbytes, 2.0 * M * 512 * 512),
+        "datadep_tn_zeros": (lambda: ops.gemm_tn(Zr, Zr), gbytes, 2.0 * M * 512 * 512),
+        "datadep_tn_dense": (lambda: ops.gemm_tn(X, H), gbytes, 2.0 * M * 512 * 512),
+        "datadep_k2_zeros": (lambda: ops.abmil_pool_fwd(Zr.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
+        "datadep_k2_dense": (lambda: ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
+        "datadep_copy_zeros": (lambda: H2.copy_(Zr), gbytes, 0),
+        "datadep_copy_dense": (lambda: H2.copy_(X), gbytes, 0),
         "pair_fc_gate_u": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gate_u(H, W_il, b_il, c_il, bc1)), 2 * gbytes, 0),
         "pair_fc_biasgate": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gemm(H, W_il, ops.PG_BIAS, bias=b_il)), 2 * gbytes, 0),
         "pair_fc_gatescore": (lambda: (ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True, out=H), ops.panel_gate_score(H, W_il, b_il, c_il, bc1)), 2 * gbytes, 0),
