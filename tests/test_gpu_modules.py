@@ -171,6 +171,47 @@ def test_bf16_forward_paths_against_the_oracle_with_the_same_storage_roundings()
         assert (M.detach().cpu() - M_ref).abs().max().item() <= 2e-3 * M_ref.abs().max().item(), grad
 
 
+def test_bf16_backward_against_the_oracle_with_the_same_storage_roundings():
+    """The same statement for the C2 aggregator's gradients: autograd through the f32 oracle with the bf16 storage roundings of the HIP
+    path inserted - activations H1..H3 (rounded forward, straight through backward) and the gradient tensors the backward kernels
+    leave in HBM as bf16 (dZ3, dZ2, dZ1 = the gradients at the three pre-activations, and dT at the attention pre-activation) -
+    against the HIP bf16 backward: every parameter gradient within 2e-3 of its largest entry (5e-2 norm-wise is what the
+    bf16-vs-f32 comparison allows)."""
+    import torch.nn.functional as F
+    dev = _dev()
+    B, N = 4, 2048
+    p = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.abmil(8)).items()}
+    x = T(P.bags(8, "emb.x", B, N, 512))
+    w = T(detrand.normal(8, "emb.w", (B, 512)))
+
+    def st(t):                                   # round forward, identity backward
+        return t + (_r16(t) - t).detach()
+
+    def grad_r16(t):                             # the gradient arriving at t is stored as bf16
+        t.register_hook(lambda g: _r16(g))
+        return t
+    h = _r16(x)
+    for k in ("encoder.0", "encoder.3", "encoder.6"):
+        # (the bias gradients are column sums of the f32 values, taken before those are rounded for storage: the bias joins after the hook)
+        z = grad_r16(F.linear(h, st(p[k + ".weight"]))) + p[k + ".bias"]
+        h = st(torch.relu(z))
+    t_pre = grad_r16(F.linear(h, st(p["attention.0.weight"]))) + p["attention.0.bias"]
+    s = F.linear(torch.tanh(t_pre), p["attention.2.weight"], p["attention.2.bias"]).squeeze(-1)
+    A = torch.softmax(s, 1) / math.sqrt(N)
+    M = torch.einsum("bn,bnl->bl", A, h)
+    out = torch.relu(F.linear(M, p["decoder.0.weight"], p["decoder.0.bias"]))
+    (out * w).sum().backward()
+    m16 = _abmil(8, torch.bfloat16)
+    o16, _ = m16(x.to(dev))
+    (o16 * w.to(dev)).sum().backward()
+    for k, v in m16.named_parameters():
+        if v.grad is None or k == "attention.2.bias":
+            continue
+        ref = p[k].grad
+        err = (v.grad.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-3, (k, err)
+
+
 def test_full_layer_interleaved_hidden_golden(golden):
     """G9: the two views share one hidden state exactly like the reference's attribute."""
     from murcl_amd.models.rlmil import Full_layer
