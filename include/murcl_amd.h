@@ -187,6 +187,10 @@ int murcl_dsmil_qv_bwd(const float* R, const float* qmax, const float* xm, const
 int murcl_dsmil_stream_plan(int B, int N, int d, int C);
 int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits = vscale * X.v */, float* A, float* Z, float* ws,
                           int B, int N, int d, int C, int dtype, murcl_stream_t stream);
+/* soft-max over n of GIVEN logits S [B,N,C] and the pooling with it, same pass structure: A = soft-max_n(S), Z = A^T X.  CLAM-SB's
+ * clam.py:144,170 behind the gate GEMM (C = 1, d = 512).  Plan / workspace as murcl_dsmil_attn_pool; A may not alias S. */
+int murcl_softmax_pool(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
+                       murcl_stream_t stream);
 int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls, float scale,
                               float* R, float* gpart, float* ws, int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,

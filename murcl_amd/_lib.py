@@ -54,6 +54,7 @@ SIGNATURES = {
     "murcl_dsmil_qv": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "murcl_dsmil_qv_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_softmax_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_softmax_bwd": [_P, _P, _I, _I, _I, _P, _P, _P],
     "murcl_clam_inst_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P],

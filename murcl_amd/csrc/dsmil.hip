@@ -559,7 +559,7 @@ extern "C" int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, i
 #ifndef DS_WAVE_SUM
 #define DS_WAVE_SUM wave_sum_valu
 #endif
-template <typename T, int MODE>          // MODE 0: forward, 1: backward
+template <typename T, int MODE>          // MODE 0: forward, 1: backward, 2: forward with the logits given (Ain = S [rows, C]; V unused)
 __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__ X, const float* __restrict__ V,
                                                            const float* __restrict__ Ain, const float* __restrict__ G,
                                                            int N, int d, int C, int rows_per_wave, float* __restrict__ S,
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
     const long row0 = wid * rows_per_wave;
     if (row0 >= rows_total) return;
     const long row1 = min(rows_total, row0 + rows_per_wave);
-    const float* v = V + (size_t)(row0 / N) * C * d;
+    const float* v = MODE == 2 ? nullptr : V + (size_t)(row0 / N) * C * d;
     float zacc[2][2][8], gacc[(MODE == 1) ? 2 : 1][2][8], vr[2][2][8];
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};      // MODE 1: l_run = sum_n w[n,c]
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
             const int k = st * 512 + lane * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { zacc[c][st][e] = 0.f; vr[c][st][e] = 0.f; if (MODE == 1) gacc[c][st][e] = 0.f; }
-            if (c < C && k < d) load8<float>(v + (size_t)c * d + k, vr[c][st]);
+            if (MODE != 2 && c < C && k < d) load8<float>(v + (size_t)c * d + k, vr[c][st]);
         }
     const bool with_g = MODE == 1 && G != nullptr;
     for (long rb = row0; rb < row1; rb += 4) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 acc[u][c] = 0.f;
-                aw[u][c] = (MODE == 1 && live && c < C) ? Ain[row * C + c] : 0.f;
+                aw[u][c] = (MODE != 0 && live && c < C) ? Ain[row * C + c] : 0.f;      // MODE 2: the row's logit
                 gw[u][c] = (with_g && live && c < C) ? G[row * C + c] : 0.f;
             }
 #pragma unroll
@@ -604,21 +604,23 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                     for (int e = 0; e < 8; ++e) xv[u][st][e] = 0.f;
             }
         }
+        if (MODE != 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
+                    for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][st][e] * vr[c][st][e];
+                        for (int e = 0; e < 8; ++e) acc[u][c] += xv[u][st][e] * vr[c][st][e];
+        }
         float wgt[4][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             float sd[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sd[u] = (c < C) ? DS_WAVE_SUM(acc[u][c]) * vscale : 0.f;
-            if (MODE == 0) {
+            for (int u = 0; u < 4; ++u) sd[u] = MODE == 2 ? aw[u][c] : ((c < C) ? DS_WAVE_SUM(acc[u][c]) * vscale : 0.f);
+            if (MODE != 1) {
                 float mx = m_run[c];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                 for (int u = 0; u < 4; ++u) {
                     wgt[u][c] = (rb + u < row1 && c < C) ? __expf(sd[u] - mx) : 0.f;
                     ladd += wgt[u][c];
-                    if (lane == 0 && rb + u < row1 && c < C) S[(rb + u) * C + c] = sd[u];
+                    if (MODE == 0 && lane == 0 && rb + u < row1 && c < C) S[(rb + u) * C + c] = sd[u];
                 }
                 l_run[c] = l_run[c] * alpha + ladd;
                 m_run[c] = mx;
@@ -724,12 +726,12 @@ __global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restric
     if (MODE == 0 && blockIdx.y == 0 && tid == 0) { ml[bc * 2] = m; ml[bc * 2 + 1] = l; }
 }
 // A = e^{S - m} / l in place, S [B,N,C]
-__global__ __launch_bounds__(256) void dsmil_normalise_kernel(float* __restrict__ S, const float* __restrict__ ml, long total, int N,
-                                                              int C) {
+__global__ __launch_bounds__(256) void dsmil_normalise_kernel(const float* S, float* A, const float* __restrict__ ml, long total, int N,
+                                                              int C) {                 // (A may alias S)
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const long bc = (i / ((long)N * C)) * C + i % C;
-        S[i] = __expf(S[i] - ml[bc * 2]) / ml[bc * 2 + 1];
+        A[i] = __expf(S[i] - ml[bc * 2]) / ml[bc * 2 + 1];
     }
 }
 // plan: rows a wave takes (0: shape not covered -> rows_dot + soft-max + weighted_rowsum); the workspace holds
@@ -762,7 +764,37 @@ extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale
     const long total = rows * C;
     int g2 = (int)((total + 255) / 256);
     if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, A, ml, total, N, C);
+    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, A, A, ml, total, N, C);
+    return MURCL_CHECK_LAUNCH();
+}
+// The same soft-max + pooling pass for logits that already exist (CLAM-SB: the gate GEMM's epilogue produced them, clam.py:144,170):
+// A [B,N,C] = soft-max_n(S), Z [B,C,d] = A^T X, one pass over X + merge + normalise instead of soft-max, zero-fill and an atomically
+// accumulated weighted row sum.  Same plan / workspace as murcl_dsmil_attn_pool.
+extern "C" int murcl_softmax_pool(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
+                                  hipStream_t s) {
+    if (B <= 0) return 0;
+    const int rpw = murcl_dsmil_stream_plan(B, N, d, C);
+    if (!rpw || !ws) return -1;
+    const long rows = (long)B * N, waves = rows / rpw;
+    float* part = ws;
+    float* stat = part + waves * C * d;
+    float* ml = stat + waves * C * 2;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)X, nullptr, S, nullptr, N, d, C, rpw, nullptr, part, stat, nullptr, rows, 1.f);
+    else if (dtype == MURCL_DTYPE_BF16)
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 2>), grid, dim3(256), 0, s, (const bf16_t*)X, nullptr, S, nullptr, N, d, C, rpw, nullptr, part, stat, nullptr, rows, 1.f);
+    else
+        return -1;
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
+    rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    const long total = rows * C;
+    int g2 = (int)((total + 255) / 256);
+    if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, S, A, ml, total, N, C);
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls /* may be NULL */,

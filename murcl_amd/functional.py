@@ -38,6 +38,7 @@ _FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B sw
 _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
 _FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
+_CLAM_POOL = _os.environ.get("MURCL_CLAM_POOL", "0") == "1"          # dev A/B switch, OFF: CLAM's soft-max + pooling as one streaming pass (online soft-max) - measured 20-40 us SLOWER at C3 than soft-max + weighted_rowsum (four rows in flight per wave: latency-bound at d = 512)
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
@@ -843,8 +844,12 @@ class CLAMFn(torch.autograd.Function):
                 U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
         if not fused_gate and not gate_u:
             s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
-        A = ops.softmax_rows(s)                                                        # clam.py:144
-        M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
+        one = ops.softmax_pool(h.view(B, N, L), s.view(B, N, 1)) if _CLAM_POOL else None    # soft-max (clam.py:144) + pooling (:170), one pass
+        if one is not None:
+            A, M = one[0].view(B, N), one[1].view(B, L)
+        else:
+            A = ops.softmax_rows(s)                                                    # clam.py:144
+            M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)       # clam.py:170
         dev = x.device
         inst_loss = torch.zeros((B,), dtype=torch.float32, device=dev)
         saved_inst = None

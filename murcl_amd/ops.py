@@ -761,6 +761,23 @@ def dsmil_attn_pool(X, v, scale=1.0):
     return A, Z
 
 
+def softmax_pool(X, S):
+    """A [B,N,C] = soft-max_n(S), Z [B,C,d] = A^T X from ONE pass over X (online soft-max per wave, merged per bag), or None when the
+    shape is not covered (then softmax_rows + weighted_rowsum).  X [B,N,d] f32/bf16, S [B,N,C] f32 logits."""
+    X, S = _c(X), _c(S)
+    B, N, d = X.shape
+    C = S.shape[2]
+    rpw = _lib.lib().murcl_dsmil_stream_plan(B, N, d, C)
+    if not rpw:
+        return None
+    A = torch.empty_like(S)
+    Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
+    ws = torch.empty(((B * N // rpw) * C * (d + 2) + 2 * B * C,), dtype=torch.float32, device=X.device)
+    with _span(lambda: (f"softmax_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
+        check(_lib.lib().murcl_softmax_pool(ptr(X), ptr(S), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()), "softmax_pool")
+    return A, Z
+
+
 def dsmil_attn_pool_bwd(X, dZ, A, Z, dcls=None, scale=1.0):
     """One pass over X for the backward of (attention, pooling): R [B,C,d] = scale * sum_n dS[n,c] X[n] with dS = A (dA - sum A dA),
     dA = X dZ^T, neither stored; with ``dcls`` [B,N,C] also dWc [C,d] = dcls^T X.  None when the shape is not covered."""

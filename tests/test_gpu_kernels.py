@@ -438,6 +438,10 @@ def test_dsmil_attention_and_pooling_in_one_pass_and_their_backward_in_one_more(
     A, Z = one
     _close(A, A64, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A")
     _close(Z, Z64, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z")
+    # the same pass with the logits given (murcl_softmax_pool)
+    A2, Z2 = ops.softmax_pool(X, S.float().to(dev))
+    _close(A2, A64, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A (given logits)")
+    _close(Z2, Z64, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z (given logits)")
     _close(A, sep_A, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A vs separate")
     _close(Z, sep_Z, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z vs separate")
     np.testing.assert_allclose(A.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
