@@ -559,6 +559,27 @@ extern "C" int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, i
 #ifndef DS_WAVE_SUM
 #define DS_WAVE_SUM wave_sum_valu
 #endif
+// 8 consecutive elements as loaded (no conversion yet): the next batch of rows waits in this form while the current one is consumed
+template <typename T> struct DsRaw;
+template <> struct DsRaw<float> { f32x4 a, b; };
+template <> struct DsRaw<bf16_t> { u32x4 v; };
+__device__ __forceinline__ void ds_load_raw(const float* p, DsRaw<float>& r) { r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); }
+__device__ __forceinline__ void ds_load_raw(const bf16_t* p, DsRaw<bf16_t>& r) { r.v = *(const u32x4*)p; }
+__device__ __forceinline__ void ds_zero_raw(DsRaw<float>& r) { r.a = f32x4{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+__device__ __forceinline__ void ds_zero_raw(DsRaw<bf16_t>& r) { r.v = u32x4{0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ void ds_to_float(const DsRaw<float>& r, float* v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = r.a[e]; v[4 + e] = r.b[e]; }
+}
+__device__ __forceinline__ void ds_to_float(const DsRaw<bf16_t>& r, float* v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = bf_lo(r.v[e]); v[2 * e + 1] = bf_hi(r.v[e]); }
+}
+#ifndef DS_PREFETCH
+#define DS_PREFETCH (MODE != 2)   // the next four rows are requested before the current four are consumed.  Measured (C5 share): keeping
+#endif                            // the rows in their loaded form until they are consumed is what mattered - bf16 passes 96 -> 52-62 us with
+                                  // or without the early request (one batch of converted rows per wave left the loads exposed); the early
+                                  // request itself: -3 % in bf16, neutral in f32, +20 % on the given-logits form at d = 512 (so not there)
 template <typename T, int MODE>          // MODE 0: forward, 1: backward, 2: forward with the logits given (Ain = S [rows, C]; V unused)
 __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__ X, const float* __restrict__ V,
                                                            const float* __restrict__ Ain, const float* __restrict__ G,
@@ -583,8 +604,23 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
             if (MODE != 2 && c < C && k < d) load8<float>(v + (size_t)c * d + k, vr[c][st]);
         }
     const bool with_g = MODE == 1 && G != nullptr;
+    DsRaw<T> nxt[4][2];
+    auto request = [&](long rb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long row = min(rb + u, row1 - 1);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int k = st * 512 + lane * 8;
+                if (k < d) ds_load_raw(X + row * d + k, nxt[u][st]);
+                else ds_zero_raw(nxt[u][st]);
+            }
+        }
+    };
+    if (DS_PREFETCH) request(row0);
     for (long rb = row0; rb < row1; rb += 4) {
         float acc[4][2], xv[4][2][8], aw[4][2], gw[4][2];
+        if (!DS_PREFETCH) request(rb);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long row = min(rb + u, row1 - 1);
@@ -596,14 +632,9 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                 gw[u][c] = (with_g && live && c < C) ? G[row * C + c] : 0.f;
             }
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const int k = st * 512 + lane * 8;
-                if (k < d) load8<T>(X + row * d + k, xv[u][st]);
-                else
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[u][st][e] = 0.f;
-            }
+            for (int st = 0; st < 2; ++st) ds_to_float(nxt[u][st], xv[u][st]);
         }
+        if (DS_PREFETCH && rb + 4 < row1) request(rb + 4);
         if (MODE != 2) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
