@@ -18,6 +18,10 @@
 // layout (column sums for the bias gradients are taken there too, from the f32 values), round to bf16, transpose
 // through a wave-private LDS patch so that each lane owns 8 consecutive columns of a row and store 16 B per lane in
 // whole 128/256-byte row segments.  The forward variant emits the bit mask, so the backward reads 1/16 of the bytes of H for ReLU'.
+// CLAM-SB's epilogues (round 3): PG_GATE / PG_GATE_U take the two gate Linears interleaved in 16-row blocks, so that the lane that
+// holds a_d also holds b_d, and emit per-wave partial attention scores sum_d tanh(a_d) sigmoid(b_d) c_d (PG_GATE_U also stores the
+// pre-activations for the backward pass); the DROP template flag applies nn.Dropout from a seed inside the epilogue (behind the ReLU
+// of PG_BIAS_RELU, on the two gate branches of PG_GATE_U) - masks are never materialised.
 // Mask layout (M*N/8 bytes): blocks of 128 B per (32-row tile, 32-column group), tile-major.  A block is 64
 // 16-bit words, one per MFMA lane L = 16*((n&15)>>2) + (m&15); element (m, n) of the block is the lane's
 // accumulator value idx = 8*((m>>4)&1) + 4*((n>>4)&1) + (n&3) and sits at bit (7 - idx/2) + 8*(idx&1):
