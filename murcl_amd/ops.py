@@ -592,14 +592,20 @@ def refresh_views(owned):
             st["ver"] = (PARAM_EPOCH, st["ver"][1])
     if not todo:
         return
-    mkey = tuple(k for k, _ in todo)
-    merged = _MERGED.get(mkey)
-    if merged is None:
-        if len(_MERGED) >= 8:
-            _MERGED.clear()
-        merged = _MERGED[mkey] = (torch.cat([st["table"] for _, st in todo]) if len(todo) > 1 else todo[0][1]["table"],
-                                  sum(st["n"] for _, st in todo), max(st["max_tiles"] for _, st in todo))
-    check(_lib.lib().murcl_cast_batch(ptr(merged[0]), merged[1], merged[2], stream()), "cast_batch")
+    # the launch grid is (largest tile count) x (jobs): tables of many small jobs (CLAM's 128 row / column blocks of 16 tiles) are not
+    # merged with tables holding a large matrix (the GRU's 3072 x 1024: 3072 tiles) - 400 k almost all empty workgroups took 78 us
+    groups = {}
+    for item in todo:
+        groups.setdefault(item[1]["max_tiles"].bit_length() // 3, []).append(item)
+    for grp in groups.values():
+        mkey = tuple(k for k, _ in grp)
+        merged = _MERGED.get(mkey)
+        if merged is None:
+            if len(_MERGED) >= 16:
+                _MERGED.clear()
+            merged = _MERGED[mkey] = (torch.cat([st["table"] for _, st in grp]) if len(grp) > 1 else grp[0][1]["table"],
+                                      sum(st["n"] for _, st in grp), max(st["max_tiles"] for _, st in grp))
+        check(_lib.lib().murcl_cast_batch(ptr(merged[0]), merged[1], merged[2], stream()), "cast_batch")
     for _, st in todo:
         st["ver"] = (PARAM_EPOCH, tuple(p._version for p in st["keep"]))
 
