@@ -54,6 +54,10 @@ template <> __device__ __forceinline__ f32x4 k2_mma<float>(f32x4 a, f32x4 b, f32
 
 // Tile issue shared by forward and backward: LDS-DMA instruction ii = j*NW + wave copies 1 KiB =
 // one row (bf16) / half a row (f32); global base is wave-uniform (SGPRs), per-lane offset = lane*16.
+#ifndef K2_LOAD_NT
+#define K2_LOAD_NT 0              // 1: H tiles are loaded with the non-temporal policy (read once per pass: they should not displace the rows
+#endif                            // the pass has not reached yet from the Infinity Cache).  Measured in the step: K2 forward 54.3 -> 58.5 us - off
+#define K2_GLDS(base, voff, dst) do { if (K2_LOAD_NT) glds16_u_nt(base, voff, dst); else glds16_u(base, voff, dst); } while (0)
 template <typename T, int NWO = 0>
 __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N, unsigned slot_lds, int wave, int lane) {
     typedef K2<T, NWO> C_;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N
             const int ii = j * C_::NW + wave;
             const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
             const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
-            glds16_u(base + (size_t)(row * C_::ROWB + half * 1024), voff, slot_lds + row * C_::PADB + half * 1024);
+            K2_GLDS(base + (size_t)(row * C_::ROWB + half * 1024), voff, slot_lds + row * C_::PADB + half * 1024);
         }
     } else {
 #pragma unroll
@@ -75,8 +79,8 @@ __device__ __forceinline__ void k2_issue_tile(const T* bag_base, int row0, int N
             const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
             const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
             const int grow = min(row0 + row, N - 1);              // rows past N: clamped, masked by the caller
-            glds16_u((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, voff,
-                     slot_lds + row * C_::PADB + half * 1024);
+            K2_GLDS((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, voff,
+                    slot_lds + row * C_::PADB + half * 1024);
         }
     }
 }
@@ -89,7 +93,7 @@ __device__ __forceinline__ void k2_issue_piece(const T* bag_base, int row0, int 
     const int row = (sizeof(T) == 2) ? ii : (ii >> 1);
     const int half = (sizeof(T) == 2) ? 0 : (ii & 1);
     const int grow = min(row0 + row, N - 1);                      // rows past N: clamped, masked by the caller
-    glds16_u((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, lane * 16, slot_lds + row * C_::PADB + half * 1024);
+    K2_GLDS((const char*)bag_base + (size_t)grow * C_::ROWB + half * 1024, lane * 16, slot_lds + row * C_::PADB + half * 1024);
 }
 
 // Walks a workgroup's tile sequence without integer division in the loop: item = blockIdx + k*gridDim,
