@@ -96,6 +96,13 @@ extern "C" int murcl_subbag_select(const int* cluster_ids, const int* cluster_of
 }
 
 // ------------------------------------------------------------------------------------------ gather (+ mix-up)
+// A wave takes SG_ROWS consecutive output rows; with SG_ROWS > 1 their (wave-uniform) index / partner / lambda look-ups run as
+// independent scalar chains and all 2 x SG_ROWS source rows are requested before the first is consumed.  Measured (round 3, 64 x 8192
+// raw patches): 1 row per wave - many small waves, latency hidden by occupancy - is the fastest (T = 6 step 5.03-5.05 ms against
+// 5.09 with 4 rows and 5.21-5.34 with 8), so that is the default.
+#ifndef SG_ROWS
+#define SG_ROWS 1
+#endif
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __restrict__ feats,
                                                                 const long* __restrict__ bag_row_off,
@@ -103,40 +110,60 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
                                                                 const float* __restrict__ lam,
                                                                 const int* __restrict__ perm, TO* __restrict__ out,
                                                                 int VB, int B, int feat_size, int d) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;                   // output row (view * B + b) * feat_size + r
-    if (row >= (long)VB * feat_size) return;
-    const int vb = (int)(row / feat_size), r = (int)(row - (long)vb * feat_size);
-    const int b = vb % B, v0 = vb - b;                              // the bag's rows by b; its view's block of idx / lam / perm by v0
-    const int i0 = idx[(size_t)vb * feat_size + r];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long total = (long)VB * feat_size;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * SG_ROWS;    // first output row (view * B + b) * feat_size + r of this wave
+    if (row0 >= total) return;
     const bool mix = lam != nullptr;
-    const int pb = mix ? perm[vb] : b;                              // mix-up partner: a bag of the same view
-    const int i1 = mix ? idx[(size_t)(v0 + pb) * feat_size + r] : -1;
-    const float l0 = mix ? lam[vb] : 1.f, l1 = 1.f - l0;
-    const TI* s0 = feats + (bag_row_off[b] + (i0 < 0 ? 0 : i0)) * d;
-    const TI* s1 = feats + (bag_row_off[pb] + (i1 < 0 ? 0 : i1)) * d;
-    TO* o = out + row * d;
+    const TI* s0[SG_ROWS];
+    const TI* s1[SG_ROWS];
+    float l0[SG_ROWS];
+    bool on0[SG_ROWS], on1[SG_ROWS], live[SG_ROWS];
+#pragma unroll
+    for (int u = 0; u < SG_ROWS; ++u) {
+        const long row = min(row0 + u, total - 1);
+        live[u] = row0 + u < total;
+        const int vb = (int)(row / feat_size), r = (int)(row - (long)vb * feat_size);
+        const int b = vb % B, v0 = vb - b;                          // the bag's rows by b; its view's block of idx / lam / perm by v0
+        const int i0 = idx[(size_t)vb * feat_size + r];
+        const int pb = mix ? perm[vb] : b;                          // mix-up partner: a bag of the same view
+        const int i1 = mix ? idx[(size_t)(v0 + pb) * feat_size + r] : -1;
+        l0[u] = mix ? lam[vb] : 1.f;
+        on0[u] = i0 >= 0;
+        on1[u] = i1 >= 0;
+        s0[u] = feats + (bag_row_off[b] + (i0 < 0 ? 0 : i0)) * d;
+        s1[u] = feats + (bag_row_off[pb] + (i1 < 0 ? 0 : i1)) * d;
+    }
     for (int c = lane * 8; c < d; c += 512) {
-        float x[8], y[8], v[8];
+        float x[SG_ROWS][8], y[SG_ROWS][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = y[e] = 0.f;
-        if (i0 >= 0) load8<TI>(s0 + c, x);
-        if (mix) {
-            if (i1 >= 0) load8<TI>(s1 + c, y);
+        for (int u = 0; u < SG_ROWS; ++u) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = l0 * x[e];
-                const float cc = l1 * y[e];
-                v[e] = a + cc;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = x[e];
+            for (int e = 0; e < 8; ++e) x[u][e] = y[u][e] = 0.f;
+            if (on0[u]) load8<TI>(s0[u] + c, x[u]);
+            if (mix && on1[u]) load8<TI>(s1[u] + c, y[u]);
         }
-        store8<TO>(o + c, v);
+#pragma unroll
+        for (int u = 0; u < SG_ROWS; ++u) {
+            if (!live[u]) continue;
+            float v[8];
+            if (mix) {
+                const float l1 = 1.f - l0[u];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = l0[u] * x[u][e];
+                    const float cc = l1 * y[u][e];
+                    v[e] = a + cc;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x[u][e];
+            }
+            store8<TO>(out + (row0 + u) * d + c, v);
+        }
     }
 }
-
 extern "C" int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
                                        const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in,
                                        int dtype_out, hipStream_t stream) {
@@ -144,7 +171,7 @@ extern "C" int murcl_subbag_gather_mix(const void* feats, const long* bag_row_of
     if (d % 8) return -1;
     if ((lam == nullptr) != (perm == nullptr)) return -1;
     const long rows = (long)views * B * feat_size;
-    dim3 grid((unsigned)((rows + 3) / 4));
+    dim3 grid((unsigned)((rows + 4 * SG_ROWS - 1) / (4 * SG_ROWS)));
 #define GM(TI, TO) hipLaunchKernelGGL((subbag_gather_mix_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)feats, \
                                       bag_row_off, idx, lam, perm, (TO*)out, views * B, B, feat_size, d)
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32) GM(float, float);
