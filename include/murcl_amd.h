@@ -60,6 +60,21 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * the partial bias-gradient rows murcl_panel_gemm leaves in its colsum_ws when called without colsum_out - folded into the
  * launch that adds up the workspace (a small launch of its own on the other paths). */
 
+/* Several weight gradients C_g[N1_g,N2_g] += A_g[M_g,N1_g]^T . B_g[M_g,N2_g] as ONE launch of the square-tile kernel + ONE
+ * reduce launch: the backward of the three encoder nn.Linear layers of abmil.py:12-21 (and of CLAM-SB's fc + gate pair,
+ * clam.py:69-72), deferred until the last input gradient of the pass exists.  The (product, tile) pairs share one round of
+ * workgroups (one per CU), so the per-launch fixed costs and the partial-tile traffic are paid once.  `probs` is a HOST array of
+ * n <= 4 descriptors; colsum_part / colsum_rows / colsum_out as in murcl_gemm_tn_ws (colsum_out without colsum_part: column
+ * sums of A_g by their own launch).  Products the square-tile kernel does not take (see murcl_gemm_tn_ws), or a workspace below
+ * murcl_gemm_tn_grouped_workspace_bytes (0 = the group is not eligible), run one by one through murcl_gemm_tn_ws. */
+typedef struct murcl_tn_problem {
+    const void* A; const void* B; float* C;
+    const float* colsum_part; float* colsum_out;
+    int M, N1, N2, lda, ldb, ldc, colsum_rows;
+} murcl_tn_problem;
+long murcl_gemm_tn_grouped_workspace_bytes(const murcl_tn_problem* probs, int n, int dtype);
+int murcl_gemm_tn_grouped(const murcl_tn_problem* probs, int n, int dtype, float* ws, long ws_bytes, murcl_stream_t stream);
+
 /* Weight-stationary bf16 variant of murcl_gemm_nt for the patch-level layers (M = bags*patches rows, K in
  * {512,128}): same Linear forward / input-gradient as above (abmil.py:12-21,23-24 and their autograd), with
  * ReLU' taken from a 1-bit-per-element mask ([M,N/8] bytes; bit e of byte c <=> column 8c+e of the forward

@@ -22,6 +22,8 @@ SIGNATURES = {
     "murcl_gemm_tn": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "murcl_gemm_tn_workspace_bytes": [_I, _I, _I, _I],
     "murcl_gemm_tn_ws": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
+    "murcl_gemm_tn_grouped_workspace_bytes": [_P, _I, _I],
+    "murcl_gemm_tn_grouped": [_P, _I, _I, _P, _L, _P],
     "murcl_panel_gemm_colsum_rows": [_I, _I, _I, _I],
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
@@ -90,8 +92,16 @@ SIGNATURES = {
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L,
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
+
+
+
+class TnProblem(ctypes.Structure):
+    """murcl_tn_problem of include/murcl_amd.h (one product of murcl_gemm_tn_grouped)."""
+    _fields_ = [("A", _P), ("B", _P), ("C", _P), ("colsum_part", _P), ("colsum_out", _P),
+                ("M", _I), ("N1", _I), ("N2", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("colsum_rows", _I)]
+
 
 _lib = None
 

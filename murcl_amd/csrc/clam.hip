@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
     __shared__ float red[256][25];
     const int tid = threadIdx.x, G = D >> 3, RL = 256 / G;
     const int cg = tid % G, rl = tid / G;
-    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     const int W = (GATED ? 2 : 1) * D;
     const int off_a = IL ? 32 * (cg >> 1) + 8 * (cg & 1) : 8 * cg;
     const int off_b = IL ? off_a + 16 : D + 8 * cg;
@@ -143,6 +142,11 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) { w[e] = (rl < RL) ? wc[8 * cg + e] : 0.f; wacc[e] = csa[e] = csb[e] = 0.f; }
     const int L = 8 * HC * G;
+    // a workgroup walks row segments seg, seg + grid, ...: the grid is capped at the rows of `part`, so calls with more bags
+    // than that (stage 1 of the contrastive step: 2 T B = 1536 sub-bags) give a workgroup several segments, each inside one bag
+    const long nseg = (rows + rows_per_block - 1) / rows_per_block;
+    for (long seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const long r0 = seg * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float dm[HC > 0 ? 8 * HC : 1], mdm = 0.f;
     if (HC > 0 && rl < RL) {
         const long bag = r0 / rows_per_bag;
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void gated_score_bwd_kernel(const T* __restric
             }
         }
     }
+    }   // segments
     // reduce over the row lanes, then this workgroup's row of partial sums (part [grid][3D+1] = dwc | dbc | colsum of
     // dU; summed by gated_score_reduce_kernel - thousands of atomic adders on D addresses would serialise at the memory side)
 #pragma unroll
@@ -326,13 +331,16 @@ static int gs_bwd_launch(const void* U, const float* wc, const void* keep_a, con
             return -1;
         hc = L / (8 * G);
         if (hc != 1 && hc != 2 && hc != 4) return -1;
-        while (rows_per_bag % rpb) rpb += RL;              // a workgroup's rows lie in one bag
-        if ((rows + rpb - 1) / rpb > 1024) return -1;
+        // a segment's rows lie in one bag: the smallest divisor of rows_per_bag at or above the target (rows_per_bag itself
+        // at the latest, so the search ends for every shape - ADVICE r3: stepping by RL from above rows_per_bag never did)
+        if (rpb >= rows_per_bag) rpb = rows_per_bag;
+        else while (rows_per_bag % rpb) ++rpb;
     } else if (!ds) {
         return -1;
     }
     if (interleaved && (!gated || D % 16)) return -1;
-    const int grid = (int)((rows + rpb - 1) / rpb);
+    const long nseg = (rows + rpb - 1) / rpb;
+    const int grid = (int)(nseg < 1024 ? nseg : 1024);     // part_ws has 1024 rows; a workgroup walks segments grid apart
 #define GS_BWD(T, G_, IL_, HC_) hipLaunchKernelGGL((gated_score_bwd_kernel<T, G_, IL_, HC_>), dim3(grid), dim3(256), 0, st, (const T*)U, wc, (const T*)keep_a, (const T*)keep_b, ds, (T*)dU, part_ws, rows, D, (int)rpb, drop, (const T*)h, dM, Mp, Asm, rows_per_bag)
     if (hc == 1) GS_BWD(bf16_t, true, true, 1);
     else if (hc == 2) GS_BWD(bf16_t, true, true, 2);

@@ -1042,34 +1042,43 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     }
 }
 
-// ------------------------------------------------------------------------------------- TN, square-tile bf16 variant
+// ------------------------------------------------------------------------------------- TN, square-tile bf16 variant, grouped
 // 256 x 256 output tiles (N1 % 256 == 0, N2 % 256 == 0), split over the patch rows, partial tiles stored to a workspace
 // and summed by a second launch - no float atomics.  Against the 256 x 128 kernel above: every slab byte is moved
 // L2 -> LDS twice instead of three times (the big weight gradients are bound by that traffic: 1.6 GB at ~12 TB/s for
 // 537 MB of operands), each wave takes all 32 rows of a slab (no k-group halves, no final LDS reduction), and the
-// 64 MB of partial tiles leave as plain 64-byte row segments (~6 TB/s) instead of 32 MB of memory-side atomics (~1.3 TB/s).
+// partial tiles leave as plain 64-byte row segments (~6 TB/s) instead of memory-side atomics (~1.3 TB/s).
 // Eight waves as 2 (n1) x 4 (n2) wave tiles of 128 x 64; slabs of 32 patch rows x (256 + 256) columns = 32 KiB run
 // through a four-slot ring with three slabs in flight.
-#ifndef TN_SQ_ACC_LAYOUT
-#define TN_SQ_ACC_LAYOUT 0     // 1: partial tiles in accumulator layout (32 whole-KiB stores per wave instead of 128 four-byte ones) - measured r03: neutral (139-143 vs 141 us) and the reduce launch 1 us slower
-#endif
-__global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         float* __restrict__ part, int M, int N1, int N2, int lda,
-                                                         int ldb, int m_per_split, int nsplit) {
+//
+// GROUPED (round 4): one launch takes up to TN_MAXG products (the three encoder weight gradients of a backward pass, deferred
+// until the last input gradient exists: abmil.py:12-21).  The launch is ONE workgroup per CU whatever the group holds: the
+// (product, tile) pairs share the 256 CUs, each pair's patch rows cut into as many splits as fit (3 products x 4 tiles -> 21
+// splits of ~12.5 k rows = 391 slabs per workgroup, where three separate launches ran 64 splits of 128 slabs each).  What that
+// buys: ring fill, weight-less prologue, the partial-tile epilogue and the launch ramp are paid once per step instead of three
+// times (~24 us of every launch did not shrink with M, DESIGN r3), the partial tiles drop from 3 x 64 x 1 MiB to 21 x 3 MiB
+// written and read once, and two reduce launches disappear.  Partials stay f32.
+constexpr int TN_MAXG = 4, TN_MAXWG = 256;
+struct TnGroupArgs {
+    const bf16_t* A[TN_MAXG];
+    const bf16_t* B[TN_MAXG];
+    long part_off[TN_MAXG];          // float offset of product g's partial tiles [sp_g][N1_g * N2_g] in the workspace
+    int M[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG], lda[TN_MAXG], ldb[TN_MAXG], mps[TN_MAXG];
+    unsigned map[TN_MAXWG];          // workgroup -> (g << 28) | (tile << 16) | split; 0xFFFFFFFF: no work
+};
+__global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, float* __restrict__ ws) {
     constexpr int ROWS = 32, PITCH = 512, A_BYTES = ROWS * PITCH, SLOT = 2 * A_BYTES, NSLOT = 4;   // 32 KiB slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned code = ga.map[blockIdx.x];
+    if (code == 0xFFFFFFFFu) return;
+    const int g = code >> 28, tile = (code >> 16) & 0xFFF, sp = code & 0xFFFF;
+    const bf16_t* __restrict__ A = ga.A[g];
+    const bf16_t* __restrict__ B = ga.B[g];
+    const int M = ga.M[g], N1 = ga.N1[g], N2 = ga.N2[g], lda = ga.lda[g], ldb = ga.ldb[g], m_per_split = ga.mps[g];
+    float* __restrict__ part = ws + ga.part_off[g];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T1 = N1 >> 8, T2 = N2 >> 8, tiles = T1 * T2;
-    int tile, sp;
-    if ((nsplit & 7) == 0) {                      // all tiles of one M-split on one XCD (they share the slabs in its L2)
-        const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
-        sp = xcd + 8 * (w / tiles);
-        tile = w % tiles;
-    } else {
-        tile = blockIdx.x % tiles;
-        sp = blockIdx.x / tiles;
-    }
+    const int T1 = N1 >> 8;
     const int t1 = tile % T1, t2 = tile / T1;
     const int n10 = t1 << 8, n20 = t2 << 8;
     const int mbeg = sp * m_per_split, mend = min(M, mbeg + m_per_split);
@@ -1111,8 +1120,8 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
     // (j) -> offset ^ (i << 5) as in the kernel above
     unsigned abase, bbase;
     {
-        const int g = lane >> 4, u = lane & 15, rq = u >> 2, p4 = u & 3;
-        const int row = 8 * g + rq;
+        const int gq = lane >> 4, u = lane & 15, rq = u >> 2, p4 = u & 3;
+        const int row = 8 * gq + rq;
         const int ca = 2 * (wr * 8) + (p4 >> 1), cb = 2 * (wc * 4) + (p4 >> 1);
         abase = row * PITCH + ((ca ^ swz(row)) << 4) + ((p4 & 1) << 3);
         bbase = A_BYTES + row * PITCH + ((cb ^ swz(row)) << 4) + ((p4 & 1) << 3);
@@ -1161,17 +1170,8 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
-    // ---- this split's partial tile -> the workspace IN ACCUMULATOR LAYOUT: part[sp][tile][wave][i][j][lane][4], one 16-byte
-    // store per lane and (i, j) = 1 KiB contiguous per instruction (32 per wave).  In the matrix's own row-major layout the
-    // same values are 128 four-byte stores per wave, each touching four 64-byte row segments: a fifth of the kernel's vector
-    // memory instructions for 1/32 of its bytes.  tn_reduce_kernel walks the workspace in this order and scatters into C once.
-#if TN_SQ_ACC_LAYOUT
-    float* pt = part + (size_t)sp * N1 * N2 + ((size_t)tile * 8 + wave) * (8 * 4 * 64 * 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4*)(pt + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
-#else
+    // ---- this split's partial tile -> the workspace in the matrix's own row-major layout: part[sp][n1][n2] (the accumulator-
+    // layout alternative - 32 whole-KiB stores per wave instead of 128 four-byte ones - measured neutral in round 3)
     float* pt = part + (size_t)sp * N1 * N2;
     const int q4 = lane >> 4, r16 = lane & 15;
 #pragma unroll
@@ -1185,24 +1185,36 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const bf16_t* __restric
                 pt[(size_t)n1 * N2 + n2] = acc[i][j][r];
             }
         }
-#endif
 }
-// C[n] += sum_s part[s][n]   (n over N1*N2 elements as float4; eight splits of loads in flight per thread)
-// Blocks past the matrix part (cs_part given) add up [cs_rows][N1] partial column-sum rows into cs_out the same way: the
-// bias gradient of the layer, whose partial rows the input-gradient kernel left behind, rides along in this launch.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long n4,
-                                                        int nsplit, int N2, int ldc, const float* __restrict__ cs_part,
-                                                        int cs_rows, int N1, float* __restrict__ cs_out) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long mat_blocks = (n4 + 255) / 256;
-    if ((long)blockIdx.x >= mat_blocks) {
+// C_g[n] += sum_s part_g[s][n]   (n over N1*N2 elements as float4; four splits of loads in flight per thread), every product of
+// the group in ONE launch.  Blocks past the matrix parts add up [cs_rows][N1] partial column-sum rows into cs_out the same
+// way: the bias gradient of a layer, whose partial rows the input-gradient kernel left behind, rides along.
+struct TnReduceArgs {
+    float* C[TN_MAXG];
+    const float* cs_part[TN_MAXG];
+    float* cs_out[TN_MAXG];
+    long part_off[TN_MAXG], n4[TN_MAXG];
+    int nsplit[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG], ldc[TN_MAXG], cs_rows[TN_MAXG];
+    int blk0[TN_MAXG + 1];           // first matrix block of product g (blk0[n] = all matrix blocks)
+    int cs_blk0[TN_MAXG + 1];        // first column-sum block of product g, counted from blk0[n]
+    int n;
+};
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, const TnReduceArgs ra) {
+    int blk = blockIdx.x;
+    if (blk >= ra.blk0[ra.n]) {
         // column-sum blocks: 16 four-column groups x 16 row slices per block, every thread's rows in flight at once, the
         // slices meet in LDS (one serial pass over all rows per thread would take one memory round trip per few rows)
+        blk -= ra.blk0[ra.n];
+        int g = 0;
+        while (g + 1 < ra.n && blk >= ra.cs_blk0[g + 1]) ++g;
+        blk -= ra.cs_blk0[g];
+        const float* __restrict__ cs_part = ra.cs_part[g];
         if (cs_part == nullptr) return;
+        const int cs_rows = ra.cs_rows[g];
         __shared__ f32x4 red[256];
         const int cg = threadIdx.x & 15, rs = threadIdx.x >> 4;
-        const long j = ((long)blockIdx.x - mat_blocks) * 16 + cg;
-        const int ng = N1 / 4;
+        const long j = (long)blk * 16 + cg;
+        const int ng = ra.N1[g] / 4;
         f32x4 b0 = {0, 0, 0, 0}, b1 = b0;
         if (j < ng) {
             const f32x4* q = (const f32x4*)cs_part + j;
@@ -1223,13 +1235,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
             f32x4 t = red[cg];
 #pragma unroll
             for (int k = 1; k < 16; ++k) t += red[16 * k + cg];
-            f32x4* o = (f32x4*)cs_out + j;
+            f32x4* o = (f32x4*)ra.cs_out[g] + j;
             *o = *o + t;
         }
         return;
     }
+    int g = 0;
+    while (g + 1 < ra.n && blk >= ra.blk0[g + 1]) ++g;
+    const long i = (long)(blk - ra.blk0[g]) * 256 + threadIdx.x;
+    const long n4 = ra.n4[g];
     if (i >= n4) return;
-    const f32x4* p = (const f32x4*)part + i;
+    const int nsplit = ra.nsplit[g], N2 = ra.N2[g];
+    const f32x4* p = (const f32x4*)(ws + ra.part_off[g]) + i;
     f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
     int s = 0;
     for (; s + 3 < nsplit; s += 4) {
@@ -1238,42 +1255,78 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
     for (; s < nsplit; ++s) a0 += p[(size_t)s * n4];
     const f32x4 t = (a0 + a1) + (a2 + a3);
-#if TN_SQ_ACC_LAYOUT
-    // float4 i of the workspace = lane (i & 63) of block (ii, jj) of wave w of tile tl: rows n1 .. n1+3 of column n2
-    const int ln = (int)(i & 63), ij = (int)(i >> 6) & 31, w = (int)(i >> 11) & 7, tl = (int)(i >> 14);
-    const int T1 = N1 >> 8, t1 = tl % T1, t2 = tl / T1;
-    const int n1 = (t1 << 8) + (w >> 2) * 128 + (ij >> 2) * 16 + 4 * (ln >> 4);
-    const int n2 = (t2 << 8) + (w & 3) * 64 + (ij & 3) * 16 + (ln & 15);
-    float* c = C + (size_t)n1 * ldc + n2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[(size_t)r * ldc] += t[r];
-#else
     const long e = i * 4, row = e / N2, col = e % N2;
-    f32x4* c = (f32x4*)(C + row * ldc + col);
+    f32x4* c = (f32x4*)(ra.C[g] + row * ra.ldc[g] + col);
     *c = *c + t;
-#endif
-}
-static int tn_sq_plan(int M, int N1, int N2, int* splits_out, int* mps_out) {
-    const int tiles = (N1 / 256) * (N2 / 256);
-    int sp = (256 + tiles - 1) / tiles;                   // one 128 KiB-LDS workgroup per CU
-    sp = ((sp + 7) / 8) * 8;
-    while (sp > 8 && (long)(sp - 8) * 32 * 8 >= M) sp -= 8;             // keep >= 8 slabs per split
-    int mps = (M + sp - 1) / sp;
-    mps = ((mps + 31) / 32) * 32;
-    if ((long)mps * (sp - 1) >= M) sp = (M + mps - 1) / mps;
-    *splits_out = sp;
-    *mps_out = mps;
-    return tiles;
 }
 static bool tn_sq_ok(int M, int N1, int N2, int ldc, int dtype) {
     return dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 256 == 0 && M >= 16384 && ldc % 4 == 0;
 }
+// The launch plan of a group: rows per split and split count of every product such that all (product, tile, split) workgroups
+// fit one round of the chip (<= 256, one 128 KiB-LDS workgroup per CU) with about equal row counts, and the workgroup -> work
+// map: the tiles of one (product, split) read the same slabs, so they sit on ONE XCD (blocks b and b + 8k share an XCD's L2).
+struct TnPlan { int sp[TN_MAXG], mps[TN_MAXG], tiles[TN_MAXG]; long part_off[TN_MAXG]; long ws_floats; int wgs; };
+static bool tn_group_plan(int n, const int* M, const int* N1, const int* N2, TnPlan* pl, unsigned* map) {
+    if (n < 1 || n > TN_MAXG) return false;
+    long work = 0;
+    int pairs = 0;
+    for (int g = 0; g < n; ++g) {
+        pl->tiles[g] = (N1[g] / 256) * (N2[g] / 256);
+        if (pl->tiles[g] > 32) return false;              // a (product, split) group must fit an XCD's 32 workgroup slots
+        work += (long)pl->tiles[g] * M[g];
+        pairs += pl->tiles[g];
+    }
+    if (pairs > TN_MAXWG) return false;
+    long R = ((work + TN_MAXWG - 1) / TN_MAXWG + 31) / 32 * 32;        // rows per workgroup, whole slabs
+    if (R < 8 * 32) R = 8 * 32;                                        // keep >= 8 slabs per split
+    for (;; R += 32) {
+        int total = 0;
+        for (int g = 0; g < n; ++g) {
+            pl->sp[g] = (int)((M[g] + R - 1) / R);
+            total += pl->sp[g] * pl->tiles[g];
+        }
+        if (total <= TN_MAXWG) { pl->wgs = total; break; }
+    }
+    long off = 0;
+    for (int g = 0; g < n; ++g) {
+        long mps = ((M[g] + pl->sp[g] - 1) / pl->sp[g] + 31) / 32 * 32;  // even shares inside a product (R is only the cap)
+        pl->mps[g] = (int)mps;
+        pl->sp[g] = (int)((M[g] + mps - 1) / mps);
+        pl->part_off[g] = off;
+        off += (long)pl->sp[g] * N1[g] * N2[g];
+    }
+    pl->ws_floats = off;
+    if (!map) return true;
+    for (int b = 0; b < TN_MAXWG; ++b) map[b] = 0xFFFFFFFFu;
+    int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool fits = true;
+    // splits in the outer loop: the products' groups alternate, so every XCD streams a mix of all operands
+    int spmax = 0;
+    for (int g = 0; g < n; ++g) spmax = pl->sp[g] > spmax ? pl->sp[g] : spmax;
+    for (int s = 0; s < spmax && fits; ++s)
+        for (int g = 0; g < n; ++g) {
+            if (s >= pl->sp[g]) continue;
+            int x = 0;
+            for (int k = 1; k < 8; ++k) if (used[k] < used[x]) x = k;
+            if (used[x] + pl->tiles[g] > 32) { fits = false; break; }
+            for (int t = 0; t < pl->tiles[g]; ++t) map[x + 8 * (used[x] + t)] = ((unsigned)g << 28) | ((unsigned)t << 16) | (unsigned)s;
+            used[x] += pl->tiles[g];
+        }
+    if (!fits) {                                         // fragmentation: plain linear fill (correct, tiles may straddle XCDs)
+        int b = 0;
+        for (int bb = 0; bb < TN_MAXWG; ++bb) map[bb] = 0xFFFFFFFFu;
+        for (int g = 0; g < n; ++g)
+            for (int s = 0; s < pl->sp[g]; ++s)
+                for (int t = 0; t < pl->tiles[g]; ++t) map[b++] = ((unsigned)g << 28) | ((unsigned)t << 16) | (unsigned)s;
+    }
+    return true;
+}
 // bytes of workspace murcl_gemm_tn_ws wants for this shape (0: the shape takes the atomics path, no workspace needed)
 extern "C" long murcl_gemm_tn_workspace_bytes(int M, int N1, int N2, int dtype) {
     if (!tn_sq_ok(M, N1, N2, N2, dtype)) return 0;
-    int sp, mps;
-    tn_sq_plan(M, N1, N2, &sp, &mps);
-    return (long)sp * N1 * N2 * 4;
+    TnPlan pl;
+    if (!tn_group_plan(1, &M, &N1, &N2, &pl, nullptr)) return 0;
+    return pl.ws_floats * 4;
 }
 
 extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int dtype, int accumulate, hipStream_t s);
@@ -1441,6 +1494,46 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     return MURCL_CHECK_LAUNCH();
 }
 
+// One launch of the grouped square-tile kernel + one reduce launch for n eligible products (tn_sq_ok, 16-byte aligned rows).
+typedef murcl_tn_problem TnProblem;     // include/murcl_amd.h
+static int tn_sq_launch(const TnProblem* pr, int n, float* ws, hipStream_t stream) {
+    int M[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG];
+    for (int g = 0; g < n; ++g) { M[g] = pr[g].M; N1[g] = pr[g].N1; N2[g] = pr[g].N2; }
+    TnPlan pl;
+    TnGroupArgs ga;
+    if (!tn_group_plan(n, M, N1, N2, &pl, ga.map)) return -1;
+    TnReduceArgs ra;
+    ra.n = n;
+    int blk = 0, csb = 0;
+    for (int g = 0; g < TN_MAXG; ++g) {
+        const int h = g < n ? g : 0;                          // unused slots repeat product 0 (never indexed)
+        ga.A[g] = (const bf16_t*)pr[h].A; ga.B[g] = (const bf16_t*)pr[h].B;
+        ga.M[g] = pr[h].M; ga.N1[g] = pr[h].N1; ga.N2[g] = pr[h].N2; ga.lda[g] = pr[h].lda; ga.ldb[g] = pr[h].ldb;
+        ga.mps[g] = pl.mps[h]; ga.part_off[g] = pl.part_off[h];
+        ra.C[g] = pr[h].C; ra.cs_part[g] = pr[h].colsum_part; ra.cs_out[g] = pr[h].colsum_out; ra.cs_rows[g] = pr[h].colsum_rows;
+        ra.part_off[g] = pl.part_off[h]; ra.n4[g] = (long)pr[h].N1 * pr[h].N2 / 4; ra.nsplit[g] = pl.sp[h];
+        ra.N1[g] = pr[h].N1; ra.N2[g] = pr[h].N2; ra.ldc[g] = pr[h].ldc;
+        if (g < n) {
+            ra.blk0[g] = blk; blk += (int)((ra.n4[g] + 255) / 256);
+            ra.cs_blk0[g] = csb; csb += pr[g].colsum_part ? (pr[g].N1 / 4 + 15) / 16 : 0;
+        }
+    }
+    for (int g = n; g <= TN_MAXG; ++g) { ra.blk0[g] = blk; ra.cs_blk0[g] = csb; }
+    auto k = gemm_tn_sq_kernel;
+    constexpr int LDS = 4 * 32768;
+    static MurclOncePerDevice once;
+    if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
+    hipLaunchKernelGGL(k, dim3(TN_MAXWG), dim3(512), LDS, stream, ga, ws);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blk + csb)), dim3(256), 0, stream, (const float*)ws, ra);
+    return MURCL_CHECK_LAUNCH();
+}
+static bool tn_sq_problem_ok(const TnProblem& p, int dtype) {
+    return tn_sq_ok(p.M, p.N1, p.N2, p.ldc, dtype) && (p.lda * 2) % 16 == 0 && (p.ldb * 2) % 16 == 0 &&
+           (!p.colsum_part || (p.colsum_out && p.colsum_rows > 0));
+}
+
 // murcl_gemm_tn with a caller-provided workspace: the big bf16 weight gradients (N1, N2 multiples of 256, M >= 16384) run
 // on 256 x 256 tiles with the split partial sums stored to `ws` and added to C by a reduce launch (no float atomics);
 // every other shape, or a workspace that is too small, falls through to murcl_gemm_tn.
@@ -1449,8 +1542,8 @@ extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, i
                                 int colsum_rows, hipStream_t stream) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
     if (colsum_part && (!colsum_out || colsum_rows <= 0 || N1 % 4)) return -1;
-    if (splits > 0 || !ws || !tn_sq_ok(M, N1, N2, ldc, dtype) || (lda * 2) % 16 || (ldb * 2) % 16 ||
-        ws_bytes < murcl_gemm_tn_workspace_bytes(M, N1, N2, dtype)) {
+    const long need = murcl_gemm_tn_workspace_bytes(M, N1, N2, dtype);
+    if (splits > 0 || !ws || !need || !tn_sq_ok(M, N1, N2, ldc, dtype) || (lda * 2) % 16 || (ldb * 2) % 16 || ws_bytes < need) {
         if (colsum_part) {                      // the partial rows are added up by their own small launch
             const int rc = murcl_colsum(colsum_part, colsum_out, colsum_rows, N1, N1, MURCL_DTYPE_F32, 1, stream);
             if (rc) return rc;
@@ -1458,23 +1551,50 @@ extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, i
         }
         return murcl_gemm_tn(A, B, C, M, N1, N2, lda, ldb, ldc, dtype, splits, colsum_out, stream);
     }
-    int sp, mps;
-    const int tiles = tn_sq_plan(M, N1, N2, &sp, &mps);
     if (colsum_out && !colsum_part) {
         const int rc = murcl_colsum(A, colsum_out, M, N1, lda, dtype, 1, stream);
         if (rc) return rc;
     }
-    auto k = gemm_tn_sq_kernel;
-    constexpr int LDS = 4 * 32768;
-    static MurclOncePerDevice once;
-    if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
-    hipLaunchKernelGGL(k, dim3(tiles * sp), dim3(512), LDS, stream, (const bf16_t*)A, (const bf16_t*)B, ws, M, N1, N2, lda, ldb,
-                       mps, sp);
-    int rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    const long n4 = (long)N1 * N2 / 4;
-    const unsigned cs_blocks = colsum_part ? (unsigned)((N1 / 4 + 15) / 16) : 0u;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n4 + 255) / 256) + cs_blocks), dim3(256), 0, stream, ws, C, n4, sp, N2, ldc,
-                       colsum_part, colsum_rows, N1, colsum_out);
-    return MURCL_CHECK_LAUNCH();
+    const TnProblem p{A, B, C, colsum_part, colsum_part ? colsum_out : nullptr, M, N1, N2, lda, ldb, ldc, colsum_rows};
+    return tn_sq_launch(&p, 1, ws, stream);
+}
+
+// Several weight gradients C_g[N1_g,N2_g] += A_g[M_g,N1_g]^T B_g[M_g,N2_g] in ONE launch of the square-tile kernel + ONE reduce
+// launch (the three encoder layers of a backward pass: abmil.py:12-21; CLAM-SB's fc + gate pair: clam.py:69-72).  colsum_part /
+// colsum_rows / colsum_out per product as in murcl_gemm_tn_ws (colsum_out without colsum_part: the column sums of A_g by their
+// own launch).  Products the square-tile kernel does not take, or a workspace below murcl_gemm_tn_grouped_workspace_bytes, run one
+// by one through murcl_gemm_tn_ws with the same workspace.
+extern "C" long murcl_gemm_tn_grouped_workspace_bytes(const TnProblem* pr, int n, int dtype) {
+    if (n < 1 || n > TN_MAXG) return 0;
+    int M[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG];
+    for (int g = 0; g < n; ++g) {
+        if (!tn_sq_problem_ok(pr[g], dtype)) return 0;
+        M[g] = pr[g].M; N1[g] = pr[g].N1; N2[g] = pr[g].N2;
+    }
+    TnPlan pl;
+    if (!tn_group_plan(n, M, N1, N2, &pl, nullptr)) return 0;
+    return pl.ws_floats * 4;
+}
+extern "C" int murcl_gemm_tn_grouped(const TnProblem* pr, int n, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const long need = (n <= TN_MAXG) ? murcl_gemm_tn_grouped_workspace_bytes(pr, n, dtype) : 0;
+    if (!need || !ws || ws_bytes < need) {
+        for (int g = 0; g < n; ++g) {
+            const TnProblem& p = pr[g];
+            const int rc = murcl_gemm_tn_ws(p.A, p.B, p.C, p.M, p.N1, p.N2, p.lda, p.ldb, p.ldc, dtype, 0, p.colsum_out, ws, ws_bytes,
+                                            p.colsum_part, p.colsum_rows, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    TnProblem q[TN_MAXG];
+    for (int g = 0; g < n; ++g) {
+        q[g] = pr[g];
+        if (q[g].colsum_out && !q[g].colsum_part) {
+            const int rc = murcl_colsum(q[g].A, q[g].colsum_out, q[g].M, q[g].N1, q[g].lda, dtype, 1, stream);
+            if (rc) return rc;
+            q[g].colsum_out = nullptr;
+        }
+    }
+    return tn_sq_launch(q, n, ws, stream);
 }

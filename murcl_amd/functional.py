@@ -43,6 +43,7 @@ _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B s
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
 _DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
+_GROUP_WGRAD = _os.environ.get("MURCL_GROUP_WGRAD", "1") == "1"   # dev A/B switch: the three encoder weight gradients as one grouped launch
 _FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
 
 
@@ -91,6 +92,22 @@ def _wgrad(dy, x, w, b=None, bias_parts=None):
         return None
     assert bias_parts is None
     return ops.gemm_tn(dy, x)
+
+
+def _wgrad_group(items):
+    """[(dy, x, w, b, bias_parts)] -> [dW or None]: ``_wgrad`` for several layers in one grouped launch (``ops.gemm_tn_grouped``)."""
+    probs = []
+    for dy, x, w, b, parts in items:
+        if _direct(w):
+            probs.append((dy, x, w.grad, b.grad.view(-1) if parts is not None else None, parts))
+            _touch(w)
+            if parts is not None:
+                _touch(b)
+        else:
+            assert parts is None
+            probs.append((dy, x, None, None, None))
+    Cs = ops.gemm_tn_grouped(probs)
+    return [None if _direct(it[2]) else C for it, C in zip(items, Cs)]
 
 
 # Deferred weight gradients.  A recurrent head that is stepped T times per optimizer step (the MuRCL loop: T patch steps
@@ -329,18 +346,28 @@ class ABMILFn(torch.autograd.Function):
             # directly into the flat gradient buffer the rows are added up inside the weight gradient's reduce launch
             fold = lambda w, b: _FOLD_BIAS and _direct(w) and _direct(b)      # noqa: E731
             f3, f2, f1 = fold(w3, b3), fold(w2, b2), fold(w1, b1)
+            # the three weight gradients wait until the last input gradient exists and run as ONE grouped launch (one round of
+            # workgroups, one reduce launch: ops.gemm_tn_grouped) unless a data-parallel reducer asked for per-layer milestones
+            grouped = _GROUP_WGRAD and _MILESTONE is None
             dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N,
                                          colsum=True, colsum_into=None if f3 else into(b3), colsum_defer=f3)
-            dw3 = _wgrad(dz3, h2, w3, b3, db3 if f3 else None)
-            db3 = None if f3 else db3
-            _final(w3, b3)
+            if not grouped:
+                dw3 = _wgrad(dz3, h2, w3, b3, db3 if f3 else None)
+                _final(w3, b3)
             dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True,
                                          colsum_into=None if f2 else into(b2), colsum_defer=f2)
-            dw2 = _wgrad(dz2, h1, w2, b2, db2 if f2 else None)
-            db2 = None if f2 else db2
-            _final(w2, b2)
+            if not grouped:
+                dw2 = _wgrad(dz2, h1, w2, b2, db2 if f2 else None)
+                _final(w2, b2)
             dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True,
                                          colsum_into=None if f1 else into(b1), colsum_defer=f1)
+            if grouped:
+                dw3, dw2, dw1 = _wgrad_group([(dz3, h2, w3, b3, db3 if f3 else None), (dz2, h1, w2, b2, db2 if f2 else None),
+                                              (dz1, x2, w1, b1, db1 if f1 else None)])
+                _final(w3, b3, w2, b2, w1, b1)
+            db3, db2 = None if f3 else db3, None if f2 else db2
+            if grouped:
+                db1 = None if f1 else db1
         else:
             dz3, ws = ops.gemm_nt(dT, wat, epi=ops.EPI_RANK1_MASK, mask=h3, rowscale=A.view(-1),
                                   rank1=dM, rows_per_bag=N, colsum=True)
@@ -353,7 +380,9 @@ class ABMILFn(torch.autograd.Function):
             _final(w2, b2)
             dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
             db1 = _bgrad(ws, b1)
-        if m3 is not None and f1:
+        if m3 is not None and grouped:
+            pass
+        elif m3 is not None and f1:
             dw1, db1 = _wgrad(dz1, x2, w1, b1, db1), None
         else:
             dw1 = _wgrad(dz1, x2, w1)
@@ -914,7 +943,9 @@ class CLAMFn(torch.autograd.Function):
             # ds_n = A_n (h_n . dM - M . dM) needs no reduction over the bag; U / dU in the interleaved column order of the forward
             dU, dwc, dbc, dbab = ops.gated_score_bwd_il(U, wc.reshape(-1).contiguous(), ka, kb, h=h, dM=dM, Mp=M, A=A.view(-1),
                                                         rows_per_bag=N)
-            dwab = ops.gemm_tn(dU, h).view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)   # rows back in [Wa; Wb] order
+            dwab = None                                                               # with dw1 below: one grouped launch
+            if not _GROUP_WGRAD:
+                dwab = ops.gemm_tn(dU, h).view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)   # rows back in [Wa; Wb] order
             wab_t = ctx.wab_t                                                         # [L, 2D] interleaved columns, as dU's
         else:
             # pooling: dA[n] = h[n].dM ; soft-max backward ; gate backward
@@ -953,7 +984,11 @@ class CLAMFn(torch.autograd.Function):
             ops.scatter_add_rows_masked(dz1, h, rows_all, g, write_back=db1 is not None)
             if db1 is not None:
                 ops.colsum(g, out=db1, accumulate=True)                                  # [B*2k, L] f32: the rows just added
-        dw1 = ops.gemm_tn(dz1, x2)
+        if dwab is None:                         # gate + first-layer weight gradients (clam.py:69-72) share one round of workgroups
+            dwab, dw1 = ops.gemm_tn_grouped([(dU, h, None, None, None), (dz1, x2, None, None, None)])
+            dwab = dwab.view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)         # rows back in [Wa; Wb] order
+        else:
+            dw1 = ops.gemm_tn(dz1, x2)
         if db1 is None:
             db1 = ops.colsum(dz1)
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75

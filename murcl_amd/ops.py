@@ -324,6 +324,42 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3
     return C
 
 
+def gemm_tn_grouped(problems):
+    """Several weight gradients in ONE launch (+ one reduce launch): ``problems`` = list of (A [M,N1], B [M,N2], out or None,
+    colsum_into or None, colsum_parts or None) with the meanings of ``gemm_tn``; returns the list of C tensors.  bf16 products
+    with N1, N2 multiples of 256 and M >= 16384 share one round of workgroups (murcl_gemm_tn_grouped); anything else, or more
+    than four products, runs through ``gemm_tn`` one by one."""
+    eligible = (_TN_SQ and 1 < len(problems) <= 4 and all(
+        A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0 and A.shape[0] >= 16384
+        and A.shape[0] == B.shape[0] and (cp is None or ci is not None) for A, B, _, ci, cp in problems))
+    if not eligible:
+        return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp in problems]
+    n = len(problems)
+    arr = (_lib.TnProblem * n)()
+    keep, Cs = [], []
+    for g, (A, B, out, ci, cp) in enumerate(problems):
+        _need_cuda(A, B)
+        A, B = _c(A), _c(B)
+        M, N1 = A.shape
+        N2 = B.shape[1]
+        C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
+        assert C.dtype == torch.float32 and C.is_contiguous() and tuple(C.shape) == (N1, N2)
+        if ci is not None:
+            assert ci.dtype == torch.float32 and ci.is_contiguous() and ci.numel() == N1
+        keep.append((A, B, cp))
+        Cs.append(C)
+        arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), ptr(cp[0]) if cp else None, ptr(ci), M, N1, N2, N1, N2, N2, cp[1] if cp else 0)
+    wsb = _lib.lib().murcl_gemm_tn_grouped_workspace_bytes(arr, n, BF16)
+    if not wsb:
+        return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp in problems]
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=Cs[0].device)
+    with _span(lambda: (f"gemm_tn_sq_grouped{n}<bf16>",
+               dict(flops=sum(2.0 * A.shape[0] * A.shape[1] * B.shape[1] for A, B, _ in keep),
+                    bytes=sum(A.shape[0] * (A.shape[1] + B.shape[1]) * 2 + A.shape[1] * B.shape[1] * 4 for A, B, _ in keep)))):
+        check(_lib.lib().murcl_gemm_tn_grouped(arr, n, BF16, ptr(ws), wsb, stream()), "gemm_tn_grouped")
+    return Cs
+
+
 def pool_chunks(B, N, dtype_code):
     cr, nc = ctypes.c_int(), ctypes.c_int()
     _lib.lib().murcl_abmil_pool_workspace(B, N, dtype_code, ctypes.byref(cr), ctypes.byref(nc))

@@ -53,3 +53,41 @@ def test_unsupported_arguments_are_rejected_without_launching():
                                   _lib.F32, 1, None) == -1          # L != 512
     assert L.murcl_ntxent_fwd_bwd(None, 7, 128, 1.0, None, None, None, 0, 1, 0, None, None) == -1   # odd n
     assert L.murcl_ntxent_fwd_bwd(None, 24, 128, 1.0, None, None, None, 0, 1, 5, None, None) == -1  # n not a multiple of 2*pair_stride
+
+
+def test_grouped_weight_gradient_plan_runs_on_host():
+    """murcl_gemm_tn_grouped_workspace_bytes is pure host arithmetic: the three encoder weight gradients of BASELINE configs[1]
+    (262144 rows, 512 x 512 each) share ONE round of 256 workgroups = 12 (product, tile) pairs x 21 row splits, i.e. 21 x 3 MiB
+    of partial tiles where three separate launches wrote 3 x 64 MiB; an ineligible member makes the group ineligible (0)."""
+    from murcl_amd import _lib
+    L = _lib.lib()
+
+    def probs(*shapes):
+        arr = (_lib.TnProblem * len(shapes))()
+        for g, (M, N1, N2) in enumerate(shapes):
+            arr[g] = _lib.TnProblem(None, None, None, None, None, M, N1, N2, N1, N2, N2, 0)
+        return arr
+
+    one = L.murcl_gemm_tn_workspace_bytes(262144, 512, 512, _lib.BF16)
+    assert one == 64 * 512 * 512 * 4
+    three = L.murcl_gemm_tn_grouped_workspace_bytes(probs(*[(262144, 512, 512)] * 3), 3, _lib.BF16)
+    assert three == 3 * 21 * 512 * 512 * 4
+    # unequal row counts: the longer product gets more splits; every split keeps >= 8 slabs of 32 rows
+    two = L.murcl_gemm_tn_grouped_workspace_bytes(probs((65536, 512, 512), (262144, 512, 512)), 2, _lib.BF16)
+    assert 0 < two <= 64 * 512 * 512 * 4
+    assert L.murcl_gemm_tn_grouped_workspace_bytes(probs((262144, 512, 512), (262144, 128, 512)), 2, _lib.BF16) == 0
+    assert L.murcl_gemm_tn_grouped_workspace_bytes(probs((262144, 512, 512)), 1, _lib.F32) == 0
+    assert L.murcl_gemm_tn_grouped_workspace_bytes(probs(*[(262144, 512, 512)] * 4), 5, _lib.BF16) == 0
+
+
+def test_gate_backward_launcher_returns_for_more_bags_than_partial_rows():
+    """with more than 1024 bags the one-pass gate backward's host code looped forever looking for a rows-per-block
+    that divides the bag (stage 1 of the contrastive step with CLAM_SB sends 2 T B = 1536 sub-bags).  No GPU is needed to see it
+    return: the launch itself fails or succeeds, the planning loop must end."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from murcl_amd import _lib; L = _lib.lib();"
+            "rc = L.murcl_gated_score_bwd_il(None, None, None, None, None, None, None, ctypes.c_void_p(16), 1536 * 1024, 256, _lib.BF16, 0.0, 0, 0,"
+            " ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 512, 1024, None); print('returned', rc)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "returned" in r.stdout, r.stderr[-500:]

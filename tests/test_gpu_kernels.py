@@ -244,6 +244,47 @@ def test_panel_dgrad_partial_bias_rows_fold_into_the_weight_gradient(M):
     _close(gb, b0.double() + cs_ref.double().cpu(), rtol=1e-5, atol=1e-4 * math.sqrt(M), msg="db")
 
 
+@pytest.mark.parametrize("shapes", [[(65536, 512, 512)] * 3, [(16384 + 37, 512, 512), (40000, 256, 512), (16384, 512, 256)],
+                                    [(32768, 512, 512), (32768, 512, 512)], [(20000, 512, 512)] * 4,
+                                    [(16384, 512, 512), (16384, 128, 512)]])
+def test_grouped_weight_gradients_equal_the_single_launches(shapes):
+    """murcl_gemm_tn_grouped (one round of workgroups for several products, one reduce launch) against float64 A^T B and against
+    ops.gemm_tn per product: accumulation into existing gradients, the bias gradient from partial rows (one product) and from
+    the column sums of A (another), ragged row counts, unequal shapes; an ineligible member sends the group down the single path."""
+    from murcl_amd import ops
+    dev = _dev()
+    probs, refs = [], []
+    for g, (M, N1, N2) in enumerate(shapes):
+        A = _rand(21, f"A{g}{M}{N1}", (M, N1), 0.5).bfloat16()
+        B = _rand(21, f"B{g}{M}{N2}", (M, N2)).bfloat16()
+        W0, b0 = _rand(21, f"w{g}", (N1, N2)), _rand(21, f"b{g}", (N1,))
+        parts_rows = _rand(21, f"p{g}", (37, N1)) if g == 0 else None
+        out = W0.clone().to(dev) if g != 1 else None
+        cs = b0.clone().to(dev) if g in (0, 2) else None
+        parts = (parts_rows.to(dev), 37) if g == 0 else None
+        probs.append((A.to(dev), B.to(dev), out, cs, parts))
+        dW = A.double().t() @ B.double() + (W0.double() if g != 1 else 0.0)
+        db = None
+        if g == 0:
+            db = b0.double() + parts_rows.double().sum(0)
+        elif g == 2:
+            db = b0.double() + A.double().sum(0)
+        refs.append((dW, db, M))
+    Cs = ops.gemm_tn_grouped(probs)
+    for g, ((dW, db, M), C, pr) in enumerate(zip(refs, Cs, probs)):
+        s = math.sqrt(M)
+        assert _rel_fro(C, dW) < 2e-3, (g, _rel_fro(C, dW))
+        _close(C, dW, rtol=1e-4, atol=2e-2 * s, msg=f"dW{g}")
+        if pr[2] is not None:
+            assert C.data_ptr() == pr[2].data_ptr()
+        if db is not None:
+            _close(pr[3], db, rtol=1e-4, atol=1e-3 * s, msg=f"db{g}")
+        # the same product alone: same tiles and MFMA order inside a split, another split count -> f32 summation order only
+        single = ops.gemm_tn(pr[0], pr[1])
+        base = C.double().cpu() - (dW - pr[0].double().cpu().t() @ pr[1].double().cpu())
+        assert _rel_fro(base, single.double().cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N", [(32, 128), (4096, 512), (96, 1024)])
 def test_dropout_applied_in_place_with_the_mask_never_materialised(dtype, M, N):
@@ -358,7 +399,7 @@ def test_panel_gate_u_scores_and_pre_activations_from_one_gemm(M, drop):
 
 
 @pytest.mark.parametrize("drop", [False, True])
-@pytest.mark.parametrize("B,N", [(2, 64), (3, 2048), (5, 96)])
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 2048), (5, 96), (1100, 64), (1536, 40)])      # > 1024 bags: a workgroup walks several bags
 def test_gate_backward_in_one_pass_over_interleaved_pre_activations(B, N, drop):
     """murcl_gated_score_bwd_il: (a) with ds given = murcl_gated_score_bwd on the de-interleaved tensors, bit for bit; (b) with ds
     derived in the pass (ds_n = A_n (h_n . dM - M . dM)) = rows_dot -> softmax_rows_bwd -> gated_score_bwd, to f32 rounding."""

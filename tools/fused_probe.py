@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Dev tool: check and time the fused-encoder prototype (csrc/fused_encoder_probe.hip) at the BASELINE configs[1] shape.
+"""Dev tool: check and time the fused-encoder prototype (tools/_abl/fused_encoder_probe.hip) at the BASELINE configs[1] shape.
 
     python tools/fused_probe.py            # correctness vs torch (small M), then timings at M = 262144
 """
@@ -13,7 +13,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from murcl_amd import _lib  # noqa: E402
 
-L = ctypes.CDLL(_lib.LIB_PATH)
+import subprocess
+PROBES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_abl", "lib", "probes.so")
+if not os.path.exists(PROBES):
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_abl", "build_probes.py")])
+L = ctypes.CDLL(PROBES)          # lab equipment: its own library, not part of libmurcl_amd.so
 f = L.murcl_debug_fused_encoder
 f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 f.restype = ctypes.c_int

@@ -3,7 +3,11 @@
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from murcl_amd import _lib
-L = ctypes.CDLL(_lib.LIB_PATH)
+import subprocess
+PROBES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_abl", "lib", "probes.so")
+if not os.path.exists(PROBES):
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_abl", "build_probes.py")])
+L = ctypes.CDLL(PROBES)          # lab equipment: its own library, not part of libmurcl_amd.so
 f = L.murcl_debug_stream_probe
 f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 nbytes = 512 << 20
