@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
 // buys: ring fill, weight-less prologue, the partial-tile epilogue and the launch ramp are paid once per step instead of three
 // times (~24 us of every launch did not shrink with M, DESIGN r3), the partial tiles drop from 3 x 64 x 1 MiB to 21 x 3 MiB
 // written and read once, and two reduce launches disappear.  Partials stay f32.
+#ifndef TN_SQ_NSLOT
+#define TN_SQ_NSLOT 4          // ring slots of 32 KiB (5 = all 160 KiB of LDS, four slabs in flight)
+#endif
 constexpr int TN_MAXG = 4, TN_MAXWG = 256;
 struct TnGroupArgs {
     const bf16_t* A[TN_MAXG];
@@ -1067,7 +1070,7 @@ struct TnGroupArgs {
     unsigned map[TN_MAXWG];          // workgroup -> (g << 28) | (tile << 16) | split; 0xFFFFFFFF: no work
 };
 __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, float* __restrict__ ws) {
-    constexpr int ROWS = 32, PITCH = 512, A_BYTES = ROWS * PITCH, SLOT = 2 * A_BYTES, NSLOT = 4;   // 32 KiB slots
+    constexpr int ROWS = 32, PITCH = 512, A_BYTES = ROWS * PITCH, SLOT = 2 * A_BYTES, NSLOT = TN_SQ_NSLOT;   // 32 KiB slots
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned code = ga.map[blockIdx.x];
     if (code == 0xFFFFFFFFu) return;
@@ -1133,14 +1136,15 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
-    const int pre = min(3, nslab);
+    const int pre = min(NSLOT - 1, nslab);
     for (int s = 0; s < pre; ++s) stage(s);
     for (int s = 0; s < nslab; ++s) {
-        // slab s landed (up to two younger slabs stay in flight: 4 LDS-DMA ops per thread and slab), visible to all waves;
-        // then the slot of slab s-1 - every wave has its fragments in registers - takes slab s+3
-        if (s + 2 < nslab) { WAIT_VMCNT(8); } else if (s + 1 < nslab) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
+        // slab s landed (up to NSLOT - 2 younger slabs stay in flight: 4 LDS-DMA ops per thread and slab), visible to all waves;
+        // then the slot of slab s-1 - every wave has its fragments in registers - takes slab s + NSLOT - 1
+        if (NSLOT >= 5 && s + 3 < nslab) { WAIT_VMCNT(12); }
+        else if (s + 2 < nslab) { WAIT_VMCNT(8); } else if (s + 1 < nslab) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
         LDS_BARRIER();
-        if (s + 3 < nslab) stage(s + 3);
+        if (s + NSLOT - 1 < nslab) stage(s + NSLOT - 1);
         char* slab = smem + (s % NSLOT) * SLOT;
         const int rows_here = min(ROWS, mend - (mbeg + (nslab - 1 - s) * ROWS));
         if (rows_here < ROWS) {                                              // ragged tail of the split: zero the missing rows
@@ -1520,7 +1524,7 @@ static int tn_sq_launch(const TnProblem* pr, int n, float* ws, hipStream_t strea
     }
     for (int g = n; g <= TN_MAXG; ++g) { ra.blk0[g] = blk; ra.cs_blk0[g] = csb; }
     auto k = gemm_tn_sq_kernel;
-    constexpr int LDS = 4 * 32768;
+    constexpr int LDS = TN_SQ_NSLOT * 32768;
     static MurclOncePerDevice once;
     if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
     hipLaunchKernelGGL(k, dim3(TN_MAXWG), dim3(512), LDS, stream, ga, ws);

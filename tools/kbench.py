@@ -127,6 +127,11 @@ def main():
         "wrowsum_f32_d1024": (lambda: ops.weighted_rowsum(Xf, A2), Xf.numel() * 4, 0),
         "rows_dot_wsum_f32_d1024": (lambda: ops.rows_dot_wsum(Xf, V2, A2), Xf.numel() * 4, 0),
     })
+    G3 = [torch.zeros((512, 512), device=dev) for _ in range(3)]
+    cases.update({
+        "tn_g3": (lambda: ops.gemm_tn_grouped([(X, H, G3[0], None, None), (Rb, X, G3[1], None, None), (H, Rb, G3[2], None, None)]),
+                  3 * gbytes, 3 * 2.0 * M * 512 * 512),
+    })
     for name, (fn, nbytes, flops) in cases.items():
         if a.only and not any(tok in name for tok in a.only.split(",")):
             continue
