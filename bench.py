@@ -329,12 +329,113 @@ def launch_argv(gpus, argv, port=None):
             "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
 
 
+def count_gpus(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs of this node WITHOUT touching the HIP / HSA runtime: KFD topology nodes with a non-zero ``simd_count`` (CPU nodes report
+    0).  ``torch.cuda.device_count()`` falls through to ``hipGetDeviceCount`` on ROCm builds without amdsmi, which initialises
+    the runtime in the parent that is about to start its ranks as children - so it is only the fallback for a node whose sysfs
+    is not readable."""
+    n, seen = 0, False
+    try:
+        for node in sorted(os.listdir(topology)):
+            try:
+                with open(os.path.join(topology, node, "properties")) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            seen = True
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        pass
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if seen and vis:
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n if seen else torch.cuda.device_count()
+
+
+def comm_diagnostics(model, fc, opt, crit, views, world, device, reps=20):
+    """The `comm` block of the bench line (world > 1, or MURCL_FORCE_DIST=1 on one rank): what the collectives of the step cost
+    by themselves, and how much of them the step leaves exposed - so that a scaling curve can be READ, not only recorded.
+    Every rank runs it (the passes contain collectives); all times are HIP-event medians on the launch stream, taken outside the
+    timed region.
+
+    * `z_all_gather_us`: the one data-path exchange: all_gather_into_tensor of [2 B_local, 128] f32 per rank.
+    * `grad_all_reduce_us`: the SUM all-reduce of each optimizer group's flat gradient buffer, alone on an idle GPU.
+    * `exposed_us_per_step`: median step with the collectives minus median step without them on the same rank (same kernels, the
+      local NT-Xent instead of the gathered one): the part of the communication the backward pass does not cover.
+    * `rccl`: the RCCL knobs in the environment (channel / CU budget) - the persistent kernels of the step are one workgroup per CU
+      with 128-130 KiB of LDS, so every CU RCCL's channels occupy delays a workgroup by a whole round."""
+    import torch.distributed as dist
+    from murcl_amd import dist as mdist
+
+    def ev_median(fn, n=reps):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dist.barrier()
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        ts.sort()
+        return round(ts[len(ts) // 2], 1)
+
+    B = views[0].shape[0]
+    nranks = dist.get_world_size()
+    z_local = torch.randn((2 * B, 128), device=device)
+    zg = torch.empty((nranks * 2 * B, 128), device=device)
+    out = {"ranks": nranks, "backend": dist.get_backend(),
+           "z_all_gather_us": ev_median(lambda: mdist.all_gather_rows(zg, z_local)),
+           "z_all_gather_bytes_per_rank": z_local.numel() * 4}
+    ar = {}
+    for gi, g in enumerate(opt.flat_grads()):
+        buf = torch.zeros_like(g)
+        us = ev_median(lambda: mdist.all_reduce_sum(buf))
+        ar[f"group{gi}"] = {"bytes": buf.numel() * 4, "us": us,
+                            "busbw_GBps": round(2 * (nranks - 1) / nranks * buf.numel() * 4 / (us * 1e-6) / 1e9, 1) if nranks > 1 else None}
+    out["grad_all_reduce_us"] = ar
+
+    def step_median(step, n=40):
+        for _ in range(5):
+            step()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        evs[0].record()
+        for i in range(n):
+            step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        return per[n // 2] * 1e3
+    with_comm = step_median(make_step(model, fc, opt, crit, views, 2))          # the multi-rank branch (also with one rank)
+    local = step_median(make_step(model, fc, opt, crit, views, 1))
+    out["step_us_with_collectives"] = round(with_comm, 1)
+    out["step_us_local_only"] = round(local, 1)
+    out["exposed_us_per_step"] = round(with_comm - local, 1)
+    out["overlap"] = "head-group all-reduce launched from an autograd hook under the aggregator backward (dist.OverlappedGradReduce); " \
+                     "model group + z all-gather are on the critical path"
+    knobs = ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_PEER", "RCCL_ENABLE_INTRANET", "NCCL_ALGO", "NCCL_PROTO",
+             "NCCL_BUFFSIZE", "HSA_ENABLE_IPC_MODE_LEGACY", "RCCL_MSCCL_ENABLE", "MURCL_MILESTONES")
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                                          # noqa: BLE001
+        ver = None
+    out["rccl"] = {"version": ver, "env": {k: os.environ[k] for k in knobs if k in os.environ},
+                   "channels_note": "RCCL does not export its channel / CU count through torch; NCCL_DEBUG=INFO prints it at init "
+                                    "(\"N coll channels\"); cap it with NCCL_MAX_NCHANNELS if exposed_us_per_step grows with N"}
+    return out
+
+
 def self_launch(gpus, argv):
     """``python bench.py --gpus N`` without a launcher (the reference needs none: one process, nn.DataParallel,
     train_MuRCL.py:145): this parent - which has made NO GPU call, so nothing is re-executed over an initialised device -
     starts the N ranks as CHILD processes, lets rank 0's JSON line through on its stdout and returns the children's exit code."""
     import subprocess
-    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    have = count_gpus()                               # from sysfs: the parent makes no HIP / HSA call at all
     if have < gpus:
         print(f"bench.py: --gpus {gpus} but this node has {have} GPU(s)", file=sys.stderr, flush=True)
         return 2
@@ -451,6 +552,12 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    comm = None
+    if world > 1 or force_dist:
+        try:
+            comm = comm_diagnostics(model, fc, opt, crit, views, world, device)
+        except Exception as e:                                                 # noqa: BLE001  (diagnostics must not take the line with them)
+            comm = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -475,9 +582,10 @@ def main():
                    algorithmic_bytes_per_launch=int(r["bytes"] / r["calls"]),
                    algorithmic_flops_per_launch=int(r["flops"] / r["calls"]))
         if key.startswith("gemm_tn_sq"):
-            out["note"] = ("one weight gradient = gemm_tn_sq_kernel (256x256 tiles, partial sums to a workspace) + tn_reduce_kernel (adds them "
-                           "to the gradient): avg_launch_ms and traffic cover BOTH launches plus ~2-3 us of event records; rocprofv3 lists "
-                           "them separately (profiles/r02_z_kernel_stats.csv: ~135 + ~12 us)")
+            out["note"] = ("the three encoder weight gradients of the step as ONE grouped launch of gemm_tn_sq_kernel (256x256 tiles, 12 "
+                           "(layer, tile) pairs x 21 row splits = one workgroup per CU, partial sums to a workspace) + ONE tn_reduce_kernel "
+                           "(adds them to the gradients, bias-gradient rows ride along): avg_launch_ms and traffic cover BOTH launches plus "
+                           "~2-3 us of event records; rocprofv3 lists them separately (profiles/r04_*_kernel_stats.csv)")
         return out
 
     out = {
@@ -499,6 +607,7 @@ def main():
                    "sharding": "bags by WSI; all-gather of z + grad all-reduce" if world > 1 else "single GPU"},
         "roofline": roof(dominant),
         "roofline_k2": roof(k2_key),
+        "comm": comm,
         "loss": round(float(loss.item()), 6),
         "step_stats": stats,
         "timed_region_host_enqueue_ms": {"median": round(sorted(host_ms)[len(host_ms) // 2], 3), "max": round(max(host_ms), 3),

@@ -40,7 +40,8 @@ def test_parent_spawns_children_and_relays_their_exit_code(monkeypatch):
         calls.append((argv, env, cwd))
         return _Done()
 
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(b, "count_gpus", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("the parent counts GPUs from sysfs")))
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
@@ -56,9 +57,48 @@ def test_parent_spawns_children_and_relays_their_exit_code(monkeypatch):
 def test_parent_refuses_more_ranks_than_gpus(monkeypatch, capsys):
     import torch
     b = _bench()
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(b, "count_gpus", lambda: 1)
     assert b.self_launch(8, ["--gpus", "8"]) == 2
     assert "--gpus 8 but this node has 1 GPU" in capsys.readouterr().err
+
+
+def test_gpus_are_counted_from_the_kfd_topology_without_a_runtime_call(tmp_path, monkeypatch):
+    """count_gpus reads /sys/class/kfd/kfd/topology/nodes/*/properties: nodes with simd_count > 0 are GPUs (CPU nodes report 0);
+    a visibility mask caps the count; only a node without readable sysfs falls back to torch."""
+    import torch
+    b = _bench()
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: (_ for _ in ()).throw(AssertionError("no runtime call when sysfs is readable")))
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert b.count_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert b.count_gpus(str(tmp_path)) == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 5)
+    assert b.count_gpus(str(tmp_path / "missing")) == 5
+
+
+@pytest.mark.gpu
+def test_forced_distributed_run_carries_the_comm_block():
+    """MURCL_FORCE_DIST=1: the RCCL code path with one rank; the bench line then carries `comm`: HIP-event time
+    of the z all-gather and of each gradient all-reduce, and the exposed (non-overlapped) part of a step."""
+    env = dict(os.environ, MURCL_FORCE_DIST="1", MASTER_PORT="29533")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--stat-steps", "0",
+                        "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = out["comm"]
+    assert "error" not in c, c
+    assert c["ranks"] == 1 and c["z_all_gather_us"] > 0 and c["z_all_gather_bytes_per_rank"] == 2 * 64 * 128 * 4
+    assert set(c["grad_all_reduce_us"]) == {"group0", "group1"} and all(v["us"] > 0 and v["bytes"] > 0 for v in c["grad_all_reduce_us"].values())
+    assert c["step_us_with_collectives"] > 0 and c["step_us_local_only"] > 0
+    assert abs(c["exposed_us_per_step"] - (c["step_us_with_collectives"] - c["step_us_local_only"])) < 0.2
+    assert "env" in c["rccl"]
 
 
 @pytest.mark.gpu
