@@ -292,8 +292,8 @@ def other_rows(device):
     def dsmil_fb():
         for p in md.parameters():
             p.grad = None
-        classes, bag = md._run(xd)
-        (bag.sum() + classes.max(1)[0].sum()).backward()            # bag term + max-instance term (train_RLMIL.py:516-529)
+        classes, bag, cmax = md._run(xd, want_max=True)
+        (bag.sum() + cmax.sum()).backward()                         # bag term + max-instance term (train_RLMIL.py:516-529)
     ms = _timed_ms(dsmil_fb)
     # Round 3: K6 reassociated (functional.DSMILFn) - the attention logits are X . (Wq^T q_max), so no GEMM over all patches is
     # left; the row is three streaming passes over X (instance scores; attention + pooling with an online soft-max; the whole

@@ -148,6 +148,14 @@ int murcl_ntxent_fwd_bwd(const float* z, int n, int P, float temperature, float*
  * step (train_MuRCL.py:249,277): z [batches][n][P] -> loss [batches], dz [batches][n][P] (may be NULL), sim [batches][n/2]. */
 int murcl_ntxent_fwd_bwd_batched(const float* z, int batches, int n, int P, float temperature, float* loss, float* dz,
                                  float* sim, murcl_stream_t stream);
+/* n <= 128 (one GPU's batch) with ONE cross-workgroup exchange instead of every workgroup recomputing all n x n logits: a workgroup
+ * forms the logits of its own 16 rows, publishes their lse as {value, generation} granules and collects the others' by agent-scope
+ * polls (losses.py:24-41 unchanged in value: same MFMA operand order, same reductions).  `batches` independent problems per launch;
+ * rows / pair_stride / grad window as murcl_ntxent_fwd_bwd.  xchg: murcl_ntxent_xchg_bytes(batches) bytes, zeroed ONCE by the caller
+ * and then passed to every call (never to two launches that may overlap in time). */
+long murcl_ntxent_xchg_bytes(int batches);
+int murcl_ntxent_small_xchg(const float* z, int batches, int n, int P, float temperature, float* loss, float* dz, float* sim,
+                            int grad_lo, int grad_hi, int pair_stride, void* xchg, murcl_stream_t stream);
 
 /* K12 -- get_feats (utils/datasets.py:274-308): per bag b and cluster j (ascending id list of length n_j):
  * size_j = rint(float(n_j)*ratio[b]), l_j = floor(actions[b][j]*float(n_j-size_j)), ids cluster_j[l_j : l_j+size_j]
@@ -177,6 +185,9 @@ int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int
  * because every column of A sums to one.  rows_dot: out[b,n,c] = X[b,n,:].V[b,c,:].  attn_bwd: soft-max backward,
  * dQ written into dY[:, qcol0:qcol0+128] and dqmax[b,c,:]. */
 int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_out, murcl_stream_t stream);
+/* ... and the maxima themselves, max_out [B,C] = scores[b, m[b,c], c]: the max-instance class scores of the DSMIL training body
+ * (train_RLMIL.py:516, `torch.max(outputs_ins, 0)`), which the kernel holds once it has found the critical instances. */
+int murcl_dsmil_argmax_max(const float* scores, int B, int N, int ld, int C, int* m_out, float* max_out, murcl_stream_t stream);
 /* The same attention without the [B*N,128] queries (dsmil.py:64-78 reassociated): Q[n].qmax[c]/sqrt(128) = X[n].v[c] + const with
  * v[c] = Wq^T qmax[c] / sqrt(128), and a soft-max over n ignores the constant - so the scores are a murcl_rows_dot of X against
  * v (a [B*C, d] matrix from two tiny GEMMs), murcl_dsmil_softmax turns them into A in place, and in the backward pass
@@ -199,6 +210,12 @@ int murcl_dsmil_qv(const void* X, const int* m, const float* Wq, const float* bq
                    float* v, int dtype, murcl_stream_t stream);
 int murcl_dsmil_qv_bwd(const float* R, const float* qmax, const float* xm, const float* Wq, int BC, int d, float* dq_ws, float* dWq,
                        float* dbq, murcl_stream_t stream);
+/* qv_bwd with the gradient dcmax [B*C] of the max-instance class scores (murcl_dsmil_argmax_max; train_RLMIL.py:527-529): the
+ * instance classifier's dWc [C,d] (+)= sum_b dcmax[b,c] xm[b,c] and dbc [C] (+)= sum_b dcmax[b,c] come out of the same second launch -
+ * no dense [B,N,C] gradient of the instance scores is formed for that term. */
+int murcl_dsmil_qv_bwd_cls(const float* R, const float* qmax, const float* xm, const float* Wq, int BC, int d, float* dq_ws, float* dWq,
+                           float* dbq, const float* dcmax, int C, float* dWc, float* dbc, int accumulate /* 0: dWc, dbc overwritten */,
+                           murcl_stream_t stream);
 int murcl_dsmil_stream_plan(int B, int N, int d, int C);
 int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits = vscale * X.v */, float* A, float* Z, float* ws,
                           int B, int N, int d, int C, int dtype, murcl_stream_t stream);
@@ -218,6 +235,9 @@ int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N,
                           murcl_stream_t stream);
 int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
                    murcl_stream_t stream);
+/* the same + bias[c] (may be NULL): the instance classifier's Linear(d, C) (dsmil.py:9,15) in one launch */
+int murcl_rows_dot_bias(const void* X, const float* V, const float* bias, float* out, int B, int N, int d, int C, int dtype,
+                        murcl_stream_t stream);
 /* rows_dot and the weighted row sum sum_n G[b,n,c] X[b,n,:] over ONE pass of X (DSMIL backward: dA = X dZ^T and
  * dWc = dcls^T X both need every row of X).  murcl_rows_dot_wsum_plan returns the rows a wave takes (0: shape not covered:
  * C <= 2, d <= 1024, d % 8 == 0); part [B*N / that][C][d] receives per-wave partial sums of the weighted rows, which the

@@ -38,14 +38,18 @@ SIGNATURES = {
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
     "murcl_ntxent_fwd_bwd_batched": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
+    "murcl_ntxent_xchg_bytes": [_I],
+    "murcl_ntxent_small_xchg": [_P, _I, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
     "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_mixup": [_P, _P, _P, _P, _I, _L, _I, _P],
     "murcl_dsmil_argmax": [_P, _I, _I, _I, _I, _P, _P],
+    "murcl_dsmil_argmax_max": [_P, _I, _I, _I, _I, _P, _P, _P],
     "murcl_gather_rows": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "murcl_dsmil_attn": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
     "murcl_weighted_rowsum": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_rows_dot_bias": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot_wsum_plan": [_I, _I, _I, _I],
     "murcl_rows_dot_wsum": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_bwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _P, _P],
@@ -55,6 +59,7 @@ SIGNATURES = {
     "murcl_dsmil_stream_plan": [_I, _I, _I, _I],
     "murcl_dsmil_qv": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "murcl_dsmil_qv_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "murcl_dsmil_qv_bwd_cls": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_softmax_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -92,7 +97,7 @@ SIGNATURES = {
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
 
 

@@ -14,7 +14,7 @@
 
 // per (bag, class): first index of the maximum of scores[b, :, c]   (scores [B,N,ld] f32, classes in columns 0..C-1)
 __global__ __launch_bounds__(256) void dsmil_argmax_kernel(const float* __restrict__ scores, int N, int ld, int C,
-                                                           int* __restrict__ m_out) {
+                                                           int* __restrict__ m_out, float* __restrict__ max_out) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
@@ -34,11 +34,21 @@ __global__ __launch_bounds__(256) void dsmil_argmax_kernel(const float* __restri
         }
         __syncthreads();
     }
-    if (tid == 0) m_out[b * C + c] = bi[0];
+    if (tid == 0) {
+        m_out[b * C + c] = bi[0];
+        if (max_out) max_out[b * C + c] = bv[0];
+    }
 }
 extern "C" int murcl_dsmil_argmax(const float* scores, int B, int N, int ld, int C, int* m_out, hipStream_t s) {
     if (B <= 0 || C <= 0) return 0;
-    hipLaunchKernelGGL(dsmil_argmax_kernel, dim3(B, C), dim3(256), 0, s, scores, N, ld, C, m_out);
+    hipLaunchKernelGGL(dsmil_argmax_kernel, dim3(B, C), dim3(256), 0, s, scores, N, ld, C, m_out, (float*)nullptr);
+    return MURCL_CHECK_LAUNCH();
+}
+// ... and the maxima themselves, max_out [B,C] = scores[b, m[b,c], c]: the max-instance class scores of train_RLMIL.py:516
+// (`torch.max(outputs_ins, 0)`), which the kernel has in hand when it has found the critical instances
+extern "C" int murcl_dsmil_argmax_max(const float* scores, int B, int N, int ld, int C, int* m_out, float* max_out, hipStream_t s) {
+    if (B <= 0 || C <= 0) return 0;
+    hipLaunchKernelGGL(dsmil_argmax_kernel, dim3(B, C), dim3(256), 0, s, scores, N, ld, C, m_out, max_out);
     return MURCL_CHECK_LAUNCH();
 }
 
@@ -254,7 +264,8 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
 #endif
 template <typename T>
 __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, const float* __restrict__ V, int N, int d,
-                                                       int C, float* __restrict__ out, long rows_total) {
+                                                       int C, float* __restrict__ out, long rows_total,
+                                                       const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * RD_RPW;
     if (row0 >= rows_total) return;
@@ -309,24 +320,29 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
             if (rb + u >= row1) break;
             for (int c = 0; c < C; ++c) {
                 const float s = RD_WAVE_SUM(acc[u][c]);
-                if (lane == 0) out[(rb + u) * C + c] = s;
+                if (lane == 0) out[(rb + u) * C + c] = bias ? s + bias[c] : s;
             }
         }
     }
 }
-extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
-                              hipStream_t s) {
+// bias (may be NULL) [C]: out[b,n,c] = X[b,n,:] . V[b,c,:] + bias[c] - the instance classifier's Linear (dsmil.py:9,15) in one launch
+extern "C" int murcl_rows_dot_bias(const void* X, const float* V, const float* bias, float* out, int B, int N, int d, int C, int dtype,
+                                   hipStream_t s) {
     if (B <= 0) return 0;
     if (C > 4 || d % 8) return -1;
     const long rows = (long)B * N;
     dim3 grid((unsigned)((rows + 4 * RD_RPW - 1) / (4 * RD_RPW)));
     if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL(rows_dot_kernel<float>, grid, dim3(256), 0, s, (const float*)X, V, N, d, C, out, rows);
+        hipLaunchKernelGGL(rows_dot_kernel<float>, grid, dim3(256), 0, s, (const float*)X, V, N, d, C, out, rows, bias);
     else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL(rows_dot_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, V, N, d, C, out, rows);
+        hipLaunchKernelGGL(rows_dot_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, V, N, d, C, out, rows, bias);
     else
         return -1;
     return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
+                              hipStream_t s) {
+    return murcl_rows_dot_bias(X, V, nullptr, out, B, N, d, C, dtype, s);
 }
 
 // rows_dot and a weighted row sum over the SAME pass of X (DSMIL backward: dA = X dZ^T needs every row of X, and so does
@@ -710,7 +726,8 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
 template <int MODE>
 __global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restrict__ part, const float* __restrict__ stat, int W, int d,
                                                           int C, const float* __restrict__ Zin, float scale,
-                                                          float* __restrict__ out, float* __restrict__ ml) {
+                                                          float* __restrict__ out, float* __restrict__ ml,
+                                                          const float* Sn, float* An, int N) {
     __shared__ float wgt[1024];
     __shared__ float red[256];
     __shared__ float acc[4][64];
@@ -755,14 +772,16 @@ __global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restric
         out[(size_t)bc * d + k] = MODE == 0 ? t / l : (t - l * Zin[(size_t)bc * d + k]) * scale;
     }
     if (MODE == 0 && blockIdx.y == 0 && tid == 0) { ml[bc * 2] = m; ml[bc * 2 + 1] = l; }
-}
-// A = e^{S - m} / l in place, S [B,N,C]
-__global__ __launch_bounds__(256) void dsmil_normalise_kernel(const float* S, float* A, const float* __restrict__ ml, long total, int N,
-                                                              int C) {                 // (A may alias S)
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const long bc = (i / ((long)N * C)) * C + i % C;
-        A[i] = __expf(S[i] - ml[bc * 2]) / ml[bc * 2 + 1];
+    if (MODE == 0 && An) {
+        // A = e^{S - m} / l for this workgroup's slice of the bag's rows (An may alias Sn): the statistics are in hand, so the
+        // separate normalise launch over A is folded in here
+        const int per = (N + gridDim.y - 1) / gridDim.y;
+        const int n1 = min(N, (int)(blockIdx.y + 1) * per);
+        const float rl = 1.f / l;
+        for (int n = blockIdx.y * per + tid; n < n1; n += 256) {
+            const size_t i = ((size_t)b * N + n) * C + c;
+            An[i] = __expf(Sn[i] - m) * rl;
+        }
     }
 }
 // plan: rows a wave takes (0: shape not covered -> rows_dot + soft-max + weighted_rowsum); the workspace holds
@@ -789,13 +808,8 @@ extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale
         return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
-    rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    const long total = rows * C;
-    int g2 = (int)((total + 255) / 256);
-    if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, A, A, ml, total, N, C);
+    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml,
+                       (const float*)A, A, N);
     return MURCL_CHECK_LAUNCH();
 }
 // The same soft-max + pooling pass for logits that already exist (CLAM-SB: the gate GEMM's epilogue produced them, clam.py:144,170):
@@ -819,13 +833,8 @@ extern "C" int murcl_softmax_pool(const void* X, const float* S, float* A, float
         return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml);
-    rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    const long total = rows * C;
-    int g2 = (int)((total + 255) / 256);
-    if (g2 > 2048) g2 = 2048;
-    hipLaunchKernelGGL(dsmil_normalise_kernel, dim3(g2), dim3(256), 0, s, S, A, ml, total, N, C);
+    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml,
+                       S, A, N);
     return MURCL_CHECK_LAUNCH();
 }
 extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls /* may be NULL */,
@@ -846,7 +855,8 @@ extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const f
         return -1;
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr);
+    hipLaunchKernelGGL(dsmil_merge_kernel<1>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, Z, scale, R, nullptr,
+                       (const float*)nullptr, (float*)nullptr, N);
     return MURCL_CHECK_LAUNCH();
 }
 
@@ -925,9 +935,28 @@ __global__ __launch_bounds__(256) void dsmil_dq_kernel(const float* __restrict__
 // backward launch 2, grid (DS_Q rows o of Wq, ceil(d / 1024)): dWq[o,:] = sum_r q_r[o] R_r + dq_r[o] x_m,r ;  dbq[o] = sum_r dq_r[o]
 __global__ __launch_bounds__(256) void dsmil_dwq_kernel(const float* __restrict__ R, const float* __restrict__ qmax,
                                                         const float* __restrict__ dq, const float* __restrict__ xm, int BC, int d,
-                                                        float* __restrict__ dWq, float* __restrict__ dbq) {
+                                                        float* __restrict__ dWq, float* __restrict__ dbq,
+                                                        const float* __restrict__ dcmax, int C, float* __restrict__ dWc,
+                                                        float* __restrict__ dbc, int accumulate) {
     const int o = blockIdx.x, tid = threadIdx.x;
     const int k = blockIdx.y * 1024 + tid * 4;
+    if (o >= DS_Q) {
+        // workgroups past the rows of Wq: the instance classifier's gradient from the max-instance term (train_RLMIL.py:516,527-529):
+        // class c's score at its critical instance is Wc[c] . x_m[b,c] + bc[c], so dWc[c] += sum_b dcmax[b,c] x_m[b,c], dbc[c] += sum_b dcmax[b,c]
+        const int c = o - DS_Q;
+        if (k < d) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = c; r < BC; r += C) acc += dcmax[r] * *(const f32x4*)(xm + (size_t)r * d + k);
+            f32x4* w = (f32x4*)(dWc + (size_t)c * d + k);
+            *w = accumulate ? *w + acc : acc;
+        }
+        if (blockIdx.y == 0 && tid == 0) {
+            float t = 0.f;
+            for (int r = c; r < BC; r += C) t += dcmax[r];
+            dbc[c] = accumulate ? dbc[c] + t : t;
+        }
+        return;
+    }
     if (k < d) {
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         for (int r = 0; r < BC; ++r) {
@@ -962,6 +991,21 @@ extern "C" int murcl_dsmil_qv_bwd(const float* R, const float* qmax, const float
     hipLaunchKernelGGL(dsmil_dq_kernel, dim3(BC, DS_Q / DQ_OPB), dim3(256), 0, s, R, Wq, d, dq_ws);
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_dwq_kernel, dim3(DS_Q, (d + 1023) / 1024), dim3(256), 0, s, R, qmax, dq_ws, xm, BC, d, dWq, dbq);
+    hipLaunchKernelGGL(dsmil_dwq_kernel, dim3(DS_Q, (d + 1023) / 1024), dim3(256), 0, s, R, qmax, dq_ws, xm, BC, d, dWq, dbq,
+                       (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, 0);
+    return MURCL_CHECK_LAUNCH();
+}
+// ... with the gradient of the max-instance class scores dcmax [B*C] (murcl_dsmil_argmax_max): dWc [C,d] and dbc [C] are ADDED to in
+// the same second launch (C more workgroup rows) - no dense [B,N,C] gradient of the instance scores is ever formed for that term
+extern "C" int murcl_dsmil_qv_bwd_cls(const float* R, const float* qmax, const float* xm, const float* Wq, int BC, int d, float* dq_ws,
+                                      float* dWq, float* dbq, const float* dcmax, int C, float* dWc, float* dbc, int accumulate,
+                                      hipStream_t s) {
+    if (BC <= 0) return 0;
+    if (d % 4 || d > DQ_MAXD || !dq_ws || C <= 0 || BC % C || !dcmax || !dWc || !dbc) return -1;
+    hipLaunchKernelGGL(dsmil_dq_kernel, dim3(BC, DS_Q / DQ_OPB), dim3(256), 0, s, R, Wq, d, dq_ws);
+    int rc = MURCL_CHECK_LAUNCH();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dsmil_dwq_kernel, dim3(DS_Q + C, (d + 1023) / 1024), dim3(256), 0, s, R, qmax, dq_ws, xm, BC, d, dWq, dbq, dcmax, C,
+                       dWc, dbc, accumulate);
     return MURCL_CHECK_LAUNCH();
 }

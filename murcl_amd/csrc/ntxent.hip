@@ -459,6 +459,187 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------ n <= 128, round 4: one exchange
+// ntxent_small_kernel above makes every one of its n/16 workgroups recompute ALL n x n logits (the column term P_ji of the gradient
+// needs lse_j of every row): 64 tiles of exact-f32 MFMAs on one CU = ~8 us of its ~21.  Here a workgroup forms only the logits of
+// its OWN 16 rows (8 tiles), publishes their lse (and loss terms) as 8-byte {value, generation} granules - one agent-scope store
+// each, MI355X_MICROARCH.md "data-tagged granules" - and collects the other workgroups' granules with agent-scope polls: one
+// hand-off (~1-2 us) instead of 7/8 of the matrix work.  The exchange buffer is caller-owned, zeroed ONCE (a tag never equals a
+// live generation), and every launch carries a new generation number, so nothing is reset between launches.  All workgroups of a
+// batch must be resident together: n/16 <= 8 workgroups per batch on 256 CUs; the spin is bounded (gives up -> NaN loss).
+#define NXX_LD 132
+__device__ __forceinline__ unsigned long long nxx_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void nxx_store(unsigned long long* p, float v, unsigned gen) {
+    __hip_atomic_store(p, ((unsigned long long)gen << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(1024) void ntxent_xchg_kernel(const float* __restrict__ z, int n, int ps, float inv_tau,
+                                                           float* __restrict__ dz, float* __restrict__ sim,
+                                                           float* __restrict__ loss_out, int grad_lo, int grad_hi,
+                                                           unsigned long long* __restrict__ xchg, unsigned gen) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    z += (size_t)blockIdx.y * n * NX_P;
+    if (dz) dz += (size_t)blockIdx.y * n * NX_P;
+    if (sim) sim += (size_t)blockIdx.y * (n / 2);
+    loss_out += blockIdx.y;
+    xchg += (size_t)blockIdx.y * 256;                 // [128] lse granules, [128] loss-term granules
+    float* zh = sm;                                   // [128][NXX_LD]
+    float* Ss = sm + 128 * NXX_LD;                    // [16][NXX_LD] logits of the own rows, then their gradient weights
+    float* lse_all = Ss + 16 * NXX_LD;                // [128]
+    float* inorm = lse_all + 128;                     // [128]
+    float* dotp = inorm + 128;                        // [8][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int tr = blockIdx.x;
+
+    // ---- phase 0: normalised rows (8 threads per row, 16 columns each); rows >= n are zero
+    {
+        const int i = tid >> 3, c0 = (tid & 7) * 16;
+        float v[16], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const f32x4 t = (i < n) ? *(const f32x4*)(z + (size_t)i * NX_P + c0 + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[e + k] = t[k]; ss += t[k] * t[k]; }
+        }
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-8f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zh[i * NXX_LD + c0 + e] = v[e] * inv;
+        if ((tid & 7) == 0) inorm[i] = inv;
+    }
+    __syncthreads();
+
+    // ---- phase 1: the logits of the own 16 rows against all 128 rows: 8 tiles, one per wave 0..7 (exact-f32 MFMA, same operand
+    // order as ntxent_small_kernel: bit-identical logits)
+    if (wave < 8) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ar = zh + (16 * tr + r16) * NXX_LD + q4;
+        const float* br = zh + (16 * wave + r16) * NXX_LD + q4;
+#pragma unroll 8
+        for (int kk = 0; kk < NX_P / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * kk], br[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ss[(4 * q4 + r) * NXX_LD + 16 * wave + r16] = acc[r] * inv_tau;
+    }
+    __syncthreads();
+
+    // ---- phase 2: statistics of row i = 16 tr + wave (one wave per row, two columns per lane); publish lse_i and the row's loss term
+    const int i = 16 * tr + wave;
+    const int pos = nx_pos(i, ps);
+    const float s0 = Ss[wave * NXX_LD + lane], s1 = Ss[wave * NXX_LD + lane + 64];
+    const bool ok0 = i < n && lane < n && lane != i, ok1 = i < n && lane + 64 < n && lane + 64 != i;
+    float my_lse = 0.f;
+    {
+        const float m = wave_max(fmaxf(ok0 ? s0 : -INFINITY, ok1 ? s1 : -INFINITY));
+        const float l = wave_sum((ok0 ? __expf(s0 - m) : 0.f) + (ok1 ? __expf(s1 - m) : 0.f));
+        if (i < n) my_lse = m + __logf(l);
+        if (lane == 0) {
+            const float sp = (i < n) ? Ss[wave * NXX_LD + pos] : 0.f;
+            nxx_store(xchg + i, my_lse, gen);
+            nxx_store(xchg + 128 + i, (i < n) ? (my_lse - sp) / (float)n : 0.f, gen);
+            if (i < n && sim && nx_view0(i, ps)) sim[nx_bag(i, ps)] = sp / inv_tau;
+        }
+    }
+    // ---- phase 3: collect every row's lse (waves 0, 1) and, in workgroup 0, the loss terms (waves 2, 3): agent-scope polls
+    if (wave < 4 && (wave < 2 || tr == 0)) {
+        const int idx = (wave & 1) * 64 + lane + (wave >> 1) * 128;
+        float v = 0.f;
+        if ((idx & 127) < (int)gridDim.x * 16) {                            // rows of workgroups that exist (the others: never read)
+            unsigned long long g = nxx_load(xchg + idx);
+            int tries = 0;
+            while ((unsigned)(g >> 32) != gen && tries < (1 << 22)) {
+                __builtin_amdgcn_s_sleep(1);
+                g = nxx_load(xchg + idx);
+                ++tries;
+            }
+            v = __uint_as_float((unsigned)g);
+            if ((unsigned)(g >> 32) != gen) v = __builtin_nanf("");      // gave up: make it visible
+        }
+        if (wave < 2) {
+            lse_all[idx] = v;
+        } else {                                                           // loss = sum of the 128 terms, fixed order
+            const float t = wave_sum(v);
+            if (wave == 2) dotp[0] = t; else dotp[1] = t;
+        }
+    }
+    __syncthreads();
+    if (tr == 0 && tid == 0) loss_out[0] = dotp[0] + dotp[1];
+    if (!dz) return;
+    __syncthreads();                                                       // (dotp is reused below)
+
+    // ---- phase 4: gradient weights of the own rows in place: W_ij = (P_ij + P_ji - 2 [j == pos(i)]) / (n tau)
+    {
+        const float scale = inv_tau / (float)n;
+        float w0 = 0.f, w1 = 0.f;
+        if (ok0) w0 = __expf(s0 - my_lse) + __expf(s0 - lse_all[lane]) - (lane == pos ? 2.f : 0.f);
+        if (ok1) w1 = __expf(s1 - my_lse) + __expf(s1 - lse_all[lane + 64]) - (lane + 64 == pos ? 2.f : 0.f);
+        Ss[wave * NXX_LD + lane] = w0 * scale;
+        Ss[wave * NXX_LD + lane + 64] = w1 * scale;
+    }
+    __syncthreads();
+
+    // ---- phase 5: G = W zh for the own 16 rows (waves 0..7 take one 16-column tile each), dz = (g - (zh.g) zh) / |z|
+    {
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+        float zv[4], pd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wave < 8) {
+            const float* ar = Ss + r16 * NXX_LD + q4;
+#pragma unroll 8
+            for (int kk = 0; kk < 128 / 4; ++kk) {
+                const float a = ar[4 * kk];
+                const float b = zh[(4 * kk + q4) * NXX_LD + 16 * wave + r16];
+                g = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, g, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                zv[r] = zh[(16 * tr + 4 * q4 + r) * NXX_LD + 16 * wave + r16];
+                pd[r] = g[r] * zv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = row16_sum(pd[r]);
+                if (r16 == 0) dotp[wave * 16 + 4 * q4 + r] = t;
+            }
+        }
+        __syncthreads();
+        if (wave < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * q4 + r, row = 16 * tr + rl;
+                if (row >= n) continue;
+                const int bag = nx_bag(row, ps);
+                const bool want = bag >= grad_lo && bag < grad_hi;
+                float dot = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) dot += dotp[w * 16 + rl];
+                dz[(size_t)row * NX_P + 16 * wave + r16] = want ? (g[r] - dot * zv[r]) * inorm[row] : 0.f;
+            }
+        }
+    }
+}
+// bytes of the exchange buffer for `batches` problems: allocate once per device, ZERO it once, pass it to every call
+extern "C" long murcl_ntxent_xchg_bytes(int batches) { return (long)(batches > 0 ? batches : 1) * 256 * 8; }
+// `batches` independent NT-Xent problems of n <= 128 rows each (rows / pair_stride / gradient window as murcl_ntxent_fwd_bwd) in ONE
+// launch of the exchange kernel.  xchg: murcl_ntxent_xchg_bytes(batches) bytes, zeroed once by the caller, never shared by launches
+// that may overlap in time (one per device / stream).
+extern "C" int murcl_ntxent_small_xchg(const float* z, int batches, int n, int P, float temperature, float* loss, float* dz, float* sim,
+                                       int grad_lo, int grad_hi, int pair_stride, void* xchg, hipStream_t stream) {
+    if (P != NX_P || n <= 0 || (n & 1) || n > 128 || batches <= 0 || !xchg) return -1;
+    const int ps = pair_stride > 0 ? pair_stride : n / 2;
+    if (n % (2 * ps)) return -1;
+    static unsigned generation = 0;
+    unsigned gen = ++generation;
+    if (gen == 0) gen = ++generation;                  // 0 is the tag of a freshly zeroed buffer
+    constexpr int LDS = (128 * NXX_LD + 16 * NXX_LD + 128 * 2 + 128) * 4;
+    static MurclOncePerDevice once;
+    if (once.first()) hipFuncSetAttribute((const void*)ntxent_xchg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL(ntxent_xchg_kernel, dim3((n + 15) / 16, batches), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz, sim,
+                       loss, grad_lo, grad_hi, (unsigned long long*)xchg, gen);
+    return MURCL_CHECK_LAUNCH();
+}
+
 extern "C" long murcl_ntxent_workspace_bytes(int n) {
     const long ntile = (n + NXT_TC - 1) / NXT_TC;
     return ((long)n * NX_P + n + ntile * n * 3 + 16) * 4;          // z-hat, 1/|z|, per-tile row statistics

@@ -672,16 +672,18 @@ class DSMILFn(torch.autograd.Function):
     QD = 128
 
     @staticmethod
-    def forward(ctx, x, wc, bc, wq, bq, wv, bv):
+    def forward(ctx, x, wc, bc, wq, bq, wv, bv, want_max=False):
+        """``want_max``: also return cmax [B,C] = the max-instance class scores (train_RLMIL.py:516, ``torch.max(outputs_ins, 0)``) as a
+        differentiable output - the arg-max launch has them in hand, and their gradient reaches the instance classifier through the
+        B*C critical rows only (no dense [B,N,C] gradient, no ATen max / scatter / fill launches)."""
         B, N, d = x.shape
         T = x.dtype
         C = wc.shape[0]
         QD = DSMILFn.QD
         LD = QD + ((C + 7) // 8) * 8
         x2 = x.reshape(B * N, d)
-        cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d)).view(B * N, C)       # instance scores (dsmil.py:9-16)
-        cls += bc
-        m = ops.dsmil_argmax(cls, B, N, C)                                              # critical instances (:71-73)
+        cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d), bias=bc).view(B * N, C)    # instance scores (dsmil.py:9-16)
+        m, cmax = ops.dsmil_argmax(cls, B, N, C, want_max=True)                         # critical instances (:71-73) and their scores
         reassoc = _DSMIL_REASSOC and C <= 4
         qv = reassoc and _DSMIL_QV and wq.shape[0] == QD and d % 4 == 0 and d <= 2048
         xm = None
@@ -712,10 +714,12 @@ class DSMILFn(torch.autograd.Function):
         ctx.meta = (B, N, d, C, LD, reassoc, qv)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
-        return classes, bag, m
+        if not want_max:
+            ctx.mark_non_differentiable(cmax)
+        return classes, bag, m, cmax
 
     @staticmethod
-    def backward(ctx, dclasses, dbag, _dm):
+    def backward(ctx, dclasses, dbag, _dm, dcmax=None):
         x, Y, m, qmax, A, Z, wv, wq, xm_saved = ctx.saved_tensors
         B, N, d, C, LD, reassoc, qv = ctx.meta
         T, QD = x.dtype, DSMILFn.QD
@@ -735,7 +739,18 @@ class DSMILFn(torch.autograd.Function):
             if dclasses is not None:
                 fused = ops.rows_dot_wsum(x, dZ, dcls)
             dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
-        if one is not None and qv:
+        dwc = dbc = None
+        cmax_done = False
+        if one is not None and qv and dcmax is not None:
+            # ... and the max-instance term's share of the instance classifier's gradient from the same second launch
+            if dclasses is not None:
+                dwc, dbc = one[1], dcls.view(B * N, C).sum(0)
+            else:
+                dwc, dbc = torch.empty((C, d), dtype=torch.float32, device=dev), torch.empty((C,), dtype=torch.float32, device=dev)
+            dwq, dbq = ops.dsmil_qv_bwd(one[0].view(B * C, d), qmax, xm_saved, wq, dcmax=dcmax.float(), dwc=dwc, dbc=dbc,
+                                        accumulate=dclasses is not None)
+            cmax_done = True
+        elif one is not None and qv:
             dwq, dbq = ops.dsmil_qv_bwd(one[0].view(B * C, d), qmax, xm_saved, wq)         # dq = R Wq^T, dWq = q^T R + dq^T x_m, dbq
         elif one is not None:
             R = one[0].view(B * C, d)
@@ -764,8 +779,7 @@ class DSMILFn(torch.autograd.Function):
         else:
             ops.gemm_tn(dqmax if T == torch.float32 else ops.cast(dqmax, T), xm, out=dwq)
             dbq = ops.colsum(dqmax) if dbq is None else ops.colsum(dqmax, out=dbq, accumulate=True)
-        dwc = dbc = None
-        if dclasses is not None:
+        if dclasses is not None and not cmax_done:
             # the C instance-score columns: dWc = dcls^T X as a weighted row sum over all patches (a 128-wide wgrad tile
             # for 2 columns would read X a second time through the GEMM path)
             if one is not None:
@@ -773,7 +787,14 @@ class DSMILFn(torch.autograd.Function):
             else:
                 dwc = fused[1] if fused is not None else ops.weighted_rowsum(x2.view(1, B * N, d), dcls.view(1, B * N, C)).view(C, d)
             dbc = dcls.view(B * N, C).sum(0)
-        return None, dwc, dbc, dwq, dbq, dwv, dbv
+        if dcmax is not None and not cmax_done:
+            # paths without the two-launch [B*C]-row algebra: the same sums in plain tensor ops on the B*C critical rows
+            xm_f = (xm_saved if qv else ops.cast(ops.gather_rows(x2, m, B, C, N, 0, d), torch.float32)).view(B, C, d)
+            g = dcmax.float().view(B, C, 1)
+            dwc_m, dbc_m = (g * xm_f).sum(0), g.view(B, C).sum(0)
+            dwc = dwc_m if dwc is None else dwc + dwc_m
+            dbc = dbc_m if dbc is None else dbc + dbc_m
+        return None, dwc, dbc, dwq, dbq, dwv, dbv, None
 
 
 _INST_CONST = {}

@@ -36,14 +36,17 @@ class MILNet(nn.Module):
         self.compute_dtype = torch.float32
         self.last_critical = None          # m [B,C]: arg-max patch per class of the latest call
 
-    def _run(self, x):
+    def _run(self, x, want_max=False):
+        """-> (classes [B,N,C], bag [B,C,d]); with ``want_max`` also the max-instance class scores [B,C] = classes.max(1)[0]
+        (train_RLMIL.py:516) as a differentiable output of the same launches (what the training step uses)."""
         from .. import ops
         if x.dtype != self.compute_dtype:
             x = ops.cast(x.float().contiguous(), self.compute_dtype)
         fc, b = self.i_classifier.fc[0], self.b_classifier
-        classes, bag, m = DSMILFn.apply(x.contiguous(), fc.weight, fc.bias, b.q.weight, b.q.bias, b.v[1].weight, b.v[1].bias)
+        classes, bag, m, cmax = DSMILFn.apply(x.contiguous(), fc.weight, fc.bias, b.q.weight, b.q.bias, b.v[1].weight, b.v[1].bias,
+                                              bool(want_max))
         self.last_critical = m
-        return classes, bag
+        return (classes, bag, cmax) if want_max else (classes, bag)
 
     def forward(self, x):
         if isinstance(x, torch.Tensor) and x.dim() == 3 and x.shape[0] == 1:

@@ -430,6 +430,19 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
     return dT_full[:B * N], dba, dwb, dbb
 
 
+_NTX_XCHG = _os.environ.get("MURCL_NTX_XCHG", "1") == "1"     # dev A/B switch: n <= 128 through the one-exchange kernel
+_NTX_BUF = {}
+
+
+def _ntx_xchg(dev, batches):
+    """The exchange buffer of murcl_ntxent_small_xchg for this device: allocated (and zeroed) once, grown when a call needs more."""
+    need = _lib.lib().murcl_ntxent_xchg_bytes(batches)
+    buf = _NTX_BUF.get(dev)
+    if buf is None or buf.numel() < need:
+        buf = _NTX_BUF[dev] = torch.zeros((need,), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None, pair_stride=None):
     """z [2B,128] f32 -> (loss [1], dz [2B,128] or None, sim [B]).  Rows: cat(view 0, view 1) by default; with
     ``pair_stride`` = bags per rank, an all-gathered [rank][view][bag] batch (global bag id = rank * pair_stride + b)."""
@@ -441,10 +454,15 @@ def ntxent(z, temperature, want_grad=True, grad_lo=0, grad_hi=None, pair_stride=
         grad_hi = Bh
     ps = Bh if pair_stride is None else int(pair_stride)
     dev = z.device
-    ws = torch.empty((_lib.lib().murcl_ntxent_workspace_bytes(n) + 3) // 4, dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dz = torch.empty_like(z) if want_grad else None
     sim = torch.empty((Bh,), dtype=torch.float32, device=dev)
+    if n <= 128 and P == 128 and _NTX_XCHG:
+        with _span(lambda: ("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4))):
+            check(_lib.lib().murcl_ntxent_small_xchg(ptr(z), 1, n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo, grad_hi,
+                                                     ps, ptr(_ntx_xchg(dev, 1)), stream()), "ntxent_small_xchg")
+        return loss, dz, sim
+    ws = torch.empty((_lib.lib().murcl_ntxent_workspace_bytes(n) + 3) // 4, dtype=torch.float32, device=dev)
     with _span(lambda: ("ntxent", dict(flops=6.0 * n * n * P, bytes=2 * n * P * 4))):
         check(_lib.lib().murcl_ntxent_fwd_bwd(ptr(z), n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), grad_lo,
                                               grad_hi, ps, ptr(ws), stream()), "ntxent_fwd_bwd")
@@ -460,6 +478,11 @@ def ntxent_batched(z, temperature, want_grad=True):
     loss = torch.empty((T_,), dtype=torch.float32, device=dev)
     dz = torch.empty_like(z) if want_grad else None
     sim = torch.empty((T_, n // 2), dtype=torch.float32, device=dev)
+    if _NTX_XCHG and P == 128 and n <= 128:
+        with _span(lambda: ("ntxent", dict(flops=6.0 * T_ * n * n * P, bytes=2 * T_ * n * P * 4))):
+            check(_lib.lib().murcl_ntxent_small_xchg(ptr(z), T_, n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), 0, n // 2, n // 2,
+                                                     ptr(_ntx_xchg(dev, T_)), stream()), "ntxent_small_xchg")
+        return loss, dz, sim
     with _span(lambda: ("ntxent", dict(flops=6.0 * T_ * n * n * P, bytes=2 * T_ * n * P * 4))):
         check(_lib.lib().murcl_ntxent_fwd_bwd_batched(ptr(z), T_, n, P, float(temperature), ptr(loss), ptr(dz), ptr(sim), stream()),
               "ntxent_fwd_bwd_batched")
@@ -733,11 +756,15 @@ def sgd_step(p, g, buf, lr, momentum, nesterov, weight_decay, first, zero_grad=F
 
 
 # ------------------------------------------------------------------------------------------ DSMIL (K6)
-def dsmil_argmax(scores_view, B, N, C):
-    """scores_view: [B*N, >=C] f32 view (row stride = its stride(0)); -> m [B,C] int32."""
+def dsmil_argmax(scores_view, B, N, C, want_max=False):
+    """scores_view: [B*N, >=C] f32 view (row stride = its stride(0)); -> m [B,C] int32 (, the maxima [B,C] f32 with ``want_max``)."""
     m = torch.empty((B, C), dtype=torch.int32, device=scores_view.device)
-    check(_lib.lib().murcl_dsmil_argmax(ptr(scores_view), B, N, scores_view.stride(0), C, ptr(m), stream()), "dsmil_argmax")
-    return m
+    if not want_max:
+        check(_lib.lib().murcl_dsmil_argmax(ptr(scores_view), B, N, scores_view.stride(0), C, ptr(m), stream()), "dsmil_argmax")
+        return m
+    mx = torch.empty((B, C), dtype=torch.float32, device=scores_view.device)
+    check(_lib.lib().murcl_dsmil_argmax_max(ptr(scores_view), B, N, scores_view.stride(0), C, ptr(m), ptr(mx), stream()), "dsmil_argmax_max")
+    return m, mx
 
 
 def gather_rows(src, m, B, C, N, col0, width):
@@ -774,14 +801,23 @@ def dsmil_qv(X, m, wq, bq, B, N, C):
     return xm, qmax, v
 
 
-def dsmil_qv_bwd(R, qmax, xm, wq):
-    """-> (dWq [128,d] = qmax^T R + (R Wq^T)^T xm, dbq [128]) in two launches."""
+def dsmil_qv_bwd(R, qmax, xm, wq, dcmax=None, dwc=None, dbc=None, accumulate=True):
+    """-> (dWq [128,d] = qmax^T R + (R Wq^T)^T xm, dbq [128]) in two launches.  With ``dcmax`` [B,C] (the gradient of the
+    max-instance class scores) the second launch also adds sum_b dcmax[b,c] xm[b,c] to ``dwc`` [C,d] and sum_b dcmax[b,c] to ``dbc`` [C]
+    (``accumulate=False``: overwrites them)."""
     R, qmax, xm, wq = _c(R), _c(qmax), _c(xm), _c(wq)
     BC, d = R.shape
     dq = torch.empty_like(qmax)
     dwq = torch.empty_like(wq)
     dbq = torch.empty((wq.shape[0],), dtype=torch.float32, device=R.device)
-    check(_lib.lib().murcl_dsmil_qv_bwd(ptr(R), ptr(qmax), ptr(xm), ptr(wq), BC, d, ptr(dq), ptr(dwq), ptr(dbq), stream()), "dsmil_qv_bwd")
+    if dcmax is None:
+        check(_lib.lib().murcl_dsmil_qv_bwd(ptr(R), ptr(qmax), ptr(xm), ptr(wq), BC, d, ptr(dq), ptr(dwq), ptr(dbq), stream()), "dsmil_qv_bwd")
+        return dwq, dbq
+    dcmax = _c(dcmax)
+    C = dcmax.shape[-1]
+    assert dcmax.numel() == BC and dwc.is_contiguous() and dbc.is_contiguous() and tuple(dwc.shape) == (C, d) and dbc.numel() == C
+    check(_lib.lib().murcl_dsmil_qv_bwd_cls(ptr(R), ptr(qmax), ptr(xm), ptr(wq), BC, d, ptr(dq), ptr(dwq), ptr(dbq), ptr(dcmax), C,
+                                            ptr(dwc), ptr(dbc), int(accumulate), stream()), "dsmil_qv_bwd_cls")
     return dwq, dbq
 
 
@@ -868,14 +904,17 @@ def weighted_rowsum(X, A):
     return Z
 
 
-def rows_dot(X, V):
-    """out[b,n,c] = X[b,n,:] . V[b,c,:]."""
+def rows_dot(X, V, bias=None):
+    """out[b,n,c] = X[b,n,:] . V[b,c,:] (+ bias[c])."""
     X, V = _c(X), _c(V)
     B, N, d = X.shape
     C = V.shape[1]
     out = torch.empty((B, N, C), dtype=torch.float32, device=X.device)
+    if bias is not None:
+        bias = _c(bias)
+        assert bias.dtype == torch.float32 and bias.numel() == C
     with _span(lambda: (f"rows_dot<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
-        check(_lib.lib().murcl_rows_dot(ptr(X), ptr(V), ptr(out), B, N, d, C, dt(X), stream()), "rows_dot")
+        check(_lib.lib().murcl_rows_dot_bias(ptr(X), ptr(V), ptr(bias), ptr(out), B, N, d, C, dt(X), stream()), "rows_dot")
     return out
 
 

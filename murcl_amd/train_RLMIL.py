@@ -56,8 +56,8 @@ def _aggregate(arch, model, feats, labels):
     if arch == "CLAM_SB":
         M, _, _, inst_loss, _, _ = model._run(feats if feats.dim() == 3 else feats.unsqueeze(0), labels, True)
         return M, M.detach(), inst_loss
-    classes, bag = model._run(feats if feats.dim() == 3 else feats.unsqueeze(0))
-    return bag.mean(1), bag.detach().mean(1), classes.max(1)[0]                          # :515-518,527
+    _, bag, cmax = model._run(feats if feats.dim() == 3 else feats.unsqueeze(0), want_max=True)
+    return bag.mean(1), bag.detach().mean(1), cmax                                         # :515-518,527 (cmax = classes.max(1)[0])
 
 
 def _head_loss(arch, fc, head_in, extra, labels, t, bag_weight):

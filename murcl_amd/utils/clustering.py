@@ -14,7 +14,7 @@ import json
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, ops
 from .._lib import check, ptr, stream
 
 
@@ -77,22 +77,29 @@ def lloyd(X, centers, max_iter=300, tol=1e-4):
 def kmeans_plusplus(X, K, generator):
     """Greedy k-means++ seeding as scikit-learn runs it (``_kmeans_plusplus``: 2 + log K candidate rows per step, drawn
     with probability ~ squared distance to the nearest chosen centre; the candidate that lowers the potential most wins)."""
-    N = X.shape[0]
+    N, d = X.shape
     trials = 2 + int(np.log(K))
+    if d % 32:                                                # the GEMM's reduction runs in 128-byte slabs: zero columns change no distance
+        X = torch.nn.functional.pad(X, (0, 32 - d % 32)).contiguous()
+
+    def cross(rows):
+        """rows [r, d] . X^T -> [r, N] on the repo's own f32 GEMM (exact-f32 MFMA), not a library matmul."""
+        return ops.gemm_nt(rows.contiguous(), X)
+
     xx = (X * X).sum(1)
     first = int(torch.randint(N, (1,), generator=generator, device=X.device).item())
-    centers = [X[first]]
-    d2 = (xx - 2 * (X @ centers[0]) + xx[first]).clamp_min_(0)
+    centers = [X[first, :d]]
+    d2 = (xx - 2 * cross(X[first:first + 1]).view(-1) + xx[first]).clamp_min_(0)
     for _ in range(1, K):
         pot = d2.sum()
         if float(pot) <= 0:                                   # fewer distinct rows than clusters
             centers.append(X[int(torch.randint(N, (1,), generator=generator, device=X.device).item())])
             continue
         cand = torch.multinomial(d2 / pot, trials, replacement=True, generator=generator)
-        dc = (xx[None, :] - 2 * (X[cand] @ X.t()) + xx[cand][:, None]).clamp_min_(0)      # [trials, N]
+        dc = (xx[None, :] - 2 * cross(X[cand]) + xx[cand][:, None]).clamp_min_(0)         # [trials, N]
         dc = torch.minimum(dc, d2[None, :])
         best = int(dc.sum(1).argmin().item())
-        centers.append(X[cand[best]])
+        centers.append(X[cand[best], :d])
         d2 = dc[best]
     return torch.stack(centers, 0)
 

@@ -622,6 +622,37 @@ def test_ntxent_batched_equals_one_problem_at_a_time(T_, Bh):
     assert d2 is None and torch.equal(l2, loss) and torch.equal(s2, sim)
 
 
+@pytest.mark.parametrize("Bh", [2, 9, 33, 64])
+def test_ntxent_one_exchange_kernel_equals_the_recompute_kernel(Bh, monkeypatch):
+    """murcl_ntxent_small_xchg (round 4: a workgroup forms only its own 16 rows of logits and the workgroups exchange their lse as
+    {value, generation} granules) against ntxent_small_kernel (every workgroup recomputes all logits): same logits bit for bit, so
+    loss / gradient / cosines agree to the last reduction-order bits - over MANY back-to-back launches on changing data (a stale
+    granule of an earlier launch, or a missed one, would show as a wrong lse), single and batched, with and without a window."""
+    from murcl_amd import ops
+    dev = _dev()
+    for it in range(40):
+        z = _rand(31, f"x{Bh}.{it}", (2 * Bh, 128), 1.0 + 0.1 * it).to(dev)
+        monkeypatch.setattr(ops, "_NTX_XCHG", False)
+        l0, d0, s0 = ops.ntxent(z, 0.5)
+        lw, dw, _ = ops.ntxent(z, 0.5, grad_lo=0, grad_hi=max(1, Bh // 2))
+        monkeypatch.setattr(ops, "_NTX_XCHG", True)
+        l1, d1, s1 = ops.ntxent(z, 0.5)
+        lx, dx, _ = ops.ntxent(z, 0.5, grad_lo=0, grad_hi=max(1, Bh // 2))
+        assert abs(l1.item() - l0.item()) <= 2e-6 * abs(l0.item()), it
+        _close(d1, d0.cpu(), rtol=1e-5, atol=1e-6 * d0.abs().max().item(), msg=f"dz {it}")
+        assert torch.equal(s1, s0)
+        _close(dx, dw.cpu(), rtol=1e-5, atol=1e-6 * d0.abs().max().item(), msg=f"dz window {it}")
+    zb = _rand(31, f"b{Bh}", (5, 2 * Bh, 128)).to(dev)
+    monkeypatch.setattr(ops, "_NTX_XCHG", False)
+    lb0, db0, sb0 = ops.ntxent_batched(zb, 1.0)
+    monkeypatch.setattr(ops, "_NTX_XCHG", True)
+    for _ in range(10):
+        lb1, db1, sb1 = ops.ntxent_batched(zb, 1.0)
+        _close(lb1, lb0.cpu(), rtol=2e-6, atol=0, msg="batched loss")
+        _close(db1, db0.cpu(), rtol=1e-5, atol=1e-6 * db0.abs().max().item(), msg="batched dz")
+        assert torch.equal(sb1, sb0)
+
+
 @pytest.mark.parametrize("Bh,step", [(32, 8), (256, 64), (200, 40)])
 def test_ntxent_sharded_rows_match_global(Bh, step):
     """Rank-local gradient slices assemble to the global gradient; 256 = the global batch of 4 ranks."""

@@ -624,6 +624,40 @@ def test_dsmil_reassociated_attention_equals_the_literal_order(monkeypatch, dtyp
             assert (got[2][k] - lit[2][k]).abs().max().item() <= tol * scale, (name, k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("also_dense", [False, True])
+def test_dsmil_max_instance_scores_come_out_of_the_argmax_launch(dtype, also_dense, monkeypatch):
+    """Round 4: ``_run(want_max=True)`` returns the max-instance class scores (train_RLMIL.py:516, ``torch.max(outputs_ins, 0)``) as its
+    own differentiable output: equal to ``classes.max(1)[0]`` bit for bit, and a loss on it gives the parameter gradients of the dense
+    route (ATen max -> scatter into a [B,N,C] gradient -> the streaming backward with dcls) - alone and together with a dense term."""
+    dev = _dev()
+    B, N, d = 3, 1024, 1024
+    x = T(P.bags(23, "dm.x", B, N, d)).to(dev).to(dtype)
+    w = T(detrand.normal(23, "dm.w", (B, 2))).to(dev)
+
+    def run(route):
+        m = _dsmil(23, d=d, dtype=dtype)
+        if route == "max":
+            classes, bag, cmax = m._run(x, want_max=True)
+        else:
+            classes, bag = m._run(x)
+            cmax = classes.max(1)[0]
+        loss = bag.sum() + (cmax * w).sum()
+        if also_dense:
+            loss = loss + 0.01 * (classes * classes).sum()
+        loss.backward()
+        return cmax.detach(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    cm_a, g_a = run("max")
+    cm_b, g_b = run("dense")
+    assert torch.equal(cm_a, cm_b)
+    assert set(g_a) == set(g_b)
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    for k in g_a:
+        scale = max(g_b[k].abs().max().item(), 1e-6 * max(v.abs().max().item() for v in g_b.values()))
+        assert (g_a[k] - g_b[k]).abs().max().item() <= tol * scale, k
+
+
 # ------------------------------------------------------------------ PPO (K10/K11)
 def test_ppo_act_evaluate_update_vs_reference_golden(golden):
     """G8: act (injected eps) -> actions/logp/hidden; evaluate; one update (K_epochs=1, Adam lr 1e-3) -> parameters."""

@@ -66,8 +66,8 @@ if "dsmil" in only or not only:
         with torch.no_grad(): m(x)
     def fb():                          # bag term + max-instance term (train_RLMIL.py:516-529), batched as the training step has it
         for p in m.parameters(): p.grad = None
-        classes, bag = m._run(x)
-        (bag.sum() + classes.max(1)[0].sum()).backward()
+        classes, bag, cmax = m._run(x, want_max=True)
+        (bag.sum() + cmax.sum()).backward()
     report("a9-a11 DSMIL (K6) C5/8", "forward (2 passes over X)", timed(fwd), 2 * B * N * d * 4, B, "bags")
     report("a9-a11 DSMIL (K6) C5/8", "forward+backward (4 passes over X)", timed(fb), 4 * B * N * d * 4, B, "bags")
 # ---- C4 per-GPU share: sub-bag builder, 64 raw bags x 8192 x 512 -> 2 views x 1024
