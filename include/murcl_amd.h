@@ -65,13 +65,21 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * clam.py:69-72), deferred until the last input gradient of the pass exists.  The (product, tile) pairs share one round of
  * workgroups (one per CU), so the per-launch fixed costs and the partial-tile traffic are paid once.  `probs` is a HOST array of
  * n <= 4 descriptors; colsum_part / colsum_rows / colsum_out as in murcl_gemm_tn_ws (colsum_out without colsum_part: column
- * sums of A_g by their own launch).  Products the square-tile kernel does not take (see murcl_gemm_tn_ws), or a workspace below
+ * sums of A_g by their own launch; not with flags).  flags / scale: applied by the reduce launch (grouped path only: a group with
+ * flags that is not eligible returns -1).  Products the square-tile kernel does not take (see murcl_gemm_tn_ws), or a workspace below
  * murcl_gemm_tn_grouped_workspace_bytes (0 = the group is not eligible), run one by one through murcl_gemm_tn_ws. */
 typedef struct murcl_tn_problem {
     const void* A; const void* B; float* C;
     const float* colsum_part; float* colsum_out;
     int M, N1, N2, lda, ldb, ldc, colsum_rows;
+    int flags;          /* MURCL_TN_* below; 0 = C (and colsum_out) accumulated into */
+    float scale;        /* with MURCL_TN_SCALE: the product (and the column sums) times this factor */
 } murcl_tn_problem;
+#define MURCL_TN_OVERWRITE 1    /* C = product, colsum_out = sums (no read of either: the caller need not zero them) */
+#define MURCL_TN_DEINTERLEAVE 2 /* rows of the product arrive as 16-row blocks alternating between two halves (the gate pair of
+                                 * murcl_panel_gemm epilogue 5: a-rows, b-rows, a-rows ...): row r of the product is written to row
+                                 * ((r >> 4) & 1) * N1/2 + (r >> 5) * 16 + (r & 15) of C, i.e. C = [dWa; dWb] in natural order */
+#define MURCL_TN_SCALE 4
 long murcl_gemm_tn_grouped_workspace_bytes(const murcl_tn_problem* probs, int n, int dtype);
 int murcl_gemm_tn_grouped(const murcl_tn_problem* probs, int n, int dtype, float* ws, long ws_bytes, murcl_stream_t stream);
 
@@ -223,6 +231,12 @@ int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits 
  * clam.py:144,170 behind the gate GEMM (C = 1, d = 512).  Plan / workspace as murcl_dsmil_attn_pool; A may not alias S. */
 int murcl_softmax_pool(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
                        murcl_stream_t stream);
+/* CLAM-SB's soft-max over the patches + attention pooling (clam.py:144,170) as one streaming pass over X and a small reduce launch:
+ * A [B,N] = soft-max_n(S [B,N]), Z [B,d] = sum_n A[b,n] X[b,n,:].  Every (bag, 128-row chunk) workgroup recomputes the bag's
+ * statistics from its N scores, a wave keeps 8 whole rows in flight; ws: murcl_softmax_pool2_ws_floats floats (0: not covered). */
+long murcl_softmax_pool2_ws_floats(int B, int N, int d);
+int murcl_softmax_pool2(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int dtype,
+                        murcl_stream_t stream);
 int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls, float scale,
                               float* R, float* gpart, float* ws, int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,

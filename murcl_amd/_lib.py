@@ -60,6 +60,8 @@ SIGNATURES = {
     "murcl_dsmil_qv": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "murcl_dsmil_qv_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "murcl_dsmil_qv_bwd_cls": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "murcl_softmax_pool2_ws_floats": [_I, _I, _I],
+    "murcl_softmax_pool2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_softmax_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -97,7 +99,7 @@ SIGNATURES = {
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
+_RESTYPE = {"murcl_softmax_pool2_ws_floats": _L, "murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
 
 
@@ -105,7 +107,10 @@ _RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "
 class TnProblem(ctypes.Structure):
     """murcl_tn_problem of include/murcl_amd.h (one product of murcl_gemm_tn_grouped)."""
     _fields_ = [("A", _P), ("B", _P), ("C", _P), ("colsum_part", _P), ("colsum_out", _P),
-                ("M", _I), ("N1", _I), ("N2", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("colsum_rows", _I)]
+                ("M", _I), ("N1", _I), ("N2", _I), ("lda", _I), ("ldb", _I), ("ldc", _I), ("colsum_rows", _I), ("flags", _I), ("scale", _F)]
+
+
+TN_OVERWRITE, TN_DEINTERLEAVE, TN_SCALE = 1, 2, 4
 
 
 _lib = None

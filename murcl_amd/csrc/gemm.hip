@@ -1198,7 +1198,8 @@ struct TnReduceArgs {
     const float* cs_part[TN_MAXG];
     float* cs_out[TN_MAXG];
     long part_off[TN_MAXG], n4[TN_MAXG];
-    int nsplit[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG], ldc[TN_MAXG], cs_rows[TN_MAXG];
+    int nsplit[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG], ldc[TN_MAXG], cs_rows[TN_MAXG], flags[TN_MAXG];
+    float scale[TN_MAXG];
     int blk0[TN_MAXG + 1];           // first matrix block of product g (blk0[n] = all matrix blocks)
     int cs_blk0[TN_MAXG + 1];        // first column-sum block of product g, counted from blk0[n]
     int n;
@@ -1239,8 +1240,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
             f32x4 t = red[cg];
 #pragma unroll
             for (int k = 1; k < 16; ++k) t += red[16 * k + cg];
+            if (ra.flags[g] & MURCL_TN_SCALE) t *= ra.scale[g];
             f32x4* o = (f32x4*)ra.cs_out[g] + j;
-            *o = *o + t;
+            *o = (ra.flags[g] & MURCL_TN_OVERWRITE) ? t : *o + t;
         }
         return;
     }
@@ -1258,10 +1260,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
         a0 += v0; a1 += v1; a2 += v2; a3 += v3;
     }
     for (; s < nsplit; ++s) a0 += p[(size_t)s * n4];
-    const f32x4 t = (a0 + a1) + (a2 + a3);
-    const long e = i * 4, row = e / N2, col = e % N2;
+    f32x4 t = (a0 + a1) + (a2 + a3);
+    const int fl = ra.flags[g];
+    if (fl & MURCL_TN_SCALE) t *= ra.scale[g];
+    const long e = i * 4, col = e % N2;
+    long row = e / N2;
+    if (fl & MURCL_TN_DEINTERLEAVE) row = ((row >> 4) & 1) * (ra.N1[g] >> 1) + (row >> 5) * 16 + (row & 15);
     f32x4* c = (f32x4*)(ra.C[g] + row * ra.ldc[g] + col);
-    *c = *c + t;
+    *c = (fl & MURCL_TN_OVERWRITE) ? t : *c + t;
 }
 static bool tn_sq_ok(int M, int N1, int N2, int ldc, int dtype) {
     return dtype == MURCL_DTYPE_BF16 && N1 % 256 == 0 && N2 % 256 == 0 && M >= 16384 && ldc % 4 == 0;
@@ -1516,7 +1522,7 @@ static int tn_sq_launch(const TnProblem* pr, int n, float* ws, hipStream_t strea
         ga.mps[g] = pl.mps[h]; ga.part_off[g] = pl.part_off[h];
         ra.C[g] = pr[h].C; ra.cs_part[g] = pr[h].colsum_part; ra.cs_out[g] = pr[h].colsum_out; ra.cs_rows[g] = pr[h].colsum_rows;
         ra.part_off[g] = pl.part_off[h]; ra.n4[g] = (long)pr[h].N1 * pr[h].N2 / 4; ra.nsplit[g] = pl.sp[h];
-        ra.N1[g] = pr[h].N1; ra.N2[g] = pr[h].N2; ra.ldc[g] = pr[h].ldc;
+        ra.N1[g] = pr[h].N1; ra.N2[g] = pr[h].N2; ra.ldc[g] = pr[h].ldc; ra.flags[g] = pr[h].flags; ra.scale[g] = pr[h].scale;
         if (g < n) {
             ra.blk0[g] = blk; blk += (int)((ra.n4[g] + 255) / 256);
             ra.cs_blk0[g] = csb; csb += pr[g].colsum_part ? (pr[g].N1 / 4 + 15) / 16 : 0;
@@ -1559,7 +1565,7 @@ extern "C" int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, i
         const int rc = murcl_colsum(A, colsum_out, M, N1, lda, dtype, 1, stream);
         if (rc) return rc;
     }
-    const TnProblem p{A, B, C, colsum_part, colsum_part ? colsum_out : nullptr, M, N1, N2, lda, ldb, ldc, colsum_rows};
+    const TnProblem p{A, B, C, colsum_part, colsum_part ? colsum_out : nullptr, M, N1, N2, lda, ldb, ldc, colsum_rows, 0, 1.f};
     return tn_sq_launch(&p, 1, ws, stream);
 }
 
@@ -1583,6 +1589,8 @@ extern "C" int murcl_gemm_tn_grouped(const TnProblem* pr, int n, int dtype, floa
     if (n <= 0) return 0;
     const long need = (n <= TN_MAXG) ? murcl_gemm_tn_grouped_workspace_bytes(pr, n, dtype) : 0;
     if (!need || !ws || ws_bytes < need) {
+        for (int g = 0; g < n; ++g)
+            if (pr[g].flags) return -1;                 // overwrite / de-interleave / scale live in the grouped reduce launch only
         for (int g = 0; g < n; ++g) {
             const TnProblem& p = pr[g];
             const int rc = murcl_gemm_tn_ws(p.A, p.B, p.C, p.M, p.N1, p.N2, p.lda, p.ldb, p.ldc, dtype, 0, p.colsum_out, ws, ws_bytes,
@@ -1594,6 +1602,7 @@ extern "C" int murcl_gemm_tn_grouped(const TnProblem* pr, int n, int dtype, floa
     TnProblem q[TN_MAXG];
     for (int g = 0; g < n; ++g) {
         q[g] = pr[g];
+        if (q[g].flags && ((q[g].colsum_out && !q[g].colsum_part) || ((q[g].flags & MURCL_TN_DEINTERLEAVE) && q[g].N1 % 32))) return -1;
         if (q[g].colsum_out && !q[g].colsum_part) {
             const int rc = murcl_colsum(q[g].A, q[g].colsum_out, q[g].M, q[g].N1, q[g].lda, dtype, 1, stream);
             if (rc) return rc;

@@ -39,6 +39,7 @@ _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B sw
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
 _FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
 _CLAM_POOL = _os.environ.get("MURCL_CLAM_POOL", "0") == "1"          # dev A/B switch, OFF: CLAM's soft-max + pooling as one streaming pass (online soft-max) - measured 20-40 us SLOWER at C3 than soft-max + weighted_rowsum (four rows in flight per wave: latency-bound at d = 512)
+_CLAM_POOL2 = _os.environ.get("MURCL_CLAM_POOL2", "1") == "1"        # dev A/B switch: CLAM's soft-max + pooling as one pass over h with the bag's statistics recomputed per chunk (round 4)
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
@@ -106,7 +107,7 @@ def _wgrad_group(items):
         else:
             assert parts is None
             probs.append((dy, x, None, None, None))
-    Cs = ops.gemm_tn_grouped(probs)
+    Cs = ops.gemm_tn_grouped(probs, fresh=True)           # (products without a pre-seated gradient are written, not accumulated: no fill)
     return [None if _direct(it[2]) else C for it, C in zip(items, Cs)]
 
 
@@ -798,6 +799,15 @@ class DSMILFn(torch.autograd.Function):
 
 
 _INST_CONST = {}
+_ZERO_CONST = {}
+
+
+def _zeros_const(dev, n):
+    """A shared read-only zero vector (the instance loss of a call without instance evaluation): no fill launch per call."""
+    z = _ZERO_CONST.get((dev, n))
+    if z is None:
+        z = _ZERO_CONST[(dev, n)] = torch.zeros((n,), dtype=torch.float32, device=dev)
+    return z
 
 
 def _inst_constants(dev, B, N, k, n_cls, subtyping):
@@ -895,13 +905,15 @@ class CLAMFn(torch.autograd.Function):
         if not fused_gate and not gate_u:
             s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
         one = ops.softmax_pool(h.view(B, N, L), s.view(B, N, 1)) if _CLAM_POOL else None    # soft-max (clam.py:144) + pooling (:170), one pass
+        if one is None and _CLAM_POOL2:
+            one = ops.softmax_pool2(h.view(B, N, L), s.view(B, N))                     # ... with 8 whole rows in flight per wave
         if one is not None:
             A, M = one[0].view(B, N), one[1].view(B, L)
         else:
             A = ops.softmax_rows(s)                                                    # clam.py:144
             M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)       # clam.py:170
         dev = x.device
-        inst_loss = torch.zeros((B,), dtype=torch.float32, device=dev)
+        inst_loss = _zeros_const(dev, B) if inst_cfg is None else torch.zeros((B,), dtype=torch.float32, device=dev)
         saved_inst = None
         ids = None
         inst_pt = None
@@ -964,8 +976,11 @@ class CLAMFn(torch.autograd.Function):
             # ds_n = A_n (h_n . dM - M . dM) needs no reduction over the bag; U / dU in the interleaved column order of the forward
             dU, dwc, dbc, dbab = ops.gated_score_bwd_il(U, wc.reshape(-1).contiguous(), ka, kb, h=h, dM=dM, Mp=M, A=A.view(-1),
                                                         rows_per_bag=N)
-            dwab = None                                                               # with dw1 below: one grouped launch
-            if not _GROUP_WGRAD:
+            # gate + first-layer weight gradients (clam.py:69-72) wait for dz1 and share one round of workgroups; the reduce launch
+            # also undoes the 16-row interleave, applies the Dropout factor and sums the bias-gradient rows (no ATen launches)
+            grouped = _GROUP_WGRAD and ops.gemm_tn_grouped_ok([(dU, h, None, None, None), (h, x2, None, None, None)])
+            dwab = None
+            if not grouped:
                 dwab = ops.gemm_tn(dU, h).view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)   # rows back in [Wa; Wb] order
             wab_t = ctx.wab_t                                                         # [L, 2D] interleaved columns, as dU's
         else:
@@ -975,6 +990,7 @@ class CLAMFn(torch.autograd.Function):
             dU, dwc, dbc, dbab = ops.gated_score_bwd(U, wc.reshape(-1).contiguous(), ds, ka, kb, gated=gated)   # dbab: column sums, same pass
             dwab = ops.gemm_tn(dU, h)                                                     # [2D, L] (gated) / [D, L]
             wab_t = None
+            grouped = False
         wab = None if wab_t is not None else (torch.cat([wa, wb], 0) if gated else wa)
         # dZ1 = (dU [Wa;Wb] + A (x) dM) * relu'(h)   (h here is already the dropped h: zero where dropped)
         if (T == torch.bfloat16 and dU.shape[1] == 512 and ops.panel_supported(B * N, L, 512, ops.PG_RANK1_MASK, N)):
@@ -982,18 +998,22 @@ class CLAMFn(torch.autograd.Function):
             # few rows it adds
             dz1, _, db1 = ops.panel_gemm(dU, wab_t if wab_t is not None else ops.transpose_cast(wab, T), ops.PG_RANK1_MASK,
                                          bitmask=m1 if m1 is not None else ops.relu_bitmask(h),
-                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
+                                         rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True, colsum_defer=grouped)
+            db1_parts = db1 if grouped else None
         else:
-            db1 = None
+            db1 = db1_parts = None
+            assert not grouped
             dz1 = ops.gemm_nt(dU, ops.transpose_cast(wab, T), epi=ops.EPI_RANK1_MASK, mask=h, rowscale=A.view(-1),
                               rank1=dM, rows_per_bag=N)
         # instance branch: classifier grads + sparse feature grads added under the same ReLU mask
-        dinst_w = dinst_b = None
+        dinst_w = dinst_b = db1_extra = None
         if ctx.saved_inst is not None and dinst is not None and ctx.saved_inst[0] == "fused":
             _, ids, dl, w_st, k, n_cls = ctx.saved_inst
             dwi, dbi, gsum = ops.clam_inst_bwd(h, ids, w_st, dl, dinst.float(), B, N, k, n_cls, dz1)
             dinst_w, dinst_b = dwi.view(n_cls, 2, -1), dbi.view(n_cls, 2)
-            if db1 is not None:
+            if grouped:
+                db1_extra = gsum
+            elif db1 is not None:
                 db1 = db1 + gsum
         elif ctx.saved_inst is not None and dinst is not None:
             rows_all, feats, dl_g, scale, k, n_cls = ctx.saved_inst
@@ -1003,18 +1023,26 @@ class CLAMFn(torch.autograd.Function):
             dinst_b = ops.colsum(dlog).view(n_cls, 2)
             g = ops.gemm_nt(dlog, inst_w.reshape(n_cls * 2, -1).t().contiguous())      # [B*2k, L]; K = 2 n_cls is padded
             ops.scatter_add_rows_masked(dz1, h, rows_all, g, write_back=db1 is not None)
-            if db1 is not None:
+            if grouped:
+                db1_extra = ops.colsum(g)
+            elif db1 is not None:
                 ops.colsum(g, out=db1, accumulate=True)                                  # [B*2k, L] f32: the rows just added
-        if dwab is None:                         # gate + first-layer weight gradients (clam.py:69-72) share one round of workgroups
-            dwab, dw1 = ops.gemm_tn_grouped([(dU, h, None, None, None), (dz1, x2, None, None, None)])
-            dwab = dwab.view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)         # rows back in [Wa; Wb] order
-        else:
-            dw1 = ops.gemm_tn(dz1, x2)
-        if db1 is None:
-            db1 = ops.colsum(dz1)
+        kp = None
         if k1 is not None:                       # the surviving entries of the keep mask all equal 1/0.75
             kp = k1.keep_q if isinstance(k1, ops.DropSeed) else 0.75
-            dw1, db1 = dw1 / kp, db1 / kp
+        if grouped:
+            db1 = torch.empty((L,), dtype=torch.float32, device=dz1.device)
+            sc = None if kp is None else {"scale": 1.0 / kp}
+            dwab, dw1 = ops.gemm_tn_grouped([(dU, h, None, None, None, {"deinterleave": True}),
+                                             (dz1, x2, None, db1, db1_parts, dict(sc or {}, overwrite=True))], fresh=True)
+            if db1_extra is not None:            # the rows the instance branch added to dz1 after its column sums were taken
+                db1 = db1 + (db1_extra if kp is None else db1_extra / kp)
+        else:
+            dw1 = ops.gemm_tn(dz1, x2)
+            if db1 is None:
+                db1 = ops.colsum(dz1)
+            if kp is not None:
+                dw1, db1 = dw1 / kp, db1 / kp
         if not gated:
             return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None, None)
         return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),

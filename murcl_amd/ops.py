@@ -324,40 +324,72 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3
     return C
 
 
-def gemm_tn_grouped(problems):
+def gemm_tn_grouped(problems, fresh=False):
     """Several weight gradients in ONE launch (+ one reduce launch): ``problems`` = list of (A [M,N1], B [M,N2], out or None,
-    colsum_into or None, colsum_parts or None) with the meanings of ``gemm_tn``; returns the list of C tensors.  bf16 products
+    colsum_into or None, colsum_parts or None[, opts]) with the meanings of ``gemm_tn``; returns the list of C tensors.  bf16 products
     with N1, N2 multiples of 256 and M >= 16384 share one round of workgroups (murcl_gemm_tn_grouped); anything else, or more
-    than four products, runs through ``gemm_tn`` one by one."""
-    eligible = (_TN_SQ and 1 < len(problems) <= 4 and all(
-        A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0 and A.shape[0] >= 16384
-        and A.shape[0] == B.shape[0] and (cp is None or ci is not None) for A, B, _, ci, cp in problems))
-    if not eligible:
-        return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp in problems]
+    than four products, runs through ``gemm_tn`` one by one.  ``opts`` (dict, grouped path only - check ``gemm_tn_grouped_ok``):
+    ``scale`` (product and column sums times a factor), ``deinterleave`` (rows arrive as alternating 16-row blocks of two halves: C
+    = [first half; second half] in natural order).  ``fresh``: products without ``out`` / column sums into a fresh tensor are WRITTEN
+    by the reduce launch (no zero-fill launch before it)."""
+    problems = [tuple(p) + (None,) * (6 - len(p)) for p in problems]
+    if not gemm_tn_grouped_ok(problems):
+        assert all(p[5] is None for p in problems), "scale / deinterleave need the grouped launch (gemm_tn_grouped_ok)"
+        return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp, _ in problems]
     n = len(problems)
     arr = (_lib.TnProblem * n)()
     keep, Cs = [], []
-    for g, (A, B, out, ci, cp) in enumerate(problems):
+    for g, (A, B, out, ci, cp, opts) in enumerate(problems):
         _need_cuda(A, B)
         A, B = _c(A), _c(B)
         M, N1 = A.shape
         N2 = B.shape[1]
-        C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
+        flags, scale = 0, 1.0
+        if out is None and fresh:
+            C = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+            flags |= _lib.TN_OVERWRITE
+        else:
+            C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
         assert C.dtype == torch.float32 and C.is_contiguous() and tuple(C.shape) == (N1, N2)
         if ci is not None:
             assert ci.dtype == torch.float32 and ci.is_contiguous() and ci.numel() == N1
+        if opts:
+            if opts.get("scale") is not None:
+                flags, scale = flags | _lib.TN_SCALE, float(opts["scale"])
+            if opts.get("deinterleave"):
+                flags |= _lib.TN_DEINTERLEAVE
+            if opts.get("overwrite"):
+                flags |= _lib.TN_OVERWRITE
         keep.append((A, B, cp))
         Cs.append(C)
-        arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), ptr(cp[0]) if cp else None, ptr(ci), M, N1, N2, N1, N2, N2, cp[1] if cp else 0)
+        arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), ptr(cp[0]) if cp else None, ptr(ci), M, N1, N2, N1, N2, N2, cp[1] if cp else 0,
+                                flags, scale)
     wsb = _lib.lib().murcl_gemm_tn_grouped_workspace_bytes(arr, n, BF16)
-    if not wsb:
-        return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp in problems]
+    assert wsb, "gemm_tn_grouped_ok and the library disagree"
     ws = torch.empty((wsb // 4,), dtype=torch.float32, device=Cs[0].device)
     with _span(lambda: (f"gemm_tn_sq_grouped{n}<bf16>",
                dict(flops=sum(2.0 * A.shape[0] * A.shape[1] * B.shape[1] for A, B, _ in keep),
                     bytes=sum(A.shape[0] * (A.shape[1] + B.shape[1]) * 2 + A.shape[1] * B.shape[1] * 4 for A, B, _ in keep)))):
         check(_lib.lib().murcl_gemm_tn_grouped(arr, n, BF16, ptr(ws), wsb, stream()), "gemm_tn_grouped")
     return Cs
+
+
+def gemm_tn_grouped_ok(problems):
+    """Does this list run as ONE grouped launch?  (bf16, 2-4 products, N1 and N2 multiples of 256, M >= 16384, at most 32 tiles each,
+    all (product, tile) pairs within one round of workgroups.)"""
+    if not (_TN_SQ and 1 < len(problems) <= 4):
+        return False
+    pairs = 0
+    for p in problems:
+        A, B, ci, cp = p[0], p[1], p[3], p[4]
+        if not (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and A.shape[1] % 256 == 0 and B.shape[1] % 256 == 0
+                and A.shape[0] >= 16384 and A.shape[0] == B.shape[0] and (cp is None or ci is not None)):
+            return False
+        tiles = (A.shape[1] // 256) * (B.shape[1] // 256)
+        if tiles > 32:
+            return False
+        pairs += tiles
+    return pairs <= 256
 
 
 def pool_chunks(B, N, dtype_code):
@@ -836,6 +868,22 @@ def dsmil_attn_pool(X, v, scale=1.0):
     with _span(lambda: (f"dsmil_attn_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=4.0 * B * N * d * C))):
         check(_lib.lib().murcl_dsmil_attn_pool(ptr(X), ptr(v), float(scale), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()),
               "dsmil_attn_pool")
+    return A, Z
+
+
+def softmax_pool2(X, S):
+    """CLAM-SB's A [B,N] = soft-max_n(S [B,N]) and M [B,d] = sum_n A X (clam.py:144,170) from ONE pass over X + a small reduce launch
+    (murcl_softmax_pool2), or None when the shape is not covered.  X [B,N,d] f32/bf16, S [B,N] f32."""
+    X, S = _c(X), _c(S)
+    B, N, d = X.shape
+    wsf = _lib.lib().murcl_softmax_pool2_ws_floats(B, N, d)
+    if not wsf:
+        return None
+    A = torch.empty((B, N), dtype=torch.float32, device=X.device)
+    Z = torch.empty((B, d), dtype=torch.float32, device=X.device)
+    ws = torch.empty((wsf,), dtype=torch.float32, device=X.device)
+    with _span(lambda: (f"softmax_pool2<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d))):
+        check(_lib.lib().murcl_softmax_pool2(ptr(X), ptr(S), ptr(A), ptr(Z), ptr(ws), B, N, d, dt(X), stream()), "softmax_pool2")
     return A, Z
 
 

@@ -285,6 +285,30 @@ def test_grouped_weight_gradients_equal_the_single_launches(shapes):
         assert _rel_fro(base, single.double().cpu()) < 1e-5
 
 
+def test_grouped_weight_gradients_write_scale_and_deinterleave_in_the_reduce_launch():
+    """murcl_tn_problem.flags: products written into uninitialised tensors (no zero-fill launch), a factor applied to product and
+    column sums (CLAM's Dropout scale), and the 16-row a/b interleave of the gate pair undone on the way out (clam.py:69-72 backward):
+    against float64 and against the plain grouped call followed by the tensor ops the flags replace."""
+    from murcl_amd import ops
+    dev = _dev()
+    M, D, L = 32768, 256, 512
+    dU = _rand(22, "dU", (M, 2 * D), 0.5).bfloat16().to(dev)
+    h = _rand(22, "h", (M, L)).bfloat16().to(dev)
+    dz = _rand(22, "dz", (M, L), 0.5).bfloat16().to(dev)
+    x = _rand(22, "x", (M, 512)).bfloat16().to(dev)
+    parts = _rand(22, "parts", (41, L)).to(dev)
+    plain = ops.gemm_tn_grouped([(dU, h, None, None, None), (dz, x, None, None, None)])
+    ref_ab = plain[0].view(D // 16, 2, 16, L).permute(1, 0, 2, 3).reshape(2 * D, L)
+    db = torch.full((L,), float("nan"), device=dev)                       # must be overwritten, never read
+    got = ops.gemm_tn_grouped([(dU, h, None, None, None, {"deinterleave": True}),
+                               (dz, x, None, db, (parts, 41), {"scale": 1.0 / 0.75, "overwrite": True})], fresh=True)
+    assert torch.equal(got[0], ref_ab)
+    _close(got[1], (plain[1] / 0.75).cpu(), rtol=1e-6, atol=0, msg="scaled dW")
+    _close(db, (parts.double().sum(0) / 0.75).cpu(), rtol=1e-5, atol=1e-5, msg="scaled db")
+    s = math.sqrt(M)
+    _close(got[1], dz.double().cpu().t() @ x.double().cpu() / 0.75, rtol=1e-4, atol=2e-2 * s, msg="dW vs f64")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N", [(32, 128), (4096, 512), (96, 1024)])
 def test_dropout_applied_in_place_with_the_mask_never_materialised(dtype, M, N):
