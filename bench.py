@@ -248,7 +248,7 @@ def other_rows(device):
     steps use (train_RLMIL.supervised_step), median of 10 HIP-event timings.  Two accountings per row: `survey_8d` = the
     ALGORITHMIC work of SURVEY section 8(d) (FLOPs of the K4 / K6 chain forward + backward against the dense bf16 MFMA peak; X
     once forward and twice backward against 8 TB/s), and `chain_traffic_*` = the bytes the un-fused operator chain as built
-    moves (15 passes over [B*N,512] for CLAM, 4 over X for DSMIL) - the second says how well the passes stream, not how close
+    moves (14 passes over [B*N,512] for CLAM: 5 forward + 9 backward; for the reassociated DSMIL chain the two accountings coincide: 3 passes over X) - the second says how well the passes stream, not how close
     the row is to its algorithmic floor."""
     from murcl_amd.models.clam import CLAM_SB
     from murcl_amd.models.dsmil import build_dsmil

@@ -487,7 +487,10 @@ class ABMILStepFn(torch.autograd.Function):
         s, t = session, session.t
         B, N, d = x.shape
         T = x.dtype
-        assert t < s.steps and (B, N, d) == (s.bags, s.N, s.d), "EncoderSession: shape / step count differ from what it was built for"
+        if not (t < s.steps and (B, N, d) == (s.bags, s.N, s.d)):
+            # (a session left behind by a step that raised: drop it rather than trip every later call)
+            raise RuntimeError("EncoderSession: shape / step count differ from what it was built for - a previous step may have "
+                               "raised before clearing model.encoder.session; set it to None")
         x2 = s.x[t].view(B * N, d)
         if x.data_ptr() != x2.data_ptr():
             x2.copy_(x.reshape(B * N, d))

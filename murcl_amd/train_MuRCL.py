@@ -178,6 +178,10 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         optimizer.zero_grad()
         with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each
             loss.backward(ops.unit_grad(loss))
+        # the session's ONE aggregator backward runs when autograd has reached the node of every patch step: a step whose
+        # aggregator output never reached the loss would silently drop every encoder gradient of the step
+        assert session is None or session.pending == 0, \
+            f"EncoderSession: {session.pending} of {session.t} patch steps were not reached by backward - encoder gradients not computed"
         if world > 1:
             mdist.all_reduce_grads(optimizer.flat_grads())
         optimizer.step()                                                                     # :293-295
