@@ -39,7 +39,7 @@ _GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B sw
 _FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
 _FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
 _CLAM_POOL = _os.environ.get("MURCL_CLAM_POOL", "0") == "1"          # dev A/B switch, OFF: CLAM's soft-max + pooling as one streaming pass (online soft-max) - measured 20-40 us SLOWER at C3 than soft-max + weighted_rowsum (four rows in flight per wave: latency-bound at d = 512)
-_CLAM_POOL2 = _os.environ.get("MURCL_CLAM_POOL2", "1") == "1"        # dev A/B switch: CLAM's soft-max + pooling as one pass over h with the bag's statistics recomputed per chunk (round 4)
+_CLAM_POOL2 = _os.environ.get("MURCL_CLAM_POOL2", "0") == "1"        # dev A/B switch, OFF: CLAM's soft-max + pooling as one pass over h, 8 whole rows in flight per wave, the bag's statistics recomputed per 128-row chunk (round 4) - measured 90 + 5 us against 15 + 6 + 68 us for soft-max + zero-fill + weighted_rowsum at C3: no gain (same-box A/B of bench rows: 1.06 vs 1.04-1.07 ms)
 _DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
 _DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
 _DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
