@@ -325,11 +325,21 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const T* __restrict__ X, 
         }
     }
 }
+#ifndef RD_STREAM
+#define RD_STREAM 1                // shapes the K6 stream passes cover take their load schedule (dsmil_stream_kernel<T, 3>: V in registers per wave,
+#endif                             // the next four rows requested before the current four are consumed) - same sums in the same order, bit for bit
+static int rows_dot_stream_launch(const void* X, const float* V, const float* bias, float* out, int B, int N, int d, int C, int dtype,
+                                  hipStream_t s);
 // bias (may be NULL) [C]: out[b,n,c] = X[b,n,:] . V[b,c,:] + bias[c] - the instance classifier's Linear (dsmil.py:9,15) in one launch
 extern "C" int murcl_rows_dot_bias(const void* X, const float* V, const float* bias, float* out, int B, int N, int d, int C, int dtype,
                                    hipStream_t s) {
     if (B <= 0) return 0;
     if (C > 4 || d % 8) return -1;
+    // (measured r04_m, isolated: d = 1024 f32 108 -> 98 us = 0.69 of 8 TB/s, bf16 53.5 -> 48.1 us = 0.70; d = 512 bf16 55 -> 57 us: not there)
+    if (RD_STREAM && d > 512 && (dtype == MURCL_DTYPE_F32 || dtype == MURCL_DTYPE_BF16)) {
+        const int rc = rows_dot_stream_launch(X, V, bias, out, B, N, d, C, dtype, s);
+        if (rc != -2) return rc;
+    }
     const long rows = (long)B * N;
     dim3 grid((unsigned)((rows + 4 * RD_RPW - 1) / (4 * RD_RPW)));
     if (dtype == MURCL_DTYPE_F32)
@@ -596,7 +606,8 @@ __device__ __forceinline__ void ds_to_float(const DsRaw<bf16_t>& r, float* v) {
 #endif                            // the rows in their loaded form until they are consumed is what mattered - bf16 passes 96 -> 52-62 us with
                                   // or without the early request (one batch of converted rows per wave left the loads exposed); the early
                                   // request itself: -3 % in bf16, neutral in f32, +20 % on the given-logits form at d = 512 (so not there)
-template <typename T, int MODE>          // MODE 0: forward, 1: backward, 2: forward with the logits given (Ain = S [rows, C]; V unused)
+template <typename T, int MODE>          // MODE 0: forward, 1: backward, 2: forward with the logits given (Ain = S [rows, C]; V unused),
+                                         // 3: the logits only, S = X . v + bias (G = bias [C] or NULL): rows_dot on this pass's load schedule
 __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__ X, const float* __restrict__ V,
                                                            const float* __restrict__ Ain, const float* __restrict__ G,
                                                            int N, int d, int C, int rows_per_wave, float* __restrict__ S,
@@ -667,6 +678,13 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
             float sd[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) sd[u] = MODE == 2 ? aw[u][c] : ((c < C) ? DS_WAVE_SUM(acc[u][c]) * vscale : 0.f);
+            if (MODE == 3) {
+                const float bv = (G != nullptr && c < C) ? G[c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lane == 0 && rb + u < row1 && c < C) S[(rb + u) * C + c] = G != nullptr ? sd[u] + bv : sd[u];
+                continue;
+            }
             if (MODE != 1) {
                 float mx = m_run[c];
 #pragma unroll
@@ -694,6 +712,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                 }
             }
         }
+        if (MODE == 3) continue;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -706,6 +725,7 @@ __global__ __launch_bounds__(256) void dsmil_stream_kernel(const T* __restrict__
                         if (MODE == 1) gacc[c][st][e] += gw[u][c] * xv[u][st][e];
                     }
     }
+    if (MODE == 3) return;
     float* pr = part + (size_t)wid * C * d;
     float* gr = (MODE == 1 && with_g) ? gpart + (size_t)wid * C * d : nullptr;
     for (int c = 0; c < C; ++c) {
@@ -783,6 +803,19 @@ __global__ __launch_bounds__(256) void dsmil_merge_kernel(const float* __restric
             An[i] = __expf(Sn[i] - m) * rl;
         }
     }
+}
+// rows_dot on the stream passes' load schedule; -2: shape not covered (the caller runs rows_dot_kernel)
+static int rows_dot_stream_launch(const void* X, const float* V, const float* bias, float* out, int B, int N, int d, int C, int dtype,
+                                  hipStream_t s) {
+    const int rpw = murcl_rows_dot_wsum_plan(B, N, d, C);
+    if (!rpw) return -2;
+    const long rows = (long)B * N, waves = rows / rpw;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MURCL_DTYPE_F32)
+        hipLaunchKernelGGL((dsmil_stream_kernel<float, 3>), grid, dim3(256), 0, s, (const float*)X, V, nullptr, bias, N, d, C, rpw, out, nullptr, nullptr, nullptr, rows, 1.f);
+    else
+        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 3>), grid, dim3(256), 0, s, (const bf16_t*)X, V, nullptr, bias, N, d, C, rpw, out, nullptr, nullptr, nullptr, rows, 1.f);
+    return MURCL_CHECK_LAUNCH();
 }
 // plan: rows a wave takes (0: shape not covered -> rows_dot + soft-max + weighted_rowsum); the workspace holds
 // (B*N/plan) * C * (d [+ d with dcls] + 2) floats
