@@ -514,7 +514,7 @@ def main():
     k2_key = f"abmil_pool_fwd<{args.dtype}>"
 
     # -- timed region: exactly K steps; only the dominant kernel and K2 carry HIP events, on every third launch
-    ops.TIMERS = ops.KernelTimers(only={dominant, k2_key}, every=3)
+    ops.TIMERS = ops.KernelTimers(only={dominant, k2_key}, every=3, pool=4 * (args.steps + 40))
     # settle: untimed steps (in the timed region's configuration) back to back right up to the barrier that opens it, so
     # that at least SETTLE_STEPS steps precede the timed ones whatever --warmup says and the few milliseconds of host work
     # above (reading the breakdown events) are not the last thing the GPU saw
@@ -522,14 +522,25 @@ def main():
     for _ in range(warmup_extra):
         step()
     ops.TIMERS.reset()
+    diag = os.environ.get("MURCL_BENCH_DIAG") == "1"          # dev: one HIP event per timed step (where does a short region lose time?)
+    devs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if diag else None
     barrier()
     t0 = time.perf_counter()
     host_t = [t0]
-    for _ in range(args.steps):
+    if diag:
+        devs[0].record()
+    for i in range(args.steps):
         loss = step()
+        if diag:
+            devs[i + 1].record()
         host_t.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if diag and rank == 0:
+        per = [devs[i].elapsed_time(devs[i + 1]) for i in range(args.steps)]
+        print("DIAG gpu ms per timed step:", [round(p, 3) for p in per], file=sys.stderr)
+        print("DIAG host ms per timed step:", [round((host_t[i + 1] - host_t[i]) * 1e3, 2) for i in range(args.steps)], file=sys.stderr)
+        print("DIAG elapsed", round(elapsed * 1e3, 3), "sum gpu", round(sum(per), 3), file=sys.stderr)
     host_ms = [(host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps)]
     live = ops.TIMERS.summary()
     ops.TIMERS = None

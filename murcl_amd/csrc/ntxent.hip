@@ -464,9 +464,11 @@ __global__ __launch_bounds__(1024) void ntxent_small_kernel(const float* __restr
 // needs lse_j of every row): 64 tiles of exact-f32 MFMAs on one CU = ~8 us of its ~21.  Here a workgroup forms only the logits of
 // its OWN 16 rows (8 tiles), publishes their lse (and loss terms) as 8-byte {value, generation} granules - one agent-scope store
 // each, MI355X_MICROARCH.md "data-tagged granules" - and collects the other workgroups' granules with agent-scope polls: one
-// hand-off (~1-2 us) instead of 7/8 of the matrix work.  The exchange buffer is caller-owned, zeroed ONCE (a tag never equals a
-// live generation), and every launch carries a new generation number, so nothing is reset between launches.  All workgroups of a
-// batch must be resident together: n/16 <= 8 workgroups per batch on 256 CUs; the spin is bounded (gives up -> NaN loss).
+// hand-off (~1-2 us) instead of 7/8 of the matrix work.  The exchange buffer is caller-owned and zeroed ONCE; nothing is reset
+// between launches: the generation lives in the buffer itself (two control words behind the granules) - every workgroup reads it
+// at its start (the buffer's first 64 bytes), tags its granules with generation + 1, and the workgroup that finishes last advances it, so launches on a stream
+// (and replays of a captured launch) never see each other's granules as their own.  All workgroups of a batch must be resident
+// together: n/16 <= 8 workgroups per batch on 256 CUs; the spin is bounded (gives up -> NaN loss).
 #define NXX_LD 132
 __device__ __forceinline__ unsigned long long nxx_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -477,8 +479,10 @@ __device__ __forceinline__ void nxx_store(unsigned long long* p, float v, unsign
 __global__ __launch_bounds__(1024) void ntxent_xchg_kernel(const float* __restrict__ z, int n, int ps, float inv_tau,
                                                            float* __restrict__ dz, float* __restrict__ sim,
                                                            float* __restrict__ loss_out, int grad_lo, int grad_hi,
-                                                           unsigned long long* __restrict__ xchg, unsigned gen) {
+                                                           unsigned long long* __restrict__ xchg, unsigned* __restrict__ ctrl) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ unsigned gen_s;
+    if (threadIdx.x == 0) gen_s = __hip_atomic_load(ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (visible after phase 0's barrier)
     z += (size_t)blockIdx.y * n * NX_P;
     if (dz) dz += (size_t)blockIdx.y * n * NX_P;
     if (sim) sim += (size_t)blockIdx.y * (n / 2);
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(1024) void ntxent_xchg_kernel(const float* __restri
     }
     __syncthreads();
 
+    const unsigned gen = gen_s;
     // ---- phase 1: the logits of the own 16 rows against all 128 rows: 8 tiles, one per wave 0..7 (exact-f32 MFMA, same operand
     // order as ntxent_small_kernel: bit-identical logits)
     if (wave < 8) {
@@ -566,6 +571,14 @@ __global__ __launch_bounds__(1024) void ntxent_xchg_kernel(const float* __restri
     }
     __syncthreads();
     if (tr == 0 && tid == 0) loss_out[0] = dotp[0] + dotp[1];
+    if (tid == 0) {
+        // every poll of this workgroup is over: the last workgroup of the launch to get here advances the generation
+        const unsigned total = gridDim.x * gridDim.y;
+        if (__hip_atomic_fetch_add(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+            __hip_atomic_store(ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctrl, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (!dz) return;
     __syncthreads();                                                       // (dotp is reused below)
 
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(1024) void ntxent_xchg_kernel(const float* __restri
     }
 }
 // bytes of the exchange buffer for `batches` problems: allocate once per device, ZERO it once, pass it to every call
-extern "C" long murcl_ntxent_xchg_bytes(int batches) { return (long)(batches > 0 ? batches : 1) * 256 * 8; }
+extern "C" long murcl_ntxent_xchg_bytes(int batches) { return (long)(batches > 0 ? batches : 1) * 256 * 8 + 64; }   // granules + control words
 // `batches` independent NT-Xent problems of n <= 128 rows each (rows / pair_stride / gradient window as murcl_ntxent_fwd_bwd) in ONE
 // launch of the exchange kernel.  xchg: murcl_ntxent_xchg_bytes(batches) bytes, zeroed once by the caller, never shared by launches
 // that may overlap in time (one per device / stream).
@@ -629,14 +642,15 @@ extern "C" int murcl_ntxent_small_xchg(const float* z, int batches, int n, int P
     if (P != NX_P || n <= 0 || (n & 1) || n > 128 || batches <= 0 || !xchg) return -1;
     const int ps = pair_stride > 0 ? pair_stride : n / 2;
     if (n % (2 * ps)) return -1;
-    static unsigned generation = 0;
-    unsigned gen = ++generation;
-    if (gen == 0) gen = ++generation;                  // 0 is the tag of a freshly zeroed buffer
+    // the control words (generation, arrival count) are the first 64 bytes of the buffer, the granules follow: calls with different
+    // `batches` share one generation
+    unsigned* ctrl = (unsigned*)xchg;
+    xchg = (char*)xchg + 64;
     constexpr int LDS = (128 * NXX_LD + 16 * NXX_LD + 128 * 2 + 128) * 4;
     static MurclOncePerDevice once;
     if (once.first()) hipFuncSetAttribute((const void*)ntxent_xchg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(ntxent_xchg_kernel, dim3((n + 15) / 16, batches), dim3(1024), LDS, stream, z, n, ps, 1.0f / temperature, dz, sim,
-                       loss, grad_lo, grad_hi, (unsigned long long*)xchg, gen);
+                       loss, grad_lo, grad_hi, (unsigned long long*)xchg, ctrl);
     return MURCL_CHECK_LAUNCH();
 }
 

@@ -24,8 +24,13 @@ class KernelTimers:
     region carries a few event records per step instead of one pair per launch (each pair costs ~2-3 us of stream
     time)."""
 
-    def __init__(self, only=None, every=1):
+    def __init__(self, only=None, every=1, pool=0):
         self.only, self.every, self.records, self._seen = only, max(1, int(every)), {}, {}
+        # ``pool``: events created up front (hipEventCreate costs tens of microseconds of host time: not inside a timed region)
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(pool))]
+
+    def event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def span(self, key, work=None):
         if self.only is not None and key not in self.only:
@@ -54,8 +59,8 @@ class _Span:
         self.o, self.k, self.w = owner, key, work or {}
 
     def __enter__(self):
-        self.a = torch.cuda.Event(enable_timing=True)
-        self.b = torch.cuda.Event(enable_timing=True)
+        self.a = self.o.event()
+        self.b = self.o.event()
         self.a.record()
 
     def __exit__(self, *exc):

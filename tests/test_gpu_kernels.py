@@ -700,6 +700,33 @@ def test_ntxent_one_exchange_kernel_equals_the_recompute_kernel(Bh, monkeypatch)
         assert torch.equal(sb1, sb0)
 
 
+def test_ntxent_exchange_generation_lives_on_the_device():
+    """The generation number of murcl_ntxent_small_xchg is read from (and advanced in) the exchange buffer by the kernel itself, not
+    passed from the host: a launch that is REPLAYED (a captured hipGraph) gets a new generation every time.  Replays on changing
+    inputs must equal eager calls."""
+    from murcl_amd import ops
+    dev = _dev()
+    Bh = 48
+    z = _rand(33, "g0", (2 * Bh, 128)).to(dev)
+    ops.ntxent(z, 0.5)                                   # exchange buffer, kernel attributes: before the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.ntxent(z, 0.5)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_g, dz_g, sim_g = ops.ntxent(z, 0.5)
+    for it in range(6):
+        z.copy_(_rand(33, f"g{it + 1}", (2 * Bh, 128), 1.0 + 0.2 * it).to(dev))
+        g.replay()
+        torch.cuda.synchronize()
+        l, d, s_ = loss_g.clone(), dz_g.clone(), sim_g.clone()
+        l0, d0, s0 = ops.ntxent(z, 0.5)
+        assert torch.equal(l, l0) and torch.equal(d, d0) and torch.equal(s_, s0), it
+
+
 @pytest.mark.parametrize("Bh,step", [(32, 8), (256, 64), (200, 40)])
 def test_ntxent_sharded_rows_match_global(Bh, step):
     """Rank-local gradient slices assemble to the global gradient; 256 = the global batch of 4 ranks."""
