@@ -17,7 +17,7 @@ cat gpurun_out/${T}_gpu_tests.log
 python -c "
 import json
 for f in ('${T}_bench','${T}_bench_driver_args','${T}_bench_force_dist'):
-    d=json.load(open('gpurun_out/%s.json'%f)); print(f, d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline_k2']['frac'], d['step_stats']['median_ms'] if d['step_stats'] else None, d.get('m_full'), d.get('comm'))
+    d=json.loads([l for l in open('gpurun_out/%s.json'%f) if l.startswith('{')][-1]); print(f, d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline_k2']['frac'], d['step_stats']['median_ms'] if d['step_stats'] else None, d.get('m_full'), d.get('comm'))
 d=json.load(open('gpurun_out/${T}_bench.json'))
 for k,v in d.get('rows',{}).items(): print(k, v.get('ms'))
 print(d.get('cpu_baseline'))
