@@ -352,6 +352,23 @@ int murcl_gru_gates_bwd(const float* dh, const float* gates, const float* gh, co
 int murcl_gru_gates_bwd_into(const float* dh, const float* gates, const float* gh, const float* hprev, float* dgi,
                              float* dgh, float* dhprev, int B, int H, int gh_bcast, int accumulate, murcl_stream_t stream);
 
+/* One nn.GRU time step as ONE launch each way (rlmil.py:47,78 ActorCritic.gru; :14-35 Full_layer.rnn): a workgroup owns a
+ * 16-row x 16-unit tile of all three gate blocks, forms its slice of h W_hh^T (forward) or dgh W_hh (backward) on the exact-f32
+ * matrix pipe and finishes the gate math in the epilogue - replaces murcl_gemm_nt + murcl_gru_gates_* pairs (same arithmetic;
+ * only the summation order inside the products differs).  H % 16 == 0; murcl_gru_step_supported(B, H, Kx) != 0 otherwise.
+ * murcl_gru_step_fwd: gi [B,3H] = x W_ih^T + b_ih, or - with x [B,Kx] and w_ih [3H,Kx] given (Kx % 16 == 0) - gi is the bias
+ *   row b_ih [3H] and the input product is formed here too.  hprev [B,H] (a zero state has no product: use
+ *   murcl_gru_gates_fwd with gh_bcast).  Writes hnew [B,H], gates [B,3H] = (r,z,n) and gh [B,3H] = h W_hh^T + b_hh (either may
+ *   be NULL when no backward follows).
+ * murcl_gru_step_bwd: dh [B,H] holds the step's upstream gradient; adds dgh_next [B,3H] . W_hh (w_hh_t = W_hh^T [H,3H]), writes
+ *   the total back, then the gate backward exactly as murcl_gru_gates_bwd_into (dgi, dgh, dhprev (+)= dh * z; dhprev may be NULL). */
+int murcl_gru_step_supported(int B, int H, int Kx);
+int murcl_gru_step_fwd(const float* x, const float* w_ih, int Kx, const float* gi, const float* hprev, const float* w_hh,
+                       const float* b_hh, float* hnew, float* gates, float* gh, int B, int H, murcl_stream_t stream);
+int murcl_gru_step_bwd(const float* dgh_next, const float* w_hh_t, float* dh, const float* gates, const float* gh,
+                       const float* hprev, float* dgi, float* dgh, float* dhprev, int B, int H, int gh_bcast, int accumulate,
+                       murcl_stream_t stream);
+
 /* The PPO sampler as native launch sequences (models/rlmil.py:66-97 act, :99-127,169-181 evaluate + loss + backward):
  * one call enqueues the whole chain of GEMM / GRU / head launches, so the host pays one call instead of one per launch
  * (the rollouts are a few hundred rows: launch-bound).  params / grads: HOST arrays of 12 device pointers in

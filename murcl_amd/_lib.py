@@ -89,6 +89,9 @@ SIGNATURES = {
     "murcl_gru_gates_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "murcl_gru_gates_bwd_into": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "murcl_gru_step_supported": [_I, _I, _I],
+    "murcl_gru_step_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "murcl_gru_step_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "murcl_ppo_act_workspace": [_I, _I, _I],
     "murcl_ppo_act": [_P, _I, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P],
     "murcl_ppo_epoch_workspace": [_I, _I, _I, _I],

@@ -196,6 +196,11 @@ static int ps_nt(const float* A, const float* B, float* C, int M, int N, int K, 
     return murcl_gemm_nt(A, B, C, M, N, K, K, K, N, MURCL_F32, MURCL_F32, epi, bias, nullptr, 0, nullptr, nullptr, 0, nullptr,
                          accumulate, s);
 }
+static int ps_gru_step() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MURCL_GRU_STEP"); v = (e && e[0] == '0') ? 0 : 1; }      // dev A/B switch
+    return v;
+}
 static int ps_shape_ok(int S, int H, int K) {
     return S > 0 && H > 0 && K > 0 && K <= PS_MAXK && S % 32 == 0 && H % 32 == 0;
 }
@@ -218,12 +223,18 @@ extern "C" int murcl_ppo_act(const float* const* params, int S, int H, int K, co
     float* gates = gh + (size_t)B * 3 * H;
     PS_CHECK(ps_nt(state, params[P_W1], e1, B, PS_E1, S, MURCL_EPI_BIAS_RELU, params[P_B1], 0, stream));
     PS_CHECK(ps_nt(e1, params[P_W2], e2, B, H, PS_E1, MURCL_EPI_BIAS_RELU, params[P_B2], 0, stream));
-    PS_CHECK(ps_nt(e2, params[P_WIH], gi, B, 3 * H, H, MURCL_EPI_BIAS, params[P_BIH], 0, stream));
-    if (hidden_prev) {
-        PS_CHECK(ps_nt(hidden_prev, params[P_WHH], gh, B, 3 * H, H, MURCL_EPI_BIAS, params[P_BHH], 0, stream));
-        PS_CHECK(murcl_gru_gates_fwd(gi, gh, hidden_prev, hidden_new, gates, B, H, 0, stream));
-    } else {                                                          // W_hh . 0 + b_hh: one broadcast row
-        PS_CHECK(murcl_gru_gates_fwd(gi, params[P_BHH], nullptr, hidden_new, gates, B, H, 1, stream));
+    if (hidden_prev && ps_gru_step() && murcl_gru_step_supported(B, H, H)) {
+        // the GRU cell as ONE launch: both products of a 16 x 16-unit tile of the three gate blocks, gates in the epilogue
+        PS_CHECK(murcl_gru_step_fwd(e2, params[P_WIH], H, params[P_BIH], hidden_prev, params[P_WHH], params[P_BHH], hidden_new, nullptr,
+                                    nullptr, B, H, stream));
+    } else {
+        PS_CHECK(ps_nt(e2, params[P_WIH], gi, B, 3 * H, H, MURCL_EPI_BIAS, params[P_BIH], 0, stream));
+        if (hidden_prev) {
+            PS_CHECK(ps_nt(hidden_prev, params[P_WHH], gh, B, 3 * H, H, MURCL_EPI_BIAS, params[P_BHH], 0, stream));
+            PS_CHECK(murcl_gru_gates_fwd(gi, gh, hidden_prev, hidden_new, gates, B, H, 0, stream));
+        } else {                                                      // W_hh . 0 + b_hh: one broadcast row
+            PS_CHECK(murcl_gru_gates_fwd(gi, params[P_BHH], nullptr, hidden_new, gates, B, H, 1, stream));
+        }
     }
     hipLaunchKernelGGL(ps_act_head_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, hidden_new, params[P_WA], params[P_BA], eps,
                        std_, B, H, K, action, logp);
@@ -269,6 +280,7 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
     float* w2_t = whh_t + (size_t)H * 3 * H;
     const size_t bh = (size_t)B * H, b3 = (size_t)B * 3 * H;
 
+    const bool fused = ps_gru_step() && murcl_gru_step_supported(B, H, 0);    // one launch per GRU time step and direction
     // ---------------- forward (rlmil.py:103-112)
     PS_CHECK(ps_nt(states, params[P_W1], e1, R, PS_E1, S, MURCL_EPI_BIAS_RELU, params[P_B1], 0, stream));
     PS_CHECK(ps_nt(e1, params[P_W2], e2, R, H, PS_E1, MURCL_EPI_BIAS_RELU, params[P_B2], 0, stream));
@@ -276,6 +288,9 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
     for (int t = 0; t < T; ++t) {
         if (t == 0) {
             PS_CHECK(murcl_gru_gates_fwd(gi, params[P_BHH], nullptr, hs, gates, B, H, 1, stream));
+        } else if (fused) {
+            PS_CHECK(murcl_gru_step_fwd(nullptr, nullptr, 0, gi + t * b3, hs + (t - 1) * bh, params[P_WHH], params[P_BHH], hs + t * bh,
+                                        gates + t * b3, gh + t * b3, B, H, stream));
         } else {
             PS_CHECK(ps_nt(hs + (t - 1) * bh, params[P_WHH], gh + t * b3, B, 3 * H, H, MURCL_EPI_BIAS, params[P_BHH], 0, stream));
             PS_CHECK(murcl_gru_gates_fwd(gi + t * b3, gh + t * b3, hs + (t - 1) * bh, hs + t * bh, gates + t * b3, B, H, 0, stream));
@@ -293,6 +308,18 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
     PS_CHECK(murcl_transpose_cast(params[P_WIH], wih_t, 3 * H, H, MURCL_F32, stream));
     if (T > 1) PS_CHECK(murcl_transpose_cast(params[P_WHH], whh_t, 3 * H, H, MURCL_F32, stream));
     PS_CHECK(murcl_transpose_cast(params[P_W2], w2_t, H, PS_E1, MURCL_F32, stream));
+    if (fused && T > 1) {
+        // dh_{t-1} += dgh_t . W_hh, then step t-1's gate backward on the finished tile: one launch per step
+        const int t1 = T - 1;
+        PS_CHECK(murcl_gru_gates_bwd_into(dhs + t1 * bh, gates + t1 * b3, gh + t1 * b3, hs + (t1 - 1) * bh, dgi + t1 * b3, dgh + t1 * b3,
+                                          dhs + (t1 - 1) * bh, B, H, 0, 1, stream));
+        for (int t = T - 1; t >= 1; --t) {
+            const int u = t - 1;                                                     // the step whose gates this launch differentiates
+            PS_CHECK(murcl_gru_step_bwd(dgh + t * b3, whh_t, dhs + u * bh, gates + u * b3, u ? gh + u * b3 : params[P_BHH],
+                                        u ? hs + (u - 1) * bh : nullptr, dgi + u * b3, dgh + u * b3, u ? dhs + (u - 1) * bh : dhp, B, H,
+                                        u ? 0 : 1, u ? 1 : 0, stream));
+        }
+    } else
     for (int t = T - 1; t >= 0; --t) {
         if (t == 0) {
             PS_CHECK(murcl_gru_gates_bwd_into(dhs, gates, params[P_BHH], nullptr, dgi, dgh, dhp, B, H, 1, 0, stream));

@@ -231,6 +231,39 @@ class ActorCritic(nn.Module):
                 action = mu
         return action.detach()
 
+    def act_views(self, states, memories, restart_batch=False, eps=None):
+        """``act(training=True)`` for several independent rollouts (the two views of a MuRCL step, train_MuRCL.py:259-265) as ONE
+        policy step over their stacked rows: every row of the step - encoder, GRU cell, head, sample, log-prob - depends on
+        its own state / hidden row only, so the views' calls are the same arithmetic with half the launches.  Each memory
+        receives its own rows (views of the step's outputs), exactly what per-view calls append."""
+        from .. import ops
+        flat = [s.flatten(1) for s in states]
+        if not (len(states) > 1 and all(s.is_cuda for s in flat) and self._native_ok(flat[0].shape[1])
+                and len({tuple(s.shape) for s in flat}) == 1):
+            return [self.act(s, m, restart_batch, True, e)
+                    for s, m, e in zip(states, memories, eps if eps is not None else [None] * len(states))]
+        with torch.no_grad():
+            n = flat[0].shape[0]
+            if restart_batch:
+                for m in memories:
+                    del m.hidden[:]
+                    m.hidden.append(torch.zeros(1, n, self.hidden_state_dim, device=flat[0].device))
+            state = ops.stack_rows([s.float() for s in flat])
+            noise = (torch.randn((n * len(flat), self.action_size), device=state.device) if eps is None
+                     else ops.stack_rows([e.float() for e in eps]))
+            hidden = None if restart_batch else ops.stack_rows([m.hidden[-1][0] for m in memories])
+            h, action, logp = ops.ppo_act(self.pointer_table(), state.shape[1], self.hidden_state_dim, self.action_size, state,
+                                          hidden, noise, self.action_std)
+            out = []
+            for i, (s, m) in enumerate(zip(states, memories)):
+                rows = slice(i * n, (i + 1) * n)
+                m.hidden.append(h[rows].unsqueeze(0))
+                m.states.append(s)
+                m.actions.append(action[rows])
+                m.logprobs.append(logp[rows])
+                out.append(action[rows])
+        return out
+
     def evaluate(self, state, action):
         """states [T,B,S], actions [T,B,K] -> (logp, value, entropy) each [T,B] (rlmil.py:99-127)."""
         T_, B = state.shape[0], state.shape[1]
@@ -276,6 +309,10 @@ class PPO:
 
     def select_action(self, state, memory, restart_batch=False, training=True, eps=None):
         return self.policy_old.act(state, memory, restart_batch, training, eps)
+
+    def select_actions(self, states, memories, restart_batch=False, eps=None):
+        """``select_action`` for the views of one patch step at once (``ActorCritic.act_views``)."""
+        return self.policy_old.act_views(states, memories, restart_batch, eps)
 
     def update(self, memory, group=None):
         """PPO.update (rlmil.py:152-184).  Data-parallel (one process per GPU, rollout rows sharded by bag, SURVEY.md

@@ -777,6 +777,59 @@ def gru_gates_bwd(dh, gates, gh, hprev, dgi=None, dgh=None):
     return dgi, dgh, dhp
 
 
+def gru_gates_bwd_into(dh, gates, gh, hprev, dgi, dgh, dhprev=None, accumulate=False):
+    """Gate backward of one step into caller buffers; dhprev (+)= dh * z (``accumulate``: back-propagation through time, where
+    dhprev already holds that step's own upstream gradient)."""
+    _need_cuda(dh, gates, gh)
+    B, H = dh.shape
+    assert all(t.is_contiguous() for t in (dh, gates, gh, dgi, dgh)) and (dhprev is None or dhprev.is_contiguous())
+    check(_lib.lib().murcl_gru_gates_bwd_into(ptr(dh), ptr(gates), ptr(gh), ptr(hprev), ptr(dgi), ptr(dgh), ptr(dhprev), B, H,
+                                              int(gh.shape[0] == 1 and B != 1), int(accumulate), stream()), "gru_gates_bwd_into")
+
+
+_GRU_STEP = _os.environ.get("MURCL_GRU_STEP", "1") != "0"          # dev A/B switch: one launch per GRU time step and direction
+
+
+def gru_step_ok(B, H, Kx=0):
+    """Whether the one-launch GRU step kernels (``gru_step_fwd`` / ``gru_step_bwd``) take this shape."""
+    return _GRU_STEP and bool(_lib.lib().murcl_gru_step_supported(int(B), int(H), int(Kx)))
+
+
+def gru_step_fwd(gi, hprev, w_hh, b_hh, hnew=None, gates=None, gh=None, x=None, w_ih=None, want_backward=True):
+    """One GRU time step from a non-zero state as ONE launch (murcl_gru_step_fwd): h W_hh^T for a 16 x 16-unit tile of all three
+    gate blocks, the gate math in the epilogue.  gi [B,3H] = x W_ih^T + b_ih - or, with ``x`` [B,Kx] and ``w_ih`` given, gi = b_ih
+    [3H] and the input product is formed by the same launch.  -> (hnew [B,H], gates [B,3H], gh [B,3H]) (the last two None
+    with ``want_backward=False``)."""
+    _need_cuda(gi, hprev, w_hh)
+    B, H = hprev.shape
+    dev = hprev.device
+    if hnew is None:
+        hnew = torch.empty((B, H), dtype=torch.float32, device=dev)
+    if want_backward:
+        gates = torch.empty((B, 3 * H), dtype=torch.float32, device=dev) if gates is None else gates
+        gh = torch.empty((B, 3 * H), dtype=torch.float32, device=dev) if gh is None else gh
+    assert all(t is None or (t.is_contiguous() and t.dtype == torch.float32) for t in (gi, hprev, w_hh, b_hh, hnew, gates, gh, x, w_ih))
+    assert gi.numel() == (3 * H if x is not None else B * 3 * H) and w_hh.shape == (3 * H, H)
+    Kx = 0
+    if x is not None:
+        Kx = x.shape[1]
+        assert x.shape[0] == B and w_ih.shape == (3 * H, Kx)
+    check(_lib.lib().murcl_gru_step_fwd(ptr(x), ptr(w_ih), Kx, ptr(gi), ptr(hprev), ptr(w_hh), ptr(b_hh), ptr(hnew), ptr(gates),
+                                        ptr(gh), B, H, stream()), "gru_step_fwd")
+    return hnew, gates, gh
+
+
+def gru_step_bwd(dgh_next, w_hh_t, dh, gates, gh, hprev, dgi, dgh, dhprev=None, accumulate=False):
+    """dh [B,H] += dgh_next [B,3H] . W_hh (``w_hh_t`` = W_hh^T [H,3H]) IN PLACE, then this step's gate backward on the finished
+    rows (dgi, dgh; dhprev (+)= dh * z) - one launch (murcl_gru_step_bwd) for ``gemm_nt(accumulate)`` + ``gru_gates_bwd_into``."""
+    _need_cuda(dgh_next, dh, gates, gh)
+    B, H = dh.shape
+    assert all(t is None or (t.is_contiguous() and t.dtype == torch.float32) for t in (dgh_next, w_hh_t, dh, gates, gh, hprev, dgi, dgh, dhprev))
+    assert w_hh_t.shape == (H, 3 * H) and dgh_next.shape == (B, 3 * H)
+    check(_lib.lib().murcl_gru_step_bwd(ptr(dgh_next), ptr(w_hh_t), ptr(dh), ptr(gates), ptr(gh), ptr(hprev), ptr(dgi), ptr(dgh),
+                                        ptr(dhprev), B, H, int(gh.shape[0] == 1 and B != 1), int(accumulate), stream()), "gru_step_bwd")
+
+
 def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, zero_grad=False):
     _need_cuda(p, g, m, v)
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
@@ -1186,6 +1239,20 @@ def policy_head_bwd(mu, act, dlogp, std):
     check(_lib.lib().murcl_policy_head_bwd(ptr(mu), ptr(_c(act)), ptr(_c(dlogp)), float(std), mu.shape[0], mu.shape[1],
                                            ptr(dz), stream()), "policy_head_bwd")
     return dz
+
+
+def stack_rows(ts):
+    """[n_i, ...] tensors -> their rows stacked; free (a view) when they already are consecutive blocks of one buffer (halves
+    of a batched output, slices of one noise draw), one ``torch.cat`` otherwise."""
+    t0 = ts[0]
+    if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:]
+           and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts):
+        off, ok = t0.storage_offset(), True
+        for t in ts:
+            ok, off = ok and t.storage_offset() == off, off + t.numel()
+        if ok:
+            return t0.as_strided((sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(ts, 0)
 
 
 def pointer_table(tensors):

@@ -123,8 +123,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
             acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else acts_u[t]      # [2,B,K]: one launch each
         else:
             eps = [noise[t - 1, 0], noise[t - 1, 1]] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
-            acts = [ppo.select_action(s, m, restart_batch=(t == 1), eps=e)
-                    for s, m, e in zip(states, memory_list, eps)]                            # :259-265
+            acts = ppo.select_actions(states, memory_list, restart_batch=(t == 1), eps=eps)  # :259-265, both views in one policy step
         if injected is not None and injected.get("trace") is not None:
             injected["trace"].append([a.detach().clone() for a in acts])
         views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=dt_,

@@ -809,6 +809,85 @@ def test_gru_gates_fwd_bwd():
     _close(h0, (1 - z) * n, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,H,Kx", [(64, 512, 0), (128, 512, 512), (17, 32, 0), (5, 48, 80), (33, 1024, 0), (64, 512, 1024)])
+def test_gru_step_forward_in_one_launch(B, H, Kx):
+    """murcl_gru_step_fwd (h W_hh^T, optionally x W_ih^T, and the gate math in one launch) against torch.nn.GRUCell's formula
+    in f64; ragged row counts, hidden sizes that leave partial 256-k chunks, a longer input side."""
+    from murcl_amd import ops
+    dev = _dev()
+    hp, whh, bhh = _rand(41, "hp", (B, H)), _rand(41, "whh", (3 * H, H)) / math.sqrt(H), _rand(41, "bhh", (3 * H,))
+    bih = _rand(41, "bih", (3 * H,))
+    if Kx:
+        x, wih = _rand(41, "x", (B, Kx)), _rand(41, "wih", (3 * H, Kx)) / math.sqrt(Kx)
+        gi = x.double() @ wih.double().t() + bih.double()
+    else:
+        gi = _rand(41, "gi", (B, 3 * H)).double()
+    gh = hp.double() @ whh.double().t() + bhh.double()
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn = (1 - z) * n + z * hp.double()
+    assert ops.gru_step_ok(B, H, Kx)
+    if Kx:
+        hnew, gates, gh_k = ops.gru_step_fwd(bih.to(dev), hp.to(dev), whh.to(dev), bhh.to(dev), x=x.to(dev), w_ih=wih.to(dev))
+    else:
+        hnew, gates, gh_k = ops.gru_step_fwd(gi.float().to(dev), hp.to(dev), whh.to(dev), bhh.to(dev))
+    _close(hnew, hn, rtol=1e-4, atol=2e-5)
+    _close(gates, torch.cat([r, z, n], 1), rtol=1e-4, atol=2e-5)
+    _close(gh_k, gh, rtol=1e-4, atol=2e-5)
+    h2, g2, gh2 = ops.gru_step_fwd(bih.to(dev) if Kx else gi.float().to(dev), hp.to(dev), whh.to(dev), bhh.to(dev),
+                                   x=x.to(dev) if Kx else None, w_ih=wih.to(dev) if Kx else None, want_backward=False)
+    assert g2 is None and gh2 is None and torch.equal(h2, hnew)
+
+
+@pytest.mark.parametrize("B,H,first", [(64, 512, False), (64, 512, True), (17, 32, False), (33, 1024, False), (5, 48, True)])
+def test_gru_step_backward_in_one_launch(B, H, first):
+    """murcl_gru_step_bwd = gemm_nt(dgh_next, W_hh^T, accumulate into dh) + gru_gates_bwd_into; `first`: the step from the zero
+    state (gh is the bias row, no previous hidden state, dh * z is not accumulated)."""
+    from murcl_amd import ops
+    dev = _dev()
+    dgh_n, whh = _rand(42, "dghn", (B, 3 * H)), _rand(42, "whh", (3 * H, H)) / math.sqrt(H)
+    dh0, gates = _rand(42, "dh", (B, H)), torch.rand((B, 3 * H), generator=torch.Generator().manual_seed(5)) * 0.9 + 0.05
+    gh = _rand(42, "gh", (1 if first else B, 3 * H))
+    hp, dprev0 = (None if first else _rand(42, "hp", (B, H))), _rand(42, "dprev", (B, H))
+    d = dh0.double() + dgh_n.double() @ whh.double()
+    r, z, n = gates[:, :H].double(), gates[:, H:2 * H].double(), gates[:, 2 * H:].double()
+    ghn = gh[:, 2 * H:].double()
+    dn = d * (1 - z) * (1 - n * n)
+    dz = d * ((0 if first else hp.double()) - n) * z * (1 - z)
+    dr = dn * ghn * r * (1 - r)
+    dh, dprev = dh0.to(dev).clone(), dprev0.to(dev).clone()
+    dgi, dgh = torch.empty((B, 3 * H), device=dev), torch.empty((B, 3 * H), device=dev)
+    ops.gru_step_bwd(dgh_n.to(dev), whh.t().contiguous().to(dev), dh, gates.to(dev), gh.to(dev), None if first else hp.to(dev), dgi, dgh,
+                     dprev, accumulate=not first)
+    _close(dh, d, rtol=1e-4, atol=2e-5)
+    _close(dgi, torch.cat([dr, dz, dn], 1), rtol=1e-4, atol=2e-5)
+    _close(dgh, torch.cat([dr, dz, dn * r], 1), rtol=1e-4, atol=2e-5)
+    _close(dprev, (0 if first else dprev0.double()) + d * z, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("T,B,I,H", [(6, 64, 512, 512), (3, 9, 48, 32), (1, 4, 32, 32)])
+def test_gru_sequence_function_against_torch_gru(T, B, I, H):
+    """functional.GRUSeqFn (one launch per time step and direction) against torch.nn.GRU on the CPU: all hidden states and
+    every gradient."""
+    from murcl_amd.functional import GRUSeqFn
+    dev = _dev()
+    torch.manual_seed(7)
+    ref = torch.nn.GRU(I, H)
+    x = _rand(43, "x", (T, B, I)).requires_grad_()
+    dhs = _rand(43, "dhs", (T, B, H))
+    out, _ = ref(x)
+    (out * dhs).sum().backward()
+    ps = [p.detach().to(dev).requires_grad_() for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xd = x.detach().to(dev).requires_grad_()
+    hs = GRUSeqFn.apply(xd, *ps)
+    (hs * dhs.to(dev)).sum().backward()
+    _close(hs, out, rtol=1e-4, atol=2e-5)
+    _close(xd.grad, x.grad, rtol=1e-3, atol=5e-5)
+    for p, q in zip(ps, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
+        _close(p.grad, q.grad, rtol=1e-3, atol=2e-4)
+
+
 def test_adam_matches_oracle():
     from murcl_amd import ops
     dev = _dev()

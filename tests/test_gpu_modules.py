@@ -690,6 +690,30 @@ def test_ppo_act_evaluate_update_vs_reference_golden(golden):
         assert torch.equal(a, b)
 
 
+def test_ppo_two_views_in_one_policy_step_match_per_view_calls():
+    """PPO.select_actions (both views of a patch step as the rows of ONE policy step) fills each view's Memory with what two
+    select_action calls would: actions, log-probs, hidden states, stored states - every row depends on its own row only."""
+    from murcl_amd.models.rlmil import PPO, Memory
+    dev = _dev()
+    seed, B, S_, H, K = 23, 64, 512, 512, 10
+    ppo = PPO(512, S_, H, False, action_std=0.5, action_size=K)
+    sd = P.to_torch(P.actor_critic(seed, S_, H, K))
+    ppo.policy_old.load_state_dict(sd)
+    one, two = [Memory(), Memory()], [Memory(), Memory()]
+    for t in range(3):
+        st = T(detrand.normal(seed, f"v.s{t}", (2 * B, S_))).to(dev)
+        eps = T(detrand.normal(seed, f"v.e{t}", (2, B, K))).to(dev)
+        states = list(st.split(B, 0))
+        acts = ppo.select_actions(states, two, restart_batch=(t == 0), eps=[eps[0], eps[1]])
+        for v in range(2):
+            a = ppo.select_action(states[v], one[v], restart_batch=(t == 0), eps=eps[v])
+            np.testing.assert_allclose(acts[v].cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(two[v].logprobs[-1].cpu().numpy(), one[v].logprobs[-1].cpu().numpy(), rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(two[v].hidden[-1].cpu().numpy(), one[v].hidden[-1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+            assert two[v].hidden[-1].shape == one[v].hidden[-1].shape and len(two[v].hidden) == len(one[v].hidden)
+            assert torch.equal(two[v].states[-1], one[v].states[-1]) and torch.equal(two[v].actions[-1], acts[v])
+
+
 def test_ppo_returns_and_loss_vs_oracle():
     from murcl_amd import ops
     dev = _dev()
