@@ -383,10 +383,15 @@ long murcl_ppo_act_workspace(int B, int S, int H);
 int murcl_ppo_act(const float* const* params, int S, int H, int K, const float* state, const float* hidden_prev,
                   const float* eps, float std_, int B, float* hidden_new, float* action, float* logp, float* ws,
                   murcl_stream_t stream);
+/* murcl_ppo_epoch_wt: the same with wt = HOST array {W_ih^T [H,3H], W_hh^T [H,3H], W_2^T [2048,H]} of device pointers prepared by
+ * the caller (one murcl_cast_batch launch per optimizer step) instead of three transposes inside every call. */
 long murcl_ppo_epoch_workspace(int T, int B, int S, int H);
 int murcl_ppo_epoch(const float* const* params, float* const* grads, int S, int H, int K, const float* states,
                     const float* actions, const float* old_logp, const float* returns, int T, int B, long n_total,
                     float std_, float eps_clip, float entropy, float* ws, float* loss_out, murcl_stream_t stream);
+int murcl_ppo_epoch_wt(const float* const* params, float* const* grads, const float* const* wt, int S, int H, int K,
+                       const float* states, const float* actions, const float* old_logp, const float* returns, int T, int B,
+                       long n_total, float std_, float eps_clip, float entropy, float* ws, float* loss_out, murcl_stream_t stream);
 
 /* 1-bit ReLU' mask (x > 0) of an activation tensor x [M,N] in murcl_panel_gemm's bit-mask layout (M*N/8 bytes;
  * M % 32 == 0, N % 32 == 0), for layers whose forward did not emit it (clam.py:69 with a 1024-wide input). */

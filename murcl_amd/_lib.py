@@ -96,6 +96,7 @@ SIGNATURES = {
     "murcl_ppo_act": [_P, _I, _I, _I, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P],
     "murcl_ppo_epoch_workspace": [_I, _I, _I, _I],
     "murcl_ppo_epoch": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _L, _F, _F, _F, _P, _P, _P],
+    "murcl_ppo_epoch_wt": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _L, _F, _F, _F, _P, _P, _P],
     "murcl_cast_batch": [_P, _I, _I, _P],
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_dropout_relu_bitmask": [_P, _P, _I, _I, _F, _F, ctypes.c_ulonglong, _I, _P],

@@ -438,7 +438,8 @@ constexpr int SL_K = 256, SL_ROW = 1024 + 16, SL_T = 32, SL_BUF = 2 * SL_T * SL_
 __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                 float* __restrict__ C, int M, int N, int K, int lda,
                                                                 int ldb, int ldc, const float* __restrict__ bias,
-                                                                int relu, int accumulate, int k_per_split) {
+                                                                int relu, int accumulate, int k_per_split,
+                                                                const float* __restrict__ mask, int ldmask, int one_slot) {
     extern __shared__ __attribute__((aligned(16))) char sl_smem[];
     // gridDim.z > 1: K split over workgroups (long reductions with few output tiles); the partial tiles are added
     // atomically into a zeroed C (bias from split 0; a ReLU, if any, is the launcher's separate pass)
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
     auto issue = [&](int c) {
         const int k0 = c * SL_K;
         const unsigned voff = (unsigned)min(lane * 16, (K - k0) * 4 - 16);
-        const unsigned dst = lds0 + (c & 1) * SL_BUF + wave * 16 * SL_ROW;
+        const unsigned dst = lds0 + (one_slot ? 0 : (c & 1) * SL_BUF) + wave * 16 * SL_ROW;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int r = (wave & 1) * 16 + j;
@@ -468,15 +469,19 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
             glds16_u(src, voff, dst + j * SL_ROW);
         }
     };
+    // one_slot: a single chunk buffer (half the LDS: two workgroups per CU, whose round trips overlap each other's MFMAs) - for
+    // grids of several rounds of workgroups; otherwise two chunks in flight per workgroup
+    const int ahead = one_slot ? 1 : 2;
     issue(0);
-    if (nch > 1) issue(1);
+    if (nch > 1 && !one_slot) issue(1);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: the f32 MFMA's dependent latency exceeds its issue time
     const int wm = wave & 1, wn = wave >> 1;
     for (int c = 0; c < nch; ++c) {
-        if (c + 1 < nch) { SL_WAIT(16); } else { SL_WAIT(0); }
+        if (c + 1 < nch && !one_slot) { SL_WAIT(16); } else { SL_WAIT(0); }
         LDS_BARRIER();                                       // every wave's rows of chunk c have landed
-        const char* ab = sl_smem + (c & 1) * SL_BUF + (16 * wm + r16) * SL_ROW + 16 * q4;
-        const char* bb = sl_smem + (c & 1) * SL_BUF + (SL_T + 16 * wn + r16) * SL_ROW + 16 * q4;
+        const unsigned sb = one_slot ? 0u : (unsigned)(c & 1) * SL_BUF;
+        const char* ab = sl_smem + sb + (16 * wm + r16) * SL_ROW + 16 * q4;
+        const char* bb = sl_smem + sb + (SL_T + 16 * wn + r16) * SL_ROW + 16 * q4;
         const int ku = min(SL_K, K - c * SL_K) / 16;
         if (ku == SL_K / 16) {
 #pragma unroll
@@ -487,9 +492,9 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
         } else {
             for (int u = 0; u < ku; ++u) acc0 = mma16<float>(*(const f32x4*)(ab + 64 * u), *(const f32x4*)(bb + 64 * u), acc0);
         }
-        if (c + 2 < nch) {
-            LDS_BARRIER();                                   // buffer c & 1 has been read by every wave
-            issue(c + 2);
+        if (c + ahead < nch) {
+            LDS_BARRIER();                                   // that buffer has been read by every wave
+            issue(c + ahead);
         }
     }
     // lane holds C[m0 + 16wm + 4q4 + r][n0 + 16wn + r16]: the 16 lanes of a quarter write 64 contiguous bytes of a row
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
                     atomicAdd(cp, v);                        // 16 lanes of a quarter: 64 contiguous bytes per request
                 } else {
                     if (accumulate) v += *cp;
+                    if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;      // ReLU' of the layer's saved output
                     *cp = relu ? fmaxf(v, 0.f) : v;
                 }
             }
@@ -527,21 +533,40 @@ static int skinny16_enabled() {
     if (v < 0) { const char* e = getenv("MURCL_SKINNY16"); v = (e && e[0] == '0') ? 0 : 1; }     // dev A/B switch
     return v;
 }
+// K splits of the LDS form for this shape (1: single writer per element - bias / ReLU / mask / accumulate in the epilogue)
+static int skinny_lds_splits(int M, int N, int K) {
+    const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
+    const int nch = (K + SL_K - 1) / SL_K;
+    int sp = 1;
+    if (nch >= 6 && sl_tiles <= 96) {
+        sp = (int)((384 + sl_tiles - 1) / sl_tiles);
+        if (sp > nch / 2) sp = nch / 2;
+    }
+    const int kps = ((nch + sp - 1) / sp) * SL_K;
+    return (K + kps - 1) / kps;
+}
+// gru.hip: 16 x 16 tiles, K split over the waves of a workgroup (single writer, every epilogue)
+bool murcl_nt_t16_ok(int M, int N, int K);
+int murcl_nt_t16_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias,
+                        int relu, int accumulate, const float* mask, int ldmask, hipStream_t stream);
+static int nt_t16_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MURCL_NT_T16"); v = (e && e[0] == '0') ? 0 : 1; }        // dev A/B switch
+    return v;
+}
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                         int epi, const float* bias, int accumulate, hipStream_t s) {
+                         int epi, const float* bias, int accumulate, hipStream_t s, const float* mask = nullptr, int ldmask = 0) {
+    // few outputs, long reduction - the shapes the LDS form below would split over K (zero-fill + atomics + a ReLU launch): 16 x 16
+    // tiles with the K range split over the waves of one workgroup instead, everything in one launch
+    if (skinny_lds_enabled() && nt_t16_enabled() && skinny_lds_splits(M, N, K) > 1 && murcl_nt_t16_ok(M, N, K))
+        return murcl_nt_t16_launch(A, B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
+                                   (int)(epi == EPI_BIAS_RELU), accumulate, epi == EPI_MASK ? mask : nullptr, ldmask, s);
     // LDS form.  Long reductions with few output tiles (per 256-k chunk a workgroup needs ~2 us - one DMA round trip is not
     // covered by one chunk of MFMAs - so [128 x 512 x 3072] on 64 workgroups x 12 chunks takes 26 us) are split over K so that
     // every workgroup has its whole share (two chunks) in flight at once; those partial tiles meet in a zeroed C by atomics.
     if (skinny_lds_enabled()) {
-        const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
-        const int nch = (K + SL_K - 1) / SL_K;
-        int sp = 1;
-        if (nch >= 6 && sl_tiles <= 96) {
-            sp = (int)((384 + sl_tiles - 1) / sl_tiles);
-            if (sp > nch / 2) sp = nch / 2;
-        }
-        const int kps = ((nch + sp - 1) / sp) * SL_K;
-        sp = (K + kps - 1) / kps;
+        const int sp = skinny_lds_splits(M, N, K);
+        const int kps = ((((K + SL_K - 1) / SL_K) + sp - 1) / sp) * SL_K;
         if (sp > 1 && !accumulate) {
             hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
             if (e != hipSuccess) return (int)e;
@@ -550,9 +575,14 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
         static MurclOncePerDevice once;
         if (once.first())
             hipFuncSetAttribute((const void*)gemm_nt_lds32_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL_BUF);
-        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T, sp), dim3(256), 2 * SL_BUF, s, A,
+        // more than ~1.5 rounds of workgroups at one per CU: half the LDS, two per CU (MURCL_NT_ONE_SLOT: dev override)
+        static int force = -2;
+        if (force == -2) { const char* e = getenv("MURCL_NT_ONE_SLOT"); force = e ? atoi(e) : -1; }
+        const long wgs = (long)((N + SL_T - 1) / SL_T) * ((M + SL_T - 1) / SL_T) * sp;
+        const int one_slot = force >= 0 ? force : (int)(wgs > 384 && K > SL_K);
+        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T, sp), dim3(256), one_slot ? SL_BUF : 2 * SL_BUF, s, A,
                            B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
-                           (int)(relu && sp == 1), (int)(accumulate && sp == 1), kps);
+                           (int)(relu && sp == 1), (int)(accumulate && sp == 1), kps, epi == EPI_MASK ? mask : nullptr, ldmask, one_slot);
         int rc = MURCL_CHECK_LAUNCH();
         if (rc) return rc;
         if (relu && sp > 1) {
@@ -620,9 +650,11 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
     // bag-level / rollout-level f32 layers (a few hundred rows): 32-column slabs x K splits x 128-row chunks fill the chip;
     // the 128 x 128 tile kernel would put e.g. [320 x 2048] x [512 x 2048]^T on 12 workgroups (86 us against ~15)
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && M <= 1024 && K % 16 == 0 && !colsum_ws &&
-        (epilogue == EPI_NONE || epilogue == EPI_BIAS || (epilogue == EPI_BIAS_RELU && !accumulate && ldc == N)))
+        (epilogue == EPI_NONE || epilogue == EPI_BIAS || (epilogue == EPI_BIAS_RELU && !accumulate && ldc == N) ||
+         (epilogue == EPI_MASK && mask && skinny_lds_enabled() &&
+          (skinny_lds_splits(M, N, K) == 1 || (nt_t16_enabled() && murcl_nt_t16_ok(M, N, K))))))
         return launch_skinny((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, epilogue, bias,
-                             accumulate, stream);
+                             accumulate, stream, (const float*)mask, ldmask);
     GemmEpi e{bias, mask, ldmask, rowscale, rank1, rows_per_bag > 0 ? rows_per_bag : 1, colsum_ws, accumulate};
     if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16)
         return launch_nt_epi<bf16_t, bf16_t>((const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, lda, ldb, ldc,
@@ -1350,24 +1382,33 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
 // consecutive floats each) fall on four disjoint 16-bank groups.  Column sums of A (the bias gradient) come from one more
 // MFMA per step against a fragment of ones in the workgroups of the first N2 tile.
 constexpr int TS_T = 32, TS_MAXM = 512;
-__global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                                float* __restrict__ C, int M, int N1, int N2, int lda,
-                                                                int ldb, int ldc, float* __restrict__ colsum_out) {
-    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+__device__ __forceinline__ void tn_small_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
+                                              int N1, int N2, int lda, int ldb, int ldc, float* __restrict__ colsum_out, int bx,
+                                              int by, char* ts_smem, int pass_rows) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
-    const int n10 = blockIdx.x * TS_T, n20 = blockIdx.y * TS_T;
+    const int n10 = bx * TS_T, n20 = by * TS_T;
     const unsigned lds0 = lds_off(ts_smem);
     const int wm = wave & 1, wn = wave >> 1;
-    const bool do_cs = colsum_out != nullptr && blockIdx.y == 0 && wn == 0;
+    const bool do_cs = colsum_out != nullptr && by == 0 && wn == 0;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
+    // what the epilogue adds to, requested before the operands so that the read-modify-write does not wait at the end
+    f32x4 cold = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int n2 = n20 + 16 * wn + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n10 + 16 * wm + 4 * q4 + r;
+            if (n1 < N1 && n2 < N2) cold[r] = C[(size_t)n1 * ldc + n2];
+        }
+    }
     // fragment addresses: row 16u + 4e + q4, column 16w + r16 -> chunk (4w + r16/4) ^ swz(row), swz = 4 * bit 1 of the row = 4 * (q4 >> 1)
     const int sw = (q4 >> 1) << 2;
     const unsigned aoff = q4 * 128 + ((((4 * wm + (r16 >> 2)) ^ sw) << 4) | ((r16 & 3) << 2));
     const unsigned boff = q4 * 128 + ((((4 * wn + (r16 >> 2)) ^ sw) << 4) | ((r16 & 3) << 2));
-    for (int mb = 0; mb < M; mb += TS_MAXM) {
-        const int mc = min(TS_MAXM, M - mb), mp = (mc + 15) & ~15, ng = (mc + 7) >> 3;
+    for (int mb = 0; mb < M; mb += pass_rows) {
+        const int mc = min(pass_rows, M - mb), mp = (mc + 15) & ~15, ng = (mc + 7) >> 3;
         const unsigned slab_b = (unsigned)mp * 128;
         if (mb) __syncthreads();                                  // the previous pass has been read by every wave
         for (int i = wave; i < 2 * ng; i += 4) {                  // wave-uniform: one LDS-DMA instruction = 8 rows of one slab
@@ -1407,9 +1448,46 @@ __global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n1 = n10 + 16 * wm + 4 * q4 + r;
-        if (n1 < N1 && n2 < N2) C[(size_t)n1 * ldc + n2] += acc0[r] + acc1[r];
+        if (n1 < N1 && n2 < N2) C[(size_t)n1 * ldc + n2] = cold[r] + (acc0[r] + acc1[r]);
         if (do_cs && r16 == 0 && n1 < N1) colsum_out[n1] += accs[r];
     }
+}
+__global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                float* __restrict__ C, int M, int N1, int N2, int lda,
+                                                                int ldb, int ldc, float* __restrict__ colsum_out, int pass_rows) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    tn_small_tile(A, B, C, M, N1, N2, lda, ldb, ldc, colsum_out, blockIdx.x, blockIdx.y, ts_smem, pass_rows);
+}
+// Up to four such products as ONE launch (the weight gradients of a PPO epoch, rlmil.py:179: four launches of 16 us whose
+// tails and launch gaps add up): workgroup b belongs to the product g with tile0[g] <= b < tile0[g + 1]; its tile index
+// runs along N1 first, as the single-product grid does.
+struct TnSmallGroup {
+    const float* A[4]; const float* B[4]; float* C[4]; float* cs[4];
+    int M[4], N1[4], N2[4], lda[4], ldb[4], ldc[4], tile0[5], pass_rows;
+};
+__global__ __launch_bounds__(256) void gemm_tn_small_group_kernel(const TnSmallGroup ga) {
+    extern __shared__ __attribute__((aligned(16))) char ts_smem[];
+    const int b = blockIdx.x;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) g += (int)(b >= ga.tile0[i]);
+    const int t = b - ga.tile0[g], t1 = (ga.N1[g] + TS_T - 1) / TS_T;
+    tn_small_tile(ga.A[g], ga.B[g], ga.C[g], ga.M[g], ga.N1[g], ga.N2[g], ga.lda[g], ga.ldb[g], ga.ldc[g], ga.cs[g], t % t1, t / t1,
+                  ts_smem, ga.pass_rows);
+}
+// Rows of the reduction per pass through LDS (2 x 128 bytes per row).  One pass (the whole reduction in flight, one memory round
+// trip) when a single round of workgroups covers the tiles; several shorter passes when there are more tiles than that - the
+// smaller footprint puts more workgroups on a CU and THEIR round trips overlap (MURCL_TN_PASS: dev override)
+static int tn_small_pass_rows(int M, long tiles) {
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("MURCL_TN_PASS"); force = e ? atoi(e) : -1; }
+    int pr = TS_MAXM;
+    if (force > 0) pr = force;
+    else if (tiles > 512 && M > 192) pr = ((M + 1) / 2 + 15) & ~15;
+    pr = (pr + 15) & ~15;
+    if (pr > TS_MAXM) pr = TS_MAXM;
+    if (pr < 16) pr = 16;
+    return pr;
 }
 static int tn_small_enabled() {
     static int v = -1;
@@ -1452,12 +1530,13 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     // the 128 x 128 ring kernel below takes 55 us ([768 x 3072 x 512], tools/tn_trace.sh); up to 512 rows the small tiles win
     // (16.6 -> 12.2 us [128 x 3072 x 512], 7.7 -> 5.8 us [128 x 512 x 512], 23.7 -> 18.0 us [320 x 2048 x 512])
     if (dtype == MURCL_DTYPE_F32 && !x3 && splits <= 0 && M <= TS_MAXM && tn_small_enabled()) {
-        const int mp = ((M < TS_MAXM ? M : TS_MAXM) + 15) & ~15;
+        const int pr = tn_small_pass_rows(M, (long)((N1 + TS_T - 1) / TS_T) * ((N2 + TS_T - 1) / TS_T));
+        const int mp = ((M < pr ? M : pr) + 15) & ~15;
         static MurclOncePerDevice once;
         if (once.first())
             hipFuncSetAttribute((const void*)gemm_tn_small_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_MAXM * 128);
         hipLaunchKernelGGL(gemm_tn_small_f32_kernel, dim3((N1 + TS_T - 1) / TS_T, (N2 + TS_T - 1) / TS_T), dim3(256), 2 * mp * 128,
-                           stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, colsum_out);
+                           stream, (const float*)A, (const float*)B, C, M, N1, N2, lda, ldb, ldc, colsum_out, pr);
         return MURCL_CHECK_LAUNCH();
     }
     const int rows = dtype == MURCL_DTYPE_BF16 ? 64 : 32;
@@ -1585,8 +1664,40 @@ extern "C" long murcl_gemm_tn_grouped_workspace_bytes(const TnProblem* pr, int n
     if (!tn_group_plan(n, M, N1, N2, &pl, nullptr)) return 0;
     return pl.ws_floats * 4;
 }
+// f32 products of a few hundred rows each (the single-product path would take gemm_tn_small_f32_kernel for every one of them)
+static bool tn_small_group_ok(const TnProblem* pr, int n, int dtype) {
+    if (dtype != MURCL_DTYPE_F32 || n < 2 || n > 4 || !tn_small_enabled()) return false;
+    for (int g = 0; g < n; ++g) {
+        const TnProblem& p = pr[g];
+        if (p.flags || p.colsum_part || p.M <= 0 || p.M > TS_MAXM || p.N1 < 4 || p.N2 < 4 || p.N1 % 4 || p.N2 % 4 || p.lda % 4 || p.ldb % 4)
+            return false;
+    }
+    return true;
+}
 extern "C" int murcl_gemm_tn_grouped(const TnProblem* pr, int n, int dtype, float* ws, long ws_bytes, hipStream_t stream) {
     if (n <= 0) return 0;
+    if (tn_small_group_ok(pr, n, dtype)) {
+        TnSmallGroup ga;
+        int tiles = 0, mmax = 0;
+        for (int g = 0; g < 4; ++g) {
+            const TnProblem& p = pr[g < n ? g : 0];
+            ga.A[g] = (const float*)p.A; ga.B[g] = (const float*)p.B; ga.C[g] = p.C; ga.cs[g] = p.colsum_out;
+            ga.M[g] = p.M; ga.N1[g] = p.N1; ga.N2[g] = p.N2; ga.lda[g] = p.lda; ga.ldb[g] = p.ldb; ga.ldc[g] = p.ldc;
+            ga.tile0[g] = tiles;
+            if (g < n) {
+                tiles += ((p.N1 + TS_T - 1) / TS_T) * ((p.N2 + TS_T - 1) / TS_T);
+                if (p.M > mmax) mmax = p.M;
+            }
+        }
+        for (int g = n; g < 5; ++g) ga.tile0[g] = tiles;                  // unused slots: empty ranges behind the last product
+        ga.pass_rows = tn_small_pass_rows(mmax, tiles);
+        const int mp = ((mmax < ga.pass_rows ? mmax : ga.pass_rows) + 15) & ~15;
+        static MurclOncePerDevice once;
+        if (once.first())
+            hipFuncSetAttribute((const void*)gemm_tn_small_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_MAXM * 128);
+        hipLaunchKernelGGL(gemm_tn_small_group_kernel, dim3(tiles), dim3(256), 2 * mp * 128, stream, ga);
+        return MURCL_CHECK_LAUNCH();
+    }
     const long need = (n <= TN_MAXG) ? murcl_gemm_tn_grouped_workspace_bytes(pr, n, dtype) : 0;
     if (!need || !ws || ws_bytes < need) {
         for (int g = 0; g < n; ++g)

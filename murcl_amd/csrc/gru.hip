@@ -221,6 +221,49 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
     if (dhprev) dhprev[ih] = dp + d * z;
 }
 
+// ---------------------------------------------------------------- the same stream as a plain product
+// C[M,N] = epi(A[M,K] . B[N,K]^T) on 16 x 16 tiles, K split over the four waves: few outputs with a long reduction (the library's
+// 32 x 32-tile form would either walk its 256-k chunks one memory round trip after the other or split K over workgroups that
+// meet through a zero-fill launch, float atomics and, for a ReLU, a third launch).  Single writer per element: bias, ReLU,
+// ReLU' mask and accumulation in the epilogue, the result independent of any atomic order.
+__global__ __launch_bounds__(256) void gemm_nt_t16_f32_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                              float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                              const float* __restrict__ bias, int relu, int accumulate,
+                                                              const float* __restrict__ mask, int ldmask) {
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * GS_T, m0 = blockIdx.y * GS_T;
+    const int m = m0 + (tid >> 4), n = j0 + (tid & 15);
+    const bool live = m < M;
+    float bv = 0.f, c0 = 0.f, mk = 1.f;
+    if (live) {
+        if (bias) bv = bias[n];
+        if (accumulate) c0 = C[(size_t)m * ldc + n];
+        if (mask) mk = mask[(size_t)m * ldmask + n];
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    gs_stream<1, 2>(A, lda, M, m0, Bm, ldb, 0, j0, K, gs_smem, wave, lane, acc);
+    gs_park<2, 2>(gs_smem, wave, lane, 0, acc);
+    __syncthreads();
+    if (!live) return;
+    float v = (gs_total<2>(gs_smem, 0, tid) + gs_total<2>(gs_smem, 1, tid)) + bv + c0;
+    if (mask) v = mk > 0.f ? v : 0.f;
+    C[(size_t)m * ldc + n] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// host side of the above for gemm.hip's small-matrix dispatcher (C++ linkage: not part of the C-ABI)
+bool murcl_nt_t16_ok(int M, int N, int K) { return M > 0 && N >= 16 && N % 16 == 0 && K >= 16 && K % 16 == 0 && (M + GS_T - 1) / GS_T <= 65535; }
+int murcl_nt_t16_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias,
+                        int relu, int accumulate, const float* mask, int ldmask, hipStream_t stream) {
+    static MurclOncePerDevice once;
+    if (once.first())
+        hipFuncSetAttribute((const void*)gemm_nt_t16_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GruLds<1>::BYTES);
+    hipLaunchKernelGGL(gemm_nt_t16_f32_kernel, dim3(N / GS_T, (M + GS_T - 1) / GS_T), dim3(256), GruLds<1>::BYTES, stream, A, B, C, M, N, K,
+                       lda, ldb, ldc, bias, relu, accumulate, mask, ldmask);
+    return MURCL_CHECK_LAUNCH();
+}
+
 static int gs_shape_ok(int B, int H, int Kx) {
     // 16-unit tiles; whole 16-k groups per wave (k ranges that are multiples of 16); the LDS-DMA's 16-byte pieces
     return B > 0 && H >= 16 && H % 16 == 0 && Kx % 16 == 0 && (long)((B + GS_T - 1) / GS_T) <= 65535;

@@ -11,7 +11,7 @@
 //   murcl_ppo_epoch  one K_epoch of PPO.update: evaluate() forward over the rollout, the fused
 //                    heads + clipped-surrogate loss + their gradients, full backward (GRU through
 //                    time, encoder), every weight / bias gradient ADDED into the caller's gradient
-//                    buffers (FlatAdam's flat views)                                                -> 20 + 4T launches, 1 call
+//                    buffers (FlatAdam's flat views)                                                -> 11 + 2T launches, 1 call
 //
 // All intermediates live in a caller-provided workspace (murcl_ppo_epoch_workspace).  The GEMMs are the library's own
 // entry points (murcl_gemm_nt / murcl_gemm_tn); new kernels here are the fused heads.
@@ -254,9 +254,11 @@ extern "C" long murcl_ppo_epoch_workspace(int T, int B, int S, int H) {
 // (states [T,B,S], actions [T,B,K], GRU from a zero hidden state), loss, backward; parameter gradients are ADDED to
 // grads[] (same order as params[]; the caller zeroes them, all-reduces them across ranks if any, and steps Adam).
 // n_total: rollout rows over all ranks (the loss is their mean).  loss_out (may be NULL): this rank's share of the loss.
-extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, int S, int H, int K, const float* states,
-                               const float* actions, const float* old_logp, const float* returns, int T, int B, long n_total,
-                               float std_, float eps_clip, float entropy, float* ws, float* loss_out, hipStream_t stream) {
+// wt (may be NULL): {W_ih^T [H,3H], W_hh^T [H,3H], W_2^T [2048,H]} prepared by the caller (the optimizer's one launch of weight
+// views per step); NULL: transposed here into the workspace, three launches.
+static int ps_epoch(const float* const* params, float* const* grads, const float* const* wt, int S, int H, int K, const float* states,
+                    const float* actions, const float* old_logp, const float* returns, int T, int B, long n_total,
+                    float std_, float eps_clip, float entropy, float* ws, float* loss_out, hipStream_t stream) {
     const int R = T * B;
     if (R <= 0) return 0;
     if (!ps_shape_ok(S, H, K) || n_total < R) return -1;
@@ -275,9 +277,12 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
     float* dzv = dhs + r * H;
     float* lossrow = dzv + r * (PS_MAXK + 1);
     float* dhp = lossrow + r;
-    float* wih_t = dhp + (size_t)B * H;
-    float* whh_t = wih_t + (size_t)H * 3 * H;
-    float* w2_t = whh_t + (size_t)H * 3 * H;
+    float* wih_ws = dhp + (size_t)B * H;
+    float* whh_ws = wih_ws + (size_t)H * 3 * H;
+    float* w2_ws = whh_ws + (size_t)H * 3 * H;
+    const float* wih_t = wt ? wt[0] : wih_ws;
+    const float* whh_t = wt ? wt[1] : whh_ws;
+    const float* w2_t = wt ? wt[2] : w2_ws;
     const size_t bh = (size_t)B * H, b3 = (size_t)B * 3 * H;
 
     const bool fused = ps_gru_step() && murcl_gru_step_supported(B, H, 0);    // one launch per GRU time step and direction
@@ -305,9 +310,11 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
                        grads[P_WC], grads[P_BC], loss_out);
     PS_CHECK(MURCL_CHECK_LAUNCH());
     // ---------------- backward through the GRU (time-reversed), then the encoder
-    PS_CHECK(murcl_transpose_cast(params[P_WIH], wih_t, 3 * H, H, MURCL_F32, stream));
-    if (T > 1) PS_CHECK(murcl_transpose_cast(params[P_WHH], whh_t, 3 * H, H, MURCL_F32, stream));
-    PS_CHECK(murcl_transpose_cast(params[P_W2], w2_t, H, PS_E1, MURCL_F32, stream));
+    if (!wt) {
+        PS_CHECK(murcl_transpose_cast(params[P_WIH], wih_ws, 3 * H, H, MURCL_F32, stream));
+        if (T > 1) PS_CHECK(murcl_transpose_cast(params[P_WHH], whh_ws, 3 * H, H, MURCL_F32, stream));
+        PS_CHECK(murcl_transpose_cast(params[P_W2], w2_ws, H, PS_E1, MURCL_F32, stream));
+    }
     if (fused && T > 1) {
         // dh_{t-1} += dgh_t . W_hh, then step t-1's gate backward on the finished tile: one launch per step
         const int t1 = T - 1;
@@ -330,15 +337,38 @@ extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, 
             PS_CHECK(ps_nt(dgh + t * b3, whh_t, dhs + (t - 1) * bh, B, H, 3 * H, MURCL_EPI_NONE, nullptr, 1, stream));
         }
     }
-    PS_CHECK(murcl_gemm_tn(dgi, e2, grads[P_WIH], R, 3 * H, H, 3 * H, H, H, MURCL_F32, 0, grads[P_BIH], stream));
-    if (T > 1)
-        PS_CHECK(murcl_gemm_tn(dgh + b3, hs, grads[P_WHH], R - B, 3 * H, H, 3 * H, H, H, MURCL_F32, 0, nullptr, stream));
     PS_CHECK(murcl_colsum(dgh, grads[P_BHH], R, 3 * H, 3 * H, MURCL_F32, 1, stream));
-    PS_CHECK(ps_nt(dgi, wih_t, de2, R, H, 3 * H, MURCL_EPI_NONE, nullptr, 0, stream));
-    PS_CHECK(murcl_relu_bwd(de2, e2, de2, (long)r * H, stream));
-    PS_CHECK(murcl_gemm_tn(de2, e1, grads[P_W2], R, H, PS_E1, H, PS_E1, PS_E1, MURCL_F32, 0, grads[P_B2], stream));
-    PS_CHECK(ps_nt(de2, w2_t, de1, R, PS_E1, H, MURCL_EPI_NONE, nullptr, 0, stream));
-    PS_CHECK(murcl_relu_bwd(de1, e1, de1, (long)r * PS_E1, stream));
-    PS_CHECK(murcl_gemm_tn(de1, states, grads[P_W1], R, PS_E1, S, PS_E1, S, S, MURCL_F32, 0, grads[P_B1], stream));
+    // the two encoder dgrads with ReLU' (the layer's saved output > 0) in the epilogue
+    PS_CHECK(murcl_gemm_nt(dgi, wih_t, de2, R, H, 3 * H, 3 * H, 3 * H, H, MURCL_F32, MURCL_F32, MURCL_EPI_MASK, nullptr, e2, H, nullptr,
+                           nullptr, 0, nullptr, 0, stream));
+    PS_CHECK(murcl_gemm_nt(de2, w2_t, de1, R, PS_E1, H, H, H, PS_E1, MURCL_F32, MURCL_F32, MURCL_EPI_MASK, nullptr, e1, PS_E1, nullptr,
+                           nullptr, 0, nullptr, 0, stream));
+    // every weight gradient (+ the bias gradients that are column sums of its left operand) added in ONE launch
+    murcl_tn_problem pr[4];
+    int np = 0;
+    auto add = [&](const float* A_, const float* B_, float* C_, float* cs, int M_, int N1_, int N2_) {
+        murcl_tn_problem& q = pr[np++];
+        q.A = A_; q.B = B_; q.C = C_; q.colsum_part = nullptr; q.colsum_out = cs;
+        q.M = M_; q.N1 = N1_; q.N2 = N2_; q.lda = N1_; q.ldb = N2_; q.ldc = N2_; q.colsum_rows = 0; q.flags = 0; q.scale = 1.f;
+    };
+    add(de1, states, grads[P_W1], grads[P_B1], R, PS_E1, S);
+    add(de2, e1, grads[P_W2], grads[P_B2], R, H, PS_E1);
+    add(dgi, e2, grads[P_WIH], grads[P_BIH], R, 3 * H, H);
+    if (T > 1) add(dgh + b3, hs, grads[P_WHH], nullptr, R - B, 3 * H, H);
+    PS_CHECK(murcl_gemm_tn_grouped(pr, np, MURCL_F32, nullptr, 0, stream));
     return 0;
+}
+
+extern "C" int murcl_ppo_epoch(const float* const* params, float* const* grads, int S, int H, int K, const float* states,
+                               const float* actions, const float* old_logp, const float* returns, int T, int B, long n_total,
+                               float std_, float eps_clip, float entropy, float* ws, float* loss_out, hipStream_t stream) {
+    return ps_epoch(params, grads, nullptr, S, H, K, states, actions, old_logp, returns, T, B, n_total, std_, eps_clip, entropy, ws,
+                    loss_out, stream);
+}
+extern "C" int murcl_ppo_epoch_wt(const float* const* params, float* const* grads, const float* const* wt, int S, int H, int K,
+                                  const float* states, const float* actions, const float* old_logp, const float* returns, int T, int B,
+                                  long n_total, float std_, float eps_clip, float entropy, float* ws, float* loss_out,
+                                  hipStream_t stream) {
+    return ps_epoch(params, grads, wt, S, H, K, states, actions, old_logp, returns, T, B, n_total, std_, eps_clip, entropy, ws, loss_out,
+                    stream);
 }

@@ -375,8 +375,13 @@ class _HipPolicyKernels:
         if pol._native_ok(S) and all(p.grad is not None and p.grad.is_contiguous() for p in pol._plist()):
             # evaluate() forward + loss + backward as ONE native launch sequence adding into the flat gradient buffer
             ppo.optimizer.zero_grad()
+            g, enc = pol.gru, pol.state_encoder
+            wt = None
+            if all(ops.is_managed(w) for w in (g.weight_ih_l0, g.weight_hh_l0, enc[2].weight)):
+                # the dgrad operands W^T: the optimizer-managed views, rebuilt by ONE launch after each Adam step
+                wt = ops.weight_views(tuple((w, True, torch.float32) for w in (g.weight_ih_l0, g.weight_hh_l0, enc[2].weight)))
             ops.ppo_epoch(pol.pointer_table(), pol.pointer_table(grads=True), S, pol.hidden_state_dim, pol.action_size,
-                          states.flatten(2), actions, old_logp, returns, n_total, pol.action_std, ppo.eps_clip, entropy)
+                          states.flatten(2), actions, old_logp, returns, n_total, pol.action_std, ppo.eps_clip, entropy, wt=wt)
             ppo.optimizer.mark_all_touched()
             return
         logp, value, _ = pol.evaluate(states, actions)

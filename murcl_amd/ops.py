@@ -338,6 +338,22 @@ def gemm_tn_grouped(problems, fresh=False):
     = [first half; second half] in natural order).  ``fresh``: products without ``out`` / column sums into a fresh tensor are WRITTEN
     by the reduce launch (no zero-fill launch before it)."""
     problems = [tuple(p) + (None,) * (6 - len(p)) for p in problems]
+    if gemm_tn_small_grouped_ok(problems):
+        n = len(problems)
+        arr = (_lib.TnProblem * n)()
+        keep, Cs = [], []
+        for g, (A, B, out, ci, _, _) in enumerate(problems):
+            _need_cuda(A, B)
+            A, B = _c(A), _c(B)
+            (M, N1), N2 = A.shape, B.shape[1]
+            C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
+            assert C.dtype == torch.float32 and C.is_contiguous() and tuple(C.shape) == (N1, N2)
+            assert ci is None or (ci.dtype == torch.float32 and ci.is_contiguous() and ci.numel() == N1)
+            keep.append((A, B))
+            Cs.append(C)
+            arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), None, ptr(ci), M, N1, N2, N1, N2, N2, 0, 0, 1.0)
+        check(_lib.lib().murcl_gemm_tn_grouped(arr, n, F32, None, 0, stream()), "gemm_tn_grouped(small)")
+        return Cs
     if not gemm_tn_grouped_ok(problems):
         assert all(p[5] is None for p in problems), "scale / deinterleave need the grouped launch (gemm_tn_grouped_ok)"
         return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp, _ in problems]
@@ -377,6 +393,19 @@ def gemm_tn_grouped(problems, fresh=False):
                     bytes=sum(A.shape[0] * (A.shape[1] + B.shape[1]) * 2 + A.shape[1] * B.shape[1] * 4 for A, B, _ in keep)))):
         check(_lib.lib().murcl_gemm_tn_grouped(arr, n, BF16, ptr(ws), wsb, stream()), "gemm_tn_grouped")
     return Cs
+
+
+def gemm_tn_small_grouped_ok(problems):
+    """2-4 f32 products of at most 512 rows each (bag-level / rollout-level weight gradients), accumulated into their outputs:
+    ONE launch of the 32 x 32-tile single-writer kernel over all their tiles."""
+    if not (_TN_SMALL_GROUP and 1 < len(problems) <= 4):
+        return False
+    for p in problems:
+        A, B = p[0], p[1]
+        if not (A.dtype == torch.float32 and B.dtype == torch.float32 and A.dim() == 2 and B.dim() == 2 and 0 < A.shape[0] <= 512
+                and A.shape[0] == B.shape[0] and A.shape[1] % 4 == 0 and B.shape[1] % 4 == 0 and p[4] is None and not p[5]):
+            return False
+    return True
 
 
 def gemm_tn_grouped_ok(problems):
@@ -787,6 +816,7 @@ def gru_gates_bwd_into(dh, gates, gh, hprev, dgi, dgh, dhprev=None, accumulate=F
                                               int(gh.shape[0] == 1 and B != 1), int(accumulate), stream()), "gru_gates_bwd_into")
 
 
+_TN_SMALL_GROUP = _os.environ.get("MURCL_TN_SMALL_GROUP", "1") != "0"     # dev A/B switch
 _GRU_STEP = _os.environ.get("MURCL_GRU_STEP", "1") != "0"          # dev A/B switch: one launch per GRU time step and direction
 
 
@@ -1275,15 +1305,23 @@ def ppo_act(ptable, S, H, K, state, hidden_prev, eps, std):
     return hnew, action, logp
 
 
-def ppo_epoch(ptable, gtable, S, H, K, states, actions, old_logp, returns, n_total, std, eps_clip, entropy, want_loss=False):
+def ppo_epoch(ptable, gtable, S, H, K, states, actions, old_logp, returns, n_total, std, eps_clip, entropy, want_loss=False, wt=None):
     """One K_epoch of PPO.update minus the optimizer step behind ONE native call (murcl_ppo_epoch): evaluate() forward,
-    loss, backward; parameter gradients are ADDED into the tensors behind ``gtable``."""
+    loss, backward; parameter gradients are ADDED into the tensors behind ``gtable``.  ``wt``: (W_ih^T, W_hh^T, W_2^T) f32,
+    e.g. ``weight_views`` of the three parameters - without it the call transposes them itself (three launches)."""
     _need_cuda(states, actions)
     states, actions, old_logp, returns = _c(states.float()), _c(actions.float()), _c(old_logp), _c(returns)
     T_, B = states.shape[0], states.shape[1]
     dev = states.device
     ws = torch.empty((_lib.lib().murcl_ppo_epoch_workspace(T_, B, S, H) // 4,), dtype=torch.float32, device=dev)
     loss = torch.empty((1,), dtype=torch.float32, device=dev) if want_loss else None
+    if wt is not None:
+        assert len(wt) == 3 and all(t.is_contiguous() and t.dtype == torch.float32 for t in wt)
+        assert wt[0].shape == (H, 3 * H) and wt[1].shape == (H, 3 * H) and wt[2].shape[1] == H
+        check(_lib.lib().murcl_ppo_epoch_wt(ptable, gtable, pointer_table(wt), S, H, K, ptr(states), ptr(actions), ptr(old_logp),
+                                            ptr(returns), T_, B, int(n_total), float(std), float(eps_clip), float(entropy), ptr(ws),
+                                            ptr(loss), stream()), "ppo_epoch_wt")
+        return loss
     check(_lib.lib().murcl_ppo_epoch(ptable, gtable, S, H, K, ptr(states), ptr(actions), ptr(old_logp), ptr(returns), T_, B,
                                      int(n_total), float(std), float(eps_clip), float(entropy), ptr(ws), ptr(loss), stream()),
           "ppo_epoch")

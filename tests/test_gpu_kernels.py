@@ -809,6 +809,44 @@ def test_gru_gates_fwd_bwd():
     _close(h0, (1 - z) * n, rtol=1e-5, atol=1e-6)
 
 
+def test_small_f32_weight_gradients_in_one_launch():
+    """ops.gemm_tn_grouped on 2-4 f32 products of a few hundred rows (a PPO epoch's weight gradients): one launch of the 32 x 32
+    single-writer kernel; products and column sums are ADDED to what the outputs hold."""
+    from murcl_amd import ops
+    dev = _dev()
+    shapes = [(320, 2048, 512, True), (320, 512, 2048, True), (320, 1536, 512, True), (256, 1536, 512, False)]
+    for n in (2, 3, 4):
+        probs, want = [], []
+        for g, (M, N1, N2, cs) in enumerate(shapes[:n]):
+            A, B = _rand(44, f"A{g}", (M, N1)), _rand(44, f"B{g}", (M, N2))
+            C0, c0 = _rand(44, f"C{g}", (N1, N2)), _rand(44, f"c{g}", (N1,))
+            out, ci = C0.to(dev).clone(), (c0.to(dev).clone() if cs else None)
+            probs.append((A.to(dev), B.to(dev), out, ci, None))
+            want.append((C0.double() + A.double().t() @ B.double(), c0.double() + A.double().sum(0) if cs else None))
+        assert ops.gemm_tn_small_grouped_ok([tuple(p) + (None,) for p in probs])
+        Cs = ops.gemm_tn_grouped(probs)
+        for (A, B, out, ci, _), C, (wC, wc) in zip(probs, Cs, want):
+            assert C.data_ptr() == out.data_ptr()
+            _close(C, wC, rtol=1e-4, atol=2e-4)
+            if wc is not None:
+                _close(ci, wc, rtol=1e-4, atol=2e-4)
+    # ragged row counts and widths that are not multiples of the tile
+    A, B, A2, B2 = _rand(45, "A", (77, 36)), _rand(45, "B", (77, 100)), _rand(45, "A2", (5, 64)), _rand(45, "B2", (5, 32))
+    Cs = ops.gemm_tn_grouped([(A.to(dev), B.to(dev), None, None, None), (A2.to(dev), B2.to(dev), None, None, None)])
+    _close(Cs[0], A.double().t() @ B.double(), rtol=1e-4, atol=1e-4)
+    _close(Cs[1], A2.double().t() @ B2.double(), rtol=1e-4, atol=1e-4)
+
+
+def test_small_gemm_applies_relu_mask_in_the_epilogue():
+    """murcl_gemm_nt's small f32 path with MURCL_EPI_MASK: dx = (dy W) * (y > 0) in one launch (the PPO encoder's dgrads)."""
+    from murcl_amd import ops
+    dev = _dev()
+    for M, N, K in ((320, 512, 1536), (320, 2048, 512), (37, 96, 64)):
+        dy, wt, y = _rand(46, "dy", (M, K)), _rand(46, "wt", (N, K)) / math.sqrt(K), _rand(46, "y", (M, N))
+        got = ops.gemm_nt(dy.to(dev), wt.to(dev), epi=ops.EPI_MASK, mask=y.to(dev))
+        _close(got, (dy.double() @ wt.double().t()) * (y > 0), rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("B,H,Kx", [(64, 512, 0), (128, 512, 512), (17, 32, 0), (5, 48, 80), (33, 1024, 0), (64, 512, 1024)])
 def test_gru_step_forward_in_one_launch(B, H, Kx):
     """murcl_gru_step_fwd (h W_hh^T, optionally x W_ih^T, and the gate math in one launch) against torch.nn.GRUCell's formula
