@@ -55,7 +55,7 @@ def synth_views(bags, n, d, dtype, device, rank):
 
 
 def make_step(model, fc, opt, crit, views, world):
-    from murcl_amd import dist as mdist, ops
+    from murcl_amd import dist as mdist, functional, ops
     # milestones (encoder gradients reduced layer by layer under the remaining backward): opt-in - three more collectives
     # cost 85 us per step on one rank (1.83 vs 1.75 ms under MURCL_FORCE_DIST=1), more than the ~60 us of exposed
     # all-reduce they can hide; to be re-measured on a real multi-GPU node
@@ -72,7 +72,8 @@ def make_step(model, fc, opt, crit, views, world):
             loss, _ = mdist.gathered_nt_xent(z[0], z[1], 1.0)
         else:
             loss = crit(z[0], z[1])
-        loss.backward(ops.unit_grad(loss))
+        with functional.deferred_wgrads():      # as train_MuRCL.pretrain_step: the head's weight gradients as one launch
+            loss.backward(ops.unit_grad(loss))
         if reducer is not None:
             reducer.finish()
         opt.step()

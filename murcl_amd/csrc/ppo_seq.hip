@@ -36,22 +36,33 @@ __global__ __launch_bounds__(256) void ps_act_head_kernel(const float* __restric
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const float* hr = h + (size_t)r * H;
-    float acc = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float* w = Wa + (size_t)k * H;
-        float p = 0.f;
-        for (int c = lane * 4; c < H; c += 256) {
-            const f32x4 a = *(const f32x4*)(hr + c), b = *(const f32x4*)(w + c);
-            p += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-        }
-        const float z = ps_wave_sum(p) + ba[k];
-        const float m = 1.f / (1.f + expf(-z));
-        float a = m + std_ * eps[(size_t)r * K + k];
-        a = fminf(fmaxf(a, 0.f), 1.f);                       // relu, then 1 - relu(1 - a)
-        if (lane == 0) action[(size_t)r * K + k] = a;
-        const float t = (a - m) / std_;
-        acc += -0.5f * t * t;
+    // the K dots side by side: their loads and their wave reductions are independent chains (one after the other they were
+    // K serial memory + shuffle latencies: 13 us for 10 actions)
+    float p[PS_MAXK];
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k) p[k] = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 a = *(const f32x4*)(hr + c);
+        f32x4 b[PS_MAXK];
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) b[k] = *(const f32x4*)(Wa + (size_t)min(k, K - 1) * H + c);   // branch-free: rows past K repeat the last
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) p[k] += a[0] * b[k][0] + a[1] * b[k][1] + a[2] * b[k][2] + a[3] * b[k][3];
     }
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k) p[k] = ps_wave_sum(p[k]);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k)
+        if (k < K) {
+            const float z = p[k] + ba[k];
+            const float m = 1.f / (1.f + expf(-z));
+            float a = m + std_ * eps[(size_t)r * K + k];
+            a = fminf(fmaxf(a, 0.f), 1.f);                   // relu, then 1 - relu(1 - a)
+            if (lane == 0) action[(size_t)r * K + k] = a;
+            const float t = (a - m) / std_;
+            acc += -0.5f * t * t;
+        }
     if (lane == 0) logp[r] = acc - (float)K * logf(std_) - 0.5f * (float)K * PS_LOG_2PI;
 }
 
@@ -71,29 +82,36 @@ __global__ __launch_bounds__(256) void ps_eval_head_kernel(const float* __restri
     if (r >= R) return;
     const float* hr = hs + (size_t)r * H;
     float mu[PS_MAXK], da[PS_MAXK];
-    float lp = 0.f;
-    for (int k = 0; k < K; ++k) {
-        const float* w = Wa + (size_t)k * H;
-        float p = 0.f;
-        for (int c = lane * 4; c < H; c += 256) {
-            const f32x4 a = *(const f32x4*)(hr + c), b = *(const f32x4*)(w + c);
-            p += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-        }
-        const float z = ps_wave_sum(p) + ba[k];
-        const float m = 1.f / (1.f + expf(-z));
-        const float d = act[(size_t)r * K + k] - m;
-        mu[k] = m;
-        da[k] = d;
-        const float t = d / std_;
-        lp += -0.5f * t * t;
-    }
-    lp += -(float)K * logf(std_) - 0.5f * (float)K * PS_LOG_2PI;
-    float pv = 0.f;
+    // the K actor dots and the critic dot side by side (independent load and reduction chains, see ps_act_head_kernel)
+    float p[PS_MAXK], pv = 0.f;
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k) p[k] = mu[k] = da[k] = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
-        const f32x4 a = *(const f32x4*)(hr + c), b = *(const f32x4*)(Wc + c);
-        pv += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        const f32x4 a = *(const f32x4*)(hr + c), bcv = *(const f32x4*)(Wc + c);
+        pv += a[0] * bcv[0] + a[1] * bcv[1] + a[2] * bcv[2] + a[3] * bcv[3];
+        f32x4 b[PS_MAXK];
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) b[k] = *(const f32x4*)(Wa + (size_t)min(k, K - 1) * H + c);   // branch-free: rows past K repeat the last
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) p[k] += a[0] * b[k][0] + a[1] * b[k][1] + a[2] * b[k][2] + a[3] * b[k][3];
     }
-    const float v = ps_wave_sum(pv) + bc[0];
+    pv = ps_wave_sum(pv);
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k) p[k] = ps_wave_sum(p[k]);
+    float lp = 0.f;
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k)
+        if (k < K) {
+            const float z = p[k] + ba[k];
+            const float m = 1.f / (1.f + expf(-z));
+            const float d = act[(size_t)r * K + k] - m;
+            mu[k] = m;
+            da[k] = d;
+            const float t = d / std_;
+            lp += -0.5f * t * t;
+        }
+    lp += -(float)K * logf(std_) - 0.5f * (float)K * PS_LOG_2PI;
+    const float v = pv + bc[0];
     const float R_ = ret[r];
     const float ratio = expf(lp - old_logp[r]);
     const float adv = R_ - v;
@@ -108,20 +126,24 @@ __global__ __launch_bounds__(256) void ps_eval_head_kernel(const float* __restri
     else g = (ratio >= 1.f - eps_clip && ratio <= 1.f + eps_clip) ? -s2 : 0.f;
     const float dlogp = g * inv_n, dv = dvr * inv_n;
     float dz[PS_MAXK];
-    for (int k = 0; k < K; ++k) dz[k] = dlogp * da[k] / (std_ * std_) * mu[k] * (1.f - mu[k]);
+#pragma unroll
+    for (int k = 0; k < PS_MAXK; ++k) dz[k] = (k < K) ? dlogp * da[k] / (std_ * std_) * mu[k] * (1.f - mu[k]) : 0.f;
     if (lane == 0) {
         lossrow[r] = (-fminf(s1, s2) + 0.5f * dvr * dvr - 0.01f * entropy) * inv_n;
-        for (int k = 0; k < K; ++k) dzv[(size_t)r * (PS_MAXK + 1) + k] = dz[k];
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k)
+            if (k < K) dzv[(size_t)r * (PS_MAXK + 1) + k] = dz[k];
         dzv[(size_t)r * (PS_MAXK + 1) + K] = dv;
     }
     float* dr = dhs + (size_t)r * H;
     for (int c = lane * 4; c < H; c += 256) {
         const f32x4 wc = *(const f32x4*)(Wc + c);
         f32x4 o = {dv * wc[0], dv * wc[1], dv * wc[2], dv * wc[3]};
-        for (int k = 0; k < K; ++k) {
-            const f32x4 w = *(const f32x4*)(Wa + (size_t)k * H + c);
-            o[0] += dz[k] * w[0]; o[1] += dz[k] * w[1]; o[2] += dz[k] * w[2]; o[3] += dz[k] * w[3];
-        }
+        f32x4 w[PS_MAXK];
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) w[k] = *(const f32x4*)(Wa + (size_t)min(k, K - 1) * H + c);   // dz[k] = 0 past K
+#pragma unroll
+        for (int k = 0; k < PS_MAXK; ++k) { o[0] += dz[k] * w[k][0]; o[1] += dz[k] * w[k][1]; o[2] += dz[k] * w[k][2]; o[3] += dz[k] * w[k][3]; }
         *(f32x4*)(dr + c) = o;
     }
 }

@@ -153,6 +153,8 @@ class OverlappedGradReduce:
     def _fired(self, grad):
         self._pending -= 1
         if self._pending == 0:
+            from . import functional
+            functional.flush_deferred()               # weight gradients queued for one launch at the end: the head's are due now
             for gi in self.early:
                 self._submit(gi, 0, self.opt.flat_grads()[gi].numel())
         return grad

@@ -130,14 +130,27 @@ class deferred_wgrads:
         global _DEFERRED
         queue, _DEFERRED = _DEFERRED, self.prev
         if exc[0] is None and queue:
-            for w, b, dys, xs in queue.values():
-                dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
-                x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
-                if b is not None:
-                    ops.gemm_tn(dy, x, out=w.grad, colsum_into=b.grad.view(-1))
-                else:
-                    ops.gemm_tn(dy, x, out=w.grad)
+            _flush(queue)
         return False
+
+
+def _flush(queue):
+    """The queued (dy, x) pairs of every parameter as one product each, up to four small f32 products per launch."""
+    probs = []
+    for w, b, dys, xs in queue.values():
+        dy = dys[0] if len(dys) == 1 else torch.cat(dys, 0)
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, 0)
+        probs.append((dy, x, w.grad, b.grad.view(-1) if b is not None else None, None))
+    queue.clear()
+    for i in range(0, len(probs), 4):
+        ops.gemm_tn_grouped(probs[i:i + 4])
+
+
+def flush_deferred():
+    """Run what the active ``deferred_wgrads`` block has queued so far (a gradient all-reduce that starts inside the backward pass
+    needs the gradients of the layers behind it complete: dist.OverlappedGradReduce)."""
+    if _DEFERRED:
+        _flush(_DEFERRED)
 
 
 def _defer(dy, x, w, b):
