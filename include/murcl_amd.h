@@ -357,8 +357,8 @@ int murcl_gru_gates_bwd_into(const float* dh, const float* gates, const float* g
  * matrix pipe and finishes the gate math in the epilogue - replaces murcl_gemm_nt + murcl_gru_gates_* pairs (same arithmetic;
  * only the summation order inside the products differs).  H % 16 == 0; murcl_gru_step_supported(B, H, Kx) != 0 otherwise.
  * murcl_gru_step_fwd: gi [B,3H] = x W_ih^T + b_ih, or - with x [B,Kx] and w_ih [3H,Kx] given (Kx % 16 == 0) - gi is the bias
- *   row b_ih [3H] and the input product is formed here too.  hprev [B,H] (a zero state has no product: use
- *   murcl_gru_gates_fwd with gh_bcast).  Writes hnew [B,H], gates [B,3H] = (r,z,n) and gh [B,3H] = h W_hh^T + b_hh (either may
+ *   row b_ih [3H] and the input product is formed here too.  hprev [B,H]; NULL (with x given) = the zero state of a restart:
+ *   only the input product is formed, gh = b_hh.  Writes hnew [B,H], gates [B,3H] = (r,z,n) and gh [B,3H] = h W_hh^T + b_hh (either may
  *   be NULL when no backward follows).
  * murcl_gru_step_bwd: dh [B,H] holds the step's upstream gradient; adds dgh_next [B,3H] . W_hh (w_hh_t = W_hh^T [H,3H]), writes
  *   the total back, then the gate backward exactly as murcl_gru_gates_bwd_into (dgi, dgh, dhprev (+)= dh * z; dhprev may be NULL). */

@@ -539,6 +539,9 @@ static int pick_chunk(int B, int N, int tr, int n_wg) {
     // rows per item: multiple of the tile height, <= K2_MAX_CHUNK, small enough to give every workgroup >= 2 items
     int chunk = ((N + tr - 1) / tr) * tr;
     if (chunk > K2_MAX_CHUNK) chunk = K2_MAX_CHUNK;
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("MURCL_K2_CHUNK"); force = e ? atoi(e) : -1; }      // dev override (rows, multiple of 32)
+    if (force >= 4 * tr && force <= K2_MAX_CHUNK && force % tr == 0) return force < chunk ? force : chunk;
     while (chunk > 4 * tr && (long)B * ((N + chunk - 1) / chunk) < (long)K2_ITEMS_PER_WG * n_wg) {
         int c2 = ((chunk / 2 + tr - 1) / tr) * tr;
         if (c2 == chunk) break;

@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
         g_in[g] = live ? gi[(size_t)b * gi_ld + g * H + j] : 0.f;
         b_h[g] = bhh[g * H + j];
     }
-    if (live) hp = hprev[(size_t)b * H + j];
+    if (live && hprev) hp = hprev[(size_t)b * H + j];
     f32x4 ah[3], ax[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) ah[g] = ax[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (WITH_X) gs_stream<3, 3>(x, Kx, B, m0, Wih, Kx, H, j0, Kx, gs_smem, wave, lane, ax);
-    gs_stream<3, 3>(hprev, H, B, m0, Whh, H, H, j0, H, gs_smem, wave, lane, ah);
+    if (hprev) gs_stream<3, 3>(hprev, H, B, m0, Whh, H, H, j0, H, gs_smem, wave, lane, ah);    // a zero state: h W_hh^T = 0, gh = b_hh
     gs_park<NACC, 3>(gs_smem, wave, lane, 0, ah);
     if constexpr (WITH_X) gs_park<NACC, 3>(gs_smem, wave, lane, 3, ax);
     __syncthreads();
@@ -276,7 +276,7 @@ extern "C" int murcl_gru_step_fwd(const float* x, const float* w_ih, int Kx, con
                                   const float* w_hh, const float* b_hh, float* hnew, float* gates, float* gh, int B, int H,
                                   hipStream_t stream) {
     if (B <= 0) return 0;
-    if (!hprev || !w_hh || !b_hh || !gi || !hnew) return -1;
+    if (!b_hh || !gi || !hnew || (hprev && !w_hh) || (!hprev && !x)) return -1;     // no state and no input product: murcl_gru_gates_fwd
     if (!gs_shape_ok(B, H, x ? Kx : 16) || (x && (!w_ih || Kx < 16))) return -1;
     const dim3 grid(H / GS_T, (B + GS_T - 1) / GS_T);
     static MurclOncePerDevice once;

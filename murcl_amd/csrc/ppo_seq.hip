@@ -245,7 +245,7 @@ extern "C" int murcl_ppo_act(const float* const* params, int S, int H, int K, co
     float* gates = gh + (size_t)B * 3 * H;
     PS_CHECK(ps_nt(state, params[P_W1], e1, B, PS_E1, S, MURCL_EPI_BIAS_RELU, params[P_B1], 0, stream));
     PS_CHECK(ps_nt(e1, params[P_W2], e2, B, H, PS_E1, MURCL_EPI_BIAS_RELU, params[P_B2], 0, stream));
-    if (hidden_prev && ps_gru_step() && murcl_gru_step_supported(B, H, H)) {
+    if (ps_gru_step() && murcl_gru_step_supported(B, H, H)) {                                    // (hidden_prev NULL: the zero state)
         // the GRU cell as ONE launch: both products of a 16 x 16-unit tile of the three gate blocks, gates in the epilogue
         PS_CHECK(murcl_gru_step_fwd(e2, params[P_WIH], H, params[P_BIH], hidden_prev, params[P_WHH], params[P_BHH], hidden_new, nullptr,
                                     nullptr, B, H, stream));
