@@ -12,6 +12,7 @@ bash tools/pmc_mfma.sh ${T}_mfma > gpurun_out/${T}_mfma.log 2>&1
 bash tools/trace_step.sh ${T}_step > gpurun_out/${T}_trace_step.log 2>&1
 MURCL_SEQ_N=40 bash tools/trace_seq.sh ${T}_dsmil $GRAFT_REPO_ROOT/tools/dsmil_seq.py > gpurun_out/${T}_dsmil_seq.txt 2>&1
 MURCL_SEQ_N=36 bash tools/trace_seq.sh ${T}_clam $GRAFT_REPO_ROOT/tools/clam_seq.py train > gpurun_out/${T}_clam_train_seq.txt 2>&1
+bash tools/trace_stage.sh ${T} 2 ppo_returns_kernel 2 > /dev/null 2>&1
 for s in 1 2 3; do python tools/bench_full.py --stage $s --steps 30 2>&1 | tail -1; done > gpurun_out/${T}_bench_full_stages.jsonl
 cat gpurun_out/${T}_gpu_tests.log
 python -c "
