@@ -44,13 +44,17 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
     __syncthreads();
     const int* off = cluster_off + (size_t)b * (K + 1);
     const float rt = ratio[b];
-    for (int j = 0; j < K; ++j) {
+    // a wave per cluster (wave w: clusters w, w + 4, ...): the clusters' offset -> id-list -> bitmap chains are independent, so
+    // the four waves' memory round trips overlap (walked one cluster after the other by the whole workgroup they were K serial
+    // round trips: 10 us per call at K = 10)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < K; j += 4) {
         const int beg = off[j], n = off[j + 1] - beg;
         const int size = (int)rintf((float)n * rt);                                      // single f32 products:
         const int l = (int)floorf(actions[(size_t)vb * K + j] * (float)(n - size));      // nothing to contract
         int lo, hi;
         py_slice(n, l, l + size, lo, hi);
-        for (int t = lo + tid; t < hi; t += 256) {
+        for (int t = lo + lane; t < hi; t += 64) {
             const int id = cluster_ids[beg + t];
             atomicOr(&bitmap[id >> 5], 1u << (id & 31));
         }
@@ -61,16 +65,22 @@ __global__ __launch_bounds__(256) void subbag_select_kernel(const int* __restric
     const int w0 = tid * per, w1 = min(words, w0 + per);
     int cnt = 0;
     for (int w = w0; w < w1; ++w) cnt += __popc(bitmap[w]);
-    wsum[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {             // Hillis-Steele inclusive scan
-        int v = tid >= o ? wsum[tid - o] : 0;
-        __syncthreads();
-        wsum[tid] += v;
-        __syncthreads();
+    int incl = cnt;                                  // inclusive scan: lane shuffles inside a wave, then the four wave totals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
     }
-    int pos = wsum[tid] - cnt;
-    const int total = wsum[255];
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = wsum[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    int pos = base + incl - cnt;
     int* out = idx_out + (size_t)vb * feat_size;
     for (int w = w0; w < w1 && pos < feat_size; ++w) {
         unsigned m = bitmap[w];
