@@ -67,8 +67,8 @@ __device__ __forceinline__ f32x4 gs_mma(f32x4 a, f32x4 b, f32x4 c) {
 }
 
 // One operand pair streamed through the slot ring: acc[g] += A[16 x K] . Bm_g[16 x K]^T, this wave's quarter of every chunk.
-// `seq` counts chunks over the whole kernel (slot = seq % SLOTS).  Entered and left with every wave past a barrier that
-// follows its last LDS read, and nothing in flight.
+// Chunk c lands in slot c % SLOTS.  Entered and left with every wave past a barrier that follows its last LDS read, and nothing in
+// flight - so two streams (input side, recurrent side) can run one after the other through the same slots.
 template <int NB, int NACC>
 __device__ __forceinline__ void gs_stream(const float* __restrict__ A, int lda, int M, int m0, const float* __restrict__ Bm, int ldb,
                                           int gstride, int j0, int K, char* smem, int wave, int lane, f32x4 (&acc)[NACC]) {

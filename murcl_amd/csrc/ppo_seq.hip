@@ -348,15 +348,16 @@ static int ps_epoch(const float* const* params, float* const* grads, const float
                                         u ? hs + (u - 1) * bh : nullptr, dgi + u * b3, dgh + u * b3, u ? dhs + (u - 1) * bh : dhp, B, H,
                                         u ? 0 : 1, u ? 1 : 0, stream));
         }
-    } else
-    for (int t = T - 1; t >= 0; --t) {
-        if (t == 0) {
-            PS_CHECK(murcl_gru_gates_bwd_into(dhs, gates, params[P_BHH], nullptr, dgi, dgh, dhp, B, H, 1, 0, stream));
-        } else {
-            // dh_{t-1} += dh_t * z_t (direct path, added by the gate kernel) + dgh_t . W_hh (GEMM, accumulated in place)
-            PS_CHECK(murcl_gru_gates_bwd_into(dhs + t * bh, gates + t * b3, gh + t * b3, hs + (t - 1) * bh, dgi + t * b3, dgh + t * b3,
-                                              dhs + (t - 1) * bh, B, H, 0, 1, stream));
-            PS_CHECK(ps_nt(dgh + t * b3, whh_t, dhs + (t - 1) * bh, B, H, 3 * H, MURCL_EPI_NONE, nullptr, 1, stream));
+    } else {
+        for (int t = T - 1; t >= 0; --t) {
+            if (t == 0) {
+                PS_CHECK(murcl_gru_gates_bwd_into(dhs, gates, params[P_BHH], nullptr, dgi, dgh, dhp, B, H, 1, 0, stream));
+            } else {
+                // dh_{t-1} += dh_t * z_t (direct path, added by the gate kernel) + dgh_t . W_hh (GEMM, accumulated in place)
+                PS_CHECK(murcl_gru_gates_bwd_into(dhs + t * bh, gates + t * b3, gh + t * b3, hs + (t - 1) * bh, dgi + t * b3, dgh + t * b3,
+                                                  dhs + (t - 1) * bh, B, H, 0, 1, stream));
+                PS_CHECK(ps_nt(dgh + t * b3, whh_t, dhs + (t - 1) * bh, B, H, 3 * H, MURCL_EPI_NONE, nullptr, 1, stream));
+            }
         }
     }
     PS_CHECK(murcl_colsum(dgh, grads[P_BHH], R, 3 * H, 3 * H, MURCL_F32, 1, stream));

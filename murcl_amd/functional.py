@@ -553,7 +553,7 @@ class GRUStepFn(torch.autograd.Function):
         x = x.contiguous()
         if h_prev is None and x.dtype == torch.float32 and ops.gru_step_ok(x.shape[0], w_hh.shape[1], x.shape[1]):
             # restart: the input product and the gates in one launch (h W_hh^T = 0, gh = b_hh)
-            h_new, gates, _ = ops.gru_step_fwd(b_ih.detach(), None, w_hh.detach(), b_hh.detach(), x=x, w_ih=w_ih.detach(), gh=False)
+            h_new, gates, _ = ops.gru_step_fwd(b_ih.detach(), None, w_hh.detach(), b_hh.detach(), x=x, w_ih=w_ih.detach(), want_gh=False)
             ctx.save_for_backward(x, None, w_ih, w_hh, gates, b_hh.detach().view(1, -1), b_ih, b_hh)
             return h_new
         gi = ops.gemm_nt(x, w_ih, epi=ops.EPI_BIAS, bias=b_ih)

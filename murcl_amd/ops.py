@@ -825,18 +825,19 @@ def gru_step_ok(B, H, Kx=0):
     return _GRU_STEP and bool(_lib.lib().murcl_gru_step_supported(int(B), int(H), int(Kx)))
 
 
-def gru_step_fwd(gi, hprev, w_hh, b_hh, hnew=None, gates=None, gh=None, x=None, w_ih=None, want_backward=True):
+def gru_step_fwd(gi, hprev, w_hh, b_hh, hnew=None, gates=None, gh=None, x=None, w_ih=None, want_backward=True, want_gh=True):
     """One GRU time step as ONE launch (murcl_gru_step_fwd; ``hprev`` None = zero state, needs ``x``): h W_hh^T for a 16 x 16-unit tile of all three
     gate blocks, the gate math in the epilogue.  gi [B,3H] = x W_ih^T + b_ih - or, with ``x`` [B,Kx] and ``w_ih`` given, gi = b_ih
     [3H] and the input product is formed by the same launch.  -> (hnew [B,H], gates [B,3H], gh [B,3H]) (the last two None
-    with ``want_backward=False``)."""
+    with ``want_backward=False``, gh None with ``want_gh=False``)."""
     _need_cuda(gi, w_hh)
     (B, H), dev = ((hprev.shape, hprev.device) if hprev is not None else ((x.shape[0], w_hh.shape[1]), x.device))
     if hnew is None:
         hnew = torch.empty((B, H), dtype=torch.float32, device=dev)
     if want_backward:
         gates = torch.empty((B, 3 * H), dtype=torch.float32, device=dev) if gates is None else gates
-        gh = None if gh is False else (torch.empty((B, 3 * H), dtype=torch.float32, device=dev) if gh is None else gh)   # False: not wanted
+        if want_gh and gh is None:                   # (from the zero state gh = b_hh for every row: callers keep the bias row instead)
+            gh = torch.empty((B, 3 * H), dtype=torch.float32, device=dev)
     assert all(t is None or (t.is_contiguous() and t.dtype == torch.float32) for t in (gi, hprev, w_hh, b_hh, hnew, gates, gh, x, w_ih))
     assert gi.numel() == (3 * H if x is not None else B * 3 * H) and w_hh.shape == (3 * H, H)
     Kx = 0

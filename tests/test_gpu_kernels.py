@@ -876,7 +876,7 @@ def test_gru_step_forward_in_one_launch(B, H, Kx):
     if Kx:                                                 # restart: zero state, no recurrent product (gh = b_hh)
         r0, z0 = torch.sigmoid(gi[:, :H] + bhh[:H].double()), torch.sigmoid(gi[:, H:2 * H] + bhh[H:2 * H].double())
         n0 = torch.tanh(gi[:, 2 * H:] + r0 * bhh[2 * H:].double())
-        h0, g0, _ = ops.gru_step_fwd(bih.to(dev), None, whh.to(dev), bhh.to(dev), x=x.to(dev), w_ih=wih.to(dev), gh=False)
+        h0, g0, _ = ops.gru_step_fwd(bih.to(dev), None, whh.to(dev), bhh.to(dev), x=x.to(dev), w_ih=wih.to(dev), want_gh=False)
         _close(h0, (1 - z0) * n0, rtol=1e-4, atol=2e-5)
         _close(g0, torch.cat([r0, z0, n0], 1), rtol=1e-4, atol=2e-5)
     h2, g2, gh2 = ops.gru_step_fwd(bih.to(dev) if Kx else gi.float().to(dev), hp.to(dev), whh.to(dev), bhh.to(dev),

@@ -99,3 +99,23 @@ def test_draw_mixups_are_valid_draws():
     assert abs(m - (alpha + (1 - alpha) / 2)) < 0.01
     lam1, perm1 = draw_mixups(1, 2, 1.0, torch.device("cpu"))[0]
     assert torch.all(lam1 == 1.0) and sorted(perm1.tolist()) == [0, 1]
+
+
+def test_stack_rows_is_a_view_when_the_blocks_are_consecutive():
+    """ops.stack_rows (the two views' states / noise / hidden rows as one policy step): consecutive row blocks of one buffer come back as a
+    view of it, anything else as a copy with the same contents."""
+    from murcl_amd import ops
+    x = torch.arange(48.).view(12, 4)
+    a, b = x[:6], x[6:]
+    y = ops.stack_rows([a, b])
+    assert y.data_ptr() == x.data_ptr() and torch.equal(y, x)
+    halves = x.split(6, 0)                                     # CL.forward hands the views out like this
+    assert ops.stack_rows([h.detach() for h in halves]).data_ptr() == x.data_ptr()
+    z = ops.stack_rows([b, a])                                 # wrong order: a copy
+    assert z.data_ptr() != x.data_ptr() and torch.equal(z, torch.cat([b, a]))
+    n = torch.arange(120.).view(5, 2, 3, 4)                    # one noise draw [T-1, views, B, K]
+    assert ops.stack_rows([n[2, 0], n[2, 1]]).data_ptr() == n[2].data_ptr()
+    w = ops.stack_rows([x[:6], torch.zeros(6, 4)])             # different buffers: a copy
+    assert w.shape == (12, 4) and torch.equal(w[:6], x[:6])
+    s = ops.stack_rows([x[:6, :2], x[6:, :2]])                 # strided blocks: a copy
+    assert torch.equal(s, x[:, :2])
