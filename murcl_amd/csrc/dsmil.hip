@@ -20,10 +20,19 @@ __global__ __launch_bounds__(256) void dsmil_argmax_kernel(const float* __restri
     const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     const float* s = scores + (size_t)b * N * ld + c;
     float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int n = tid; n < N; n += 256) {
+    int idx = tid < N ? tid : 0x7fffffff;                    // a column of -inf: its first row, as torch.max
+    int n = tid;
+    for (; n + 7 * 256 < N; n += 8 * 256) {                  // eight loads in flight per thread (one after the other they were N/256
+        float v[8];                                          // serial round trips: 16 us at N = 8192)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s[(size_t)(n + u * 256) * ld];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > best) { best = v[u]; idx = n + u * 256; }     // ascending n: a later equal value never replaces an earlier one
+    }
+    for (; n < N; n += 256) {
         const float v = s[(size_t)n * ld];
-        if (v > best || (v == best && n < idx)) { best = v; idx = n; }
+        if (v > best) { best = v; idx = n; }
     }
     bv[tid] = best; bi[tid] = idx;
     __syncthreads();

@@ -809,6 +809,26 @@ def test_gru_gates_fwd_bwd():
     _close(h0, (1 - z) * n, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,C,ld", [(16, 8192, 2, 2), (3, 5000, 3, 132), (2, 100, 1, 1), (1, 2049, 4, 4)])
+def test_dsmil_argmax_first_index_of_the_maximum(B, N, C, ld):
+    """dsmil_argmax (eight loads in flight per thread): the FIRST index of each column's maximum (torch.max's rule on equal values,
+    dsmil.py:69), also for repeated maxima and for a column of -inf; the maxima ride along."""
+    from murcl_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    s = torch.randn((B, N, ld), generator=g)
+    s[:, :, :C] = (s[:, :, :C] * 4).round() / 4                  # many exact ties
+    s[0, :, 0] = -float("inf")                                   # a column with no finite entry
+    if N > 300:
+        s[-1, 7, C - 1] = s[-1, 299, C - 1] = 100.0              # the maximum twice: the earlier row wins
+    m, mx = ops.dsmil_argmax(s.view(B * N, ld).to(dev), B, N, C, want_max=True)
+    want_v, want_i = s[:, :, :C].max(1)
+    first = torch.stack([torch.stack([(s[b, :, c] == want_v[b, c]).nonzero()[0, 0] for c in range(C)]) for b in range(B)])
+    assert torch.equal(m.cpu().long(), first)
+    assert torch.equal(mx.cpu(), want_v)
+    assert torch.equal(ops.dsmil_argmax(s.view(B * N, ld).to(dev), B, N, C).cpu(), m.cpu())
+
+
 def test_small_f32_weight_gradients_in_one_launch():
     """ops.gemm_tn_grouped on 2-4 f32 products of a few hundred rows (a PPO epoch's weight gradients): one launch of the 32 x 32
     single-writer kernel; products and column sums are ADDED to what the outputs hold."""
