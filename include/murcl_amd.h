@@ -64,7 +64,8 @@ int murcl_gemm_tn_ws(const void* A, const void* B, float* C, int M, int N1, int 
  * reduce launch: the backward of the three encoder nn.Linear layers of abmil.py:12-21 (and of CLAM-SB's fc + gate pair,
  * clam.py:69-72), deferred until the last input gradient of the pass exists.  The (product, tile) pairs share one round of
  * workgroups (one per CU), so the per-launch fixed costs and the partial-tile traffic are paid once.  `probs` is a HOST array of
- * n <= 4 descriptors; colsum_part / colsum_rows / colsum_out as in murcl_gemm_tn_ws (colsum_out without colsum_part: column
+ * n <= 4 descriptors (f32 products of at most 512 rows each - bag-level / rollout-level layers - run as ONE launch of the 32 x 32
+ * single-writer kernel instead, no workspace; of the flags they take MURCL_TN_OVERWRITE); colsum_part / colsum_rows / colsum_out as in murcl_gemm_tn_ws (colsum_out without colsum_part: column
  * sums of A_g by their own launch; not with flags).  flags / scale: applied by the reduce launch (grouped path only: a group with
  * flags that is not eligible returns -1).  Products the square-tile kernel does not take (see murcl_gemm_tn_ws), or a workspace below
  * murcl_gemm_tn_grouped_workspace_bytes (0 = the group is not eligible), run one by one through murcl_gemm_tn_ws. */

@@ -1384,7 +1384,7 @@ extern "C" int murcl_colsum(const void* x, float* out, int R, int N, int ld, int
 constexpr int TS_T = 32, TS_MAXM = 512;
 __device__ __forceinline__ void tn_small_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M,
                                               int N1, int N2, int lda, int ldb, int ldc, float* __restrict__ colsum_out, int bx,
-                                              int by, char* ts_smem, int pass_rows) {
+                                              int by, char* ts_smem, int pass_rows, int overwrite = 0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
@@ -1400,7 +1400,7 @@ __device__ __forceinline__ void tn_small_tile(const float* __restrict__ A, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n1 = n10 + 16 * wm + 4 * q4 + r;
-            if (n1 < N1 && n2 < N2) cold[r] = C[(size_t)n1 * ldc + n2];
+            if (!overwrite && n1 < N1 && n2 < N2) cold[r] = C[(size_t)n1 * ldc + n2];
         }
     }
     // fragment addresses: row 16u + 4e + q4, column 16w + r16 -> chunk (4w + r16/4) ^ swz(row), swz = 4 * bit 1 of the row = 4 * (q4 >> 1)
@@ -1449,7 +1449,7 @@ __device__ __forceinline__ void tn_small_tile(const float* __restrict__ A, const
     for (int r = 0; r < 4; ++r) {
         const int n1 = n10 + 16 * wm + 4 * q4 + r;
         if (n1 < N1 && n2 < N2) C[(size_t)n1 * ldc + n2] = cold[r] + (acc0[r] + acc1[r]);
-        if (do_cs && r16 == 0 && n1 < N1) colsum_out[n1] += accs[r];
+        if (do_cs && r16 == 0 && n1 < N1) colsum_out[n1] = overwrite ? accs[r] : colsum_out[n1] + accs[r];
     }
 }
 __global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_f32_kernel(const float* __r
 // runs along N1 first, as the single-product grid does.
 struct TnSmallGroup {
     const float* A[4]; const float* B[4]; float* C[4]; float* cs[4];
-    int M[4], N1[4], N2[4], lda[4], ldb[4], ldc[4], tile0[5], pass_rows;
+    int M[4], N1[4], N2[4], lda[4], ldb[4], ldc[4], tile0[5], pass_rows, overwrite[4];
 };
 __global__ __launch_bounds__(256) void gemm_tn_small_group_kernel(const TnSmallGroup ga) {
     extern __shared__ __attribute__((aligned(16))) char ts_smem[];
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_group_kernel(const TnSmallG
     for (int i = 1; i < 4; ++i) g += (int)(b >= ga.tile0[i]);
     const int t = b - ga.tile0[g], t1 = (ga.N1[g] + TS_T - 1) / TS_T;
     tn_small_tile(ga.A[g], ga.B[g], ga.C[g], ga.M[g], ga.N1[g], ga.N2[g], ga.lda[g], ga.ldb[g], ga.ldc[g], ga.cs[g], t % t1, t / t1,
-                  ts_smem, ga.pass_rows);
+                  ts_smem, ga.pass_rows, ga.overwrite[g]);
 }
 // Rows of the reduction per pass through LDS (2 x 128 bytes per row).  One pass (the whole reduction in flight, one memory round
 // trip) when a single round of workgroups covers the tiles; several shorter passes when there are more tiles than that - the
@@ -1666,10 +1666,13 @@ extern "C" long murcl_gemm_tn_grouped_workspace_bytes(const TnProblem* pr, int n
 }
 // f32 products of a few hundred rows each (the single-product path would take gemm_tn_small_f32_kernel for every one of them)
 static bool tn_small_group_ok(const TnProblem* pr, int n, int dtype) {
-    if (dtype != MURCL_DTYPE_F32 || n < 2 || n > 4 || !tn_small_enabled()) return false;
+    if (dtype != MURCL_DTYPE_F32 || n < 1 || n > 4 || !tn_small_enabled()) return false;
+    bool flagged = false;
+    for (int g = 0; g < n; ++g) flagged |= pr[g].flags != 0;
+    if (n == 1 && !flagged) return false;                      // a single plain product: murcl_gemm_tn's own dispatch
     for (int g = 0; g < n; ++g) {
         const TnProblem& p = pr[g];
-        if (p.flags || p.colsum_part || p.M <= 0 || p.M > TS_MAXM || p.N1 < 4 || p.N2 < 4 || p.N1 % 4 || p.N2 % 4 || p.lda % 4 || p.ldb % 4)
+        if ((p.flags & ~MURCL_TN_OVERWRITE) || p.colsum_part || p.M <= 0 || p.M > TS_MAXM || p.N1 < 4 || p.N2 < 4 || p.N1 % 4 || p.N2 % 4 || p.lda % 4 || p.ldb % 4)
             return false;
     }
     return true;
@@ -1683,6 +1686,7 @@ extern "C" int murcl_gemm_tn_grouped(const TnProblem* pr, int n, int dtype, floa
             const TnProblem& p = pr[g < n ? g : 0];
             ga.A[g] = (const float*)p.A; ga.B[g] = (const float*)p.B; ga.C[g] = p.C; ga.cs[g] = p.colsum_out;
             ga.M[g] = p.M; ga.N1[g] = p.N1; ga.N2[g] = p.N2; ga.lda[g] = p.lda; ga.ldb[g] = p.ldb; ga.ldc[g] = p.ldc;
+            ga.overwrite[g] = (p.flags & MURCL_TN_OVERWRITE) ? 1 : 0;
             ga.tile0[g] = tiles;
             if (g < n) {
                 tiles += ((p.N1 + TS_T - 1) / TS_T) * ((p.N2 + TS_T - 1) / TS_T);

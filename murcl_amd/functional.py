@@ -750,7 +750,7 @@ class DSMILFn(torch.autograd.Function):
         A, Z = one if one is not None else (A, ops.weighted_rowsum(x, A))               # Z = A^T X  (:78)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
         classes = cls.view(B, N, C)
-        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else x.new_zeros(1))
+        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else _placeholder(x))
         ctx.meta = (B, N, d, C, LD, reassoc, qv)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
@@ -846,6 +846,15 @@ def _zeros_const(dev, n):
     z = _ZERO_CONST.get((dev, n))
     if z is None:
         z = _ZERO_CONST[(dev, n)] = torch.zeros((n,), dtype=torch.float32, device=dev)
+    return z
+
+
+def _placeholder(like):
+    """A shared one-element tensor that stands in for an absent saved tensor (``save_for_backward`` takes tensors): no fill launch per call."""
+    key = (like.device, like.dtype, "placeholder")
+    z = _ZERO_CONST.get(key)
+    if z is None:
+        z = _ZERO_CONST[key] = torch.zeros((1,), dtype=like.dtype, device=like.device)
     return z
 
 
@@ -985,8 +994,8 @@ class CLAMFn(torch.autograd.Function):
                 inst_loss = loss_g.view(B, n_cls).sum(1) * scale
                 inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row
                 saved_inst = (rows_all, feats, dl_g, scale, k, n_cls)
-        ctx.save_for_backward(x2, h, U if U is not None else x2.new_zeros(1), A, M, w1, wa, wb, wc,
-                              inst_w if inst_w is not None else x2.new_zeros(1), m1)
+        ctx.save_for_backward(x2, h, U if U is not None else _placeholder(x2), A, M, w1, wa, wb, wc,
+                              inst_w if inst_w is not None else _placeholder(x2), m1)
         ctx.gated, ctx.gate_u = gated, gate_u
         ctx.wab_t = views[2] if gate_u else None         # (a cached view: parameters do not change between a forward and its backward)
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)

@@ -53,10 +53,17 @@ class Full_layer(nn.Module):
         validation): no autograd nodes to build."""
         from .. import ops
         r = self.rnn
-        gi = ops.gemm_nt(x.contiguous(), r.weight_ih_l0, epi=ops.EPI_BIAS, bias=r.bias_ih_l0)
-        gh = r.bias_hh_l0.detach().view(1, -1) if h_prev is None else \
-            ops.gemm_nt(h_prev.contiguous(), r.weight_hh_l0, epi=ops.EPI_BIAS, bias=r.bias_hh_l0)
-        h = ops.gru_gates_fwd(gi, gh, None if h_prev is None else h_prev.contiguous())[0]
+        x = x.contiguous()
+        h_prev = None if h_prev is None else h_prev.contiguous()
+        if x.dtype == torch.float32 and ops.gru_step_ok(x.shape[0], self.hidden_state_dim, x.shape[1]):
+            # both products of the cell (from the zero state: the input product) and the gate math in one launch
+            h = ops.gru_step_fwd(r.bias_ih_l0.detach(), h_prev, r.weight_hh_l0.detach(), r.bias_hh_l0.detach(), x=x,
+                                 w_ih=r.weight_ih_l0.detach(), want_backward=False)[0]
+        else:
+            gi = ops.gemm_nt(x, r.weight_ih_l0, epi=ops.EPI_BIAS, bias=r.bias_ih_l0)
+            gh = r.bias_hh_l0.detach().view(1, -1) if h_prev is None else \
+                ops.gemm_nt(h_prev, r.weight_hh_l0, epi=ops.EPI_BIAS, bias=r.bias_hh_l0)
+            h = ops.gru_gates_fwd(gi, gh, h_prev)[0]
         return h, ops.gemm_nt(h, self.fc.weight, epi=ops.EPI_BIAS, bias=self.fc.bias)
 
     def forward(self, x, restart=False):

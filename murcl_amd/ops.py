@@ -307,6 +307,13 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3
         return out.add_(res) if out is not None else res.contiguous()
     if colsum_into is not None:
         assert colsum_into.dtype == torch.float32 and colsum_into.is_contiguous() and colsum_into.numel() == N1
+    if (out is None and colsum_into is None and A.dtype == torch.float32 and M <= 512 and splits <= 0 and not x3 and _TN_SMALL_GROUP
+            and N2 % 4 == 0):
+        # a fresh bag-level gradient: the single-writer 32 x 32 kernel WRITES it (no zero-fill launch in front, no read of C)
+        C = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+        arr = (_lib.TnProblem * 1)(_lib.TnProblem(ptr(A), ptr(B), ptr(C), None, None, M, N1, N2, N1, N2, N2, 0, _lib.TN_OVERWRITE, 1.0))
+        check(_lib.lib().murcl_gemm_tn_grouped(arr, 1, F32, None, 0, stream()), "gemm_tn(small, overwrite)")
+        return C
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
     wsb = _lib.lib().murcl_gemm_tn_workspace_bytes(M, N1, N2, dt(A)) if (splits <= 0 and _TN_SQ) else 0
@@ -346,12 +353,13 @@ def gemm_tn_grouped(problems, fresh=False):
             _need_cuda(A, B)
             A, B = _c(A), _c(B)
             (M, N1), N2 = A.shape, B.shape[1]
-            C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
+            write = out is None and ci is None                 # a fresh product is written, not added to zeros
+            C = out if out is not None else (torch.empty if write else torch.zeros)((N1, N2), dtype=torch.float32, device=A.device)
             assert C.dtype == torch.float32 and C.is_contiguous() and tuple(C.shape) == (N1, N2)
             assert ci is None or (ci.dtype == torch.float32 and ci.is_contiguous() and ci.numel() == N1)
             keep.append((A, B))
             Cs.append(C)
-            arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), None, ptr(ci), M, N1, N2, N1, N2, N2, 0, 0, 1.0)
+            arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), None, ptr(ci), M, N1, N2, N1, N2, N2, 0, _lib.TN_OVERWRITE if write else 0, 1.0)
         check(_lib.lib().murcl_gemm_tn_grouped(arr, n, F32, None, 0, stream()), "gemm_tn_grouped(small)")
         return Cs
     if not gemm_tn_grouped_ok(problems):

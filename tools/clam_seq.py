@@ -19,16 +19,21 @@ else:
 fwd_only = len(sys.argv) > 1 and sys.argv[1] == "fwd"
 inst = len(sys.argv) > 1 and sys.argv[1] == "inst"          # with the instance-level loss (clam.py:103-132), batched labels
 labels = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1)).to(dev)
+_ones = {}
+def ones(t):
+    k = (tuple(t.shape), t.dtype)
+    if k not in _ones: _ones[k] = torch.ones_like(t)
+    return _ones[k]
 for _ in range(6):
     if inst:
         for p in m.parameters(): p.grad = None
         M, _, _, il, _, _ = m._run(x, labels, True)
-        (M.sum() + il.sum()).backward()
+        torch.autograd.backward((M, il), (ones(M), ones(il)))      # the upstream gradients of a sum loss, without the harness's launches
         continue
     if fwd_only:
         with torch.no_grad(): m(x)
         continue
     for p in m.parameters(): p.grad = None
     out = m(x)
-    out[0].sum().backward()
+    torch.autograd.backward((out[0],), (ones(out[0]),))
 torch.cuda.synchronize()
