@@ -510,9 +510,9 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
                 if (gridDim.z > 1) {
                     atomicAdd(cp, v);                        // 16 lanes of a quarter: 64 contiguous bytes per request
                 } else {
-                    if (accumulate) v += *cp;
                     if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;      // ReLU' of the layer's saved output
-                    *cp = relu ? fmaxf(v, 0.f) : v;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *cp = accumulate ? *cp + v : v;                                  // (accumulation adds the finished epilogue, as gemm_nt_kernel)
                 }
             }
         }

@@ -247,9 +247,10 @@ __global__ __launch_bounds__(256) void gemm_nt_t16_f32_kernel(const float* __res
     gs_park<2, 2>(gs_smem, wave, lane, 0, acc);
     __syncthreads();
     if (!live) return;
-    float v = (gs_total<2>(gs_smem, 0, tid) + gs_total<2>(gs_smem, 1, tid)) + bv + c0;
+    float v = (gs_total<2>(gs_smem, 0, tid) + gs_total<2>(gs_smem, 1, tid)) + bv;
     if (mask) v = mk > 0.f ? v : 0.f;
-    C[(size_t)m * ldc + n] = relu ? fmaxf(v, 0.f) : v;
+    if (relu) v = fmaxf(v, 0.f);
+    C[(size_t)m * ldc + n] = v + c0;                         // accumulation adds the finished epilogue (c0 = 0 without it)
 }
 
 // host side of the above for gemm.hip's small-matrix dispatcher (C++ linkage: not part of the C-ABI)

@@ -125,6 +125,71 @@ def test_gemm_nt_bag_level_accumulate_and_row_views(M, N, K):
     _close(C, C0.double() + A.double().cpu() @ B.double().cpu().t(), rtol=2e-5, atol=2e-5)
 
 
+def test_small_f32_gemm_dispatch_fuzz():
+    """The bag-level f32 dispatcher picks among the 32 x 32 tile kernel (one or two chunk buffers), the 16 x 16 K-split-in-workgroup
+    kernel and their epilogues by shape: 160 seeded random (M, N, K, epilogue, accumulate) draws over the regimes
+    around every switch-over point (tile counts 64 / 96 / 384, 6+ chunks, N not a multiple of 16, ragged K) against f64."""
+    from murcl_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(20260401)
+    for it in range(160):
+        M = int(rng.choice([1, 7, 16, 33, 64, 100, 128, 320, 500, 768, 1024]))
+        N = int(rng.choice([16, 40, 128, 136, 512, 1536, 2048, 3072]))
+        K = int(rng.choice([32, 96, 256, 288, 512, 1024, 1536, 2048, 3072]))
+        epi = int(rng.choice([0, 1, 2, 3]))                           # none, bias, bias + ReLU, ReLU' mask
+        acc = bool(rng.integers(2)) and epi != 2
+        g = torch.Generator().manual_seed(1000 + it)
+        Ah, Bh = torch.randn((M, K), generator=g), torch.randn((N, K), generator=g) / math.sqrt(K)
+        A, B = Ah.to(dev), Bh.to(dev)
+        bias, y = torch.randn((N,), generator=g), torch.randn((M, N), generator=g)
+        C0 = torch.randn((M, N), generator=g)
+        ref = Ah.double() @ Bh.double().t()
+        kw = {}
+        if epi in (1, 2):
+            kw, ref = dict(epi=ops.EPI_BIAS if epi == 1 else ops.EPI_BIAS_RELU, bias=bias.to(dev)), ref + bias.double()
+        if epi == 2:
+            ref = torch.relu(ref)
+        if epi == 3:
+            kw, ref = dict(epi=ops.EPI_MASK, mask=y.to(dev)), ref * (y > 0)
+        if acc:
+            ref = ref + C0.double()                                   # accumulation adds the finished epilogue onto C
+        out = C0.to(dev).clone() if acc else None
+        C = ops.gemm_nt(A, B, out=out, accumulate=acc, **kw)
+        _close(C, ref, rtol=3e-5, atol=3e-5, msg=f"draw {it}: {M}x{N}x{K} epi {epi} acc {acc}")
+
+
+def test_small_f32_weight_gradient_group_fuzz():
+    """ops.gemm_tn / gemm_tn_grouped on bag-level f32 products: 60 seeded random groups of 1-4 products (M up to 512 with ragged 16-row
+    tails, widths that are not multiples of the 32-wide tile, outputs given - added to - or fresh - written -, with and without the
+    bias-gradient column sums) against f64; rows beyond one pass through LDS take the multi-pass form."""
+    from murcl_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(20260402)
+    for it in range(60):
+        n = int(rng.integers(1, 5))
+        g = torch.Generator().manual_seed(5000 + it)
+        probs, want = [], []
+        for k in range(n):
+            M = int(rng.choice([1, 5, 16, 77, 128, 200, 320, 500, 512]))
+            N1, N2 = int(rng.choice([4, 36, 64, 128, 520, 1536])), int(rng.choice([8, 32, 100, 512, 2048]))
+            A, B = torch.randn((M, N1), generator=g), torch.randn((M, N2), generator=g)
+            given, cs = bool(rng.integers(2)), bool(rng.integers(2))
+            C0, c0 = torch.randn((N1, N2), generator=g), torch.randn((N1,), generator=g)
+            out = C0.to(dev).clone() if given else None
+            ci = c0.to(dev).clone() if (cs and given) else None       # column sums ride with a given output (the direct-gradient mode)
+            probs.append((A.to(dev), B.to(dev), out, ci, None))
+            want.append(((C0.double() if given else 0) + A.double().t() @ B.double(), (c0.double() + A.double().sum(0)) if ci is not None else None))
+        if n == 1:
+            A, B, out, ci, _ = probs[0]
+            Cs = [ops.gemm_tn(A, B, out=out, colsum_into=ci)]
+        else:
+            Cs = ops.gemm_tn_grouped(probs)
+        for (A, B, out, ci, _), C, (wC, wc) in zip(probs, Cs, want):
+            _close(C, wC, rtol=1e-4, atol=3e-4, msg=f"draw {it}: {tuple(A.shape)} x {tuple(B.shape)}")
+            if wc is not None:
+                _close(ci, wc, rtol=1e-4, atol=3e-4, msg=f"draw {it}: column sums")
+
+
 # ------------------------------------------------------------------ GEMM TN
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (1000, 128, 512), (130, 3072, 512), (77, 16, 1024), (20000, 512, 128),
