@@ -226,6 +226,21 @@ def _timed_ms(fn, reps=10, warm=3):
     return ts[len(ts) // 2]
 
 
+def _timed_ms_back_to_back(fn, reps=10, warm=2):
+    """``fn`` ``reps`` times between ONE pair of events (no synchronisation in between): the steady state of a loop, where the host runs
+    ahead of the GPU - ``_timed_ms`` times single passes from an idle GPU and includes the host's way to the first launch."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
 def _kernel_table(fn, passes=3):
     """Per-kernel HIP-event times of ``fn`` (the spans ops.py defines: the kernels that carry algorithmic bytes / FLOPs), averaged
     over ``passes`` runs - an untimed extra pass, like the headline's breakdown.  -> {key: {us, GBps, frac_of_8TBps | TFLOPs}}"""
@@ -286,12 +301,14 @@ def other_rows(device):
         # the last row: Dropout(0.25) behind fc and on both gate branches live, as the training scripts run the aggregator
         m.train(name.endswith("training_mode"))
         ms = _timed_ms(lambda: clam_fb(inst))
+        ms_b2b = _timed_ms_back_to_back(lambda: clam_fb(inst))
         nbytes = 14 * B * N * 512 * 2          # passes over [B*N,512] bf16 tensors in the chain: forward 5 (x, h w/r/r, U w), backward 9
         # the two 512 x 512 projections dominate - fc forward + weight gradient (no dX), gate forward + dgrad + weight
         # gradient = 5 x 2*N*512^2 FLOP per bag (10.7 GFLOP at N = 4096); bytes: X once forward, twice backward
         flops = B * 5 * 2.0 * N * 512 * 512
         xbytes = 3 * B * N * 512 * 2
-        out[name] = dict(workload=f"CLAM_SB {B} bags x {N} x 512 bf16", ms=round(ms, 4), bags_per_s=round(B / ms * 1e3, 1),
+        out[name] = dict(workload=f"CLAM_SB {B} bags x {N} x 512 bf16", ms=round(ms, 4), ms_back_to_back=round(ms_b2b, 4),
+                         bags_per_s=round(B / ms * 1e3, 1),
                          survey_8d=dict(bound="mfma", GFLOP_fwd_bwd=round(flops / 1e9, 1),
                                         frac_of_bf16_mfma_peak=round(flops / (ms * 1e-3) / (PEAK["mfma_bf16_TFLOPs"] * 1e12), 4),
                                         x_bytes_GB=round(xbytes / 1e9, 3), frac_of_8TBps_on_x_bytes=round(xbytes / ms / 1e6 / 8000, 4)),
@@ -309,13 +326,14 @@ def other_rows(device):
         classes, bag, cmax = md._run(xd, want_max=True)
         torch.autograd.backward((bag, cmax), (_ones_like(bag), _ones_like(cmax)))     # bag term + max-instance term (train_RLMIL.py:516-529)
     ms = _timed_ms(dsmil_fb)
+    ms_b2b = _timed_ms_back_to_back(dsmil_fb)
     # Round 3: K6 reassociated (functional.DSMILFn) - the attention logits are X . (Wq^T q_max), so no GEMM over all patches is
     # left; the row is three streaming passes over X (instance scores; attention + pooling with an online soft-max; the whole
     # backward of both, dWc included) and ~30 launches on [B*C]-row tensors.  Its floor is three reads of X at the HBM roof.
     nbytes = 3 * B * N * d * 4
     floor_ms = nbytes / (PEAK["hbm_GBps"] * 1e9) * 1e3
     out["dsmil_c5_share_fwd_bwd"] = dict(workload=f"DSMIL {B} bags x {N} x {d} f32 (one GPU's share of 128 bags)", ms=round(ms, 4),
-                                         bags_per_s=round(B / ms * 1e3, 1),
+                                         ms_back_to_back=round(ms_b2b, 4), bags_per_s=round(B / ms * 1e3, 1),
                                          survey_8d=dict(bound="hbm", x_bytes_GB=round(nbytes / 1e9, 3),
                                                         frac_of_8TBps_on_x_bytes=round(nbytes / ms / 1e6 / 8000, 4),
                                                         note="reassociated K6: X twice forward (the critical instance must be known "

@@ -160,6 +160,8 @@ class OverlappedGradReduce:
         return grad
 
     def milestone(self, params):
+        from . import functional
+        functional.flush_deferred()                   # queued weight gradients of the announced layers must exist before their reduce
         spans = sorted(self._where[id(p)] for p in params if id(p) in self._where)
         merged = []
         for gi, lo, hi in spans:
