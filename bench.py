@@ -231,14 +231,17 @@ def _timed_ms_back_to_back(fn, reps=10, warm=2):
     ahead of the GPU - ``_timed_ms`` times single passes from an idle GPU and includes the host's way to the first launch."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps
+    ts = []
+    for _ in range(3):                              # median of three windows: one allocator growth inside a window would own its mean
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / reps)
+    return sorted(ts)[1]
 
 
 def _kernel_table(fn, passes=3):
