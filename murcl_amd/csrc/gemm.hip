@@ -561,9 +561,10 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
     if (skinny_lds_enabled() && nt_t16_enabled() && skinny_lds_splits(M, N, K) > 1 && murcl_nt_t16_ok(M, N, K))
         return murcl_nt_t16_launch(A, B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
                                    (int)(epi == EPI_BIAS_RELU), accumulate, epi == EPI_MASK ? mask : nullptr, ldmask, s);
-    // LDS form.  Long reductions with few output tiles (per 256-k chunk a workgroup needs ~2 us - one DMA round trip is not
-    // covered by one chunk of MFMAs - so [128 x 512 x 3072] on 64 workgroups x 12 chunks takes 26 us) are split over K so that
-    // every workgroup has its whole share (two chunks) in flight at once; those partial tiles meet in a zeroed C by atomics.
+    // LDS form.  Long reductions with few output tiles that the 16 x 16 form above does not take (N not a multiple of 16) are split
+    // over K (per 256-k chunk a workgroup needs ~2 us - one DMA round trip is not covered by one chunk of MFMAs - so
+    // [128 x 512 x 3072] on 64 workgroups x 12 chunks took 26 us) so that every workgroup has its whole share (two chunks) in
+    // flight at once; those partial tiles meet in a zeroed C by atomics.
     if (skinny_lds_enabled()) {
         const int sp = skinny_lds_splits(M, N, K);
         const int kps = ((((K + SL_K - 1) / SL_K) + sp - 1) / sp) * SL_K;
