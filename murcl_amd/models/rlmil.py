@@ -334,7 +334,9 @@ class PPO:
         if dist.is_available() and dist.is_initialized() and self.data_parallel is not False:
             world = dist.get_world_size(group)
         collectives = world > 1 or (self.data_parallel is True and dist.is_available() and dist.is_initialized())
-        rewards = torch.cat([r.reshape(1, -1) for r in memory.rewards], 0)             # [T,B] (rlmil.py:156-160)
+        from .. import ops
+        rewards = ops.stack_rows([r.reshape(1, -1) for r in memory.rewards])           # [T,B] (rlmil.py:156-160); a view when the step
+        #                                                                                computed its T rewards as one tensor
         n_total = rewards.numel() * world                                              # equal shards: B_local bags per rank
         if collectives:
             returns, stats = k.returns_raw(rewards, self.gamma)
