@@ -554,11 +554,19 @@ static int nt_t16_enabled() {
     if (v < 0) { const char* e = getenv("MURCL_NT_T16"); v = (e && e[0] == '0') ? 0 : 1; }        // dev A/B switch
     return v;
 }
+static int nt_t16_few_tiles() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("MURCL_NT_T16_FEW"); v = e ? atoi(e) : 64; }            // dev A/B knob (0: rule off); 64 tiles -> 256 of the 16 x 16 kind: one round
+    return v;
+}
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s, const float* mask = nullptr, int ldmask = 0) {
     // few outputs, long reduction - the shapes the LDS form below would split over K (zero-fill + atomics + a ReLU launch): 16 x 16
     // tiles with the K range split over the waves of one workgroup instead, everything in one launch
-    if (skinny_lds_enabled() && nt_t16_enabled() && skinny_lds_splits(M, N, K) > 1 && murcl_nt_t16_ok(M, N, K))
+    // (also a handful of tiles with three or more chunks each: [128 x 128 x 1024] is 16 workgroups walking 4 chunks, or 64 with all four in flight)
+    const long sl_tiles_ = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
+    const bool few_long = sl_tiles_ <= nt_t16_few_tiles() && (K + SL_K - 1) / SL_K >= 3;
+    if (skinny_lds_enabled() && nt_t16_enabled() && (skinny_lds_splits(M, N, K) > 1 || few_long) && murcl_nt_t16_ok(M, N, K))
         return murcl_nt_t16_launch(A, B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
                                    (int)(epi == EPI_BIAS_RELU), accumulate, epi == EPI_MASK ? mask : nullptr, ldmask, s);
     // LDS form.  Long reductions with few output tiles that the 16 x 16 form above does not take (N not a multiple of 16) are split

@@ -7,7 +7,8 @@ from murcl_amd import ops
 dev = torch.device("cuda:0")
 REPS = 16
 shapes = [(128, 512, 512), (128, 3072, 512), (64, 3072, 512), (64, 3072, 1024), (128, 128, 1024), (64, 128, 1024), (128, 1024, 128), (128, 512, 3072), (128, 1024, 3072),
-          (64, 2048, 512), (64, 512, 2048), (64, 1536, 512), (64, 512, 512), (320, 2048, 512), (320, 512, 2048), (320, 1536, 512), (320, 512, 1536)]
+          (64, 2048, 512), (64, 512, 2048), (64, 1536, 512), (64, 512, 512), (320, 2048, 512), (320, 512, 2048), (320, 1536, 512), (320, 512, 1536),
+          (32, 1024, 1024), (128, 512, 1024), (64, 512, 1024), (128, 256, 768), (128, 1024, 1024)]
 mark0 = torch.zeros(1024, device=dev, dtype=torch.float64)      # start marker: FillFunctor<double>
 mark1 = torch.zeros(1024, device=dev, dtype=torch.int16)        # end marker: FillFunctor<short>
 COLD = os.environ.get("SK_COLD", "1") == "1"      # evict the Infinity Cache between calls: weights arrive from HBM as in a step
