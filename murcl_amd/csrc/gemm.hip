@@ -565,7 +565,9 @@ static int launch_skinny(const float* A, const float* B, float* C, int M, int N,
     // tiles with the K range split over the waves of one workgroup instead, everything in one launch
     // (also a handful of tiles with three or more chunks each: [128 x 128 x 1024] is 16 workgroups walking 4 chunks, or 64 with all four in flight)
     const long sl_tiles_ = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
-    const bool few_long = sl_tiles_ <= nt_t16_few_tiles() && (K + SL_K - 1) / SL_K >= 3;
+    static int minch = -2;
+    if (minch == -2) { const char* e = getenv("MURCL_NT_T16_MINCH"); minch = e ? atoi(e) : 2; }   // dev A/B knob ([128 x 512 x 512]: 7.2 us on 64 tiles of 32 x 32, 4.8 us on 256 of 16 x 16)
+    const bool few_long = sl_tiles_ <= nt_t16_few_tiles() && (K + SL_K - 1) / SL_K >= minch;
     if (skinny_lds_enabled() && nt_t16_enabled() && (skinny_lds_splits(M, N, K) > 1 || few_long) && murcl_nt_t16_ok(M, N, K))
         return murcl_nt_t16_launch(A, B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
                                    (int)(epi == EPI_BIAS_RELU), accumulate, epi == EPI_MASK ? mask : nullptr, ldmask, s);
