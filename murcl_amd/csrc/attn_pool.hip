@@ -515,21 +515,59 @@ __global__ __launch_bounds__(256) void abmil_pool_combine_kernel(const float* __
                                                                  int N, int S, float inv_sqrt_n) {
     const int bag = blockIdx.x, tid = threadIdx.x;
     const float* pp = part + (size_t)bag * S * (K2_L + 2);
-    float m = -INFINITY;
-    for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
-    float l = 0.f, a0 = 0.f, a1 = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float* p = pp + (size_t)s * (K2_L + 2);
-        const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
-        l += p[1] * w;
-        a0 += p[2 + 2 * tid] * w;
-        a1 += p[2 + 2 * tid + 1] * w;
+    // the chunks' (m, l) headers first, one per thread: walked one chunk after the other by every thread they were 2 S dependent
+    // round trips (9 us at S = 8)
+    __shared__ float hm[256], hl[256];
+    float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
+    if (S <= 256) {
+        if (tid < S) { hm[tid] = pp[(size_t)tid * (K2_L + 2)]; hl[tid] = pp[(size_t)tid * (K2_L + 2) + 1]; }
+        __syncthreads();
+        for (int s = 0; s < S; ++s) m = fmaxf(m, hm[s]);
+        int s = 0;
+        for (; s + 3 < S; s += 4) {                          // four chunks' partial rows in flight
+            float w[4], p0[4], p1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = pp + (size_t)(s + u) * (K2_L + 2);
+                w[u] = (hm[s + u] == -INFINITY) ? 0.f : expf(hm[s + u] - m);
+                p0[u] = p[2 + 2 * tid];
+                p1[u] = p[2 + 2 * tid + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; a1 += p1[u] * w[u]; }
+        }
+        for (; s < S; ++s) {
+            const float* p = pp + (size_t)s * (K2_L + 2);
+            const float w = (hm[s] == -INFINITY) ? 0.f : expf(hm[s] - m);
+            l += hl[s] * w;
+            a0 += p[2 + 2 * tid] * w;
+            a1 += p[2 + 2 * tid + 1] * w;
+        }
+    } else {
+        for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
+        for (int s = 0; s < S; ++s) {
+            const float* p = pp + (size_t)s * (K2_L + 2);
+            const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
+            l += p[1] * w;
+            a0 += p[2 + 2 * tid] * w;
+            a1 += p[2 + 2 * tid + 1] * w;
+        }
     }
     const float inv = inv_sqrt_n / l;
     Mout[(size_t)bag * K2_L + 2 * tid] = a0 * inv;
     Mout[(size_t)bag * K2_L + 2 * tid + 1] = a1 * inv;
     if (tid == 0) { ml[2 * bag] = m; ml[2 * bag + 1] = l; }
-    for (int n = tid; n < N; n += 256) A[(size_t)bag * N + n] = expf(scores[(size_t)bag * N + n] - m) * inv;
+    const float* sc = scores + (size_t)bag * N;
+    float* ab = A + (size_t)bag * N;
+    int n = tid;
+    for (; n + 3 * 256 < N; n += 4 * 256) {                  // four score loads in flight per thread
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = sc[n + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ab[n + u * 256] = expf(v[u] - m) * inv;
+    }
+    for (; n < N; n += 256) ab[n] = expf(sc[n] - m) * inv;
 }
 
 #ifndef K2_ITEMS_PER_WG
