@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
     for (int g = 0; g < 3; ++g) ah[g] = ax[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (WITH_X) gs_stream<3, 3>(x, Kx, B, m0, Wih, Kx, H, j0, Kx, gs_smem, wave, lane, ax);
     if (hprev) gs_stream<3, 3>(hprev, H, B, m0, Whh, H, H, j0, H, gs_smem, wave, lane, ah);    // a zero state: h W_hh^T = 0, gh = b_hh
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(g_in[g]), "+v"(b_h[g]));       // (early loads: first touched behind the streams)
+    asm volatile("" : "+v"(hp));
     gs_park<NACC, 3>(gs_smem, wave, lane, 0, ah);
     if constexpr (WITH_X) gs_park<NACC, 3>(gs_smem, wave, lane, 3, ax);
     __syncthreads();
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     gs_stream<1, 2>(dgh_next, 3 * H, B, m0, whh_t, 3 * H, 0, j0, 3 * H, gs_smem, wave, lane, acc);
+    asm volatile("" : "+v"(d0), "+v"(r), "+v"(z), "+v"(nn), "+v"(ghn), "+v"(hp), "+v"(dp));   // (early loads: first touched behind the stream)
     gs_park<2, 2>(gs_smem, wave, lane, 0, acc);
     __syncthreads();
     if (!live) return;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void gemm_nt_t16_f32_kernel(const float* __res
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     gs_stream<1, 2>(A, lda, M, m0, Bm, ldb, 0, j0, K, gs_smem, wave, lane, acc);
+    asm volatile("" : "+v"(bv), "+v"(c0), "+v"(mk));         // nothing derived from the early loads may be computed (= waited for) before here
     gs_park<2, 2>(gs_smem, wave, lane, 0, acc);
     __syncthreads();
     if (!live) return;
