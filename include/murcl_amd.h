@@ -142,6 +142,17 @@ int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const f
                          const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
                          float* dbb, float* part_ws, int B, int N, int L, int D, int dtype, int exact_tanh,
                          murcl_stream_t stream);
+/* The same backward pass with the attention weight gradient formed in it (abmil.py:23-27 `attention.0.weight`):
+ * dWa [D,L] f32 (+)= dT^T H from the rows of H the pass is streaming anyway, instead of a second pass over H and dT by
+ * murcl_gemm_tn.  bf16, L = 512, D = 128 only: murcl_abmil_pool_bwd_dwa_ws_floats returns 0 for anything else (callers then
+ * use murcl_abmil_pool_bwd + murcl_gemm_tn), otherwise the number of floats of workspace `ws` (16-byte aligned) the call needs:
+ * one partial dWa and one row of partial dba / dwb / dbb sums per workgroup, added up by a second launch in a fixed order
+ * (bit-reproducible).  dba / dwb / dbb are ADDED to; dWa is added to when dwa_accumulate != 0, written otherwise. */
+long murcl_abmil_pool_bwd_dwa_ws_floats(int B, int N, int L, int D, int dtype);
+int murcl_abmil_pool_bwd_dwa(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
+                             const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
+                             float* dbb, float* dWa, int dwa_accumulate, float* ws, long ws_floats, int B, int N, int L,
+                             int D, int dtype, int exact_tanh, murcl_stream_t stream);
 
 /* K8/K9 -- NT_Xent.forward + its gradient + torch.cosine_similarity of the positive pairs in one
  * call (one launch for n <= 128, two for the larger global batch of a multi-GPU step; utils/losses.py:24-41;

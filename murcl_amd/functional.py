@@ -343,9 +343,17 @@ class ABMILFn(torch.autograd.Function):
         dM = ops.gemm_nt(dpre, ops.transposed(wd))
         # attention pooling
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
-        dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM,
-                                               into=(ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None)
-        dwa = _wgrad(dT, h3, wa)
+        into_k2 = (ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None
+        if ops.abmil_pool_bwd_dwa_on(B, N, L, wac.shape[0], T):
+            # the attention weight gradient dT^T H3 comes out of the same pass over H3 (no second read of H3 and dT)
+            dT, dba, dwb, dbb, dwa = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2,
+                                                        dwa=wa.grad if _direct(wa) else "new")
+            if _direct(wa):
+                _touch(wa)
+                dwa = None
+        else:
+            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2)
+            dwa = _wgrad(dT, h3, wa)
         if direct_k2:
             _touch(ba, wb, bb)
             _final(wa, ba, wb, bb, wd, bd)

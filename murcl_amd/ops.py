@@ -477,9 +477,25 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
     return scores, A, M, ml
 
 
-def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None):
+def abmil_pool_bwd_dwa_ok(B, N, L, D, dtype):
+    """Can ``abmil_pool_bwd(..., dwa=...)`` form the attention weight gradient inside the pooling backward pass?  (bf16, L = 512,
+    D = 128: murcl_abmil_pool_bwd_dwa.)"""
+    return dtype == torch.bfloat16 and _lib.lib().murcl_abmil_pool_bwd_dwa_ws_floats(B, N, L, D, BF16) > 0
+
+
+def abmil_pool_bwd_dwa_on(B, N, L, D, dtype):
+    """Does the ABMIL backward pass USE that form?  Off by default: measured on MI355X at the headline shape (round 5,
+    profiles/r05_d_kd_*) the one-pass kernel takes 130 + 10.5 us against 68 + 5 + 67 us for pooling backward + murcl_gemm_tn - its
+    256 KiB accumulator leaves one wave per SIMD, and nothing then covers the LDS round trips, the vector phase and the LDS-DMA
+    issue of a pair of tiles.  ``MURCL_K2B_DWA=1`` switches it on."""
+    return _K2B_DWA and abmil_pool_bwd_dwa_ok(B, N, L, D, dtype)
+
+
+def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None, dwa=None):
     """-> dT [B*N,128] (dtype of H; 32 spare rows allocated behind it), dba[128], dwb[128], dbb[1].
-    ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros."""
+    ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros.
+    ``dwa``: None - the attention weight gradient is the caller's business (``gemm_tn(dT, H)``); "new" - a fifth result dWa [D,L]
+    f32 = dT^T H, formed in the same pass over H (``abmil_pool_bwd_dwa_ok`` must hold); a [D,L] f32 tensor - ADDED to in place."""
     _need_cuda(H, Wa, dM)
     H, Wa, dM = _c(H), _c(Wa), _c(dM)
     B, N, L = H.shape
@@ -494,8 +510,23 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
     else:
         z = torch.zeros((2 * D + 1,), dtype=torch.float32, device=dev)          # one fill for the three accumulators
         dba, dwb, dbb = z[:D], z[D:2 * D], z[2 * D:]
-    part = torch.empty((512 * (2 * D + 1),), dtype=torch.float32, device=dev)      # per-workgroup parameter-gradient rows
     es = H.element_size()
+    if dwa is not None:
+        wsf = _lib.lib().murcl_abmil_pool_bwd_dwa_ws_floats(B, N, L, D, dt(H))
+        if not wsf:
+            raise ValueError("abmil_pool_bwd(dwa=...): bf16, L = 512, D = 128 only (abmil_pool_bwd_dwa_ok)")
+        acc = not isinstance(dwa, str)
+        dWa = dwa if acc else torch.empty((D, L), dtype=torch.float32, device=dev)
+        assert dWa.dtype == torch.float32 and dWa.is_contiguous() and tuple(dWa.shape) == (D, L)
+        ws = torch.empty((wsf,), dtype=torch.float32, device=dev)
+        # algorithmic bytes: H once, dT out, the saved scores (SURVEY 8(d) K2 backward) - the partial dWa rows are the kernel's own
+        with _span(lambda: (f"abmil_pool_bwd_dwa<{_DT_NAME[H.dtype]}>",
+                   dict(flops=B * (4.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
+            check(_lib.lib().murcl_abmil_pool_bwd_dwa(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
+                                                      ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(dWa), int(acc), ptr(ws), wsf,
+                                                      B, N, L, D, dt(H), int(exact_tanh), stream()), "abmil_pool_bwd_dwa")
+        return dT_full[:B * N], dba, dwb, dbb, dWa
+    part = torch.empty((512 * (2 * D + 1),), dtype=torch.float32, device=dev)      # per-workgroup parameter-gradient rows
     with _span(lambda: (f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
         check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
@@ -504,6 +535,7 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None)
     return dT_full[:B * N], dba, dwb, dbb
 
 
+_K2B_DWA = _os.environ.get("MURCL_K2B_DWA", "0") == "1"       # dev A/B switch, OFF: dWa inside the pooling backward pass (abmil_pool_bwd_dwa_on)
 _NTX_XCHG = _os.environ.get("MURCL_NTX_XCHG", "1") == "1"     # dev A/B switch: n <= 128 through the one-exchange kernel
 _NTX_BUF = {}
 

@@ -697,6 +697,54 @@ def test_abmil_pool_bwd(dtype, B, N):
     assert abs(dbb.item()) < 1e-3 * max(1.0, wbr.grad.abs().max().item())      # softmax shift invariance
 
 
+@pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (3, 40), (1, 1), (16, 2048), (300, 96), (128, 2048)])
+def test_abmil_pool_bwd_with_the_attention_weight_gradient_in_the_same_pass(B, N):
+    """murcl_abmil_pool_bwd_dwa (bf16): dT / dba / dwb / dbb as the two-launch form leaves them, dWa = dT^T H against
+    (a) the product of the STORED (bf16) dT with H in float64 - what murcl_gemm_tn forms, to 1e-4 of the largest entry -
+    and (b) the oracle's autograd of models/abmil.py:38-42 w.r.t. attention.0.weight on the bf16-rounded inputs;
+    accumulation into an existing gradient; run-to-run bit-reproducibility.  Ragged N (not a multiple of 32), single-row bags,
+    fewer / more items than workgroups."""
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(12, B, N)
+    H, Wa = H.bfloat16(), Wa.bfloat16()
+    dM = _rand(12, "dM", (B, 512))
+    Hd, Wad, bad, wbd, bbd, dMd = (t.to(dev) for t in (H, Wa, ba, wb, bb, dM))
+    assert ops.abmil_pool_bwd_dwa_ok(B, N, 512, 128, torch.bfloat16)
+    sc, A_g, M_g, ml = ops.abmil_pool_fwd(Hd, Wad, bad, wbd, bbd)
+    dT0, dba0, dwb0, dbb0 = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd)
+    dT, dba, dwb, dbb, dWa = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")
+    # the same formulas on the same inputs: the stored dT differs at most by the last bf16 bit (MFMA operand order)
+    # (a single-row bag has p = 1 and g = c: ds is the rounding noise of g - c, so every comparison gets a floor of the size of
+    #  that noise - fl for an entry of dT, flw for an entry of dWa)
+    fl = 1e-6 * (dM.abs().max() * H.float().abs().max() * wb.abs().max()).item()
+    flw = fl * H.float().abs().max().item() * math.sqrt(B * N)
+    sT = dT0.float().abs().max().item()
+    _close(dT.float(), dT0.float().cpu(), rtol=1e-2, atol=1e-2 * sT + fl, msg="dT vs the unfused kernel")
+    _close(dba, dba0.cpu(), rtol=1e-3, atol=1e-3 * dba0.abs().max().item() + fl * math.sqrt(B * N), msg="dba")
+    _close(dwb, dwb0.cpu(), rtol=1e-3, atol=1e-3 * dwb0.abs().max().item() + fl * math.sqrt(B * N), msg="dwb")
+    assert abs(dbb.item()) < 1e-3 * max(1.0, dwb0.abs().max().item())
+    ref = dT.double().t().cpu() @ H.reshape(B * N, 512).double()               # (a) the product of what was stored
+    _close(dWa, ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item(), msg="dWa vs dT^T H")
+    dWa_tn = ops.gemm_tn(dT0, Hd.view(B * N, 512))
+    _close(dWa, dWa_tn.cpu(), rtol=2e-2, atol=5e-3 * ref.abs().max().item() + flw, msg="dWa vs murcl_gemm_tn of the unfused dT")
+    # (b) oracle autograd on the rounded inputs
+    Hf, War = H.float(), Wa.float().requires_grad_()
+    s = (torch.tanh(Hf @ War.t() + ba) @ wb.t()).squeeze(-1) + bb
+    Mo = torch.einsum("bn,bnl->bl", torch.softmax(s, 1) / math.sqrt(N), Hf)
+    g_wa, = torch.autograd.grad((Mo * dM).sum(), War, retain_graph=True)
+    # the pooled vector reaches Wa through the scores only: the H factor of d(Mo)/d(A) is not a Wa path, autograd gives exactly dT^T H
+    _close(dWa, g_wa, rtol=3e-2, atol=2e-2 * g_wa.abs().max().item() + flw, msg="dWa vs the oracle")
+    # accumulation + reproducibility
+    base = _rand(12, "base", (128, 512)).to(dev)
+    acc = base.clone()
+    out = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa=acc)
+    assert out[4] is acc
+    assert torch.equal(acc, base + dWa)
+    assert torch.equal(ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")[4], dWa)
+    assert torch.equal(out[0], dT)
+
+
 # ------------------------------------------------------------------ NT-Xent
 @pytest.mark.parametrize("Bh", [2, 4, 9, 64, 65, 100, 128, 512, 777])
 @pytest.mark.parametrize("tau", [1.0, 0.5, 0.07])
