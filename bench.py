@@ -549,7 +549,8 @@ def main():
     k2_key = f"abmil_pool_fwd<{args.dtype}>"
 
     # -- timed region: exactly K steps; only the dominant kernel and K2 carry HIP events, on every third launch
-    ops.TIMERS = ops.KernelTimers(only={dominant, k2_key}, every=3, pool=4 * (args.steps + 40))
+    k2c_key = "abmil_pool_combine"                      # K2's second launch (chunk partials -> A, M, ml): part of K2's time
+    ops.TIMERS = ops.KernelTimers(only={dominant, k2_key, k2c_key}, every=3, pool=6 * (args.steps + 40))
     # settle: untimed steps (in the timed region's configuration) back to back right up to the barrier that opens it, so
     # that at least SETTLE_STEPS steps precede the timed ones whatever --warmup says and the few milliseconds of host work
     # above (reading the breakdown events) are not the last thing the GPU saw
@@ -611,27 +612,64 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
 
-    def roof(key):
-        """Roofline of one kernel from its live HIP-event time: the binding roof is whichever of
-        (algorithmic bytes / 8 TB/s) and (algorithmic FLOP / dense MFMA peak) takes longer."""
+    # SURVEY 8(d) classifies the kernels: the encoder-sized GEMMs (K1: forward, input gradients, weight gradients) are MFMA-bound
+    # (a fused encoder moves X once: intensity ~1.7 kFLOP/B), K2 and the streaming passes are HBM-bound.  The layer-wise bytes of a
+    # GEMM launch (A in + C out) are what THIS build moves per layer, not what the algorithm needs: they are reported beside the
+    # flops fraction, never instead of it.
+    def bound_of(key):
+        return "mfma" if key.startswith(("panel_gemm", "gemm_tn", "gemm_nt")) else "hbm"
+
+    def roof(key, extra_keys=()):
+        """Roofline of one kernel from its live HIP-event time in the timed region (``extra_keys``: further launches that belong to
+        the same kernel row - their time is added, their internal bytes are not)."""
         r = live[key]
-        sec = r["ms_total"] * 1e-3
+        sec_avg = r["ms_avg"] * 1e-3 + sum(live[k]["ms_avg"] * 1e-3 for k in extra_keys if k in live)
         mfma_peak = PEAK["mfma_bf16_TFLOPs"] if "bf16" in key or "K512" in key or "K128" in key else PEAK["mfma_f32_TFLOPs"]
-        t_mem = r["bytes"] / (PEAK["hbm_GBps"] * 1e9)
-        t_mma = r["flops"] / (mfma_peak * 1e12)
-        if t_mem >= t_mma:
-            ach, peak, unit, bound = r["bytes"] / sec / 1e9, PEAK["hbm_GBps"], "GB/s", "hbm"
+        by, fl = r["bytes"] / r["calls"], r["flops"] / r["calls"]
+        frac_bytes = by / sec_avg / 1e9 / PEAK["hbm_GBps"]
+        frac_flops = fl / sec_avg / 1e12 / mfma_peak
+        bound = bound_of(key)
+        if bound == "hbm":
+            ach, peak, unit, frac = by / sec_avg / 1e9, PEAK["hbm_GBps"], "GB/s", frac_bytes
         else:
-            ach, peak, unit, bound = r["flops"] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
-        out = dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 4),
-                   traffic=_pmc_traffic(key), launches=r["calls"], avg_launch_ms=round(r["ms_avg"], 4),
-                   algorithmic_bytes_per_launch=int(r["bytes"] / r["calls"]),
-                   algorithmic_flops_per_launch=int(r["flops"] / r["calls"]))
+            ach, peak, unit, frac = fl / sec_avg / 1e12, mfma_peak, "TFLOP/s", frac_flops
+        traffic, src = _pmc_traffic(key)
+        out = dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(frac, 4),
+                   frac_flops=round(frac_flops, 4), frac_layer_bytes=round(frac_bytes, 4),
+                   bound_source="SURVEY.md 8(d): K1 (encoder GEMMs) MFMA-bound, K2 / streaming passes HBM-bound",
+                   traffic=traffic, traffic_source=src, launches=r["calls"], avg_launch_ms=round(sec_avg * 1e3, 4),
+                   algorithmic_bytes_per_launch=int(by), algorithmic_flops_per_launch=int(fl))
+        if extra_keys:
+            out["launches_of_the_row"] = [key] + [k for k in extra_keys if k in live]
+            out["avg_ms_each"] = [round(live[k]["ms_avg"], 4) for k in out["launches_of_the_row"]]
         if key.startswith("gemm_tn_sq"):
             out["note"] = ("the three encoder weight gradients of the step as ONE grouped launch of gemm_tn_sq_kernel (256x256 tiles, 12 "
                            "(layer, tile) pairs x 21 row splits = one workgroup per CU, partial sums to a workspace) + ONE tn_reduce_kernel "
                            "(adds them to the gradients, bias-gradient rows ride along): avg_launch_ms and traffic cover BOTH launches plus "
-                           "~2-3 us of event records; rocprofv3 lists them separately (profiles/r04_*_kernel_stats.csv)")
+                           "~2-3 us of event records; rocprofv3 lists them separately (profiles/*_kernel_stats.csv)")
+        return out
+
+    def step_roof():
+        """The whole step against SURVEY 8(d): 2B bag-forwards x (3.493 GFLOP forward, ~9.41 GFLOP forward + backward at N = 2048)
+        on the dense bf16 MFMA peak, and the HBM bytes it moves (PMC bytes per launch of the committed passes x launches per step)
+        against the fused minimum (X once)."""
+        flops = 2 * B * 9.41e9 * (N / 2048.0)
+        fused_min = 2 * B * N * D * (2 if args.dtype == "bf16" else 4)
+        calls = {k: v["calls"] // 2 for k, v in breakdown.items()}          # the breakdown pass ran two steps
+        moved, covered, src = 0, [], None
+        for k, c in calls.items():
+            t, s_ = _pmc_traffic(k if not k.startswith("gemm_tn_sq_grouped") else "gemm_tn_sq_grouped3<bf16>")
+            if t:
+                moved += t * c
+                covered.append(k)
+                src = src or s_
+        out = dict(flops=flops, mfma_peak_TFLOPs=PEAK["mfma_bf16_TFLOPs"] if args.dtype == "bf16" else PEAK["mfma_f32_TFLOPs"],
+                   frac_of_mfma=round(flops / (ms_step * 1e-3) / 1e12 / (PEAK["mfma_bf16_TFLOPs"] if args.dtype == "bf16" else PEAK["mfma_f32_TFLOPs"]), 4),
+                   fused_min_bytes=fused_min, hbm_bytes_pmc=int(moved) if moved else None,
+                   ratio_vs_fused_min=round(moved / fused_min, 2) if moved else None,
+                   avg_hbm_GBps=round(moved / (ms_step * 1e-3) / 1e9, 1) if moved else None,
+                   pmc_kernels=sorted(covered), pmc_source=src,
+                   note="hbm_bytes_pmc sums the encoder-sized kernels only (the bag-level head moves < 3 % of the step's bytes)")
         return out
 
     out = {
@@ -651,8 +689,8 @@ def main():
                                f"per GPU, {args.dtype} patch tensors / f32 accumulate (BASELINE configs[1])",
                    "bags_per_gpu": B, "patches": N, "feat_dim": D, "global_bags": B * world,
                    "sharding": "bags by WSI; all-gather of z + grad all-reduce" if world > 1 else "single GPU"},
-        "roofline": roof(dominant),
-        "roofline_k2": roof(k2_key),
+        "roofline": dict(roof(dominant), step=step_roof()),
+        "roofline_k2": roof(k2_key, (k2c_key,)),
         "comm": comm,
         "loss": round(float(loss.item()), 6),
         "step_stats": stats,
@@ -690,13 +728,11 @@ def main():
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), else null."""
+    """(HBM bytes per launch, the run they were measured in) from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json:
+    separate --pmc passes over this script, tools/pmc_bench.sh), else (None, None)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(key)
+            d = json.load(f)
+        return d.get(key), d.get("_source")
     except (OSError, ValueError):
-        return None
-
-
-if __name__ == "__main__":
-    main()
+        return None, None

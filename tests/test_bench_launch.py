@@ -114,3 +114,15 @@ def test_gpus_1_through_the_spawn_path_prints_the_contract_line():
               "dtype", "data", "config", "roofline"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    # round 5: the bound comes from SURVEY 8(d) (the encoder GEMMs are MFMA-bound), both fractions are reported, the step as a whole
+    # is priced against the MFMA peak and the fused minimum of HBM bytes, K2 includes its combine launch, traffic names its run
+    r, k2 = out["roofline"], out["roofline_k2"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_flops", "frac_layer_bytes", "traffic_source", "step"):
+        assert k in r, k
+    if r["kernel"].startswith(("panel_gemm", "gemm_tn")):
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["frac_flops"]) < 1e-9
+    st = r["step"]
+    assert st["flops"] == pytest.approx(2 * 64 * 9.41e9) and 0 < st["frac_of_mfma"] < 1
+    assert st["fused_min_bytes"] == 2 * 64 * 2048 * 512 * 2
+    assert st["hbm_bytes_pmc"] is None or (st["ratio_vs_fused_min"] > 1 and st["pmc_source"])
+    assert k2["bound"] == "hbm" and k2["launches_of_the_row"] == ["abmil_pool_fwd<bf16>", "abmil_pool_combine"] and len(k2["avg_ms_each"]) == 2
