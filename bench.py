@@ -447,6 +447,10 @@ def comm_diagnostics(model, fc, opt, crit, views, world, device, reps=20):
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
         return per[n // 2] * 1e3
     with_comm = step_median(make_step(model, fc, opt, crit, views, 2))          # the multi-rank branch (also with one rank)
+    # (under MURCL_MILESTONES=1 the multi-rank step leaves its reducer bound as the aggregator's gradient milestone: a local step
+    #  built behind it would still launch the reducer's collectives and never finish() them)
+    from murcl_amd import functional as _fn
+    _fn.set_grad_milestone(None)
     local = step_median(make_step(model, fc, opt, crit, views, 1))
     out["step_us_with_collectives"] = round(with_comm, 1)
     out["step_us_local_only"] = round(local, 1)

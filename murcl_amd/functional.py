@@ -1011,7 +1011,14 @@ class CLAMFn(torch.autograd.Function):
             ids = torch.zeros((B, 0), dtype=torch.int32, device=dev)
         if inst_pt is None:
             inst_pt = torch.zeros((2, B, 0, 0), dtype=torch.int64, device=dev)
-        ctx.mark_non_differentiable(A, s, ids, inst_pt)
+        if inst_cfg is None:
+            # the cached zero is shared by every call without an instance branch: as a differentiable output autograd would
+            # re-point its grad_fn at this node (keeping the node's saved activations alive through the cache) - hand out a view,
+            # marked non-differentiable
+            inst_loss = inst_loss.detach()[:]
+            ctx.mark_non_differentiable(A, s, ids, inst_pt, inst_loss)
+        else:
+            ctx.mark_non_differentiable(A, s, ids, inst_pt)
         ctx.set_materialize_grads(False)
         return M, A, s, inst_loss, ids, inst_pt
 

@@ -38,8 +38,6 @@ class ABMIL(nn.Module):
     # -- kernels -------------------------------------------------------------------------
     def _bags(self, x):
         """x [B,N,d] -> [B,L] through the fused HIP path."""
-        if self.K != 1:
-            raise NotImplementedError("murcl_amd ABMIL: K != 1 attention heads are not built (no reference script sets K)")
         # L = 512, D = 128 (every launch script's values) run the one-pass K2 pooling kernel and, in bf16, the weight-stationary
         # encoder; other --L / --D (train_RLMIL.py:91-97) and --dropout > 0 while training take the general path of ABMILFn
         drops = None
@@ -53,6 +51,8 @@ class ABMIL(nn.Module):
             x = ops.cast(x.float().contiguous(), self.compute_dtype) if x.dtype != torch.float32 else \
                 ops.cast(x.contiguous(), self.compute_dtype)
         e, a, d = self.encoder, self.attention, self.decoder
+        if self.K != 1:
+            return self._bags_heads(x.contiguous(), drops)
         if self.session is not None and drops is None and torch.is_grad_enabled():
             # a sequential training step keeps all its patch steps' activations in one set of buffers and runs ONE backward
             out, A = ABMILStepFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
@@ -63,6 +63,22 @@ class ABMIL(nn.Module):
                                a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops, torch.is_grad_enabled())
         self.last_attention = A
         return out
+
+    def _bags_heads(self, x, drops):
+        """K > 1 attention heads (abmil.py:8,23-27,38-44): ``attention.2`` has K rows, the soft-max runs over the patches of every
+        head, ``torch.mm(A, H)`` is [K, L] per bag and the batch loop concatenates the blocks -> [B*K, L], bag-major.  No reference
+        script sets K, so this branch is built for the contract, not for speed: head k is the single-head operator with row k of
+        ``attention.2`` (the heads share everything else; autograd adds their parameter gradients), i.e. K encoder passes instead
+        of one.  Seeded Dropout masks are the same in every pass (one draw per call, as the reference's single encoder pass)."""
+        e, a, d = self.encoder, self.attention, self.decoder
+        outs, As = [], []
+        for k in range(self.K):
+            out, A = ABMILFn.apply(x, e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias, a[0].weight, a[0].bias,
+                                   a[2].weight[k:k + 1], a[2].bias[k:k + 1], d[0].weight, d[0].bias, drops, torch.is_grad_enabled())
+            outs.append(out)
+            As.append(A)
+        self.last_attention = torch.stack(As, 1)                       # [B, K, N]
+        return torch.stack(outs, 1).reshape(x.shape[0] * self.K, -1)
 
     def bag_forward(self, bag):
         return self._bags(bag.unsqueeze(0))

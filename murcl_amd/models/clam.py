@@ -49,6 +49,22 @@ import types as _types
 _EMPTY_RESULT = _types.MappingProxyType({})
 
 
+def _checked_instance_loss(fn):
+    """The reference calls the loss it was given on (logits [2k,2], targets [2k]) of every evaluated class (clam.py:64-65,118,131).
+    The instance branch here is one HIP launch each way that evaluates exactly ``nn.CrossEntropyLoss()`` - mean reduction, no class
+    weights, no label smoothing (the only loss the reference's scripts pass: its constructor default).  ``None`` means that
+    default; any other callable would silently produce other numbers, so it is refused."""
+    if fn is None:
+        return nn.CrossEntropyLoss()
+    plain = (type(fn) is nn.CrossEntropyLoss and fn.reduction == "mean" and fn.weight is None
+             and float(getattr(fn, "label_smoothing", 0.0)) == 0.0 and fn.ignore_index == -100)
+    if not plain:
+        raise NotImplementedError(
+            "murcl_amd CLAM_SB: instance_loss_fn must be None or a default nn.CrossEntropyLoss() - the fused instance branch "
+            f"(csrc/clam.hip) evaluates mean cross-entropy and nothing else; got {fn!r}")
+    return fn
+
+
 class CLAM_SB(nn.Module):
     def __init__(self, gate=True, size_arg="small", dropout=False, k_sample=8, n_classes=2,
                  instance_loss_fn=None, subtyping=False, in_dim=512):
@@ -63,7 +79,7 @@ class CLAM_SB(nn.Module):
         self.classifiers = nn.Linear(size[1], n_classes)
         self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
         self.k_sample, self.n_classes, self.subtyping, self.dropout = k_sample, n_classes, subtyping, dropout
-        self.instance_loss_fn = instance_loss_fn          # kept for API compat; CE is evaluated by the HIP kernel
+        self.instance_loss_fn = _checked_instance_loss(instance_loss_fn)      # clam.py:64-65; CE itself runs in the HIP kernel
         self.compute_dtype = torch.float32
         self.last_attention = None
         self._empty_results = None                   # cached per-bag result dicts of calls that report nothing (batch_forward)

@@ -312,8 +312,10 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3
         # a fresh bag-level gradient: the single-writer 32 x 32 kernel WRITES it (no zero-fill launch in front, no read of C)
         C = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
         arr = (_lib.TnProblem * 1)(_lib.TnProblem(ptr(A), ptr(B), ptr(C), None, None, M, N1, N2, N1, N2, N2, 0, _lib.TN_OVERWRITE, 1.0))
-        check(_lib.lib().murcl_gemm_tn_grouped(arr, 1, F32, None, 0, stream()), "gemm_tn(small, overwrite)")
-        return C
+        if _lib.lib().murcl_gemm_tn_grouped(arr, 1, F32, None, 0, stream()) == 0:
+            return C
+        # (the library declines flagged products when its small-tile kernel is switched off, MURCL_TN_SMALL=0: zero-fill + the
+        #  accumulating entry point below)
     C = out if out is not None else torch.zeros((N1, N2), dtype=torch.float32, device=A.device)
     wide = A.dtype == torch.bfloat16 and N1 % 256 == 0 and N2 % 128 == 0 and M >= 4096     # murcl_gemm_tn's dispatch
     wsb = _lib.lib().murcl_gemm_tn_workspace_bytes(M, N1, N2, dt(A)) if (splits <= 0 and _TN_SQ) else 0
@@ -360,8 +362,10 @@ def gemm_tn_grouped(problems, fresh=False):
             keep.append((A, B))
             Cs.append(C)
             arr[g] = _lib.TnProblem(ptr(A), ptr(B), ptr(C), None, ptr(ci), M, N1, N2, N1, N2, N2, 0, _lib.TN_OVERWRITE if write else 0, 1.0)
-        check(_lib.lib().murcl_gemm_tn_grouped(arr, n, F32, None, 0, stream()), "gemm_tn_grouped(small)")
-        return Cs
+        if _lib.lib().murcl_gemm_tn_grouped(arr, n, F32, None, 0, stream()) == 0:
+            return Cs
+        # (declined: the library's small-tile kernel is switched off, MURCL_TN_SMALL=0 - one product at a time below)
+        return [gemm_tn(A, B, out=out, colsum_into=ci) for A, B, out, ci, _, _ in problems]
     if not gemm_tn_grouped_ok(problems):
         assert all(p[5] is None for p in problems), "scale / deinterleave need the grouped launch (gemm_tn_grouped_ok)"
         return [gemm_tn(A, B, out=out, colsum_into=ci, colsum_parts=cp) for A, B, out, ci, cp, _ in problems]
@@ -541,11 +545,14 @@ _NTX_BUF = {}
 
 
 def _ntx_xchg(dev, batches):
-    """The exchange buffer of murcl_ntxent_small_xchg for this device: allocated (and zeroed) once, grown when a call needs more."""
+    """The exchange buffer of murcl_ntxent_small_xchg for this device AND stream: allocated (and zeroed) once, grown when a call needs
+    more.  Launches that may overlap in time must not share one (generation word, arrival counter, granules: ntxent.hip), and launches
+    of one stream never overlap - so the cache is keyed by (device, stream)."""
     need = _lib.lib().murcl_ntxent_xchg_bytes(batches)
-    buf = _NTX_BUF.get(dev)
+    key = (dev, stream())
+    buf = _NTX_BUF.get(key)
     if buf is None or buf.numel() < need:
-        buf = _NTX_BUF[dev] = torch.zeros((need,), dtype=torch.uint8, device=dev)
+        buf = _NTX_BUF[key] = torch.zeros((need,), dtype=torch.uint8, device=dev)
     return buf
 
 

@@ -93,7 +93,7 @@ def kmeans_plusplus(X, K, generator):
     for _ in range(1, K):
         pot = d2.sum()
         if float(pot) <= 0:                                   # fewer distinct rows than clusters
-            centers.append(X[int(torch.randint(N, (1,), generator=generator, device=X.device).item())])
+            centers.append(X[int(torch.randint(N, (1,), generator=generator, device=X.device).item()), :d])   # (X may carry zero pad columns)
             continue
         cand = torch.multinomial(d2 / pot, trials, replacement=True, generator=generator)
         dc = (xx[None, :] - 2 * cross(X[cand]) + xx[cand][:, None]).clamp_min_(0)         # [trials, N]

@@ -709,6 +709,88 @@ def g16_abmil_general():
     np.savez(os.path.join(OUT, "g16_abmil_general.npz"), **res)
 
 
+def _grad_entry(g):
+    """Small gradients in full (float32), the 512 x 512-sized ones as fingerprints (G20 holds a full set for ABMIL)."""
+    return g.numpy().astype(np.float32) if g.numel() <= 70000 else _summ(g)
+
+
+def g18_clam_big():
+    """CLAM_SB(size_arg="big") - the attention net's hidden width 384 instead of 256 (clam.py:66-67; --size_arg big in both entry
+    scripts): raw scores, soft-max, top-k ids, pooled M, the instance branch for both labels and the parameter gradients (small tensors in full) of
+    the combined objective, eval mode."""
+    seed, B, N, d = 18, 3, 300, 512
+    x = T(P.bags(seed, "g18.x", B, N, d))
+    m = r_clam.CLAM_SB(gate=True, size_arg="big", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=d)
+    m.load_state_dict(P.to_torch(P.clam_sb(seed, size=(512, 384))))
+    m.eval()
+    res = {}
+    with torch.no_grad():
+        raw = torch.cat([m.bag_forward(x[b], attention_only=True) for b in range(B)])
+        A = torch.softmax(raw, 1)
+        for b in range(B):
+            assert _topk_margin(A[b], 8) > 1e-4, "golden top-k margin too small"
+        res["raw"], res["A"] = raw.numpy(), A.numpy()
+        res["top_p"], res["top_n"] = torch.topk(A, 8)[1].numpy(), torch.topk(-A, 8)[1].numpy()
+        res["M_batch"] = m(x)[0].numpy()
+    for label in (0, 1):
+        losses, preds, tgts = [], [], []
+        with torch.no_grad():
+            for b in range(B):
+                _, rdb = m.bag_forward(x[b], label=torch.tensor([label]), instance_eval=True)
+                losses.append(float(rdb["instance_loss"]))
+                preds.append(rdb["inst_preds"])
+                tgts.append(rdb["inst_labels"])
+        res[f"l{label}.inst_loss"], res[f"l{label}.preds"], res[f"l{label}.targets"] = np.array(losses), np.stack(preds), np.stack(tgts)
+    tot = 0
+    for b in range(B):
+        Mb, rdb = m.bag_forward(x[b], label=torch.tensor([1]), instance_eval=True)
+        tot = tot + Mb.sum() + rdb["instance_loss"]
+    tot.backward()
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _grad_entry(v.grad)
+    np.savez_compressed(os.path.join(OUT, "g18_clam_big.npz"), **res)
+
+
+def g19_abmil_heads():
+    """ABMIL(K=3): three attention heads (abmil.py:8,23-27,38-44) - out [B*K, L] (the batch loop concatenates the [K, L] blocks),
+    the attention weights [B, K, N] and the parameter gradients (small tensors in full) of a weighted sum of the outputs."""
+    seed, B, N, d, K = 19, 3, 200, 512, 3
+    m = r_abmil.ABMIL(d, L=512, D=128, K=K, dim_out=2)
+    m.load_state_dict(P.to_torch(P.abmil(seed, K=K, dim_out=2)))
+    x = T(P.bags(seed, "g19.x", B, N, d))
+    out, _ = m(x)
+    w = T(detrand.normal(seed, "g19.w", (B * K, 512)))
+    (out * w).sum().backward()
+    res = {"out": out.detach().numpy()}
+    with torch.no_grad():
+        A = []
+        for b in range(B):
+            a = torch.softmax(m.attention(m.encoder(x[b])).t(), dim=1)
+            A.append(a / np.sqrt(a.shape[-1]))
+        res["A"] = torch.stack(A).numpy()
+        res["out_single"] = m(x[:1])[0].numpy()                       # the x.shape[0] == 1 branch: [K, L]
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _grad_entry(v.grad)
+    np.savez_compressed(os.path.join(OUT, "g19_abmil_heads.npz"), **res)
+
+
+def g20_abmil_full_grads():
+    """G1 again with every parameter gradient stored IN FULL (the 34-number fingerprints of g1_abmil.npz pin norm, maximum
+    and the first values only): the reference's ABMIL at the C1 shape, loss = out.sum()."""
+    seed, B, N, d = 985, 4, 256, 512
+    m = r_abmil.ABMIL(d, L=512, D=128, dim_out=128)
+    m.load_state_dict(P.to_torch(P.abmil(seed)))
+    out, _ = m(T(P.bags(seed, "g1.x", B, N, d)))
+    out.sum().backward()
+    res = {"out": out.detach().numpy()}
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = v.grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "g20_abmil_full_grads.npz"), **res)
+
+
 def g17_rl_two_steps():
     """G12 with a second optimizer step (Adam's first step is sign-like, a second one makes the comparison bite):
     TWO consecutive batches through the reference's own ``train()`` (train_MuRCL.py:189-343) at train_stage 2 and 3, T = 3,
@@ -935,7 +1017,8 @@ def g11_manifest():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general, g17_rl_two_steps):
+    for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general, g17_rl_two_steps,
+               g18_clam_big, g19_abmil_heads, g20_abmil_full_grads):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

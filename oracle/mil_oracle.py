@@ -43,6 +43,20 @@ def abmil_forward(p, x, drop_masks=None):
     return out, A, s, M
 
 
+def abmil_forward_heads(p, x):
+    """ABMIL with K > 1 attention heads (models/abmil.py:23-27,38-44): ``attention.2`` has K rows, the soft-max runs over the
+    patches of every head, ``torch.mm(A, H)`` is [K, L] per bag and the batch loop concatenates them: out [B*K, L] (bag-major,
+    head-minor), A [B, K, N]."""
+    h = torch.relu(_lin(x, p, "encoder.0"))
+    h = torch.relu(_lin(h, p, "encoder.3"))
+    h = torch.relu(_lin(h, p, "encoder.6"))
+    s = _lin(torch.tanh(_lin(h, p, "attention.0")), p, "attention.2").transpose(1, 2)        # abmil.py:38-39: [B, K, N]
+    A = torch.softmax(s, dim=2) / math.sqrt(s.shape[2])                                      # abmil.py:40-41
+    M = torch.einsum("bkn,bnl->bkl", A, h)                                                   # abmil.py:42
+    out = torch.relu(_lin(M, p, "decoder.0"))                                                # abmil.py:44
+    return out.reshape(-1, out.shape[-1]), A
+
+
 def abmil_attn_pool(h, wa, ba, wb, bb):
     """The K2 kernel in isolation: scores, softmax/sqrt(N), pooling (abmil.py:38-42)."""
     s = F.linear(torch.tanh(F.linear(h, wa, ba)), wb, bb).squeeze(-1)

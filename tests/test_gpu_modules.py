@@ -916,3 +916,96 @@ def test_dropout_scale_is_the_realised_keep_probability():
     assert abs(k.mean().item() - 1.0) < 2e-3                # unbiased: E[keep multiplier] = 1
     k75 = ops.dropout_mask((1 << 12, 64), torch.float32, 0.75, _dev(), seed=5)
     assert abs(k75[k75 != 0][0].item() - 1.0 / 0.75) < 1e-6
+
+
+# ------------------------------------------------------------------ round 5: the constructor branches VERDICT r4 listed
+def _check_grad_entries(named, gold, prefix, rtol, zero_keys=()):
+    """Gradients the golden stores in full: every entry within rtol of the LARGEST entry (north_star's 1e-4 at rtol = 1e-4);
+    34-number fingerprints as _check_summ."""
+    n = 0
+    for k, v in named:
+        key = prefix + k
+        if key not in gold.files:
+            continue
+        want = gold[key]
+        if k in zero_keys:                                    # exact zeros in exact arithmetic (soft-max shift invariance)
+            n += 1
+            continue
+        if want.shape == tuple(v.grad.shape):
+            np.testing.assert_allclose(v.grad.cpu().numpy(), want, rtol=rtol, atol=rtol * np.abs(want).max(), err_msg=key)
+        else:
+            _check_summ(_summ(v.grad), want, max(rtol, 3e-4), key)
+        n += 1
+    assert n > 0
+
+
+def test_abmil_every_gradient_entry_vs_reference_golden(golden):
+    """G20: the reference's gradients of ALL ABMIL parameters at the C1 shape, stored in full - every entry of every gradient of
+    the f32 path within 1e-4 of the tensor's largest entry (north_star's tolerance; G1 pins fingerprints only)."""
+    g = golden("g20_abmil_full_grads")
+    m = _abmil(985)
+    out, _ = m(T(P.bags(985, "g1.x", 4, 256, 512)).to(_dev()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    out.sum().backward()
+    _check_grad_entries(m.named_parameters(), g, "grad.", 1e-4, zero_keys=("attention.2.bias",))
+    assert m.attention[2].bias.grad.abs().max().item() < 1e-4 * m.attention[2].weight.grad.abs().max().item()
+
+
+def test_abmil_three_attention_heads_vs_reference_golden(golden):
+    """G19: ABMIL(K=3) (abmil.py:8,23-27,38-44) - out [B*K, L] bag-major, attention [B, K, N], the x.shape[0] == 1 branch and
+    the parameter gradients of a weighted sum of the outputs."""
+    from murcl_amd.models.abmil import ABMIL
+    g = golden("g19_abmil_heads")
+    m = ABMIL(512, L=512, D=128, K=3, dim_out=2)
+    m.load_state_dict(P.to_torch(P.abmil(19, K=3, dim_out=2)))
+    m = m.to(_dev())
+    x = T(P.bags(19, "g19.x", 3, 200, 512)).to(_dev())
+    out, det = m(x)
+    assert out.shape == (9, 512) and not det.requires_grad
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), g["A"], rtol=1e-4, atol=1e-9)
+    (out * T(detrand.normal(19, "g19.w", (9, 512))).to(_dev())).sum().backward()
+    _check_grad_entries(m.named_parameters(), g, "grad.", 2e-4, zero_keys=("attention.2.bias",))
+    np.testing.assert_allclose(m(x[:1])[0].detach().cpu().numpy(), g["out_single"], rtol=1e-4, atol=1e-5)
+    # bf16 storage path: K single-head passes through the one-pass pooling kernels
+    m16 = ABMIL(512, L=512, D=128, K=3, dim_out=2)
+    m16.load_state_dict(P.to_torch(P.abmil(19, K=3, dim_out=2)))
+    m16.compute_dtype = torch.bfloat16
+    o16, _ = m16.to(_dev())(x)
+    assert (o16 - out).abs().max().item() <= 3e-2 * out.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_clam_size_big_vs_reference_golden(golden, dtype):
+    """G18: CLAM_SB(size_arg="big") - a 384-wide attention net (clam.py:66-67; --size_arg big of both entry scripts).  f32 at the
+    golden's 1e-4; bf16 (the fused gate kernels are built for D = 256: this width takes the generic chain) against the reference
+    at the bf16 tolerances of the D = 256 tests."""
+    from murcl_amd.models.clam import CLAM_SB
+    g = golden("g18_clam_big")
+    m = CLAM_SB(gate=True, size_arg="big", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512)
+    m.load_state_dict(P.to_torch(P.clam_sb(18, size=(512, 384))))
+    m.compute_dtype = dtype
+    m = m.to(_dev()).eval()
+    x = T(P.bags(18, "g18.x", 3, 300, 512)).to(_dev())
+    f32 = dtype == torch.float32
+    M, _ = m(x)
+    sM = np.abs(g["M_batch"]).max()
+    np.testing.assert_allclose(M.detach().cpu().numpy(), g["M_batch"], rtol=1e-4 if f32 else 3e-2, atol=(1e-5 if f32 else 3e-2 * sM))
+    np.testing.assert_allclose(m.last_attention.cpu().numpy(), g["A"], rtol=2e-4 if f32 else 5e-2, atol=1e-9 if f32 else 1e-5)
+    raw = torch.cat([m.bag_forward(x[b], attention_only=True) for b in range(3)])
+    np.testing.assert_allclose(raw.cpu().numpy(), g["raw"], rtol=1e-4 if f32 else 0, atol=2e-5 if f32 else 3e-2)
+    if not f32:
+        return
+    from murcl_amd import ops
+    ids = ops.topk_ids(m.last_attention, 8).cpu().numpy()
+    np.testing.assert_array_equal(ids[:, :8], g["top_p"])
+    np.testing.assert_array_equal(ids[:, 8:], g["top_n"])
+    for label in (0, 1):
+        _, _, res = m(x, label=[label] * 3, instance_eval=True)
+        for b in range(3):
+            np.testing.assert_allclose(float(res[b]["instance_loss"].detach()), g[f"l{label}.inst_loss"][b], rtol=2e-4)
+            np.testing.assert_array_equal(res[b]["inst_preds"], g[f"l{label}.preds"][b])
+            np.testing.assert_array_equal(res[b]["inst_labels"], g[f"l{label}.targets"][b])
+    M2, _, res = m(x, label=[1, 1, 1], instance_eval=True)
+    (M2.sum() + sum(r["instance_loss"] for r in res)).backward()
+    _check_grad_entries(m.named_parameters(), g, "grad.", 3e-4, zero_keys=("attention_net.3.attention_c.bias",))

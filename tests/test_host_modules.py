@@ -44,8 +44,9 @@ def test_abmil_type_error_and_guards():
     from murcl_amd.models.abmil import ABMIL
     with pytest.raises(TypeError):
         ABMIL(512)("not a tensor")
-    with pytest.raises(NotImplementedError):
-        ABMIL(512, K=2)._bags(torch.zeros(1, 4, 512))                 # K != 1 heads: no reference script sets K
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ABMIL(512, K=2)._bags(torch.zeros(1, 4, 512))                 # K != 1 heads are built (round 5) - on the GPU only
+    assert ABMIL(512, K=3).attention[2].weight.shape == (3, 128)      # abmil.py:23-27
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ABMIL(512, L=256)._bags(torch.zeros(1, 4, 512))               # other L / D are built (general path) - on the GPU only
 
@@ -119,3 +120,19 @@ def test_stack_rows_is_a_view_when_the_blocks_are_consecutive():
     assert w.shape == (12, 4) and torch.equal(w[:6], x[:6])
     s = ops.stack_rows([x[:6, :2], x[6:, :2]])                 # strided blocks: a copy
     assert torch.equal(s, x[:, :2])
+
+
+def test_clam_sb_refuses_an_instance_loss_it_would_not_evaluate():
+    """clam.py:64-65,118,131 call the loss they were given; the fused instance branch evaluates mean cross-entropy only: None and a
+    default nn.CrossEntropyLoss() are accepted, anything else raises instead of silently producing other numbers."""
+    import pytest
+    from torch import nn
+    from murcl_amd.models.clam import CLAM_SB
+    assert isinstance(CLAM_SB().instance_loss_fn, nn.CrossEntropyLoss)
+    assert isinstance(CLAM_SB(instance_loss_fn=nn.CrossEntropyLoss()).instance_loss_fn, nn.CrossEntropyLoss)
+    for bad in (nn.CrossEntropyLoss(reduction="sum"), nn.CrossEntropyLoss(label_smoothing=0.1), nn.MultiMarginLoss(),
+                nn.CrossEntropyLoss(weight=torch.tensor([1.0, 2.0])), lambda a, b: (a.sum() + b.sum())):
+        with pytest.raises(NotImplementedError):
+            CLAM_SB(instance_loss_fn=bad)
+    m = CLAM_SB(size_arg="big", dropout=True)                     # clam.py:66-67: a 384-wide attention net (index 3 with the Dropout)
+    assert m.attention_net[3].attention_a[0].weight.shape == (384, 512) and m.attention_net[3].attention_c.weight.shape == (1, 384)

@@ -434,3 +434,73 @@ def test_g16_abmil_outside_the_default_shape(golden, case):
     np.testing.assert_allclose(A.detach().numpy(), g[f"{case}.A"], rtol=2e-5, atol=1e-8)
     out.sum().backward()
     _check_grads(g, f"{case}.grad.", p)
+
+
+# ------------------------------------------------------------------------------------------------ G18 / G19 / G20 (round 5)
+def _check_grad_entries(gold, prefix, named, rtol=2e-4):
+    """Gradients stored in full (any shape but the 34-number fingerprint) are compared entry by entry at rtol of the largest
+    entry; fingerprints as in _check_grads."""
+    n = 0
+    for k, v in named.items():
+        key = prefix + k
+        if key not in gold.files:
+            continue
+        assert v.grad is not None, key
+        want = gold[key]
+        if k.endswith("attention.2.bias") or k.endswith("attention_c.bias"):
+            scale = named[k[:-4] + "weight"].grad.abs().max().item()          # exact zeros in exact arithmetic: rounding noise on both sides
+            assert v.grad.abs().max().item() < 1e-4 * scale and np.abs(want).max() < 1e-4 * scale, key
+        elif want.shape == tuple(v.grad.shape):
+            np.testing.assert_allclose(v.grad.numpy(), want, rtol=rtol, atol=rtol * np.abs(want).max(), err_msg=key)
+        else:
+            got = _summ(v.grad)
+            np.testing.assert_allclose(got[:2], want[:2], rtol=rtol, err_msg=key)
+            np.testing.assert_allclose(got[2:], want[2:], rtol=rtol, atol=rtol * want[1], err_msg=key)
+        n += 1
+    assert n > 0
+
+
+def test_g18_clam_sb_size_big(golden):
+    """CLAM_SB(size_arg="big") (clam.py:66-67): the oracle with a 384-wide attention net vs the reference."""
+    g = golden("g18_clam_big")
+    p = _leaf(P.clam_sb(18, size=(512, 384)))
+    x = T(P.bags(18, "g18.x", 3, 300, 512))
+    M, A, s, h = O.clam_sb_forward(p, x)
+    np.testing.assert_allclose(s.detach().numpy(), g["raw"], **TOL)
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(M.detach().numpy(), g["M_batch"], **TOL)
+    for label in (0, 1):
+        for b in range(3):
+            loss, preds, tgts, *_ = O.clam_instance_eval(p, A[b], h[b], label, 2, 8, True)
+            np.testing.assert_allclose(float(loss), g[f"l{label}.inst_loss"][b], rtol=2e-5)
+            np.testing.assert_array_equal(np.asarray(preds), g[f"l{label}.preds"][b])
+            np.testing.assert_array_equal(np.asarray(tgts), g[f"l{label}.targets"][b])
+    tot = 0
+    for b in range(3):
+        loss, *_ = O.clam_instance_eval(p, A[b], h[b], 1, 2, 8, True)
+        tot = tot + M[b].sum() + loss
+    tot.backward()
+    _check_grad_entries(g, "grad.", p)
+
+
+def test_g19_abmil_with_three_attention_heads(golden):
+    """ABMIL(K=3) (abmil.py:8,23-27,38-44): out [B*K, L] bag-major, A [B, K, N], gradients of a weighted sum."""
+    g = golden("g19_abmil_heads")
+    p = _leaf(P.abmil(19, K=3, dim_out=2))
+    x = T(P.bags(19, "g19.x", 3, 200, 512))
+    out, A = O.abmil_forward_heads(p, x)
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], **TOL)
+    np.testing.assert_allclose(A.detach().numpy(), g["A"], rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(O.abmil_forward_heads(p, x[:1])[0].detach().numpy(), g["out_single"], **TOL)
+    (out * T(detrand.normal(19, "g19.w", (9, 512)))).sum().backward()
+    _check_grad_entries(g, "grad.", p)
+
+
+def test_g20_abmil_every_gradient_entry(golden):
+    """G1 with the parameter gradients stored in full: every entry of every gradient within 2e-5 of the largest."""
+    g = golden("g20_abmil_full_grads")
+    p = _leaf(P.abmil(985))
+    out, *_ = O.abmil_forward(p, T(P.bags(985, "g1.x", 4, 256, 512)))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], **TOL)
+    out.sum().backward()
+    _check_grad_entries(g, "grad.", p, rtol=2e-5)
