@@ -356,6 +356,36 @@ def other_rows(device):
     return out
 
 
+def graph_replay_ms(step, reps=50):
+    """The headline step captured ONCE as a hipGraph and replayed: GPU time of the step with no host in the loop -
+    what a 20-step window reads when the host cannot fall behind (one 8.9 ms host stall cost a 20-step region 25 %,
+    profiles/r04_zv_bench_driver_args.json), and what is left for RCCL's enqueue at W = 8.  TIMING ONLY: launch arguments are
+    frozen at capture (Adam's bias-correction step count, the weight-view refresh decision), so the replayed updates are those of
+    the captured step number; a training loop would pass the step count through device memory before replaying."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):                                   # lazily allocated per-stream state (NT-Xent exchange buffer) exists before capture
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        step()
+    for _ in range(10):
+        g.replay()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        g.replay()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(reps))
+    total = evs[0].elapsed_time(evs[reps]) / reps
+    return dict(ms_per_step_graph=round(total, 4), median_ms=round(per[reps // 2], 4), max_ms=round(per[-1], 4), replays=reps,
+                note="one captured step replayed as a hipGraph: timing only (launch arguments such as Adam's step count are frozen at capture)")
+
+
 def launch_argv(gpus, argv, port=None):
     """The command line ``python bench.py --gpus N ...`` turns itself into when no launcher started it: the driver's own form
     (one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1)."""
@@ -422,7 +452,8 @@ def comm_diagnostics(model, fc, opt, crit, views, world, device, reps=20):
     nranks = dist.get_world_size()
     z_local = torch.randn((2 * B, 128), device=device)
     zg = torch.empty((nranks * 2 * B, 128), device=device)
-    out = {"ranks": nranks, "backend": dist.get_backend(),
+    from murcl_amd import ops as _ops
+    out = {"ranks": nranks, "backend": dist.get_backend(), "cu_budget": _ops.cu_budget(),
            "z_all_gather_us": ev_median(lambda: mdist.all_gather_rows(zg, z_local)),
            "z_all_gather_bytes_per_rank": z_local.numel() * 4}
     ar = {}
@@ -496,6 +527,8 @@ def main():
     ap.add_argument("--bags", type=int, default=64)
     ap.add_argument("--patches", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
+                    help="after the timed region, capture one step as a hipGraph and report ms_per_step_graph (single GPU)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -615,6 +648,12 @@ def main():
 
     ms_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
+    graph = None
+    if world == 1 and not force_dist and args.graph:
+        try:
+            graph = graph_replay_ms(step)
+        except Exception as e:                                                 # noqa: BLE001  (a diagnostic must not take the line with it)
+            graph = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # SURVEY 8(d) classifies the kernels: the encoder-sized GEMMs (K1: forward, input gradients, weight gradients) are MFMA-bound
     # (a fused encoder moves X once: intensity ~1.7 kFLOP/B), K2 and the streaming passes are HBM-bound.  The layer-wise bytes of a
@@ -696,6 +735,8 @@ def main():
         "roofline": dict(roof(dominant), step=step_roof()),
         "roofline_k2": roof(k2_key, (k2c_key,)),
         "comm": comm,
+        "graph": graph,
+        "ms_per_step_graph": graph.get("ms_per_step_graph") if graph else None,
         "loss": round(float(loss.item()), 6),
         "step_stats": stats,
         "timed_region_host_enqueue_ms": {"median": round(sorted(host_ms)[len(host_ms) // 2], 3), "max": round(max(host_ms), 3),
@@ -740,3 +781,7 @@ def _pmc_traffic(key):
         return d.get(key), d.get("_source")
     except (OSError, ValueError):
         return None, None
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,14 @@ int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int M, int N, i
                           int rows_per_bag, float* colsum_out, int colsum_accumulate, float* colsum_ws, int walk_reverse,
                           float keep_p, unsigned long long seed_a, unsigned long long seed_b, murcl_stream_t stream);
 
+/* Launch policy of the persistent kernels (csrc/runtime.hip): the number of CUs the encoder-sized launches size their ONE round of
+ * workgroups for - 256 by default.  A data-parallel step whose RCCL collectives overlap its backward pass (the multi-GPU form of
+ * train_MuRCL.py:145's nn.DataParallel) sets 256 - (CUs left to RCCL's channels): with a static share per workgroup a launch that
+ * cannot place ALL its workgroups at once runs a second round, i.e. takes twice as long.  murcl_set_cu_budget returns the budget in
+ * force (a multiple of 8 in [64, 256]). */
+int murcl_cu_budget(void);
+int murcl_set_cu_budget(int cus);
+
 /* K2 -- ABMIL attention pooling, abmil.py:38-42:  scores[b,n] = wb.tanh(Wa H[b,n]+ba)+bb,
  * A = softmax_N(scores)/sqrt(N), M[b] = A[b].H[b];  ml[b] = (max, sum exp) of the soft-max.
  * H [B,N,L] and Wa [D,L] in `dtype`; L = 512, D = 128.  part_ws: B*n_chunks*(L+2) floats with
@@ -239,16 +247,6 @@ int murcl_dsmil_qv_bwd_cls(const float* R, const float* qmax, const float* xm, c
 int murcl_dsmil_stream_plan(int B, int N, int d, int C);
 int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale /* logits = vscale * X.v */, float* A, float* Z, float* ws,
                           int B, int N, int d, int C, int dtype, murcl_stream_t stream);
-/* soft-max over n of GIVEN logits S [B,N,C] and the pooling with it, same pass structure: A = soft-max_n(S), Z = A^T X.  CLAM-SB's
- * clam.py:144,170 behind the gate GEMM (C = 1, d = 512).  Plan / workspace as murcl_dsmil_attn_pool; A may not alias S. */
-int murcl_softmax_pool(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
-                       murcl_stream_t stream);
-/* CLAM-SB's soft-max over the patches + attention pooling (clam.py:144,170) as one streaming pass over X and a small reduce launch:
- * A [B,N] = soft-max_n(S [B,N]), Z [B,d] = sum_n A[b,n] X[b,n,:].  Every (bag, 128-row chunk) workgroup recomputes the bag's
- * statistics from its N scores, a wave keeps 8 whole rows in flight; ws: murcl_softmax_pool2_ws_floats floats (0: not covered). */
-long murcl_softmax_pool2_ws_floats(int B, int N, int d);
-int murcl_softmax_pool2(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int dtype,
-                        murcl_stream_t stream);
 int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls, float scale,
                               float* R, float* gpart, float* ws, int B, int N, int d, int C, int dtype, murcl_stream_t stream);
 int murcl_dsmil_softmax_bwd(const float* A, const float* dA, int B, int N, int C, float* dS, float* dots_ws,

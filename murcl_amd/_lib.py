@@ -28,6 +28,8 @@ SIGNATURES = {
     "murcl_panel_gemm_supported": [_I, _I, _I, _I, _I],
     "murcl_panel_gemm": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "murcl_panel_gemm_drop": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
+    "murcl_cu_budget": [],
+    "murcl_set_cu_budget": [_I],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_dropout_mask": [_P, _L, _F, _F, ctypes.c_ulonglong, _I, _P],
@@ -62,10 +64,7 @@ SIGNATURES = {
     "murcl_dsmil_qv": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "murcl_dsmil_qv_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "murcl_dsmil_qv_bwd_cls": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P],
-    "murcl_softmax_pool2_ws_floats": [_I, _I, _I],
-    "murcl_softmax_pool2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "murcl_softmax_pool": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_attn_pool_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_dsmil_softmax_bwd": [_P, _P, _I, _I, _I, _P, _P, _P],
     "murcl_clam_inst_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _P],
@@ -105,7 +104,7 @@ SIGNATURES = {
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_abmil_pool_bwd_dwa_ws_floats": _L, "murcl_softmax_pool2_ws_floats": _L, "murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
+_RESTYPE = {"murcl_abmil_pool_bwd_dwa_ws_floats": _L, "murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
 
 

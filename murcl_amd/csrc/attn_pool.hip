@@ -577,9 +577,7 @@ static int pick_chunk(int B, int N, int tr, int n_wg) {
     // rows per item: multiple of the tile height, <= K2_MAX_CHUNK, small enough to give every workgroup >= 2 items
     int chunk = ((N + tr - 1) / tr) * tr;
     if (chunk > K2_MAX_CHUNK) chunk = K2_MAX_CHUNK;
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("MURCL_K2_CHUNK"); force = e ? atoi(e) : -1; }      // dev override (rows, multiple of 32)
-    if (force >= 4 * tr && force <= K2_MAX_CHUNK && force % tr == 0) return force < chunk ? force : chunk;
+    // (tools/k2_chunk_probe.py, round 4: this choice is within 3 % of the best chunk at every (bags, rows) shape tried)
     while (chunk > 4 * tr && (long)B * ((N + chunk - 1) / chunk) < (long)K2_ITEMS_PER_WG * n_wg) {
         int c2 = ((chunk / 2 + tr - 1) / tr) * tr;
         if (c2 == chunk) break;
@@ -605,7 +603,7 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     const int items = B * S;
-    const int max_grid = 256 * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
+    const int max_grid = murcl_cu_budget() * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
     const int grid = items < max_grid ? items : max_grid;
 #define K2_LAUNCH(T, EX)                                                                                        \
     {                                                                                                           \

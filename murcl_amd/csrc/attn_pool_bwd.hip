@@ -295,7 +295,7 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     const int items = B * S;
-    const int max_grid = 256 * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
+    const int max_grid = murcl_cu_budget() * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
     const int grid = items < max_grid ? items : max_grid;
     const float isn = 1.0f / sqrtf((float)N);
 #define KB_LAUNCH(T, EX)                                                                                       \

@@ -558,7 +558,8 @@ extern "C" int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_ro
 static int kd_grid(int B, int N, int* chunk, int* S) {
     murcl_abmil_pool_workspace(B, N, MURCL_DTYPE_BF16, chunk, S);
     const int items = B * *S;
-    return items < 256 ? items : 256;
+    const int cap = murcl_cu_budget();
+    return items < cap ? items : cap;
 }
 
 // C-ABI: see include/murcl_amd.h

@@ -372,97 +372,6 @@ extern "C" int murcl_gated_score_bwd_il(const void* U, const float* wc, const fl
                          h, dM, Mp, A, L, rows_per_bag, st);
 }
 
-// ---------------------------------------------------------------- CLAM-SB's soft-max + pooling (clam.py:144,170), round 4
-// A [B,N] = soft-max_n(S [B,N]),  M [B,d] = sum_n A[b,n] X[b,n,:]  as ONE streaming pass over X plus a small reduce: a workgroup
-// (bag, chunk of rows) first takes the bag's soft-max statistics from its N scores (16 KiB at N = 4096: L2-resident, recomputed by
-// every chunk of the bag), then a wave takes 8 rows at a time - one 16-byte load per lane and row = whole 1 KiB rows, 8 in flight -
-// with the weights e^{S-m}/l formed on the way, writes A for its rows and leaves the chunk's partial row [d] in the workspace; the
-// second launch adds up a bag's chunk rows (no memset, no float atomics).  Replaces softmax_rows + zero-fill + weighted_rowsum
-// (15 + 5.6 + 67.6 us at C3) and the online-soft-max pass murcl_softmax_pool (four rows in flight: latency-bound).
-#define SP2_ROWS 128                 // rows per workgroup
-template <typename T>
-__global__ __launch_bounds__(256) void softmax_pool2_kernel(const T* __restrict__ X, const float* __restrict__ S,
-                                                            float* __restrict__ A, float* __restrict__ part, int N, int d) {
-    __shared__ float red[256];
-    __shared__ float accs[4][512];
-    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* s = S + (size_t)b * N;
-    // ---- the bag's statistics
-    float mx = -INFINITY;
-    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, s[n]);
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int n = tid; n < N; n += 256) sum += expf(s[n] - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    const float rl = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    // ---- rows of this chunk, 8 per wave and batch; columns 8 lane + 512 k
-    const int r0 = chunk * SP2_ROWS, r1 = min(N, r0 + SP2_ROWS);
-    const T* x = X + (size_t)b * N * d;
-    for (int c0 = 8 * lane; c0 < d; c0 += 512) {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int n0 = r0 + wave * 8; n0 < r1; n0 += 32) {
-            float v[8][8], w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int n = min(n0 + u, r1 - 1);
-                load8<T>(x + (size_t)n * d + c0, v[u]);
-                w[u] = (n0 + u < r1) ? expf(s[n] - mx) * rl : 0.f;
-            }
-            if (c0 < 512 && lane < 8 && n0 + lane < r1) A[(size_t)b * N + n0 + lane] = expf(s[n0 + lane] - mx) * rl;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w[u] * v[u][e];
-        }
-        // the four waves' partial sums meet in LDS; 256 threads write the chunk's 512 columns of this pass
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) accs[wave][8 * lane + e] = acc[e];
-        __syncthreads();
-        float* prow = part + ((size_t)b * gridDim.x + chunk) * d + (c0 - 8 * lane);
-        for (int c = tid; c < 512 && (c0 - 8 * lane) + c < d; c += 256)
-            prow[c] = (accs[0][c] + accs[1][c]) + (accs[2][c] + accs[3][c]);
-    }
-}
-// Z[b, c] = sum_chunk part[b][chunk][c]
-__global__ __launch_bounds__(256) void softmax_pool2_reduce_kernel(const float* __restrict__ part, float* __restrict__ Z, int nchunk, int d) {
-    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
-    const float* p = part + (size_t)b * nchunk * d + c;
-    float t4[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < nchunk; k += 4)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t4[u] += p[(size_t)(k + u) * d];
-    for (; k < nchunk; ++k) t4[0] += p[(size_t)k * d];
-    Z[(size_t)b * d + c] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
-}
-// floats of workspace murcl_softmax_pool2 wants (0: shape not covered -> softmax_rows + weighted_rowsum)
-extern "C" long murcl_softmax_pool2_ws_floats(int B, int N, int d) {
-    if (B <= 0 || N <= 0 || d <= 0 || d % 512) return 0;          // (a wave spans 512 columns per pass; every lane takes part in each)
-    return (long)B * ((N + SP2_ROWS - 1) / SP2_ROWS) * d;
-}
-extern "C" int murcl_softmax_pool2(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int dtype,
-                                   hipStream_t st) {
-    if (B <= 0) return 0;
-    if (!murcl_softmax_pool2_ws_floats(B, N, d) || !ws) return -1;
-    const int nchunk = (N + SP2_ROWS - 1) / SP2_ROWS;
-    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(softmax_pool2_kernel<float>, dim3(nchunk, B), dim3(256), 0, st, (const float*)X, S, A, ws, N, d);
-    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(softmax_pool2_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, (const bf16_t*)X, S, A, ws, N, d);
-    else return -1;
-    int rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    hipLaunchKernelGGL(softmax_pool2_reduce_kernel, dim3((d + 255) / 256, B), dim3(256), 0, st, (const float*)ws, Z, nchunk, d);
-    return MURCL_CHECK_LAUNCH();
-}
-
 // ---------------------------------------------------------------- soft-max over the N patches of each bag
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, float* __restrict__ A, int N) {
     __shared__ float red[256];

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define MURCL_CHECK_LAUNCH() ((int)hipGetLastError())
 
+extern "C" int murcl_cu_budget(void);      // runtime.hip: CUs the persistent launches size their one round of workgroups for (256 by default)
+
 // hipFuncSetAttribute applies to the current device only: call sites remember which devices they have prepared
 // (one process per GPU is the norm, but a process that drives several devices must raise the LDS limit on each).
 struct MurclOncePerDevice {

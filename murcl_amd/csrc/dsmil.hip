@@ -854,31 +854,6 @@ extern "C" int murcl_dsmil_attn_pool(const void* X, const float* v, float vscale
                        (const float*)A, A, N);
     return MURCL_CHECK_LAUNCH();
 }
-// The same soft-max + pooling pass for logits that already exist (CLAM-SB: the gate GEMM's epilogue produced them, clam.py:144,170):
-// A [B,N,C] = soft-max_n(S), Z [B,C,d] = A^T X, one pass over X + merge + normalise instead of soft-max, zero-fill and an atomically
-// accumulated weighted row sum.  Same plan / workspace as murcl_dsmil_attn_pool.
-extern "C" int murcl_softmax_pool(const void* X, const float* S, float* A, float* Z, float* ws, int B, int N, int d, int C, int dtype,
-                                  hipStream_t s) {
-    if (B <= 0) return 0;
-    const int rpw = murcl_dsmil_stream_plan(B, N, d, C);
-    if (!rpw || !ws) return -1;
-    const long rows = (long)B * N, waves = rows / rpw;
-    float* part = ws;
-    float* stat = part + waves * C * d;
-    float* ml = stat + waves * C * 2;
-    dim3 grid((unsigned)((waves + 3) / 4));
-    if (dtype == MURCL_DTYPE_F32)
-        hipLaunchKernelGGL((dsmil_stream_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)X, nullptr, S, nullptr, N, d, C, rpw, nullptr, part, stat, nullptr, rows, 1.f);
-    else if (dtype == MURCL_DTYPE_BF16)
-        hipLaunchKernelGGL((dsmil_stream_kernel<bf16_t, 2>), grid, dim3(256), 0, s, (const bf16_t*)X, nullptr, S, nullptr, N, d, C, rpw, nullptr, part, stat, nullptr, rows, 1.f);
-    else
-        return -1;
-    int rc = MURCL_CHECK_LAUNCH();
-    if (rc) return rc;
-    hipLaunchKernelGGL(dsmil_merge_kernel<0>, dim3(B * C, (d + 63) / 64), dim3(256), 0, s, part, stat, N / rpw, d, C, nullptr, 1.f, Z, ml,
-                       S, A, N);
-    return MURCL_CHECK_LAUNCH();
-}
 extern "C" int murcl_dsmil_attn_pool_bwd(const void* X, const float* dZ, const float* A, const float* Z, const float* dcls /* may be NULL */,
                                          float scale, float* R, float* gpart /* [B*N/plan][C*d], with dcls */, float* ws, int B, int N,
                                          int d, int C, int dtype, hipStream_t s) {

@@ -285,150 +285,12 @@ static int launch_nt_epi(const T* A, const T* B, OutT* C, int M, int N, int K, i
     return MURCL_CHECK_LAUNCH();
 }
 
-// ------------------------------------------------------------------------------------- skinny NT (f32, M <= 128)
-// Bag-level layers (decoder, GRU projections, heads): M = bags (<= 128 rows), so a 128x128-tile grid has only
-// N/128 workgroups.  Here a workgroup owns a 32-column slab and one K split; A and B fragments come straight
-// from global memory (the operands are a few hundred KiB and L2-resident), 16x16x4 f32 MFMA, partial results
-// are added atomically into C, which the launcher pre-sets (memset; split 0 adds the bias).
-__global__ __launch_bounds__(256) void gemm_nt_skinny_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                                 float* __restrict__ C, int M, int N, int K, int lda,
-                                                                 int ldb, int ldc, const float* __restrict__ bias,
-                                                                 int k_per_split, int relu, int accumulate) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q4 = lane >> 4, r16 = lane & 15;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.z * 128 + wave * 32;       // blockIdx.z: 128-row chunks (M <= 1024)
-    if (m0 >= M) return;
-    const int kb = blockIdx.y * k_per_split, ke = min(K, kb + k_per_split);
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap[2];
-    const float* bp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ap[i] = A + (size_t)min(m0 + 16 * i + r16, M - 1) * lda + 4 * q4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bp[j] = B + (size_t)min(n0 + 16 * j + r16, N - 1) * ldb + 4 * q4;
-    // K % 16 == 0 (checked by the launcher).  The weights stream from HBM and nothing else hides that latency (a
-    // workgroup's whole job is a few KiB), so the loads of four k-steps (a 64-k chunk) are all issued before its first
-    // MFMA, and the NEXT chunk's loads are issued before this chunk's MFMAs (two register sets, ping-pong): after the
-    // first round trip the chunks arrive back to back instead of one memory round trip each (a 512-deep layer was four
-    // serial round trips: 13-26 us per launch, the largest single item of the sampler-in-the-loop steps).
-    constexpr int CH = 64, NU = CH / 16;
-    f32x4 a0[NU][2], b0[NU][2], a1[NU][2], b1[NU][2];
-    auto load_chunk = [&](f32x4 (&a)[NU][2], f32x4 (&b)[NU][2], int k0) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int kk = min(k0 + 16 * u, ke - 16);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[u][i] = *(const f32x4*)(ap[i] + kk);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[u][j] = *(const f32x4*)(bp[j] + kk);
-        }
-    };
-    auto mma_chunk = [&](f32x4 (&a)[NU][2], f32x4 (&b)[NU][2], int k0) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            if (k0 + 16 * u < ke) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mma16<float>(a[u][i], b[u][j], acc[i][j]);   // rows <- m, cols <- n
-            }
-        }
-    };
-    load_chunk(a0, b0, kb);
-    for (int k0 = kb; k0 < ke; k0 += 2 * CH) {
-        if (k0 + CH < ke) load_chunk(a1, b1, k0 + CH);
-        mma_chunk(a0, b0, k0);
-        if (k0 + 2 * CH < ke) load_chunk(a0, b0, k0 + 2 * CH);
-        if (k0 + CH < ke) mma_chunk(a1, b1, k0 + CH);
-    }
-    // lane holds C[m0 + 16i + 4q4 + r][n0 + 16j + r16]: the 16 lanes of a quarter add to 64 contiguous bytes of a row
-    // (float atomics execute at the memory side per 64-byte request; one lane per line would be ~10x slower)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 16 * j + r16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * i + 4 * q4 + r;
-                if (m < M && n < N) {
-                    float v = acc[i][j][r];
-                    if (bias && blockIdx.y == 0) v += bias[n];
-                    float* cp = C + (size_t)m * ldc + n;
-                    if (gridDim.y == 1) {          // the only writer of this element: plain store, epilogue in place
-                        if (accumulate) v += *cp;
-                        *cp = relu ? fmaxf(v, 0.f) : v;
-                    } else {
-                        atomicAdd(cp, v);
-                    }
-                }
-            }
-        }
-}
-// Second skinny form: a workgroup owns 64 rows x 16 columns (one 16 x 16 MFMA tile per wave) and the whole K range with a
-// SINGLE writer per element.  Against the 128 x 32 form above: four times the workgroups for the same output (a 128-row
-// layer with 512 outputs is 64 workgroups instead of 16 - on the exact-f32 matrix pipe, 64 FLOP/clk/SIMD, a workgroup of
-// the wide form spends ~8 us in MFMAs alone at K = 512), 256 k of both operands in flight per wave in each of two
-// register sets (K <= 512: one memory round trip), no memset, no float atomics, bias / ReLU in the epilogue.
-__global__ __launch_bounds__(256) void gemm_nt_skinny16_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                                   float* __restrict__ C, int M, int N, int K, int lda,
-                                                                   int ldb, int ldc, const float* __restrict__ bias,
-                                                                   int relu, int accumulate) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q4 = lane >> 4, r16 = lane & 15;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 64 + wave * 16;
-    if (m0 >= M) return;
-    const float* ap = A + (size_t)min(m0 + r16, M - 1) * lda + 4 * q4;
-    const float* bp = B + (size_t)min(n0 + r16, N - 1) * ldb + 4 * q4;
-    constexpr int NU = 16;                                   // 16-k steps per register set (256 k)
-    f32x4 a0[NU], b0[NU], a1[NU], b1[NU];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: the f32 MFMA's dependent latency exceeds its issue time
-    auto load_set = [&](f32x4 (&a)[NU], f32x4 (&b)[NU], int k0) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int kk = min(k0 + 16 * u, K - 16);
-            a[u] = *(const f32x4*)(ap + kk);
-            b[u] = *(const f32x4*)(bp + kk);
-        }
-    };
-    auto mma_set = [&](f32x4 (&a)[NU], f32x4 (&b)[NU], int k0) {
-#pragma unroll
-        for (int u = 0; u < NU; u += 2) {
-            if (k0 + 16 * u < K) acc0 = mma16<float>(a[u], b[u], acc0);
-            if (k0 + 16 * (u + 1) < K) acc1 = mma16<float>(a[u + 1], b[u + 1], acc1);
-        }
-    };
-    load_set(a0, b0, 0);
-    for (int k0 = 0; k0 < K; k0 += 2 * 16 * NU) {
-        if (k0 + 16 * NU < K) load_set(a1, b1, k0 + 16 * NU);
-        mma_set(a0, b0, k0);
-        if (k0 + 2 * 16 * NU < K) load_set(a0, b0, k0 + 2 * 16 * NU);
-        if (k0 + 16 * NU < K) mma_set(a1, b1, k0 + 16 * NU);
-    }
-    // lane holds C[m0 + 4q4 + r][n0 + r16]: the 16 lanes of a quarter write 64 contiguous bytes of a row
-    const int n = n0 + r16;
-    if (n < N) {
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * q4 + r;
-            if (m < M) {
-                float v = acc0[r] + acc1[r] + bv;
-                float* cp = C + (size_t)m * ldc + n;
-                if (accumulate) v += *cp;
-                *cp = relu ? fmaxf(v, 0.f) : v;
-            }
-        }
-    }
-}
-// Third skinny form: the operands go through LDS.  The two register forms above read their fragments straight from global
-// memory: one 16-byte load per lane covers 16 ROWS x 64 bytes - sixteen cache lines per instruction, half of each unused -
-// and the texture-address path, not the matrix pipe or the memory system, sets their time (a 64 x 16 x 512 workgroup
-// takes ~9 us however hot its operands are; `tools/skinny_trace.sh`).  Here a workgroup owns a 32 x 32 output tile; its 32
+// ------------------------------------------------------------------------------------- bag-level NT (f32, M <= 1024)
+// Bag-level layers (decoder, GRU projections, heads): M = bags, so a 128 x 128-tile grid has only N/128 workgroups.  The operands
+// go through LDS: fragments read straight from global memory (the two register-direct forms of rounds 1-2, removed in round 5)
+// are one 16-byte load per lane = 16 ROWS x 64 bytes - sixteen cache lines per instruction, half of each unused - and the
+// texture-address path, not the matrix pipe or the memory system, set their time (a 64 x 16 x 512 workgroup took ~9 us however hot
+// its operands; LOG.md round 2).  Here a workgroup owns a 32 x 32 output tile; its 32
 // rows of A and 32 rows of B arrive by LDS-DMA as whole 1 KiB row pieces (256 k, eight full lines per instruction, shared by
 // the four waves) into two chunk buffers with rows at a stride of 1024 + 16 bytes (conflict-free 16-byte fragment reads,
 // the K2 layout); K <= 512 is in flight at once, longer reductions ping-pong.  Single writer per element: no memset, no
@@ -518,21 +380,11 @@ __global__ __launch_bounds__(256) void gemm_nt_lds32_f32_kernel(const float* __r
         }
     }
 }
-static int skinny_lds_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MURCL_SKINNY_LDS"); v = (e && e[0] == '0') ? 0 : 1; }    // dev A/B switch
-    return v;
-}
 __global__ void relu_inplace_kernel(float* x, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fmaxf(x[i], 0.f);
 }
 
-static int skinny16_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MURCL_SKINNY16"); v = (e && e[0] == '0') ? 0 : 1; }     // dev A/B switch
-    return v;
-}
 // K splits of the LDS form for this shape (1: single writer per element - bias / ReLU / mask / accumulate in the epilogue)
 static int skinny_lds_splits(int M, int N, int K) {
     const long sl_tiles = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
@@ -549,94 +401,41 @@ static int skinny_lds_splits(int M, int N, int K) {
 bool murcl_nt_t16_ok(int M, int N, int K);
 int murcl_nt_t16_launch(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, const float* bias,
                         int relu, int accumulate, const float* mask, int ldmask, hipStream_t stream);
-static int nt_t16_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MURCL_NT_T16"); v = (e && e[0] == '0') ? 0 : 1; }        // dev A/B switch
-    return v;
-}
-static int nt_t16_few_tiles() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("MURCL_NT_T16_FEW"); v = e ? atoi(e) : 64; }            // dev A/B knob (0: rule off); 64 tiles -> 256 of the 16 x 16 kind: one round
-    return v;
-}
+constexpr int NT_T16_FEW_TILES = 64;       // products of at most this many 32 x 32 tiles (= 256 of the 16 x 16 kind: one round) ...
+constexpr int NT_T16_MIN_CHUNKS = 2;       // ... with at least this many 256-k chunks take the 16 x 16 form ([128 x 512 x 512]: 7.2 -> 4.8 us; at 128 tiles it loses: profiles/r04_w_*)
 static int launch_skinny(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                          int epi, const float* bias, int accumulate, hipStream_t s, const float* mask = nullptr, int ldmask = 0) {
     // few outputs, long reduction - the shapes the LDS form below would split over K (zero-fill + atomics + a ReLU launch): 16 x 16
     // tiles with the K range split over the waves of one workgroup instead, everything in one launch
     // (also a handful of tiles with three or more chunks each: [128 x 128 x 1024] is 16 workgroups walking 4 chunks, or 64 with all four in flight)
     const long sl_tiles_ = (long)((M + SL_T - 1) / SL_T) * ((N + SL_T - 1) / SL_T);
-    static int minch = -2;
-    if (minch == -2) { const char* e = getenv("MURCL_NT_T16_MINCH"); minch = e ? atoi(e) : 2; }   // dev A/B knob ([128 x 512 x 512]: 7.2 us on 64 tiles of 32 x 32, 4.8 us on 256 of 16 x 16)
-    const bool few_long = sl_tiles_ <= nt_t16_few_tiles() && (K + SL_K - 1) / SL_K >= minch;
-    if (skinny_lds_enabled() && nt_t16_enabled() && (skinny_lds_splits(M, N, K) > 1 || few_long) && murcl_nt_t16_ok(M, N, K))
+    const bool few_long = sl_tiles_ <= NT_T16_FEW_TILES && (K + SL_K - 1) / SL_K >= NT_T16_MIN_CHUNKS;
+    if ((skinny_lds_splits(M, N, K) > 1 || few_long) && murcl_nt_t16_ok(M, N, K))
         return murcl_nt_t16_launch(A, B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
                                    (int)(epi == EPI_BIAS_RELU), accumulate, epi == EPI_MASK ? mask : nullptr, ldmask, s);
     // LDS form.  Long reductions with few output tiles that the 16 x 16 form above does not take (N not a multiple of 16) are split
     // over K (per 256-k chunk a workgroup needs ~2 us - one DMA round trip is not covered by one chunk of MFMAs - so
     // [128 x 512 x 3072] on 64 workgroups x 12 chunks took 26 us) so that every workgroup has its whole share (two chunks) in
     // flight at once; those partial tiles meet in a zeroed C by atomics.
-    if (skinny_lds_enabled()) {
-        const int sp = skinny_lds_splits(M, N, K);
-        const int kps = ((((K + SL_K - 1) / SL_K) + sp - 1) / sp) * SL_K;
-        if (sp > 1 && !accumulate) {
-            hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
-            if (e != hipSuccess) return (int)e;
-        }
-        const bool relu = epi == EPI_BIAS_RELU;
-        static MurclOncePerDevice once;
-        if (once.first())
-            hipFuncSetAttribute((const void*)gemm_nt_lds32_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL_BUF);
-        // more than ~1.5 rounds of workgroups at one per CU: half the LDS, two per CU (MURCL_NT_ONE_SLOT: dev override)
-        static int force = -2;
-        if (force == -2) { const char* e = getenv("MURCL_NT_ONE_SLOT"); force = e ? atoi(e) : -1; }
-        const long wgs = (long)((N + SL_T - 1) / SL_T) * ((M + SL_T - 1) / SL_T) * sp;
-        const int one_slot = force >= 0 ? force : (int)(wgs > 384 && K > SL_K);
-        hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T, sp), dim3(256), one_slot ? SL_BUF : 2 * SL_BUF, s, A,
-                           B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
-                           (int)(relu && sp == 1), (int)(accumulate && sp == 1), kps, epi == EPI_MASK ? mask : nullptr, ldmask, one_slot);
-        int rc = MURCL_CHECK_LAUNCH();
-        if (rc) return rc;
-        if (relu && sp > 1) {
-            if (ldc != N) return -1;
-            const long n = (long)M * N;
-            hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, n);
-            rc = MURCL_CHECK_LAUNCH();
-        }
-        return rc;
-    }
-    if (K <= 512 && (long)((N + 15) / 16) * ((M + 63) / 64) <= 384 && skinny16_enabled()) {
-        // short reductions that fit one wave of workgroups: 64 x 16 single-writer workgroups, the whole K range in one memory
-        // round trip (measured per shape, tools/skinny_shapes.py: [128 x 512 x 512] 14.4 -> 11.1 us, [64 x 2048 x 512]
-        // 15.4 -> 11.3 us; K = 1024 with few outputs and grids beyond ~1.5 workgroups per CU are faster on the split form)
-        hipLaunchKernelGGL(gemm_nt_skinny16_f32_kernel, dim3((N + 15) / 16, (M + 63) / 64), dim3(256), 0, s, A, B, C, M, N, K, lda,
-                           ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, (int)(epi == EPI_BIAS_RELU),
-                           accumulate);
-        return MURCL_CHECK_LAUNCH();
-    }
-    const int slabs = (N + 31) / 32, chunks = (M + 127) / 128;
-    int splits = (384 + slabs * chunks - 1) / (slabs * chunks);         // ~1.5 workgroups per CU
-    // 64 or more single-writer workgroups: no K split - one launch instead of memset + atomics (+ a ReLU pass), and a
-    // result that does not depend on the order of float atomics.  (Fewer, longer streams are slower even with two chunks
-    // in flight per workgroup: a 512-deep layer on 16 single-writer workgroups took 20 % longer than 64 x 128-k splits.)
-    if (slabs * chunks >= 64) splits = 1;
-    const int kmax = (K + 127) / 128;                       // at least one 128-k chunk per split
-    if (splits > kmax) splits = kmax;
-    if (splits < 1) splits = 1;
-    int kps = ((K / 16 + splits - 1) / splits) * 16;
-    kps = ((kps + 127) / 128) * 128;
-    splits = (K + kps - 1) / kps;
-    const bool direct = splits == 1;                        // single writer per element: no zero-fill, no atomics
-    if (!direct && !accumulate) {
+    const int sp = skinny_lds_splits(M, N, K);
+    const int kps = ((((K + SL_K - 1) / SL_K) + sp - 1) / sp) * SL_K;
+    if (sp > 1 && !accumulate) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, M, s);
         if (e != hipSuccess) return (int)e;
     }
     const bool relu = epi == EPI_BIAS_RELU;
-    hipLaunchKernelGGL(gemm_nt_skinny_f32_kernel, dim3(slabs, splits, chunks), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                       (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr, kps, (int)(relu && direct),
-                       (int)(accumulate && direct));
+    static MurclOncePerDevice once;
+    if (once.first())
+        hipFuncSetAttribute((const void*)gemm_nt_lds32_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SL_BUF);
+    // more than ~1.5 rounds of workgroups at one per CU: half the LDS, two per CU (profiles/r04_r_nt_oneslot*.txt)
+    const long wgs = (long)((N + SL_T - 1) / SL_T) * ((M + SL_T - 1) / SL_T) * sp;
+    const int one_slot = (int)(wgs > 384 && K > SL_K);
+    hipLaunchKernelGGL(gemm_nt_lds32_f32_kernel, dim3((N + SL_T - 1) / SL_T, (M + SL_T - 1) / SL_T, sp), dim3(256), one_slot ? SL_BUF : 2 * SL_BUF, s, A,
+                       B, C, M, N, K, lda, ldb, ldc, (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? bias : nullptr,
+                       (int)(relu && sp == 1), (int)(accumulate && sp == 1), kps, epi == EPI_MASK ? mask : nullptr, ldmask, one_slot);
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
-    if (relu && !direct) {
+    if (relu && sp > 1) {
         if (ldc != N) return -1;
         const long n = (long)M * N;
         hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C, n);
@@ -662,8 +461,8 @@ extern "C" int murcl_gemm_nt(const void* A, const void* B, void* C, int M, int N
     // the 128 x 128 tile kernel would put e.g. [320 x 2048] x [512 x 2048]^T on 12 workgroups (86 us against ~15)
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32 && M <= 1024 && K % 16 == 0 && !colsum_ws &&
         (epilogue == EPI_NONE || epilogue == EPI_BIAS || (epilogue == EPI_BIAS_RELU && !accumulate && ldc == N) ||
-         (epilogue == EPI_MASK && mask && skinny_lds_enabled() &&
-          (skinny_lds_splits(M, N, K) == 1 || (nt_t16_enabled() && murcl_nt_t16_ok(M, N, K))))))
+         (epilogue == EPI_MASK && mask &&
+          (skinny_lds_splits(M, N, K) == 1 || murcl_nt_t16_ok(M, N, K)))))
         return launch_skinny((const float*)A, (const float*)B, (float*)C, M, N, K, lda, ldb, ldc, epilogue, bias,
                              accumulate, stream, (const float*)mask, ldmask);
     GemmEpi e{bias, mask, ldmask, rowscale, rank1, rows_per_bag > 0 ? rows_per_bag : 1, colsum_ws, accumulate};
@@ -1325,12 +1124,13 @@ static bool tn_group_plan(int n, const int* M, const int* N1, const int* N2, TnP
     int pairs = 0;
     for (int g = 0; g < n; ++g) {
         pl->tiles[g] = (N1[g] / 256) * (N2[g] / 256);
-        if (pl->tiles[g] > 32) return false;              // a (product, split) group must fit an XCD's 32 workgroup slots
+        if (pl->tiles[g] > murcl_cu_budget() / 8) return false;      // a (product, split) group must fit an XCD's workgroup slots
         work += (long)pl->tiles[g] * M[g];
         pairs += pl->tiles[g];
     }
-    if (pairs > TN_MAXWG) return false;
-    long R = ((work + TN_MAXWG - 1) / TN_MAXWG + 31) / 32 * 32;        // rows per workgroup, whole slabs
+    const int cap = murcl_cu_budget();                                  // workgroups of the one round (<= TN_MAXWG), cap / 8 per XCD
+    if (pairs > cap) return false;
+    long R = ((work + cap - 1) / cap + 31) / 32 * 32;                  // rows per workgroup, whole slabs
     if (R < 8 * 32) R = 8 * 32;                                        // keep >= 8 slabs per split
     for (;; R += ((R >> 8) + 31) / 32 * 32) {             // (steps of ~0.4 %: the search ends within a few hundred probes for any row counts)
         int total = 0;
@@ -1338,7 +1138,7 @@ static bool tn_group_plan(int n, const int* M, const int* N1, const int* N2, TnP
             pl->sp[g] = (int)((M[g] + R - 1) / R);
             total += pl->sp[g] * pl->tiles[g];
         }
-        if (total <= TN_MAXWG) { pl->wgs = total; break; }
+        if (total <= cap) { pl->wgs = total; break; }
     }
     long off = 0;
     for (int g = 0; g < n; ++g) {
@@ -1361,7 +1161,7 @@ static bool tn_group_plan(int n, const int* M, const int* N1, const int* N2, TnP
             if (s >= pl->sp[g]) continue;
             int x = 0;
             for (int k = 1; k < 8; ++k) if (used[k] < used[x]) x = k;
-            if (used[x] + pl->tiles[g] > 32) { fits = false; break; }
+            if (used[x] + pl->tiles[g] > cap / 8) { fits = false; break; }
             for (int t = 0; t < pl->tiles[g]; ++t) map[x + 8 * (used[x] + t)] = ((unsigned)g << 28) | ((unsigned)t << 16) | (unsigned)s;
             used[x] += pl->tiles[g];
         }
@@ -1488,22 +1288,14 @@ __global__ __launch_bounds__(256) void gemm_tn_small_group_kernel(const TnSmallG
 }
 // Rows of the reduction per pass through LDS (2 x 128 bytes per row).  One pass (the whole reduction in flight, one memory round
 // trip) when a single round of workgroups covers the tiles; several shorter passes when there are more tiles than that - the
-// smaller footprint puts more workgroups on a CU and THEIR round trips overlap (MURCL_TN_PASS: dev override)
+// smaller footprint puts more workgroups on a CU and THEIR round trips overlap (profiles/r04_r_tn_pass*.txt)
 static int tn_small_pass_rows(int M, long tiles) {
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("MURCL_TN_PASS"); force = e ? atoi(e) : -1; }
     int pr = TS_MAXM;
-    if (force > 0) pr = force;
-    else if (tiles > 512 && M > 192) pr = ((M + 1) / 2 + 15) & ~15;
+    if (tiles > 512 && M > 192) pr = ((M + 1) / 2 + 15) & ~15;
     pr = (pr + 15) & ~15;
     if (pr > TS_MAXM) pr = TS_MAXM;
     if (pr < 16) pr = 16;
     return pr;
-}
-static int tn_small_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MURCL_TN_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }       // dev A/B switch
-    return v;
 }
 
 
@@ -1540,7 +1332,7 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
     // one pass only: at M = 768 (the deferred head gradients of a T = 6 step) two serial passes per 32 x 32 tile take 78 us where
     // the 128 x 128 ring kernel below takes 55 us ([768 x 3072 x 512], tools/tn_trace.sh); up to 512 rows the small tiles win
     // (16.6 -> 12.2 us [128 x 3072 x 512], 7.7 -> 5.8 us [128 x 512 x 512], 23.7 -> 18.0 us [320 x 2048 x 512])
-    if (dtype == MURCL_DTYPE_F32 && !x3 && splits <= 0 && M <= TS_MAXM && tn_small_enabled()) {
+    if (dtype == MURCL_DTYPE_F32 && !x3 && splits <= 0 && M <= TS_MAXM) {
         const int pr = tn_small_pass_rows(M, (long)((N1 + TS_T - 1) / TS_T) * ((N2 + TS_T - 1) / TS_T));
         const int mp = ((M < pr ? M : pr) + 15) & ~15;
         static MurclOncePerDevice once;
@@ -1562,9 +1354,11 @@ extern "C" int murcl_gemm_tn(const void* A, const void* B, float* C, int M, int 
         // [131072 x 128]^T [. x 1024] 71 -> 63 us (32 instead of 64), the deferred head gradients [768 x 3072]^T [. x 512]
         // f32 56 -> 40 us (3 instead of 8) and [. x 1024] 99 -> 62 us (2 instead of 8); the exact-f32 dWq [131072 x 128]^T [. x 1024] is MFMA-bound
         // (313 against 289 us with two workgroups per CU: long f32 reductions keep the 512-workgroup target)
-        const int target = (dtype == MURCL_DTYPE_F32 && !x3 && M >= 16384) ? 512 : 256;
+        const int target = (dtype == MURCL_DTYPE_F32 && !x3 && M >= 16384) ? 2 * murcl_cu_budget() : murcl_cu_budget();
         splits = (target + t1 * t2 - 1) / (t1 * t2);
         if (splits >= 8) splits = ((splits + 7) / 8) * 8;                       // multiples of 8: the XCD-aware work map
+        if (murcl_cu_budget() < 256 && splits >= 8)                             // a reduced CU budget is a cap: round DOWN
+            while (splits > 8 && splits * t1 * t2 > target) splits -= 8;
         while (splits > 8 && (long)(splits - 8) * rows * 4 >= M) splits -= 8;   // keep >= 4 slabs per split
         while (splits > 1 && splits < 8 && (long)(splits - 1) * rows * 4 >= M) --splits;
     }
@@ -1677,7 +1471,7 @@ extern "C" long murcl_gemm_tn_grouped_workspace_bytes(const TnProblem* pr, int n
 }
 // f32 products of a few hundred rows each (the single-product path would take gemm_tn_small_f32_kernel for every one of them)
 static bool tn_small_group_ok(const TnProblem* pr, int n, int dtype) {
-    if (dtype != MURCL_DTYPE_F32 || n < 1 || n > 4 || !tn_small_enabled()) return false;
+    if (dtype != MURCL_DTYPE_F32 || n < 1 || n > 4) return false;
     bool flagged = false;
     for (int g = 0; g < n; ++g) flagged |= pr[g].flags != 0;
     if (n == 1 && !flagged) return false;                      // a single plain product: murcl_gemm_tn's own dispatch

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 
 // workgroups of a launch: one per CU, fewer (a multiple of 8 per column panel) when there are not enough row tiles
 static int pg_grid(int M, int panels) {
-    int grid = 256;
+    int grid = murcl_cu_budget() / (8 * panels) * (8 * panels);      // (the block -> (panel, stream) map wants whole groups of 8 per panel)
     const int n_tiles = M / PG_TR;
     if (n_tiles * panels < grid) grid = ((n_tiles * panels + 8 * panels - 1) / (8 * panels)) * 8 * panels;
     return grid;

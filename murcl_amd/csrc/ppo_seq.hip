@@ -218,11 +218,6 @@ static int ps_nt(const float* A, const float* B, float* C, int M, int N, int K, 
     return murcl_gemm_nt(A, B, C, M, N, K, K, K, N, MURCL_F32, MURCL_F32, epi, bias, nullptr, 0, nullptr, nullptr, 0, nullptr,
                          accumulate, s);
 }
-static int ps_gru_step() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MURCL_GRU_STEP"); v = (e && e[0] == '0') ? 0 : 1; }      // dev A/B switch
-    return v;
-}
 static int ps_shape_ok(int S, int H, int K) {
     return S > 0 && H > 0 && K > 0 && K <= PS_MAXK && S % 32 == 0 && H % 32 == 0;
 }
@@ -245,7 +240,7 @@ extern "C" int murcl_ppo_act(const float* const* params, int S, int H, int K, co
     float* gates = gh + (size_t)B * 3 * H;
     PS_CHECK(ps_nt(state, params[P_W1], e1, B, PS_E1, S, MURCL_EPI_BIAS_RELU, params[P_B1], 0, stream));
     PS_CHECK(ps_nt(e1, params[P_W2], e2, B, H, PS_E1, MURCL_EPI_BIAS_RELU, params[P_B2], 0, stream));
-    if (ps_gru_step() && murcl_gru_step_supported(B, H, H)) {                                    // (hidden_prev NULL: the zero state)
+    if (murcl_gru_step_supported(B, H, H)) {                                    // (hidden_prev NULL: the zero state)
         // the GRU cell as ONE launch: both products of a 16 x 16-unit tile of the three gate blocks, gates in the epilogue
         PS_CHECK(murcl_gru_step_fwd(e2, params[P_WIH], H, params[P_BIH], hidden_prev, params[P_WHH], params[P_BHH], hidden_new, nullptr,
                                     nullptr, B, H, stream));
@@ -307,7 +302,7 @@ static int ps_epoch(const float* const* params, float* const* grads, const float
     const float* w2_t = wt ? wt[2] : w2_ws;
     const size_t bh = (size_t)B * H, b3 = (size_t)B * 3 * H;
 
-    const bool fused = ps_gru_step() && murcl_gru_step_supported(B, H, 0);    // one launch per GRU time step and direction
+    const bool fused = murcl_gru_step_supported(B, H, 0);    // one launch per GRU time step and direction
     // ---------------- forward (rlmil.py:103-112)
     PS_CHECK(ps_nt(states, params[P_W1], e1, R, PS_E1, S, MURCL_EPI_BIAS_RELU, params[P_B1], 0, stream));
     PS_CHECK(ps_nt(e1, params[P_W2], e2, R, H, PS_E1, MURCL_EPI_BIAS_RELU, params[P_B2], 0, stream));

@@ -107,6 +107,20 @@ def all_reduce_grads(flat_grads, group=None):
         all_reduce_sum(g, group)
 
 
+def reserve_cus_for_collectives(group=None):
+    """Collectives that overlap the backward pass run RCCL's channel workgroups beside the persistent kernels of the step.  Those
+    kernels are ONE round of workgroups with a static share each (one per CU): with even 4 CUs held by somebody else a launch runs
+    a second round and the step goes from 1.41 to 2.15 ms (a co-running "CU thief" on one GPU, tools/cu_thief.py,
+    profiles/r05_*_cu_thief.txt); sized for 248 CUs the same thieves cost 2-3 % (and the reduced round itself ~7 %).  So with more
+    than one rank on the nccl backend the launches are sized for ``MURCL_CU_BUDGET`` CUs (default 248 = 8 left to RCCL: pair it with
+    ``NCCL_MAX_NCHANNELS<=8``; 256 switches the reserve off).  -> the budget in force, None when nothing was changed."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2 or dist.get_backend(group) != "nccl":
+        return None
+    from . import ops
+    return ops.set_cu_budget(int(os.environ.get("MURCL_CU_BUDGET", "248")))
+
+
 class OverlappedGradReduce:
     """All-reduce the optimizer's flat gradient buffers in pieces, each as soon as it is final, overlapped with backward.
 
@@ -122,6 +136,7 @@ class OverlappedGradReduce:
 
     def __init__(self, optimizer, early_groups=(1,), group=None, milestones=False):
         self.opt, self.early, self.group = optimizer, tuple(early_groups), group
+        self.cu_budget = reserve_cus_for_collectives(group)
         self._pending, self._works, self._covered = 0, [], {}
         self._where = {}
         if milestones and hasattr(optimizer, "groups"):

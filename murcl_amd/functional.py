@@ -29,23 +29,24 @@ def set_direct_grad(flag):
 
 
 _MILESTONE = None
-import os as _os
 # bit l -> encoder layer l+1 loads its input with the non-temporal policy.  Layer 3's input (H2) is not read again before
 # the backward pass, while its output (H3) is what the pooling kernel streams next: kept out of the Infinity Cache, H2
 # leaves more of H3 there (K2 forward 67.6 -> 62.4 us inside the step; the other layers measured neutral-to-slower).
-_STREAM_A = int(_os.environ.get("MURCL_STREAM_A", "4"))
-_FUSED_GATE = _os.environ.get("MURCL_FUSED_GATE", "1") == "1"       # dev A/B switch: CLAM's gate score from the gate GEMM's epilogue (forward-only)
-_GATE_U = _os.environ.get("MURCL_GATE_U", "1") == "1"               # dev A/B switch: CLAM training chain - score + pre-activations from one gate GEMM, one-pass gate backward
-_FUSED_FC_DROP = _os.environ.get("MURCL_FC_DROP", "1") == "1"       # dev A/B switch: CLAM's seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
-_FUSED_INST = _os.environ.get("MURCL_FUSED_INST", "1") == "1"        # dev A/B switch: CLAM's instance branch as one launch forward, one backward
-_CLAM_POOL = _os.environ.get("MURCL_CLAM_POOL", "0") == "1"          # dev A/B switch, OFF: CLAM's soft-max + pooling as one streaming pass (online soft-max) - measured 20-40 us SLOWER at C3 than soft-max + weighted_rowsum (four rows in flight per wave: latency-bound at d = 512)
-_CLAM_POOL2 = _os.environ.get("MURCL_CLAM_POOL2", "0") == "1"        # dev A/B switch, OFF: CLAM's soft-max + pooling as one pass over h, 8 whole rows in flight per wave, the bag's statistics recomputed per 128-row chunk (round 4) - measured 90 + 5 us against 15 + 6 + 68 us for soft-max + zero-fill + weighted_rowsum at C3: no gain (same-box A/B of bench rows: 1.06 vs 1.04-1.07 ms)
-_DSMIL_REASSOC = _os.environ.get("MURCL_DSMIL_REASSOC", "1") == "1"  # dev A/B switch: DSMIL's attention logits as X . (Wq^T q_max): no GEMM over all patches
-_DSMIL_ONEPASS = _os.environ.get("MURCL_DSMIL_ONEPASS", "1") == "1"  # dev A/B switch: ... with attention + pooling, and their backward, in one pass over X each
-_DSMIL_QV = _os.environ.get("MURCL_DSMIL_QV", "1") == "1"            # dev A/B switch: ... and the [B*C]-row algebra around them as three launches
-_DSMIL_X3 = _os.environ.get("MURCL_DSMIL_X3", "1") == "1"           # dev A/B switch: DSMIL's long f32 GEMMs as a 3-term bf16 split
-_GROUP_WGRAD = _os.environ.get("MURCL_GROUP_WGRAD", "1") == "1"   # dev A/B switch: the three encoder weight gradients as one grouped launch
-_FOLD_BIAS = _os.environ.get("MURCL_FOLD_BIAS", "1") == "1"         # dev A/B switch: encoder bias gradients folded into the wgrad reduce
+_STREAM_A = 4
+# Which of two BUILT forms a call takes where both cover its shape.  The right-hand side of each line is the form every default
+# configuration runs; the other one is the general chain that shapes outside the fused kernels' reach take anyway (other widths,
+# more classes, per-layer gradient milestones ...), so both stay tested: the parity tests flip these through monkeypatch
+# (tests/test_gpu_modules.py) - they are test hooks, not environment switches (round 5: the MURCL_* variables are gone).
+_FUSED_GATE = True        # CLAM, forward-only calls: the gate score from the gate GEMM's epilogue, no [B*N, 2D] pre-activations
+_GATE_U = True            # CLAM, training chain: score + pre-activations from one gate GEMM, one-pass gate backward
+_FUSED_FC_DROP = True     # CLAM: the seeded Dropout behind the first layer's ReLU inside that GEMM's epilogue
+_FUSED_INST = True        # CLAM: the instance branch as one launch forward, one backward
+_DSMIL_REASSOC = True     # DSMIL: attention logits as X . (Wq^T q_max) - no GEMM over all patches (C <= 4)
+_DSMIL_ONEPASS = True     # ... with attention + pooling, and their backward, in one pass over X each
+_DSMIL_QV = True          # ... and the [B*C]-row algebra around them as three launches
+_DSMIL_X3 = True          # DSMIL's long f32 GEMMs (the literal-order chain) as a 3-term bf16 split
+_GROUP_WGRAD = True       # the encoder weight gradients of a backward pass as one grouped launch
+_FOLD_BIAS = True         # encoder bias gradients folded into the wgrad reduce
 
 
 def set_grad_milestone(callback):
@@ -62,7 +63,8 @@ def _final(*params):
 
 
 def _direct(p):
-    return _DIRECT and p is not None and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+    # (non-leaf tensors - a row of ``attention.2`` handed to one head of ABMIL(K > 1) - have no pre-seated gradient)
+    return _DIRECT and p is not None and p.is_leaf and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
 
 
 # Which parameters received a gradient since their optimizer last stepped.  torch.optim.Adam skips parameters whose
@@ -117,7 +119,7 @@ def _wgrad_group(items):
 # ``deferred_wgrads()`` block the (dy, x) pairs are only queued; on exit each parameter gets ONE product over the
 # concatenated T*128 rows: the same sum, one launch and one pass of atomics instead of T.
 _DEFERRED = None
-_DEFER_ON = _os.environ.get("MURCL_DEFER_WGRADS", "1") == "1"      # dev A/B switch
+_DEFER_ON = True           # test hook (see the list at the top)
 
 
 class deferred_wgrads:
@@ -960,14 +962,8 @@ class CLAMFn(torch.autograd.Function):
                 U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
         if not fused_gate and not gate_u:
             s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
-        one = ops.softmax_pool(h.view(B, N, L), s.view(B, N, 1)) if _CLAM_POOL else None    # soft-max (clam.py:144) + pooling (:170), one pass
-        if one is None and _CLAM_POOL2:
-            one = ops.softmax_pool2(h.view(B, N, L), s.view(B, N))                     # ... with 8 whole rows in flight per wave
-        if one is not None:
-            A, M = one[0].view(B, N), one[1].view(B, L)
-        else:
-            A = ops.softmax_rows(s)                                                    # clam.py:144
-            M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)       # clam.py:170
+        A = ops.softmax_rows(s)                                                        # clam.py:144
+        M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
         dev = x.device
         inst_loss = _zeros_const(dev, B) if inst_cfg is None else torch.zeros((B,), dtype=torch.float32, device=dev)
         saved_inst = None

@@ -283,7 +283,7 @@ def relu_bitmask(x):
 
 
 import os as _os
-_TN_SQ = _os.environ.get("MURCL_TN_SQ", "1") == "1"          # dev A/B switch: 0 keeps the 256 x 128 atomics kernel
+_TN_SQ = True             # test hook: False keeps the 256 x 128 atomics kernel (the form shapes without a workspace take)
 
 
 def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3=False):
@@ -432,10 +432,21 @@ def gemm_tn_grouped_ok(problems):
                 and A.shape[0] >= 16384 and A.shape[0] == B.shape[0] and (cp is None or ci is not None)):
             return False
         tiles = (A.shape[1] // 256) * (B.shape[1] // 256)
-        if tiles > 32:
+        if tiles > cu_budget() // 8:
             return False
         pairs += tiles
-    return pairs <= 256
+    return pairs <= cu_budget()
+
+
+def cu_budget():
+    """CUs the persistent kernels size their one round of workgroups for (murcl_cu_budget; 256 unless ``set_cu_budget`` lowered it)."""
+    return _lib.lib().murcl_cu_budget()
+
+
+def set_cu_budget(cus):
+    """Leave 256 - ``cus`` CUs to somebody else (RCCL's channel workgroups while a collective overlaps the backward pass): the
+    encoder-sized launches then place all their workgroups at once instead of running a second round.  -> the budget in force."""
+    return _lib.lib().murcl_set_cu_budget(int(cus))
 
 
 def pool_chunks(B, N, dtype_code):
@@ -540,7 +551,7 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None,
 
 
 _K2B_DWA = _os.environ.get("MURCL_K2B_DWA", "0") == "1"       # dev A/B switch, OFF: dWa inside the pooling backward pass (abmil_pool_bwd_dwa_on)
-_NTX_XCHG = _os.environ.get("MURCL_NTX_XCHG", "1") == "1"     # dev A/B switch: n <= 128 through the one-exchange kernel
+_NTX_XCHG = True          # test hook: n <= 128, P = 128 through the one-exchange kernel (False: the recompute kernel other P take)
 _NTX_BUF = {}
 
 
@@ -863,13 +874,12 @@ def gru_gates_bwd_into(dh, gates, gh, hprev, dgi, dgh, dhprev=None, accumulate=F
                                               int(gh.shape[0] == 1 and B != 1), int(accumulate), stream()), "gru_gates_bwd_into")
 
 
-_TN_SMALL_GROUP = _os.environ.get("MURCL_TN_SMALL_GROUP", "1") != "0"     # dev A/B switch
-_GRU_STEP = _os.environ.get("MURCL_GRU_STEP", "1") != "0"          # dev A/B switch: one launch per GRU time step and direction
+_TN_SMALL_GROUP = True    # test hook: bag-level f32 weight gradients through the single-writer 32 x 32 kernel
 
 
 def gru_step_ok(B, H, Kx=0):
     """Whether the one-launch GRU step kernels (``gru_step_fwd`` / ``gru_step_bwd``) take this shape."""
-    return _GRU_STEP and bool(_lib.lib().murcl_gru_step_supported(int(B), int(H), int(Kx)))
+    return bool(_lib.lib().murcl_gru_step_supported(int(B), int(H), int(Kx)))
 
 
 def gru_step_fwd(gi, hprev, w_hh, b_hh, hnew=None, gates=None, gh=None, x=None, w_ih=None, want_backward=True, want_gh=True):
@@ -1003,39 +1013,6 @@ def dsmil_attn_pool(X, v, scale=1.0):
     with _span(lambda: (f"dsmil_attn_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=4.0 * B * N * d * C))):
         check(_lib.lib().murcl_dsmil_attn_pool(ptr(X), ptr(v), float(scale), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()),
               "dsmil_attn_pool")
-    return A, Z
-
-
-def softmax_pool2(X, S):
-    """CLAM-SB's A [B,N] = soft-max_n(S [B,N]) and M [B,d] = sum_n A X (clam.py:144,170) from ONE pass over X + a small reduce launch
-    (murcl_softmax_pool2), or None when the shape is not covered.  X [B,N,d] f32/bf16, S [B,N] f32."""
-    X, S = _c(X), _c(S)
-    B, N, d = X.shape
-    wsf = _lib.lib().murcl_softmax_pool2_ws_floats(B, N, d)
-    if not wsf:
-        return None
-    A = torch.empty((B, N), dtype=torch.float32, device=X.device)
-    Z = torch.empty((B, d), dtype=torch.float32, device=X.device)
-    ws = torch.empty((wsf,), dtype=torch.float32, device=X.device)
-    with _span(lambda: (f"softmax_pool2<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d))):
-        check(_lib.lib().murcl_softmax_pool2(ptr(X), ptr(S), ptr(A), ptr(Z), ptr(ws), B, N, d, dt(X), stream()), "softmax_pool2")
-    return A, Z
-
-
-def softmax_pool(X, S):
-    """A [B,N,C] = soft-max_n(S), Z [B,C,d] = A^T X from ONE pass over X (online soft-max per wave, merged per bag), or None when the
-    shape is not covered (then softmax_rows + weighted_rowsum).  X [B,N,d] f32/bf16, S [B,N,C] f32 logits."""
-    X, S = _c(X), _c(S)
-    B, N, d = X.shape
-    C = S.shape[2]
-    rpw = _lib.lib().murcl_dsmil_stream_plan(B, N, d, C)
-    if not rpw:
-        return None
-    A = torch.empty_like(S)
-    Z = torch.empty((B, C, d), dtype=torch.float32, device=X.device)
-    ws = torch.empty(((B * N // rpw) * C * (d + 2) + 2 * B * C,), dtype=torch.float32, device=X.device)
-    with _span(lambda: (f"softmax_pool<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
-        check(_lib.lib().murcl_softmax_pool(ptr(X), ptr(S), ptr(A), ptr(Z), ptr(ws), B, N, d, C, dt(X), stream()), "softmax_pool")
     return A, Z
 
 

@@ -543,29 +543,6 @@ def test_panel_forward_with_dropout_inside_the_epilogue(M):
     assert (h.double() - exact).abs().max().item() <= (h2.double() - exact).abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,N,d", [(3, 4096, 512), (2, 200, 512), (5, 1000, 1024)])
-def test_clam_softmax_and_pooling_in_one_pass(dtype, B, N, d):
-    """murcl_softmax_pool2 (clam.py:144,170: A = soft-max over the patches of a bag, M = sum_n A_n h_n) against float64 and against
-    softmax_rows + weighted_rowsum; ragged chunk tails (N not a multiple of 128 / of 8)."""
-    from murcl_amd import ops
-    dev = _dev()
-    x = _rand(51, f"x{B}{N}{d}", (B, N, d)).to(dtype)
-    s = _rand(51, f"s{B}{N}", (B, N), 3.0)
-    A_ref = torch.softmax(s.double(), 1)
-    M_ref = torch.einsum("bn,bnd->bd", A_ref, x.double())
-    got = ops.softmax_pool2(x.to(dev), s.to(dev))
-    assert got is not None
-    A, M = got
-    _close(A, A_ref, rtol=1e-5, atol=1e-9, msg="A")
-    _close(M, M_ref, rtol=1e-4, atol=1e-5 * M_ref.abs().max().item(), msg="M")
-    A2 = ops.softmax_rows(s.to(dev))
-    M2 = ops.weighted_rowsum(x.to(dev), A2.view(B, N, 1)).view(B, d)
-    _close(A, A2.cpu(), rtol=1e-5, atol=1e-9, msg="A vs softmax_rows")
-    _close(M, M2.cpu(), rtol=1e-4, atol=1e-5 * M_ref.abs().max().item(), msg="M vs weighted_rowsum")
-    assert ops.softmax_pool2(x[:, :, :320].contiguous().to(dev), s.to(dev)) is None          # d % 512: not covered
-
-
 # ------------------------------------------------------------------ K6 streaming passes (reassociated DSMIL)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,N,d,C", [(2, 64, 512, 2), (3, 1024, 1024, 2), (2, 96, 320, 1), (16, 8192, 1024, 2)])
@@ -591,10 +568,6 @@ def test_dsmil_attention_and_pooling_in_one_pass_and_their_backward_in_one_more(
     A, Z = one
     _close(A, A64, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A")
     _close(Z, Z64, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z")
-    # the same pass with the logits given (murcl_softmax_pool)
-    A2, Z2 = ops.softmax_pool(X, S.float().to(dev))
-    _close(A2, A64, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A (given logits)")
-    _close(Z2, Z64, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z (given logits)")
     _close(A, sep_A, rtol=1e-4, atol=1e-4 * A64.max().item(), msg="A vs separate")
     _close(Z, sep_Z, rtol=1e-4, atol=1e-4 * Z64.abs().max().item(), msg="Z vs separate")
     np.testing.assert_allclose(A.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
@@ -717,7 +690,8 @@ def test_abmil_pool_bwd_with_the_attention_weight_gradient_in_the_same_pass(B, N
     # the same formulas on the same inputs: the stored dT differs at most by the last bf16 bit (MFMA operand order)
     # (a single-row bag has p = 1 and g = c: ds is the rounding noise of g - c, so every comparison gets a floor of the size of
     #  that noise - fl for an entry of dT, flw for an entry of dWa)
-    fl = 1e-6 * (dM.abs().max() * H.float().abs().max() * wb.abs().max()).item()
+    #  (g comes off the matrix cores with dM as a hi + lo bf16 pair: ~2^-15 of a 512-term dot product; c = dM.M is plain f32)
+    fl = 2.0 ** -15 * math.sqrt(512) * (dM.abs().max() * H.float().abs().max() * wb.abs().max()).item()
     flw = fl * H.float().abs().max().item() * math.sqrt(B * N)
     sT = dT0.float().abs().max().item()
     _close(dT.float(), dT0.float().cpu(), rtol=1e-2, atol=1e-2 * sT + fl, msg="dT vs the unfused kernel")

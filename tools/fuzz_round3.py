@@ -33,8 +33,6 @@ while time.time() - t0 < budget:
     one = ops.dsmil_attn_pool(X, v)
     if one is not None:
         note("attn_pool.A", rel(one[0], A64), 2e-4); note("attn_pool.Z", rel(one[1], Z64), 2e-4)
-        sp = ops.softmax_pool(X, S.float())
-        note("softmax_pool.A", rel(sp[0], A64), 2e-4); note("softmax_pool.Z", rel(sp[1], Z64), 2e-4)
         dZ = torch.randn((B, C, d), generator=g, device=dev); dcls = torch.randn((B, N, C), generator=g, device=dev)
         dA = torch.einsum("bnd,bcd->bnc", X.double(), dZ.double()); dS = A64 * (dA - (A64 * dA).sum(1, keepdim=True))
         R64 = torch.einsum("bnc,bnd->bcd", dS, X.double()) * 0.3
