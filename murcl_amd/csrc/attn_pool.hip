@@ -508,40 +508,42 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     }
 }
 
-// Per bag: merge chunk partials, emit A[n] = softmax(s)_n / sqrt(N), pooled M, and (m, l).
-__global__ __launch_bounds__(256) void abmil_pool_combine_kernel(const float* __restrict__ scores,
+// Per bag: merge chunk partials, emit A[n] = softmax(s)_n / sqrt(N), pooled M, and (m, l).  K2C_SPLIT workgroups per bag (round 5:
+// one per bag left half the chip idle and made this launch 5.2-5.6 us of K2's 58): each takes 1 / K2C_SPLIT of the pooled columns and
+// of the rows of A; all of them read the bag's S (m, l) headers (a few hundred bytes, L2-resident).
+#define K2C_SPLIT 4
+__global__ __launch_bounds__(128) void abmil_pool_combine_kernel(const float* __restrict__ scores,
                                                                  const float* __restrict__ part, float* __restrict__ A,
                                                                  float* __restrict__ Mout, float* __restrict__ ml,
                                                                  int N, int S, float inv_sqrt_n) {
-    const int bag = blockIdx.x, tid = threadIdx.x;
+    const int bag = blockIdx.x / K2C_SPLIT, q = blockIdx.x % K2C_SPLIT, tid = threadIdx.x;
     const float* pp = part + (size_t)bag * S * (K2_L + 2);
+    constexpr int CPT = K2_L / K2C_SPLIT / 128;          // pooled columns per thread: 1
+    static_assert(CPT == 1, "one pooled column per thread");
+    const int col = q * (K2_L / K2C_SPLIT) + tid;
     // the chunks' (m, l) headers first, one per thread: walked one chunk after the other by every thread they were 2 S dependent
     // round trips (9 us at S = 8)
-    __shared__ float hm[256], hl[256];
-    float m = -INFINITY, l = 0.f, a0 = 0.f, a1 = 0.f;
-    if (S <= 256) {
+    __shared__ float hm[128], hl[128];
+    float m = -INFINITY, l = 0.f, a0 = 0.f;
+    if (S <= 128) {
         if (tid < S) { hm[tid] = pp[(size_t)tid * (K2_L + 2)]; hl[tid] = pp[(size_t)tid * (K2_L + 2) + 1]; }
         __syncthreads();
         for (int s = 0; s < S; ++s) m = fmaxf(m, hm[s]);
         int s = 0;
         for (; s + 3 < S; s += 4) {                          // four chunks' partial rows in flight
-            float w[4], p0[4], p1[4];
+            float w[4], p0[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* p = pp + (size_t)(s + u) * (K2_L + 2);
                 w[u] = (hm[s + u] == -INFINITY) ? 0.f : expf(hm[s + u] - m);
-                p0[u] = p[2 + 2 * tid];
-                p1[u] = p[2 + 2 * tid + 1];
+                p0[u] = pp[(size_t)(s + u) * (K2_L + 2) + 2 + col];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; a1 += p1[u] * w[u]; }
+            for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; }
         }
         for (; s < S; ++s) {
-            const float* p = pp + (size_t)s * (K2_L + 2);
             const float w = (hm[s] == -INFINITY) ? 0.f : expf(hm[s] - m);
             l += hl[s] * w;
-            a0 += p[2 + 2 * tid] * w;
-            a1 += p[2 + 2 * tid + 1] * w;
+            a0 += pp[(size_t)s * (K2_L + 2) + 2 + col] * w;
         }
     } else {
         for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
@@ -549,25 +551,25 @@ __global__ __launch_bounds__(256) void abmil_pool_combine_kernel(const float* __
             const float* p = pp + (size_t)s * (K2_L + 2);
             const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
             l += p[1] * w;
-            a0 += p[2 + 2 * tid] * w;
-            a1 += p[2 + 2 * tid + 1] * w;
+            a0 += p[2 + col] * w;
         }
     }
     const float inv = inv_sqrt_n / l;
-    Mout[(size_t)bag * K2_L + 2 * tid] = a0 * inv;
-    Mout[(size_t)bag * K2_L + 2 * tid + 1] = a1 * inv;
-    if (tid == 0) { ml[2 * bag] = m; ml[2 * bag + 1] = l; }
+    Mout[(size_t)bag * K2_L + col] = a0 * inv;
+    if (q == 0 && tid == 0) { ml[2 * bag] = m; ml[2 * bag + 1] = l; }
+    // this workgroup's quarter of the bag's rows of A
+    const int per = (N + K2C_SPLIT - 1) / K2C_SPLIT, n0 = q * per, n1 = min(N, n0 + per);
     const float* sc = scores + (size_t)bag * N;
     float* ab = A + (size_t)bag * N;
-    int n = tid;
-    for (; n + 3 * 256 < N; n += 4 * 256) {                  // four score loads in flight per thread
+    int n = n0 + tid;
+    for (; n + 3 * 128 < n1; n += 4 * 128) {                 // four score loads in flight per thread
         float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = sc[n + u * 256];
+        for (int u = 0; u < 4; ++u) v[u] = sc[n + u * 128];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ab[n + u * 256] = expf(v[u] - m) * inv;
+        for (int u = 0; u < 4; ++u) ab[n + u * 128] = expf(v[u] - m) * inv;
     }
-    for (; n < N; n += 256) ab[n] = expf(sc[n] - m) * inv;
+    for (; n < n1; n += 128) ab[n] = expf(sc[n] - m) * inv;
 }
 
 #ifndef K2_ITEMS_PER_WG
@@ -628,7 +630,7 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
 #undef K2_LAUNCH
     int rc = MURCL_CHECK_LAUNCH();
     if (rc || (!A && !M && !ml)) return rc;          // partials only: the caller runs murcl_abmil_pool_combine itself
-    hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B), dim3(256), 0, stream, scores, part_ws, A, M, ml, N, S,
+    hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B * K2C_SPLIT), dim3(128), 0, stream, scores, part_ws, A, M, ml, N, S,
                        1.0f / sqrtf((float)N));
     return MURCL_CHECK_LAUNCH();
 }
@@ -639,7 +641,7 @@ extern "C" int murcl_abmil_pool_combine(const float* scores, const float* part_w
     if (B <= 0 || N <= 0) return 0;
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
-    hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B), dim3(256), 0, stream, scores, part_ws, A, M, ml, N, S,
+    hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B * K2C_SPLIT), dim3(128), 0, stream, scores, part_ws, A, M, ml, N, S,
                        1.0f / sqrtf((float)N));
     return MURCL_CHECK_LAUNCH();
 }
