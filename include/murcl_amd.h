@@ -319,8 +319,13 @@ int murcl_clam_inst_bwd(const void* h, const int* ids, const float* W, const flo
 /* write_back != 0: g[r,k] is zeroed where the mask dropped it, so that on return g holds exactly what was added */
 int murcl_scatter_add_rows_masked(void* dst, const void* h, const long* rows, float* g, int R, int d, int dtype,
                                   int write_back, murcl_stream_t stream);
+/* nn.CrossEntropyLoss() (mean) per group of `group` consecutive rows of [R,C] logits (train_RLMIL.py:316,502,709; clam.py:118,131):
+ * loss [R/group], dlogits [R,C] = (soft-max - one-hot) / live rows of the group (NULL: not wanted), preds [R] = arg-max (NULL: not
+ * wanted), conf [R] = soft-max probability of the target class - the confidence whose differences are the RL-MIL rewards
+ * (train_RLMIL.py:345,369-371) - NULL: not wanted.  Rows with target < 0 are ignored. */
 int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
-                        long* preds, int group, murcl_stream_t stream);   /* nn.Dropout keep mask (clam.py:47-48,71-72) in the compute dtype: out[i] = scale with probability keep_p (quantised to
+                        long* preds, float* conf, int group, murcl_stream_t stream);
+/* nn.Dropout keep mask (clam.py:47-48,71-72) in the compute dtype: out[i] = scale with probability keep_p (quantised to
  * 1/256), else 0; a pure function of (seed, i) (splitmix64 counter hash), one write pass. */
 int murcl_dropout_mask(void* out, long n, float keep_p, float scale, unsigned long long seed, int dtype,
                        murcl_stream_t stream);

@@ -75,7 +75,7 @@ SIGNATURES = {
     "murcl_topk_ids": [_P, _I, _I, _I, _P, _P],
     "murcl_take_rows": [_P, _P, _P, _I, _I, _I, _P],
     "murcl_scatter_add_rows_masked": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "murcl_cross_entropy": [_P, _P, _I, _I, _P, _P, _P, _I, _P],
+    "murcl_cross_entropy": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "murcl_mul": [_P, _P, _P, _L, _I, _P],
     "murcl_policy_head_fwd": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "murcl_policy_head_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],

@@ -553,10 +553,12 @@ extern "C" int murcl_scatter_add_rows_masked(void* dst, const void* h, const lon
 // ---------------------------------------------------------------- mean cross-entropy per group of G consecutive rows
 // (C <= 32 logits per row).  One workgroup per group:  loss[g] = mean over the rows with target >= 0 of
 // [ lse(logits_r) - logits_r[target_r] ] (0 for a group without such rows); dlogits = (softmax - onehot) / count for
-// those rows, 0 for ignored rows (target < 0); pred = argmax (first max), -1 for ignored rows.
+// those rows, 0 for ignored rows (target < 0); pred = argmax (first max), -1 for ignored rows; conf = the soft-max probability of
+// the target class (the confidence the RL-MIL rewards are differences of, train_RLMIL.py:345,537,735), 0 for ignored rows.
 __global__ __launch_bounds__(64) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ targets,
                                                         int G, int C, float* __restrict__ loss,
-                                                        float* __restrict__ dlogits, long* __restrict__ preds) {
+                                                        float* __restrict__ dlogits, long* __restrict__ preds,
+                                                        float* __restrict__ conf) {
     const int grp = blockIdx.x, tid = threadIdx.x;
     float cnt = 0.f;
     for (int r = tid; r < G; r += 64) cnt += targets[(size_t)grp * G + r] >= 0 ? 1.f : 0.f;
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(64) void ce_fwd_bwd_kernel(const float* __restrict_
             if (dlogits)
                 for (int c = 0; c < C; ++c) dlogits[row * C + c] = 0.f;
             if (preds) preds[row] = -1;
+            if (conf) conf[row] = 0.f;
             continue;
         }
         float mx = x[0];
@@ -583,14 +586,15 @@ __global__ __launch_bounds__(64) void ce_fwd_bwd_kernel(const float* __restrict_
         if (dlogits)
             for (int c = 0; c < C; ++c) dlogits[row * C + c] = (expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * inv;
         if (preds) preds[row] = am;
+        if (conf) conf[row] = expf(x[t] - lse);
     }
     acc = wave_sum(acc);
     if (tid == 0) loss[grp] = acc * inv;
 }
 extern "C" int murcl_cross_entropy(const float* logits, const long* targets, int R, int C, float* loss, float* dlogits,
-                                   long* preds, int group, hipStream_t st) {
+                                   long* preds, float* conf, int group, hipStream_t st) {
     if (R <= 0 || C <= 0 || group <= 0 || R % group) return -1;
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R / group), dim3(64), 0, st, logits, targets, group, C, loss, dlogits, preds);
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R / group), dim3(64), 0, st, logits, targets, group, C, loss, dlogits, preds, conf);
     return MURCL_CHECK_LAUNCH();
 }
 

@@ -1141,19 +1141,24 @@ class PPOLossFn(torch.autograd.Function):
 
 class GroupedCrossEntropyFn(torch.autograd.Function):
     """Mean CE of every group of ``group`` consecutive rows of [R,C] logits -> [R/group] losses, one launch: the T per-patch-step
-    ``nn.CrossEntropyLoss()`` values of a step whose T x B head rows were computed together (train_RLMIL.py:316,502,709)."""
+    ``nn.CrossEntropyLoss()`` values of a step whose T x B head rows were computed together (train_RLMIL.py:316,502,709).  With
+    ``want_conf`` -> (losses, conf [R]): the soft-max confidence of each row's true class from the same launch (the RL-MIL rewards
+    are its differences between patch steps, train_RLMIL.py:345,369-371); conf is not differentiable."""
 
     @staticmethod
-    def forward(ctx, logits, targets, group):
-        loss, dl, _ = ops.cross_entropy(logits.float().contiguous(), targets.to(torch.int64).contiguous(), int(group))
-        ctx.save_for_backward(dl)
+    def forward(ctx, logits, targets, group, want_conf=False):
+        res = ops.cross_entropy(logits.float().contiguous(), targets.to(torch.int64).contiguous(), int(group), want_conf=bool(want_conf))
+        ctx.save_for_backward(res[1])
         ctx.group = int(group)
-        return loss
+        if want_conf:
+            ctx.mark_non_differentiable(res[3])
+            return res[0], res[3]
+        return res[0]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gconf=None):
         (dl,) = ctx.saved_tensors
-        return dl * g.reshape(-1, 1).repeat_interleave(ctx.group, 0), None, None
+        return dl * g.reshape(-1, 1).repeat_interleave(ctx.group, 0), None, None, None
 
 
 class CrossEntropyFn(torch.autograd.Function):

@@ -1207,17 +1207,19 @@ def scatter_add_rows_masked(dst, h, rows, g, write_back=False):
                                                    dt(dst), int(write_back), stream()), "scatter_add_rows_masked")
 
 
-def cross_entropy(logits, targets, group):
-    """Mean CE per group of `group` consecutive rows -> (loss [R/group], dlogits [R,C] (already / group), preds [R])."""
+def cross_entropy(logits, targets, group, want_conf=False):
+    """Mean CE per group of `group` consecutive rows -> (loss [R/group], dlogits [R,C] (already / group), preds [R]); with
+    ``want_conf`` a fourth result conf [R]: the soft-max probability of each row's target class."""
     logits, targets = _c(logits), _c(targets)
     R, C = logits.shape
     G = R // group
     loss = torch.empty((G,), dtype=torch.float32, device=logits.device)
     dl = torch.empty_like(logits)
     preds = torch.empty((R,), dtype=torch.int64, device=logits.device)
-    check(_lib.lib().murcl_cross_entropy(ptr(logits), ptr(targets), R, C, ptr(loss), ptr(dl), ptr(preds), group, stream()),
+    conf = torch.empty((R,), dtype=torch.float32, device=logits.device) if want_conf else None
+    check(_lib.lib().murcl_cross_entropy(ptr(logits), ptr(targets), R, C, ptr(loss), ptr(dl), ptr(preds), ptr(conf), group, stream()),
           "cross_entropy")
-    return loss, dl, preds
+    return (loss, dl, preds, conf) if want_conf else (loss, dl, preds)
 
 
 _DROP_COUNTER = 0

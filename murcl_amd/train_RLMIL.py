@@ -40,8 +40,10 @@ _BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/
 
 
 def _confidence(logits, labels):
-    """soft-max confidence of the true class (train_RLMIL.py:345,537,735)."""
-    return torch.softmax(logits.detach(), 1).gather(1, labels.view(-1, 1)).view(1, -1)
+    """soft-max confidence of the true class (train_RLMIL.py:345,537,735): the fourth output of the cross-entropy launch."""
+    from . import ops
+    lg = logits.detach().float().contiguous()
+    return ops.cross_entropy(lg, labels.to(torch.int64).contiguous(), lg.shape[0], want_conf=True)[3].view(1, -1)
 
 
 def _aggregate(arch, model, feats, labels):
@@ -93,14 +95,14 @@ def _head_all_steps(arch, fc, head_in_all, extra_all, labels, T, B, bag_weight, 
     -> (sum_t loss_t / T, [loss_t] detached, rewards [T-1] of [1,B] (also appended to ``memory``), logits of the last step)."""
     lab_all = labels.repeat(T)
     logits_all = fc.forward_sequence(head_in_all.view(T, B, -1))
-    ce = GroupedCrossEntropyFn.apply(logits_all, lab_all, B)
+    ce, conf = GroupedCrossEntropyFn.apply(logits_all, lab_all, B, True)                # conf: soft-max confidence of the true class (:345,537,735)
     if arch == "ABMIL":
         loss_t = ce                                                                        # :727
     elif arch == "CLAM_SB":
         loss_t = bag_weight * ce + (1 - bag_weight) * extra_all.view(T, B).mean(1)         # :336
     else:
         loss_t = 0.5 * ce + 0.5 * GroupedCrossEntropyFn.apply(extra_all, lab_all, B)       # :527-529
-    conf = torch.softmax(logits_all.detach(), 1).gather(1, lab_all.view(-1, 1)).view(T, 1, B)      # :345,537,735
+    conf = conf.view(T, 1, B)
     rewards = list((conf[1:] - conf[:-1]).unbind(0))                                       # :369-371,569-571
     memory.rewards.extend(rewards)
     return loss_t.sum() / T, list(loss_t.detach().unbind(0)), rewards, logits_all[-B:]
