@@ -35,6 +35,8 @@ class KernelTimers:
     def span(self, key, work=None):
         if self.only is not None and key not in self.only:
             return _NULL
+        if self.only is None and key.startswith("row:"):       # a span AROUND several launches that have spans of their own:
+            return _NULL                                       # only on request, or the breakdown would count them twice
         n = self._seen.get(key, 0)
         self._seen[key] = n + 1
         return _Span(self, key, work) if n % self.every == 0 else _NULL
@@ -478,17 +480,19 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
     part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
     es = H.element_size()
     # algorithmic bytes per bag: H once + scores out + pooled M out; Wa amortised over the launch
-    with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>",
-               dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L),
-                    bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es))):
-        # the streaming kernel alone (chunk partials); the per-bag merge is its own launch and its own span below, so
-        # that the HIP-event time of this key is the kernel rocprofv3 lists as abmil_pool_fwd_kernel
-        check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
-                                              None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
-              "abmil_pool_fwd")
-    with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
-        check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, dt(H), stream()),
-              "abmil_pool_combine")
+    work = lambda: dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L), bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es)   # noqa: E731
+    # "row:k2_fwd": ONE pair of events around BOTH launches of the K2 row (bench.py's roofline_k2: the streaming kernel and its
+    # per-bag merge; two separate pairs would add their ~2.5 us of record cost twice to a 58 us row)
+    with _span(lambda: (f"row:k2_fwd<{_DT_NAME[H.dtype]}>", work())):
+        with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>", work())):
+            # the streaming kernel alone (chunk partials): the HIP-event time of this key is the kernel rocprofv3 lists as
+            # abmil_pool_fwd_kernel
+            check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
+                                                  None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
+                  "abmil_pool_fwd")
+        with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
+            check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, dt(H), stream()),
+                  "abmil_pool_combine")
     return scores, A, M, ml
 
 

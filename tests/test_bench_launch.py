@@ -125,4 +125,5 @@ def test_gpus_1_through_the_spawn_path_prints_the_contract_line():
     assert st["flops"] == pytest.approx(2 * 64 * 9.41e9) and 0 < st["frac_of_mfma"] < 1
     assert st["fused_min_bytes"] == 2 * 64 * 2048 * 512 * 2
     assert st["hbm_bytes_pmc"] is None or (st["ratio_vs_fused_min"] > 1 and st["pmc_source"])
-    assert k2["bound"] == "hbm" and k2["launches_of_the_row"] == ["abmil_pool_fwd<bf16>", "abmil_pool_combine"] and len(k2["avg_ms_each"]) == 2
+    assert k2["bound"] == "hbm" and k2["launches_of_the_row"] == ["abmil_pool_fwd<bf16>", "abmil_pool_combine"]
+    assert len(k2["avg_ms_each_untimed_pass"]) == 2 and k2["avg_launch_ms"] > 0
