@@ -548,6 +548,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        from murcl_amd import dist as _mdist
+        _mdist.cap_rccl_channels(world)                   # RCCL's channel workgroups must fit the CUs the step leaves free
         dist.init_process_group("nccl", device_id=device)
 
     from murcl_amd import ops

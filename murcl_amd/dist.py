@@ -107,6 +107,21 @@ def all_reduce_grads(flat_grads, group=None):
         all_reduce_sum(g, group)
 
 
+def cap_rccl_channels(world):
+    """Call BEFORE ``init_process_group("nccl")`` when ``world`` > 1: RCCL runs one workgroup per channel for the length of a
+    collective and its defaults may exceed the CUs ``reserve_cus_for_collectives`` leaves free (256 - ``MURCL_CU_BUDGET``, 8 by
+    default) - channels beyond the reserve would push the persistent kernels into a second round again.  Sets ``NCCL_MAX_NCHANNELS``
+    to the reserve unless the environment already says otherwise (8 channels carry the 19.4 MB head all-reduce at the xGMI ring's
+    ~150 GB/s just as well; raise both knobs together if ``comm.grad_all_reduce_us.*.busbw_GBps`` sits far below that).
+    -> the value in force (str) or None."""
+    import os
+    if world < 2:
+        return None
+    reserve = max(1, 256 - int(os.environ.get("MURCL_CU_BUDGET", "248")))
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(reserve))
+    return os.environ["NCCL_MAX_NCHANNELS"]
+
+
 def reserve_cus_for_collectives(group=None):
     """Collectives that overlap the backward pass run RCCL's channel workgroups beside the persistent kernels of the step.  Those
     kernels are ONE round of workgroups with a static share each (one per CU): with even 4 CUs held by somebody else a launch runs

@@ -501,6 +501,8 @@ def run(args):
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from . import dist as mdist
+        mdist.cap_rccl_channels(world)                     # RCCL's channel workgroups must fit the CUs the step leaves free
         dist.init_process_group("nccl", device_id=device)
         box = [args.save_dir]
         dist.broadcast_object_list(box, src=0)                 # rank 0 resolved (and possibly incremented) the directory
