@@ -453,7 +453,9 @@ def comm_diagnostics(model, fc, opt, crit, views, world, device, reps=20):
     z_local = torch.randn((2 * B, 128), device=device)
     zg = torch.empty((nranks * 2 * B, 128), device=device)
     from murcl_amd import ops as _ops
+    from murcl_amd import functional as _fnl
     out = {"ranks": nranks, "backend": dist.get_backend(), "cu_budget": _ops.cu_budget(),
+           "cu_budget_overlapped_backward": _fnl._OVERLAP_BUDGET,
            "z_all_gather_us": ev_median(lambda: mdist.all_gather_rows(zg, z_local)),
            "z_all_gather_bytes_per_rank": z_local.numel() * 4}
     ar = {}

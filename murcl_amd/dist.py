@@ -126,14 +126,21 @@ def reserve_cus_for_collectives(group=None):
     """Collectives that overlap the backward pass run RCCL's channel workgroups beside the persistent kernels of the step.  Those
     kernels are ONE round of workgroups with a static share each (one per CU): with even 4 CUs held by somebody else a launch runs
     a second round and the step goes from 1.41 to 2.15 ms (a co-running "CU thief" on one GPU, tools/cu_thief.py,
-    profiles/r05_*_cu_thief.txt); sized for 248 CUs the same thieves cost 2-3 % (and the reduced round itself ~7 %).  So with more
-    than one rank on the nccl backend the launches are sized for ``MURCL_CU_BUDGET`` CUs (default 248 = 8 left to RCCL: pair it with
-    ``NCCL_MAX_NCHANNELS<=8``; 256 switches the reserve off).  -> the budget in force, None when nothing was changed."""
+    profiles/r05_f_cu_thief.txt); sized for 248 CUs the same thieves cost 2-4 %.  So with more than one rank on the nccl backend the
+    launches a collective can overlap are sized for ``MURCL_CU_BUDGET`` CUs (default 248 = 8 left to RCCL, ``cap_rccl_channels``;
+    256 switches the reserve off).  ``MURCL_CU_BUDGET_SCOPE``: "backward" (default) - only the aggregator's backward launches that
+    the head group's all-reduce runs beside (functional.set_overlap_cu_budget; the forward pass and the grouped weight gradients keep
+    the full chip: ~2 % instead of ~9 % of the step) - or "all" (every persistent launch, murcl_set_cu_budget).
+    -> the budget in force for the overlapped launches, None when nothing was changed."""
     import os
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2 or dist.get_backend(group) != "nccl":
         return None
-    from . import ops
-    return ops.set_cu_budget(int(os.environ.get("MURCL_CU_BUDGET", "248")))
+    from . import functional, ops
+    budget = max(64, min(256, int(os.environ.get("MURCL_CU_BUDGET", "248")))) & ~7
+    if os.environ.get("MURCL_CU_BUDGET_SCOPE", "backward") == "all":
+        return ops.set_cu_budget(budget)
+    functional.set_overlap_cu_budget(budget)
+    return budget
 
 
 class OverlappedGradReduce:

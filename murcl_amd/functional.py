@@ -49,6 +49,37 @@ _GROUP_WGRAD = True       # the encoder weight gradients of a backward pass as o
 _FOLD_BIAS = True         # encoder bias gradients folded into the wgrad reduce
 
 
+# CUs the launches of the aggregator's backward pass - pooling backward up to the last input gradient - are sized for while a
+# collective may be running beside them (None: ops.cu_budget() as it is).  The head group's gradient all-reduce is launched when
+# backward reaches the aggregator outputs (dist.OverlappedGradReduce) and is in flight for roughly these launches (19.4 MB at the
+# xGMI ring's ~150 GB/s = 0.2-0.3 ms against 65 + 65 + 82 + 2 x 133 us); the forward pass, the grouped weight gradients behind them
+# and the optimizer run with no collective beside them and keep the full chip.
+_OVERLAP_BUDGET = None
+
+
+def set_overlap_cu_budget(cus):
+    """``cus`` (or None) = the CU budget in force for the backward launches a gradient all-reduce overlaps."""
+    global _OVERLAP_BUDGET
+    _OVERLAP_BUDGET = None if cus is None else int(cus)
+
+
+class _overlap_budget:
+    """Context: the persistent launches inside are sized for ``_OVERLAP_BUDGET`` CUs (murcl_set_cu_budget), the budget that was
+    in force before is restored on exit.  Launchers read the budget when they enqueue, so this is host-side bookkeeping only."""
+
+    def __enter__(self):
+        self.prev = None
+        if _OVERLAP_BUDGET is not None:
+            self.prev = ops.cu_budget()
+            ops.set_cu_budget(min(self.prev, _OVERLAP_BUDGET))
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            ops.set_cu_budget(self.prev)
+        return False
+
+
 def set_grad_milestone(callback):
     """``callback(params)`` is called from inside the aggregator's backward as soon as the kernels that complete the
     gradients of ``params`` are enqueued (direct-gradient mode only).  A data-parallel reducer uses it to start their
@@ -343,7 +374,10 @@ class ABMILFn(torch.autograd.Function):
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd, dbd = _wbgrad(dpre, M, wd, bd)
         dM = ops.gemm_nt(dpre, ops.transposed(wd))
-        # attention pooling
+        # attention pooling.  From here to the last input gradient a data-parallel step has the head group's all-reduce in flight:
+        # these launches leave its channel workgroups their CUs (_overlap_budget: a no-op on one GPU)
+        budget_scope = _overlap_budget()
+        budget_scope.__enter__()
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
         into_k2 = (ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None
         if ops.abmil_pool_bwd_dwa_on(B, N, L, wac.shape[0], T):
@@ -385,6 +419,7 @@ class ABMILFn(torch.autograd.Function):
                 _final(w2, b2)
             dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True,
                                          colsum_into=None if f1 else into(b1), colsum_defer=f1)
+            budget_scope.__exit__()                                # the grouped weight gradients run behind the collective: full chip
             if grouped:
                 dw3, dw2, dw1 = _wgrad_group([(dz3, h2, w3, b3, db3 if f3 else None), (dz2, h1, w2, b2, db2 if f2 else None),
                                               (dz1, x2, w1, b1, db1 if f1 else None)])
@@ -404,6 +439,7 @@ class ABMILFn(torch.autograd.Function):
             _final(w2, b2)
             dz1, ws = ops.gemm_nt(dz2, w2t, epi=ops.EPI_MASK, mask=h1, colsum=True)
             db1 = _bgrad(ws, b1)
+            budget_scope.__exit__()
         if m3 is not None and grouped:
             pass
         elif m3 is not None and f1:

@@ -170,6 +170,19 @@ def test_abmil_bf16_step_under_a_reduced_cu_budget():
     finally:
         assert ops.set_cu_budget(256) == 256
     assert ops.set_cu_budget(1000) == 256 and ops.set_cu_budget(250) == 248 and ops.set_cu_budget(256) == 256      # clamped, multiples of 8
+    # the scoped form a data-parallel run uses by default (dist.reserve_cus_for_collectives): only the backward launches that the
+    # head group's all-reduce overlaps are sized for 248 CUs, and the budget is back at 256 when backward returns
+    from murcl_amd import functional
+    try:
+        functional.set_overlap_cu_budget(248)
+        m = _abmil(7, torch.bfloat16)
+        o, _ = m(x)
+        assert ops.cu_budget() == 256
+        (o * w).sum().backward()
+        assert ops.cu_budget() == 256
+        res.append((o.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}))
+    finally:
+        functional.set_overlap_cu_budget(None)
     for o, g in res[1:]:
         assert torch.equal(o, res[0][0])
         for k, v in g.items():

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--lds", type=int, default=64 * 1024)
     ap.add_argument("--budget", default="256", help="CU budgets of the persistent kernels to try (ops.set_cu_budget), e.g. 256,248,240")
+    ap.add_argument("--overlap-budget", type=int, default=0,
+                    help="size only the aggregator's backward launches (pooling backward .. last input gradient) for this many CUs "
+                         "(functional.set_overlap_cu_budget: what a data-parallel run does by default) - the tax of the scoped reserve")
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event times (adds ~2-3 us per launch)")
     a = ap.parse_args()
     if not os.path.exists(PROBES):
@@ -49,9 +52,12 @@ def main():
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     sink = torch.zeros(256, dtype=torch.int32, device=dev)
+    if a.overlap_budget:
+        from murcl_amd import functional
+        functional.set_overlap_cu_budget(a.overlap_budget)
     for budget in [int(v) for v in a.budget.split(",")]:
         got = ops.set_cu_budget(budget)
-        print(f"== CU budget {got}", flush=True)
+        print(f"== CU budget {got}" + (f", backward launches {a.overlap_budget}" if a.overlap_budget else ""), flush=True)
         for _ in range(10):
             step()
         torch.cuda.synchronize()
