@@ -425,11 +425,20 @@ int murcl_dropout_relu_bitmask(void* x, void* bits, int M, int N, float keep_p, 
  * elements (0: the job's own width), so that a job can fill a row or column block of a larger matrix - CLAM's two gate Linears
  * interleaved in 16-row blocks for murcl_panel_gemm epilogues 4 / 5 (clam.py:40-48) are 2 x D/16 such jobs. */
 int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stream_t stream);
+/* The same table as a flat grid: first_tile_dev [n_jobs + 1] int32 (device) = ascending first tile index of every job (a job of
+ * [rows, cols] has ceil(rows/32) * ceil(cols/32) tiles), total_tiles = its last entry.  For tables whose jobs differ widely in size. */
+int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, murcl_stream_t stream);
 
 /* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g
  * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */
 int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, int zero_grad, murcl_stream_t stream);
+/* The same step for up to MURCL_ADAM_MAX_JOBS flat runs in ONE launch (the two parameter groups of train_MuRCL.py:165-171 with their
+ * own lr; runs of parameters that share a step count).  `jobs_host` is a HOST array (it travels in the kernel arguments). */
+#define MURCL_ADAM_MAX_JOBS 8
+typedef struct { float *p, *g, *m, *v; long n; float lr; int step; } MurclAdamJob;
+int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                     int zero_grad, murcl_stream_t stream);
 /* torch.optim.SGD.step for one flat tensor (train_MuRCL.py:158-163, train_RLMIL.py:258-263): L2 weight decay, momentum
  * buffer (first != 0: the buffer is initialised with the gradient), dampening 0, optional Nesterov. */
 int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov, float weight_decay,

@@ -618,31 +618,43 @@ __global__ __launch_bounds__(256) void clam_inst_fwd_kernel(const T* __restrict_
                                                             float* __restrict__ dl, long* __restrict__ pt, int B) {
     __shared__ float lg[64][CI_MAXO];
     __shared__ float lsum[256];
+    __shared__ int srow[64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int O = 2 * n_cls, R = 2 * k;
-    for (int r = wave; r < R; r += 4) {
-        const T* row = h + ((size_t)b * N + ids[(size_t)b * R + r]) * L;
-        float acc[CI_MAXO];
+    if (tid < R) srow[tid] = ids[(size_t)b * R + tid];
+    __syncthreads();
+    // a wave takes the rows wave, wave + 4, ...: FOUR of them in flight at once (one row after the other was 2k / 4 dependent round
+    // trips: 18 us at k = 8), the classifier rows read once per four rows
+    for (int r0 = wave; r0 < R; r0 += 16) {
+        float acc[4][CI_MAXO];
 #pragma unroll
-        for (int o = 0; o < CI_MAXO; ++o) acc[o] = 0.f;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 0; o < CI_MAXO; ++o) acc[i][o] = 0.f;
         for (int c0 = lane * 8; c0 < L; c0 += 512) {
-            float x[8];
-            load8<T>(row + c0, x);
+            float x[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                load8<T>(h + ((size_t)b * N + srow[min(r0 + 4 * i, R - 1)]) * L + c0, x[i]);
 #pragma unroll
             for (int o = 0; o < CI_MAXO; ++o)
                 if (o < O) {
                     float w[8];
                     load8<float>(W + (size_t)o * L + c0, w);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o] += x[e] * w[e];
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][o] += x[i][e] * w[e];
                 }
         }
 #pragma unroll
-        for (int o = 0; o < CI_MAXO; ++o)
-            if (o < O) {
-                const float t = wave_sum(acc[o]);
-                if (lane == 0) lg[r][o] = t + bias[o];
-            }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 0; o < CI_MAXO; ++o)
+                if (o < O && r0 + 4 * i < R) {
+                    const float t = wave_sum(acc[i][o]);
+                    if (lane == 0) lg[r0 + 4 * i][o] = t + bias[o];
+                }
     }
     __syncthreads();
     const int lab = (int)labels[b];
@@ -675,40 +687,77 @@ __global__ __launch_bounds__(256) void clam_inst_fwd_kernel(const T* __restrict_
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) lsum[tid] += lsum[tid + o]; __syncthreads(); }
     if (tid == 0) loss[b] = lsum[0] * scale;
 }
+// grid (B, L / 64): a workgroup owns 64 columns of one bag's 2k rows; its four waves take the rows r = wave, wave + 4, ... with the
+// loads of FOUR rows (h and dz) in flight at once - the first form (one workgroup per bag, a thread walking the 2k rows with a
+// dependent load -> add -> store each) was 2k serial round trips to HBM: 46 us at 64 x 4096 x 512, k = 8.
+// A bag whose top and bottom rows coincide somewhere (N < 2k, or ties: a uniform soft-max) is walked by ONE wave in row order, so
+// a row taken twice is added twice (as index_select's backward does).
 template <typename T>
 __global__ __launch_bounds__(256) void clam_inst_bwd_kernel(const T* __restrict__ h, const int* __restrict__ ids,
                                                             const float* __restrict__ W, const float* __restrict__ dl,
                                                             const float* __restrict__ up, int N, int L, int k, int n_cls,
                                                             T* __restrict__ dz, float* __restrict__ part) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int O = 2 * n_cls, R = 2 * k;
     __shared__ float sdl[64][CI_MAXO];
+    __shared__ int srow[64];
+    __shared__ float red[4][CI_MAXO + 1][64];
     const float u = up[b];
     for (int p = tid; p < R * O; p += 256) sdl[p / O][p % O] = dl[(size_t)b * R * O + p] * u;
+    if (tid < R) srow[tid] = ids[(size_t)b * R + tid];
     __syncthreads();
-    float* prow = part + (size_t)b * (O * (L + 1) + L);
-    for (int c = tid; c < L; c += 256) {                    // a thread owns columns c, c + 256, ...: every row's column c is its own
-        float wcol[CI_MAXO], dw[CI_MAXO], gsum = 0.f;
+    int dup = 0;
+    for (int p = tid; p < R * R; p += 256) {
+        const int i = p / R, j = p - i * R;
+        dup |= (i < j && srow[i] == srow[j]);
+    }
+    const int serial = __syncthreads_or(dup);
+    const int c = blockIdx.y * 64 + lane;
+    const bool col = c < L;
+    const int nw = serial ? 1 : 4;
+    float wcol[CI_MAXO], dw[CI_MAXO], gsum = 0.f;
 #pragma unroll
-        for (int o = 0; o < CI_MAXO; ++o) { wcol[o] = o < O ? W[(size_t)o * L + c] : 0.f; dw[o] = 0.f; }
-        for (int r = 0; r < R; ++r) {
-            const size_t row = (size_t)b * N + ids[(size_t)b * R + r];
-            const float x = to_f<T>(h[row * L + c]);
-            float g = 0.f;
+    for (int o = 0; o < CI_MAXO; ++o) { wcol[o] = (o < O && col) ? W[(size_t)o * L + c] : 0.f; dw[o] = 0.f; }
+    if (wave < nw && col) {
+        for (int r0 = wave; r0 < R; r0 += 4 * nw) {
+            float x[4], z[4];
+            size_t at[4];
 #pragma unroll
-            for (int o = 0; o < CI_MAXO; ++o)
-                if (o < O) { g += sdl[r][o] * wcol[o]; dw[o] += sdl[r][o] * x; }
-            if (x > 0.f) {
-                dz[row * L + c] = from_f<T>(to_f<T>(dz[row * L + c]) + g);
-                gsum += g;
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i * nw;
+                at[i] = ((size_t)b * N + srow[min(r, R - 1)]) * L + c;
+                x[i] = to_f<T>(h[at[i]]);
+                z[i] = to_f<T>(dz[at[i]]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i * nw;
+                if (r >= R) break;
+                if (serial && i > 0) z[i] = to_f<T>(dz[at[i]]);          // (a repeated row sees the earlier addition)
+                float g = 0.f;
+#pragma unroll
+                for (int o = 0; o < CI_MAXO; ++o)
+                    if (o < O) { g += sdl[r][o] * wcol[o]; dw[o] += sdl[r][o] * x[i]; }
+                if (x[i] > 0.f) {
+                    dz[at[i]] = from_f<T>(z[i] + g);
+                    gsum += g;
+                }
             }
         }
-#pragma unroll
-        for (int o = 0; o < CI_MAXO; ++o)
-            if (o < O) prow[(size_t)o * L + c] = dw[o];
-        prow[(size_t)O * (L + 1) + c] = gsum;
     }
-    if (tid < O) {
+#pragma unroll
+    for (int o = 0; o < CI_MAXO; ++o) red[wave][o][lane] = dw[o];
+    red[wave][CI_MAXO][lane] = gsum;
+    __syncthreads();
+    float* prow = part + (size_t)b * (O * (L + 1) + L);
+    if (col)
+        for (int o = wave; o <= O; o += 4) {                 // the waves share the O + 1 output rows of these 64 columns
+            const int oo = o < O ? o : CI_MAXO;
+            const float t = (red[0][oo][lane] + red[1][oo][lane]) + (red[2][oo][lane] + red[3][oo][lane]);
+            if (o < O) prow[(size_t)o * L + c] = t;
+            else prow[(size_t)O * (L + 1) + c] = t;
+        }
+    if (blockIdx.y == 0 && tid < O) {
         float t = 0.f;
         for (int r = 0; r < R; ++r) t += sdl[r][tid];
         prow[(size_t)O * L + tid] = t;
@@ -729,8 +778,9 @@ extern "C" int murcl_clam_inst_bwd(const void* h, const int* ids, const float* W
                                    hipStream_t st) {
     if (B <= 0) return 0;
     if (k <= 0 || k > 32 || n_cls <= 0 || 2 * n_cls > CI_MAXO) return -1;
-    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(clam_inst_bwd_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)h, ids, W, dl, up, N, L, k, n_cls, (float*)dz, part);
-    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(clam_inst_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)h, ids, W, dl, up, N, L, k, n_cls, (bf16_t*)dz, part);
+    const dim3 grid(B, (L + 63) / 64);
+    if (dtype == MURCL_DTYPE_F32) hipLaunchKernelGGL(clam_inst_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)h, ids, W, dl, up, N, L, k, n_cls, (float*)dz, part);
+    else if (dtype == MURCL_DTYPE_BF16) hipLaunchKernelGGL(clam_inst_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)h, ids, W, dl, up, N, L, k, n_cls, (bf16_t*)dz, part);
     else return -1;
     return MURCL_CHECK_LAUNCH();
 }

@@ -95,6 +95,29 @@ extern "C" int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles,
     return MURCL_CHECK_LAUNCH();
 }
 
+// The same jobs with a FLAT grid: workgroup w takes tile w - first_tile[j] of the job j whose range holds it (first_tile [n_jobs + 1]
+// on the device, ascending; a binary search), so tables that mix a 3072 x 1024 matrix with 16-row blocks run as one launch without
+// the (largest tile count) x (jobs) grid of mostly empty workgroups.
+__global__ __launch_bounds__(256) void cast_flat_kernel(const MurclCastJob* __restrict__ jobs, const int* __restrict__ first_tile,
+                                                        int n_jobs) {
+    __shared__ float t[32][33];
+    int lo = 0, hi = n_jobs - 1;
+    const int w = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_tile[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const MurclCastJob j = jobs[lo];
+    const int tile = w - first_tile[lo];
+    if (j.dtype_out == MURCL_DTYPE_BF16) cast_job_tile<bf16_t>(j, tile, t);
+    else cast_job_tile<float>(j, tile, t);
+}
+extern "C" int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, hipStream_t s) {
+    if (n_jobs <= 0 || total_tiles <= 0) return 0;
+    hipLaunchKernelGGL(cast_flat_kernel, dim3(total_tiles), dim3(256), 0, s, (const MurclCastJob*)jobs_dev, first_tile_dev, n_jobs);
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
 // grid = (column groups of 16*CPT, row splits); a thread owns CPT = 16/sizeof(T) consecutive columns (16-byte loads)
 // for one of 16 row lanes; each block adds its partial sums atomically.  Row splits are capped at 64: float atomics
@@ -402,6 +425,85 @@ extern "C" int murcl_adam_step(float* p, float* g, float* m, float* v, long n, f
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, zero_grad);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// The same update for up to MURCL_ADAM_MAX_JOBS flat runs (parameter groups with their own lr / step count) in ONE launch: the
+// table travels by value in the kernel arguments, a workgroup takes AM_CHUNK consecutive elements of one run (16-byte accesses
+// when the run's four arrays are 16-byte aligned, which flat optimizer buffers are).  Element-wise the arithmetic of adam_kernel.
+#define AM_CHUNK 4096
+struct AdamTable {
+    MurclAdamJob job[MURCL_ADAM_MAX_JOBS];
+    float bc1[MURCL_ADAM_MAX_JOBS], bc2s[MURCL_ADAM_MAX_JOBS];
+    int first_chunk[MURCL_ADAM_MAX_JOBS + 1];
+    int n_jobs;
+};
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float lr_bc1, float b1, float b2, float eps, float wd,
+                                         float bc2_sqrt) {
+    float gi = g;
+    if (wd != 0.f) gi += wd * p;
+    m = b1 * m + (1.f - b1) * gi;
+    v = b2 * v + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - lr_bc1 * (m / denom);
+}
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float wd, int zero_grad) {
+    int j = 0;
+    while (j + 1 < t.n_jobs && (int)blockIdx.x >= t.first_chunk[j + 1]) ++j;
+    const MurclAdamJob jb = t.job[j];
+    const long base = (long)((int)blockIdx.x - t.first_chunk[j]) * AM_CHUNK;
+    const long n = jb.n - base < AM_CHUNK ? jb.n - base : AM_CHUNK;
+    float* p = jb.p + base; float* g = jb.g + base; float* m = jb.m + base; float* v = jb.v + base;
+    const float lr_bc1 = jb.lr / t.bc1[j], bc2s = t.bc2s[j];
+    const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
+    if (vec && n == AM_CHUNK) {
+        f32x4 P[4], G[4], M[4], V[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+            P[u] = *(const f32x4*)(p + i); G[u] = *(const f32x4*)(g + i); M[u] = *(const f32x4*)(m + i); V[u] = *(const f32x4*)(v + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = (u * 256 + threadIdx.x) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = P[u][e], ge = G[u][e], me = M[u][e], ve = V[u][e];
+                adam_one(pe, ge, me, ve, lr_bc1, b1, b2, eps, wd, bc2s);
+                P[u][e] = pe; M[u][e] = me; V[u][e] = ve;
+            }
+            *(f32x4*)(p + i) = P[u]; *(f32x4*)(m + i) = M[u]; *(f32x4*)(v + i) = V[u];
+            if (zero_grad) *(f32x4*)(g + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    for (long i = threadIdx.x; i < n; i += 256) {
+        float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+        adam_one(pi, gi, mi, vi, lr_bc1, b1, b2, eps, wd, bc2s);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+extern "C" int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                                int zero_grad, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    if (n_jobs > MURCL_ADAM_MAX_JOBS) return -1;
+    AdamTable t;
+    t.n_jobs = 0;
+    long chunks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (jobs_host[j].n <= 0) continue;
+        const int k = t.n_jobs++;
+        t.job[k] = jobs_host[j];
+        t.bc1[k] = 1.f - powf(beta1, (float)jobs_host[j].step);
+        t.bc2s[k] = sqrtf(1.f - powf(beta2, (float)jobs_host[j].step));
+        t.first_chunk[k] = (int)chunks;
+        chunks += (jobs_host[j].n + AM_CHUNK - 1) / AM_CHUNK;
+    }
+    if (!t.n_jobs) return 0;
+    if (chunks > 0x7fffffffL) return -1;
+    t.first_chunk[t.n_jobs] = (int)chunks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, weight_decay, zero_grad);
     return MURCL_CHECK_LAUNCH();
 }
 

@@ -921,6 +921,26 @@ def _inst_constants(dev, B, N, k, n_cls, subtyping):
     return c
 
 
+class StackParamsFn(torch.autograd.Function):
+    """``torch.stack`` of the n instance classifiers' weights and of their biases (clam.py:103-132 reads them per class) -> ([n,R,L],
+    [n,R]) as one launch - none between optimizer steps (``ops.stacked_views``) - instead of two ATen concatenations per forward;
+    the backward hands every parameter its slice of the stacked gradient (no launch)."""
+
+    @staticmethod
+    def forward(ctx, n, *params):
+        ws, bs = params[:n], params[n:]
+        W, b = ops.stacked_views(ws, bs)
+        ctx.n = n
+        return W.view(n, *ws[0].shape), b.view(n, *bs[0].shape)
+
+    @staticmethod
+    def backward(ctx, dW, db):
+        n = ctx.n
+        gw = [None] * n if dW is None else [dW[i] for i in range(n)]
+        gb = [None] * n if db is None else [db[i] for i in range(n)]
+        return (None, *gw, *gb)
+
+
 class CLAMFn(torch.autograd.Function):
     """CLAM_SB.bag_forward for a batch of equal-length bags, optionally with the instance-level loss
     (models/clam.py:134-181,103-132).
@@ -1001,7 +1021,7 @@ class CLAMFn(torch.autograd.Function):
         A = ops.softmax_rows(s)                                                        # clam.py:144
         M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
         dev = x.device
-        inst_loss = _zeros_const(dev, B) if inst_cfg is None else torch.zeros((B,), dtype=torch.float32, device=dev)
+        inst_loss = _zeros_const(dev, B) if inst_cfg is None else None          # (both instance branches below write their own)
         saved_inst = None
         ids = None
         inst_pt = None

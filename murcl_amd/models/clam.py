@@ -111,8 +111,13 @@ class CLAM_SB(nn.Module):
             keeps = (ops.DropSeed(0.75), ops.DropSeed(0.75), ops.DropSeed(0.75) if self.gate else None)
         inst_w = inst_b = cfg = None
         if instance_eval:
-            inst_w = torch.stack([c.weight for c in self.instance_classifiers], 0)
-            inst_b = torch.stack([c.bias for c in self.instance_classifiers], 0)
+            cls_ = list(self.instance_classifiers)
+            if x.is_cuda:
+                from ..functional import StackParamsFn
+                inst_w, inst_b = StackParamsFn.apply(len(cls_), *[c.weight for c in cls_], *[c.bias for c in cls_])
+            else:
+                inst_w = torch.stack([c.weight for c in cls_], 0)
+                inst_b = torch.stack([c.bias for c in cls_], 0)
             # labels stay where they are: a device tensor goes to the kernels as it is (no .tolist() round trip, which would
             # stall the host on everything queued so far)
             lab = labels.reshape(-1) if isinstance(labels, torch.Tensor) else [int(l) for l in labels]

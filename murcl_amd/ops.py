@@ -675,7 +675,8 @@ def weight_views(specs):
                                              ("tr", "<i4"), ("dt", "<i4")]))
         table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
         st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None,
-                                keep=[p for p, _, _ in specs], managed=False)
+                                keep=[p for p, _, _ in specs], managed=False,
+                                tiles=[((r[2] + 31) // 32) * ((r[3] + 31) // 32) for r in rec])
     st["managed"] = all(is_managed(p) for p, _, _ in specs)
     if st["ver"] != ver or not st["managed"]:
         check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
@@ -696,7 +697,8 @@ def _job_views(key, params, build):
         jobs = np.array(rec, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
                                              ("tr", "<i4"), ("dt", "<i4")]))
         table = torch.from_numpy(jobs.view(np.uint8).copy()).to(params[0].device)
-        st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None, keep=list(params), managed=False)
+        st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None, keep=list(params), managed=False,
+                                tiles=[((r[2] + 31) // 32) * ((r[3] + 31) // 32) for r in rec])
     st["managed"] = all(is_managed(p) for p in params)
     if st["ver"] != ver or not st["managed"]:
         check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
@@ -742,6 +744,32 @@ def clam_views(w1, wa, ba, wb, bb, wc, dtype):
     return _job_views(key, params, build)
 
 
+def stacked_views(ws, bs):
+    """``torch.stack`` of n same-shaped f32 weights [R,L] and of their biases [R] -> ([n*R, L], [n*R]) f32 by ONE launch (none while an
+    optimizer that announces its steps owns them and nothing changed): CLAM's per-class instance classifiers (clam.py:103-132) as the
+    one table the instance launch reads."""
+    params = tuple(ws) + tuple(bs)
+    n = len(ws)
+    R, L = ws[0].shape
+    key = tuple((p.data_ptr(), "stack", i, n) for i, p in enumerate(params))
+
+    def build():
+        dev = ws[0].device
+        for p in params:
+            _need_cuda(p)
+            assert p.dtype == torch.float32 and p.is_contiguous()
+        W = torch.empty((n * R, L), dtype=torch.float32, device=dev)
+        b = torch.empty((n * R,), dtype=torch.float32, device=dev)
+        rec = []
+        for i in range(n):
+            assert tuple(ws[i].shape) == (R, L) and tuple(bs[i].shape) == (R,)
+            rec.append((ws[i].data_ptr(), W.data_ptr() + i * R * L * 4, R, L, 0, _lib.F32))
+            rec.append((bs[i].data_ptr(), b.data_ptr() + i * R * 4, 1, R, 0, _lib.F32))
+        max_tiles = max(((rw + 31) // 32) * ((cl + 31) // 32) for _, _, rw, cl, _, _ in rec)
+        return [W, b], rec, max_tiles
+    return _job_views(key, params, build)
+
+
 _UNIT = {}
 
 
@@ -779,20 +807,21 @@ def refresh_views(owned):
             st["ver"] = (PARAM_EPOCH, st["ver"][1])
     if not todo:
         return
-    # the launch grid is (largest tile count) x (jobs): tables of many small jobs (CLAM's 128 row / column blocks of 16 tiles) are not
-    # merged with tables holding a large matrix (the GRU's 3072 x 1024: 3072 tiles) - 400 k almost all empty workgroups took 78 us
-    groups = {}
-    for item in todo:
-        groups.setdefault(item[1]["max_tiles"].bit_length() // 3, []).append(item)
-    for grp in groups.values():
-        mkey = tuple(k for k, _ in grp)
-        merged = _MERGED.get(mkey)
-        if merged is None:
-            if len(_MERGED) >= 16:
-                _MERGED.clear()
-            merged = _MERGED[mkey] = (torch.cat([st["table"] for _, st in grp]) if len(grp) > 1 else grp[0][1]["table"],
-                                      sum(st["n"] for _, st in grp), max(st["max_tiles"] for _, st in grp))
-        check(_lib.lib().murcl_cast_batch(ptr(merged[0]), merged[1], merged[2], stream()), "cast_batch")
+    # ONE launch for all of them: a flat grid over the tiles of every job (the (largest tile count) x (jobs) grid of murcl_cast_batch
+    # spent 78 us on 400 k almost all empty workgroups when CLAM's 16-row blocks met the GRU's 3072 x 1024)
+    mkey = tuple(k for k, _ in todo)
+    merged = _MERGED.get(mkey)
+    if merged is None:
+        if len(_MERGED) >= 16:
+            _MERGED.clear()
+        table = torch.cat([st["table"] for _, st in todo]) if len(todo) > 1 else todo[0][1]["table"]
+        first, acc = [0], 0
+        for _, st in todo:
+            for t_ in st["tiles"]:
+                acc += t_
+                first.append(acc)
+        merged = _MERGED[mkey] = (table, torch.tensor(first, dtype=torch.int32).to(table.device), len(first) - 1, acc)
+    check(_lib.lib().murcl_cast_batch_flat(ptr(merged[0]), ptr(merged[1]), merged[2], merged[3], stream()), "cast_batch_flat")
     for _, st in todo:
         st["ver"] = (PARAM_EPOCH, tuple(p._version for p in st["keep"]))
 
@@ -919,6 +948,27 @@ def gru_step_bwd(dgh_next, w_hh_t, dh, gates, gh, hprev, dgi, dgh, dhprev=None, 
     assert w_hh_t.shape == (H, 3 * H) and dgh_next.shape == (B, 3 * H)
     check(_lib.lib().murcl_gru_step_bwd(ptr(dgh_next), ptr(w_hh_t), ptr(dh), ptr(gates), ptr(gh), ptr(hprev), ptr(dgi), ptr(dgh),
                                         ptr(dhprev), B, H, int(gh.shape[0] == 1 and B != 1), int(accumulate), stream()), "gru_step_bwd")
+
+
+class _AdamJob(_lib.ctypes.Structure):                 # MurclAdamJob (include/murcl_amd.h)
+    _fields_ = [("p", _lib.ctypes.c_void_p), ("g", _lib.ctypes.c_void_p), ("m", _lib.ctypes.c_void_p), ("v", _lib.ctypes.c_void_p),
+                ("n", _lib.ctypes.c_long), ("lr", _lib.ctypes.c_float), ("step", _lib.ctypes.c_int)]
+
+
+ADAM_MAX_JOBS = 8
+
+
+def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False):
+    """torch.optim.Adam.step over several flat runs in ONE launch.  ``jobs``: up to ``ADAM_MAX_JOBS`` tuples (p, g, m, v, lr, step) of
+    equally long contiguous f32 tensors (each run with its own learning rate and step count)."""
+    assert 0 < len(jobs) <= ADAM_MAX_JOBS
+    arr = (_AdamJob * len(jobs))()
+    for a, (p, g, m, v, lr, step) in zip(arr, jobs):
+        _need_cuda(p)
+        assert all(t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel() for t in (p, g, m, v))
+        a.p, a.g, a.m, a.v, a.n, a.lr, a.step = ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step)
+    check(_lib.lib().murcl_adam_multi(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
+                                      float(weight_decay), int(bool(zero_grad)), stream()), "adam_multi")
 
 
 def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, zero_grad=False):

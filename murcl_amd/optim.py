@@ -92,10 +92,13 @@ class _FlatOptimizer:
         raise NotImplementedError
 
     def step(self):
-        self.step_count += 1
         for g in self.groups:
             for lo, hi, n in self._runs(g):
                 self._launch(g, lo, hi, n)
+        self._finish_step()
+
+    def _finish_step(self):
+        self.step_count += 1
         self._fn._TOUCHED -= self._ids
         ops.refresh_views(self._owned)             # cached compute-dtype / transposed weight views: one launch
         if self.fused_zero:
@@ -132,6 +135,17 @@ class FlatAdam(_FlatOptimizer):
     def _launch(self, g, lo, hi, n):
         ops.adam_step(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], self.betas, self.eps,
                       self.weight_decay, n, zero_grad=self.fused_zero)
+
+    def step(self):
+        """All groups' runs in ONE launch when there are few of them (the usual step: one run per group); the general walk otherwise."""
+        runs = [(g, lo, hi, n) for g in self.groups for lo, hi, n in self._runs(g)]
+        if not 0 < len(runs) <= ops.ADAM_MAX_JOBS:
+            for g, lo, hi, n in runs:
+                self._launch(g, lo, hi, n)
+        else:
+            ops.adam_multi([(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], n) for g, lo, hi, n in runs],
+                           self.betas, self.eps, self.weight_decay, zero_grad=self.fused_zero)
+        self._finish_step()
 
 
 class FlatSGD(_FlatOptimizer):

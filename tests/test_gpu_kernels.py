@@ -1226,3 +1226,79 @@ def test_dropout_mask_values_rate_and_reproducibility(dtype):
     lag = (keep[:, 1:] * keep[:, :-1]).mean().item()
     assert abs(lag - 0.75 ** 2) < 5 * math.sqrt(0.5625 * 0.4375 / n)
     assert ops.dropout_mask((3,), dtype, 1.0, dev).float().tolist() == [1.0, 1.0, 1.0]
+
+
+# ------------------------------------------------------------------ CLAM instance branch, backward launch
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["distinct", "ties", "short_bag"])
+def test_clam_inst_bwd_feature_gradients_and_sums_against_row_by_row_math(dtype, case):
+    """``murcl_clam_inst_bwd`` (clam.py:103-132 backward: index_select of the 2k rows, the instance classifiers, mean CE): the rows'
+    feature gradients are added into dz under h > 0 and (dW, db, column sums of what was added) come back.  Reference: the same sums
+    row by row in f64 on the stored values.  ``ties`` / ``short_bag``: a bag whose top and bottom rows coincide - such a row is added
+    twice, as index_select's backward does (round 5: the launch walks four rows at once unless it finds such a bag)."""
+    from murcl_amd import ops
+    dev = _dev()
+    B, L, k, n_cls = 5, 512, 8, 2
+    N = 12 if case == "short_bag" else 40
+    R, Oc = 2 * k, 2 * n_cls
+    h = torch.relu(_rand(5, "ib.h", (B * N, L))).to(dtype).to(dev)
+    dz0 = _rand(5, "ib.dz", (B * N, L), 0.1).to(dtype).to(dev)
+    W = _rand(5, "ib.w", (Oc, L), 0.2).to(dev)
+    dl = _rand(5, "ib.dl", (B, R, Oc), 0.3).to(dev)
+    up = (_rand(5, "ib.up", (B,)).abs() + 0.5).to(dev)
+    rng = np.random.default_rng(11)
+    ids = np.stack([rng.permutation(N)[:R] if N >= R else rng.integers(0, N, R) for _ in range(B)]).astype(np.int32)
+    if case == "ties":
+        ids[1, k:] = ids[1, :k]                      # a uniform soft-max: both selections pick the same rows
+        ids[3, R - 1] = ids[3, 0]
+    ids_t = torch.from_numpy(ids).to(dev)
+    dz = dz0.clone()
+    dW, db, gsum = ops.clam_inst_bwd(h, ids_t, W, dl, up, B, N, k, n_cls, dz)
+    hd, Wd, dld, upd = h.double().cpu(), W.double().cpu(), dl.double().cpu(), up.double().cpu()
+    want_dz = dz0.double().cpu().clone()
+    want_dW, want_db, want_g = torch.zeros(Oc, L, dtype=torch.float64), torch.zeros(Oc, dtype=torch.float64), torch.zeros(L, dtype=torch.float64)
+    for b in range(B):
+        for r in range(R):
+            row = b * N + int(ids[b, r])
+            d = dld[b, r] * upd[b]
+            g = (d @ Wd) * (hd[row] > 0)
+            want_dz[row] = (want_dz[row] + g).to(dtype).double()          # stored in the compute dtype after every addition
+            want_g += g
+            want_dW += torch.outer(d, hd[row])
+            want_db += d
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    _close(dz, want_dz, tol, tol * 0.1, "dz")
+    _close(dW, want_dW, 1e-4, 1e-5, "dW")
+    _close(db, want_db, 1e-5, 1e-6, "db")
+    _close(gsum, want_g, 1e-4, 1e-5, "column sums")
+    untouched = torch.ones(B * N, dtype=torch.bool)
+    for b in range(B):
+        untouched[b * N + torch.from_numpy(ids[b].astype(np.int64))] = False
+    assert torch.equal(dz.cpu()[untouched], dz0.cpu()[untouched])
+
+
+# ------------------------------------------------------------------ Adam over several flat runs in one launch
+def test_adam_multi_matches_one_launch_per_run_bit_for_bit():
+    """``murcl_adam_multi`` (all parameter groups of a step in one launch, train_MuRCL.py:165-171,293-295) against ``murcl_adam_step`` run
+    by run: the same element-wise arithmetic, so p / m / v agree bit for bit - aligned runs (16-byte path), a run that starts at an odd
+    element (scalar path), a run shorter than a chunk, different learning rates and step counts; g cleared when asked."""
+    from murcl_amd import ops
+    dev = _dev()
+    sizes, lrs, steps = [3 * 4096 + 8, 4097, 130, 2 * 4096], [1e-3, 3e-4, 1e-2, 5e-5], [1, 7, 2, 1000]
+    total = sum(sizes) + 1
+    base = {k: _rand(9, f"am.{k}", (total,), 0.1 if k != "v" else 0.01).to(dev) for k in "pgmv"}
+    base["v"] = base["v"].abs()
+    offs, o = [], 1                                  # the first run starts at element 1: not 16-byte aligned
+    for n in sizes:
+        offs.append(o)
+        o += n
+    for wd, zero in ((0.0, True), (1e-2, False)):
+        a = {k: t.clone() for k, t in base.items()}
+        b = {k: t.clone() for k, t in base.items()}
+        ops.adam_multi([(a["p"][o:o + n], a["g"][o:o + n], a["m"][o:o + n], a["v"][o:o + n], lr, st)
+                        for o, n, lr, st in zip(offs, sizes, lrs, steps)], (0.9, 0.999), 1e-8, wd, zero_grad=zero)
+        for o, n, lr, st in zip(offs, sizes, lrs, steps):
+            ops.adam_step(b["p"][o:o + n], b["g"][o:o + n], b["m"][o:o + n], b["v"][o:o + n], lr, (0.9, 0.999), 1e-8, wd, st, zero_grad=zero)
+        for k in "pgmv":
+            assert torch.equal(a[k], b[k]), k
+        assert bool((a["g"][1:] == 0).all()) == zero and torch.equal(a["p"][:1], base["p"][:1])
