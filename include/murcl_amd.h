@@ -202,6 +202,14 @@ int murcl_subbag_select(const int* cluster_ids, const int* cluster_off, const in
 int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
                             const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in, int dtype_out,
                             murcl_stream_t stream);
+
+/* Every random draw of one training step in ONE launch (train_MuRCL.py:235,256-258 window positions ~ U[0,1); utils/datasets.py:265-267
+ * mix-up lambda = alpha + U(0,1)(1 - alpha) [n_views, B] and a uniform random permutation of the bags perm [n_views, B] int32 per
+ * view; models/rlmil.py:85-86 the sampler's N(0,1) noise).  Counter-based (splitmix64 of seed, stream, index): uni [n_uni] f32,
+ * nrm [n_nrm] f32; any of the three parts may be empty.  B <= MURCL_DRAWS_MAX_B. */
+#define MURCL_DRAWS_MAX_B 2048
+int murcl_step_draws(unsigned long long seed, float* uni, long n_uni, float* nrm, long n_nrm, float* lam, int* perm,
+                     int n_views, int B, float alpha, murcl_stream_t stream);
 /* K13 -- mixup on an already built batch x [B, per_bag]. */
 int murcl_mixup(const void* x, const float* lam, const int* perm, void* out, int B, long per_bag, int dtype,
                 murcl_stream_t stream);
@@ -428,6 +436,12 @@ int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stre
 /* The same table as a flat grid: first_tile_dev [n_jobs + 1] int32 (device) = ascending first tile index of every job (a job of
  * [rows, cols] has ceil(rows/32) * ceil(cols/32) tiles), total_tiles = its last entry.  For tables whose jobs differ widely in size. */
 int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, murcl_stream_t stream);
+
+/* torch.stack of several lists of equally shaped tensors in ONE launch (PPO.update, rlmil.py:163-165: the rollout's states, actions
+ * and log-probabilities): job i copies `bytes` (a multiple of 4) from src to dst.  `jobs_host` is a HOST array. */
+#define MURCL_STACK_MAX_JOBS 96
+typedef struct { const void* src; void* dst; long bytes; } MurclCopyJob;
+int murcl_stack_lists(const MurclCopyJob* jobs_host, int n_jobs, murcl_stream_t stream);
 
 /* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g
  * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */

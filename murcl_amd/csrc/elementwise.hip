@@ -118,6 +118,32 @@ extern "C" int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile
     return MURCL_CHECK_LAUNCH();
 }
 
+// torch.stack of several lists of equally shaped contiguous tensors in ONE launch: job i copies `bytes` (a multiple of 4) from src to
+// dst; the table travels in the kernel arguments (PPO.update stacks T-1 states, actions and log-probabilities per rollout,
+// rlmil.py:163-165: three ATen concatenations otherwise).  grid (ceil(max bytes / 4096), jobs).
+struct StackTable { MurclCopyJob job[MURCL_STACK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void stack_lists_kernel(StackTable t) {
+    const MurclCopyJob j = t.job[blockIdx.y];
+    const long w0 = (long)blockIdx.x * 1024, n = j.bytes >> 2;
+    const unsigned* s = (const unsigned*)j.src;
+    unsigned* d = (unsigned*)j.dst;
+    for (long w = w0 + threadIdx.x; w < w0 + 1024 && w < n; w += 256) d[w] = s[w];
+}
+extern "C" int murcl_stack_lists(const MurclCopyJob* jobs_host, int n_jobs, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    if (n_jobs > MURCL_STACK_MAX_JOBS) return -1;
+    StackTable t;
+    long mx = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (jobs_host[i].bytes < 0 || (jobs_host[i].bytes & 3)) return -1;
+        t.job[i] = jobs_host[i];
+        mx = jobs_host[i].bytes > mx ? jobs_host[i].bytes : mx;
+    }
+    if (mx == 0) return 0;
+    hipLaunchKernelGGL(stack_lists_kernel, dim3((unsigned)((mx + 4095) / 4096), n_jobs), dim3(256), 0, s, t);
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
 // grid = (column groups of 16*CPT, row splits); a thread owns CPT = 16/sizeof(T) consecutive columns (16-byte loads)
 // for one of 16 row lanes; each block adds its partial sums atomically.  Row splits are capped at 64: float atomics

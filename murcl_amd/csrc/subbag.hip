@@ -222,3 +222,59 @@ extern "C" int murcl_mixup(const void* x, const float* lam, const int* perm, voi
         return -1;
     return MURCL_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------ every random number of a step
+// One launch for the draws a MuRCL training step makes before anything is computed (train_MuRCL.py:235,256-258: uniform window
+// positions; utils/datasets.py:265-267: per view lambda = alpha + U(0,1)(1 - alpha) per bag and a uniform random permutation of
+// the bags; models/rlmil.py:85-86: the sampler's N(0,1) noise) - torch.rand x2, two elementwise ops, an argsort (a radix sort, an
+// arange and three copies) and torch.randn otherwise.  Counter-based: every value is a pure function of (seed, stream, index)
+// through splitmix64, so a step's draws do not depend on the launch geometry.
+//   uni[i]  = 24 random bits / 2^24 in [0,1)                    (stream 0)
+//   nrm[i]  = sqrt(-2 ln u1) cos(2 pi u2), u1 in (0,1]          (stream 1: Box-Muller, one value per word)
+//   lam[v,b] = alpha + uni * (1 - alpha)                         (stream 2)
+//   perm[v,:] = the argsort of B random 32-bit keys (ties by index): uniform over permutations up to key ties (~B^2 / 2^33)
+// grid: n_views workgroups for (lam, perm), then ceil((n_uni + n_nrm) / 1024) for the element streams.  B <= MURCL_DRAWS_MAX_B.
+#define SD_STREAM(seed, k) ((seed) ^ (0xA0761D6478BD642Full * (unsigned long long)((k) + 1)))
+__global__ __launch_bounds__(256) void step_draws_kernel(unsigned long long seed, float* __restrict__ uni, long n_uni,
+                                                         float* __restrict__ nrm, long n_nrm, float* __restrict__ lam,
+                                                         int* __restrict__ perm, int n_views, int B, float alpha) {
+    __shared__ unsigned keys[MURCL_DRAWS_MAX_B];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < n_views) {
+        const int v = blockIdx.x;
+        for (int b = tid; b < B; b += 256) {
+            const unsigned long long r = murcl_drop_word(SD_STREAM(seed, 2), (long)v * B + b);
+            lam[(size_t)v * B + b] = alpha + (float)(r >> 40) * (1.f / 16777216.f) * (1.f - alpha);
+            keys[b] = (unsigned)r;
+        }
+        __syncthreads();
+        for (int b = tid; b < B; b += 256) {
+            const unsigned k = keys[b];
+            int rank = 0;
+            for (int j = 0; j < B; ++j) rank += (keys[j] < k) || (keys[j] == k && j < b);
+            perm[(size_t)v * B + rank] = b;
+        }
+        return;
+    }
+    const long i0 = ((long)blockIdx.x - n_views) * 1024 + tid;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = i0 + 256 * u;
+        if (i < n_uni) {
+            uni[i] = (float)(murcl_drop_word(SD_STREAM(seed, 0), i) >> 40) * (1.f / 16777216.f);
+        } else if (i < n_uni + n_nrm) {
+            const unsigned long long r = murcl_drop_word(SD_STREAM(seed, 1), i - n_uni);
+            const float u1 = ((float)(r >> 40) + 1.f) * (1.f / 16777216.f), u2 = (float)((r >> 16) & 0xFFFFFFull) * (1.f / 16777216.f);
+            nrm[i - n_uni] = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+        }
+    }
+}
+extern "C" int murcl_step_draws(unsigned long long seed, float* uni, long n_uni, float* nrm, long n_nrm, float* lam, int* perm,
+                                int n_views, int B, float alpha, hipStream_t stream) {
+    if (n_uni < 0 || n_nrm < 0 || n_views < 0 || (n_views > 0 && (B <= 0 || B > MURCL_DRAWS_MAX_B))) return -1;
+    const long blocks = n_views + (n_uni + n_nrm + 1023) / 1024;
+    if (blocks <= 0) return 0;
+    hipLaunchKernelGGL(step_draws_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed, uni, n_uni, nrm, n_nrm, lam, perm,
+                       n_views, B, alpha);
+    return MURCL_CHECK_LAUNCH();
+}

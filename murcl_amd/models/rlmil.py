@@ -344,9 +344,13 @@ class PPO:
             returns = k.returns_finish(returns, stats, n_total)                        # rlmil.py:162 over all ranks' returns
         else:
             returns = k.returns(rewards, self.gamma)
-        old_states = torch.stack(memory.states, 0).detach()
-        old_actions = torch.stack(memory.actions, 0).detach()
-        old_logprobs = torch.stack(memory.logprobs, 0).detach()
+        if memory.states[0].is_cuda:           # rlmil.py:163-165: the three stacks as one launch
+            old_states, old_actions, old_logprobs = ops.stack_lists([[t.detach() for t in memory.states], [t.detach() for t in memory.actions],
+                                                                     [t.detach() for t in memory.logprobs]])
+        else:
+            old_states = torch.stack(memory.states, 0).detach()
+            old_actions = torch.stack(memory.actions, 0).detach()
+            old_logprobs = torch.stack(memory.logprobs, 0).detach()
         for _ in range(self.K_epochs):
             k.epoch_grads(self, old_states, old_actions, old_logprobs, returns, n_total)   # rlmil.py:169-180
             if collectives:

@@ -1301,6 +1301,23 @@ def dropout_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROP_COUNTER * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
 
 
+DRAWS_MAX_B = 2048
+
+
+def step_draws(device, n_uni=0, n_nrm=0, n_views=0, B=0, alpha=0.0, seed=None):
+    """Every random draw of a training step in ONE launch (``murcl_step_draws``): -> (uni [n_uni] f32 ~ U[0,1), nrm [n_nrm] f32 ~ N(0,1),
+    lam [n_views,B] f32 = alpha + U(0,1)(1 - alpha), perm [n_views,B] int32: a uniform random permutation per view).  Counter-based on
+    ``dropout_seed()`` (torch's global seed + a call counter: ``torch.manual_seed`` makes a run reproducible)."""
+    assert device.type == "cuda" and (n_views == 0 or 0 < B <= DRAWS_MAX_B)
+    uni = torch.empty((n_uni,), dtype=torch.float32, device=device)
+    nrm = torch.empty((n_nrm,), dtype=torch.float32, device=device)
+    lam = torch.empty((n_views, B), dtype=torch.float32, device=device)
+    perm = torch.empty((n_views, B), dtype=torch.int32, device=device)
+    check(_lib.lib().murcl_step_draws(dropout_seed() if seed is None else int(seed), ptr(uni), n_uni, ptr(nrm), n_nrm, ptr(lam), ptr(perm),
+                                      n_views, B, float(alpha), stream()), "step_draws")
+    return uni, nrm, lam, perm
+
+
 def dropout_relu_bitmask(x, drop, want_bits=True):
     """x [M,N] (contiguous, M % 32 == 0, N % 128 == 0): ``x *= keep`` in place for the mask of ``drop`` (a DropSeed) and, in the
     same pass, the panel GEMM's 1-bit mask of x > 0 afterwards -> bits [M, N/8] uint8 (None without ``want_bits``)."""
@@ -1363,6 +1380,31 @@ def stack_rows(ts):
         if ok:
             return t0.as_strided((sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
     return torch.cat(ts, 0)
+
+
+class _CopyJob(ctypes.Structure):                      # MurclCopyJob (include/murcl_amd.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
+
+
+STACK_MAX_JOBS = 96
+
+
+def stack_lists(lists):
+    """``[torch.stack(l, 0) for l in lists]`` in ONE launch (``murcl_stack_lists``): every list holds equally shaped contiguous CUDA
+    tensors of a 4-byte dtype; anything else (or more than ``STACK_MAX_JOBS`` tensors in all) goes through ``torch.stack``."""
+    flat = [t for l in lists for t in l]
+    if (not flat or len(flat) > STACK_MAX_JOBS or not all(t.is_cuda and t.is_contiguous() and t.element_size() == 4 for t in flat)
+            or any(t.shape != l[0].shape or t.dtype != l[0].dtype for l in lists for t in l)):
+        return [torch.stack(l, 0) for l in lists]
+    outs = [torch.empty((len(l),) + tuple(l[0].shape), dtype=l[0].dtype, device=l[0].device) for l in lists]
+    arr, i = (_CopyJob * len(flat))(), 0
+    for l, o in zip(lists, outs):
+        nb = l[0].numel() * 4
+        for k, t in enumerate(l):
+            arr[i].src, arr[i].dst, arr[i].bytes = t.data_ptr(), o.data_ptr() + k * nb, nb
+            i += 1
+    check(_lib.lib().murcl_stack_lists(ctypes.addressof(arr), len(flat), stream()), "stack_lists")
+    return outs
 
 
 def pointer_table(tensors):

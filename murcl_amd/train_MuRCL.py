@@ -27,7 +27,7 @@ from murcl_amd.models import abmil, cl, clam, rlmil
 from murcl_amd.optim import FlatAdam, FlatSGD, make_scheduler
 from murcl_amd.utils import general as G
 from murcl_amd.utils import checkpoint as C
-from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, draw_mixups, subbag_views
+from murcl_amd.utils.datasets import BagPack, DeviceSlideStore, draw_mixups, draw_step, subbag_views
 from murcl_amd.utils.losses import NT_Xent
 
 
@@ -102,7 +102,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     train_enc = args.train_stage != 2
     if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
-    losses, rewards, sim_last, states = [], [], None, None
+    losses, rewards, sim_last, states, loss_vec = [], [], None, None, None
     late_head, agg_outs = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), []
     # stage 3: the T aggregator passes stay sequential (the sampler needs step t's states for step t+1's windows) but share ONE
     # backward over all T * 2B bags (functional.EncoderSession); ABMIL's default shape in bf16 only
@@ -115,9 +115,9 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         # every random number of the step in four launches (uniform window positions, mix-up draws, the sampler's Gaussian
         # noise) instead of ~10 tiny launches per view and patch step; none of them depends on anything computed in the step
         rl = args.train_stage != 1
-        acts_u = torch.rand((1 if rl else args.T, 2, B, K), device=dev)                      # :235,256-258
-        mix = draw_mixups(2 * args.T, B, args.alpha, dev)                                    # datasets.py:265-267
-        noise = torch.randn((args.T - 1, 2, B, K), device=dev) if rl and args.T > 1 else None    # rlmil.py:85-86
+        acts_u, noise, mix = draw_step(dev, (1 if rl else args.T, 2, B, K),                  # :235,256-258
+                                       (args.T - 1, 2, B, K) if rl and args.T > 1 else None,  # rlmil.py:85-86
+                                       2 * args.T, B, args.alpha)                             # datasets.py:265-267
     for t in range(args.T):
         if t == 0 or args.train_stage == 1:
             acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else acts_u[t]      # [2,B,K]: one launch each
@@ -154,7 +154,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
             z_all = fc.forward_view_sequence(agg_outs).view(args.T, 2, B, -1)                # :243,272 for every step at once
             if world == 1 and 2 * B <= 128:
                 loss_t, sims = criterion.forward_steps(z_all.view(args.T, 2 * B, -1))        # :249,277: one launch
-                losses = list(loss_t.unbind(0))
+                loss_vec, losses = loss_t, list(loss_t.unbind(0))
                 rewards = list((sims[:-1] - sims[1:]).unsqueeze(1).unbind(0))                # :282-283
                 for m in memory_list:
                     m.rewards.extend(rewards)
@@ -171,7 +171,8 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                     for m in memory_list:
                         m.rewards.append(reward)
                 sim_last = sim
-    loss = sum(losses) / args.T                                                              # :291
+    # :291 - the mean of the [T] loss vector is one launch (and one in the backward); sum(list) / T was T + 1 (and T + 1 back)
+    loss = loss_vec.mean() if loss_vec is not None else sum(losses) / args.T
     enc.session = None
     if train_enc:
         optimizer.zero_grad()
@@ -208,15 +209,14 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
             acts += [a.to(dev) for a in injected["actions"][t]]
             draws += list(injected["draws"][t])
     else:
-        acts = torch.rand((2 * T_, B, K), device=dev)                                        # :235,256-258
-        draws = draw_mixups(2 * T_, B, args.alpha, dev)                                      # datasets.py:265-267
+        acts, _, draws = draw_step(dev, (2 * T_, B, K), None, 2 * T_, B, args.alpha)         # :235,256-258; datasets.py:265-267
     views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch
     losses, rewards, sim_last = [], [], None
     z_all = fc.forward_view_sequence(outputs).view(T_, 2, B, -1) if _BATCHED_HEAD and fc.fc_rnn else None   # :243,272, all steps
     if z_all is not None and world == 1 and 2 * B <= 128:
         loss_t, sims = criterion.forward_steps(z_all.view(T_, 2 * B, -1))                     # :249,277 for all steps: one launch
-        loss = loss_t.sum() / T_                                                              # :291
+        loss = loss_t.mean()                                                                  # :291
         optimizer.zero_grad()
         with functional.deferred_wgrads():
             loss.backward(ops.unit_grad(loss))

@@ -203,14 +203,32 @@ def mixup_with(inputs, lambda_, rand_idx):
 
 def draw_mixups(n_views, B, alpha, device):
     """``n_views`` independent mix-up draws (datasets.py:265-267: lambda ~ alpha + U(0,1)(1-alpha) per bag, a uniform random
-    permutation of the bags) in five launches for ALL the views of a step: one uniform tensor, lambda by two elementwise
-    ops, the permutations as the row-wise argsort of i.i.d. uniforms (uniform over permutations; an exact tie, ~B^2/2^25,
-    still yields a valid permutation).  View by view the same draws are ``torch.rand`` + ``torch.randperm``: ten tiny
+    permutation of the bags) for ALL the views of a step - one launch on the GPU (``draw_step``); elsewhere one uniform tensor,
+    lambda by two elementwise ops, the permutations as the row-wise argsort of i.i.d. uniforms (uniform over permutations; an exact
+    tie, ~B^2/2^25, still yields a valid permutation).  View by view the same draws are ``torch.rand`` + ``torch.randperm``: ten tiny
     launches each, 120 per sampler-in-the-loop step at T = 6.  Returns [(lambda [B,1] f32, perm [B] int32)] * n_views."""
+    return draw_step(device, None, None, n_views, B, alpha)[2]
+
+
+def draw_step(device, uni_shape, nrm_shape, n_views, B, alpha):
+    """Every random draw of one training step: (u ~ U[0,1) of ``uni_shape`` or None - the window positions, train_MuRCL.py:235,256-258;
+    n ~ N(0,1) of ``nrm_shape`` or None - the sampler's noise, rlmil.py:85-86; the ``draw_mixups`` of ``n_views`` views).  On the GPU
+    ONE launch (``ops.step_draws``: counter-based generator seeded from torch's global seed) instead of ~12 (two ``torch.rand``, two
+    elementwise ops, an argsort - radix sort, arange, copies - and ``torch.randn``); elsewhere the same distributions from torch ops."""
+    import math
+    nu = 0 if uni_shape is None else math.prod(uni_shape)
+    nn_ = 0 if nrm_shape is None else math.prod(nrm_shape)
+    if torch.device(device).type == "cuda":
+        from .. import ops
+        if B <= ops.DRAWS_MAX_B:
+            uni, nrm, lam, perm = ops.step_draws(torch.device(device), nu, nn_, n_views, B, alpha)
+            return (None if uni_shape is None else uni.view(uni_shape), None if nrm_shape is None else nrm.view(nrm_shape),
+                    MixDraws(lam.unsqueeze(-1), perm))
     u = torch.rand((2, n_views, B), device=device)
     lam = u[0].mul(1 - alpha).add_(alpha).unsqueeze(-1)
     perm = u[1].argsort(dim=1).to(torch.int32)
-    return MixDraws(lam, perm)
+    return (None if uni_shape is None else torch.rand(uni_shape, device=device),
+            None if nrm_shape is None else torch.randn(nrm_shape, device=device), MixDraws(lam, perm))
 
 
 class MixDraws(list):
@@ -240,7 +258,13 @@ def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, 
         acts, V = action_sequences, action_sequences.shape[0]
     else:
         V = len(action_sequences)
-        acts = action_sequences[0].unsqueeze(0) if V == 1 else torch.stack([a.to(torch.float32) for a in action_sequences], 0)
+        if V == 1:
+            acts = action_sequences[0].unsqueeze(0)
+        elif all(a.is_cuda and a.dtype == torch.float32 for a in action_sequences):
+            from .. import ops                       # the sampler's per-view rows are slices of one step output: a view, no copy
+            acts = ops.stack_rows([a.reshape(1, -1) for a in action_sequences])
+        else:
+            acts = torch.stack([a.to(torch.float32) for a in action_sequences], 0)
     if out is None:
         buf = torch.empty((V * B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
     else:                                   # a caller-owned [V*B, feat_size, d] block (functional.EncoderSession keeps all patch steps' views)

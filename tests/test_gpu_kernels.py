@@ -1303,3 +1303,58 @@ def test_adam_multi_matches_one_launch_per_run():
             _close(a[k], b[k], 2e-6, 1e-9, k)
         assert torch.equal(a["g"], b["g"])
         assert bool((a["g"][1:] == 0).all()) == zero and torch.equal(a["p"][:1], base["p"][:1])
+
+
+# ------------------------------------------------------------------ the random draws of a training step, one launch
+def test_step_draws_are_valid_and_distributed_as_the_reference_draws():
+    """``murcl_step_draws`` (train_MuRCL.py:235,256-258 ``torch.rand``; utils/datasets.py:265-267 lambda and ``torch.randperm``;
+    models/rlmil.py:85-86 N(0,1) noise): value ranges, every row of perm a permutation, moments of the three distributions, position
+    uniformity of the permutations, reproducibility from the seed and independence of the streams."""
+    from murcl_amd import ops
+    from murcl_amd.utils.datasets import draw_step
+    dev = _dev()
+    nu, nn_, V, B, alpha = 200_000, 200_000, 512, 64, 0.9
+    uni, nrm, lam, perm = ops.step_draws(dev, nu, nn_, V, B, alpha, seed=1234)
+    u, n, l, p = uni.cpu().double(), nrm.cpu().double(), lam.cpu().double(), perm.cpu().long()
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 4 * math.sqrt(1 / 12 / nu) and abs(float(u.var()) - 1 / 12) < 2e-3
+    assert abs(float(n.mean())) < 4 / math.sqrt(nn_) and abs(float(n.var()) - 1.0) < 2e-2
+    assert abs(float((n ** 4).mean()) - 3.0) < 0.15 and float(n.abs().max()) < 6.5          # kurtosis of a normal; Box-Muller's 24-bit tail
+    assert float(l.min()) >= alpha and float(l.max()) <= 1.0 and abs(float(l.mean()) - (alpha + (1 - alpha) / 2)) < 1e-3
+    assert torch.equal(p.sort(dim=1).values, torch.arange(B).expand(V, B))
+    assert len({tuple(r.tolist()) for r in p}) == V
+    # every bag is equally likely at every position: chi-square over the V draws of position 0 and of the position of bag 0
+    for counts in (torch.bincount(p[:, 0], minlength=B).double(), torch.bincount((p == 0).nonzero()[:, 1], minlength=B).double()):
+        chi2 = float(((counts - V / B) ** 2 / (V / B)).sum())
+        assert chi2 < 63 + 5 * math.sqrt(2 * 63), chi2
+    # fixed points of a uniform permutation: mean 1
+    fixed = float((p == torch.arange(B)).double().sum(1).mean())
+    assert abs(fixed - 1.0) < 0.25
+    again = ops.step_draws(dev, nu, nn_, V, B, alpha, seed=1234)
+    assert all(torch.equal(a, b) for a, b in zip((uni, nrm, lam, perm), again))
+    other = ops.step_draws(dev, nu, nn_, V, B, alpha, seed=1235)
+    assert not torch.equal(uni, other[0]) and not torch.equal(perm, other[3])
+    assert abs(float(torch.corrcoef(torch.stack([uni[:nn_], nrm]))[0, 1])) < 0.01
+    # the step-level helper: shapes, and a torch.manual_seed makes it reproducible
+    torch.manual_seed(5)
+    a = draw_step(dev, (2, 2, 8, 10), (5, 2, 8, 10), 12, 8, 0.9)
+    assert a[0].shape == (2, 2, 8, 10) and a[1].shape == (5, 2, 8, 10) and len(a[2]) == 12
+    assert a[2][3][0].shape == (8, 1) and a[2][3][1].shape == (8,) and a[2][3][1].dtype == torch.int32
+    assert sorted(a[2][3][1].tolist()) == list(range(8))
+    none = draw_step(dev, None, None, 3, 4, 1.0)
+    assert none[0] is None and none[1] is None and bool((none[2].lam == 1.0).all())
+
+
+def test_stack_lists_is_torch_stack_in_one_launch():
+    """``murcl_stack_lists`` (PPO.update, rlmil.py:163-165): several lists of equally shaped tensors stacked by one launch, bit for bit;
+    lists it does not cover (a non-contiguous member) fall back to ``torch.stack``."""
+    from murcl_amd import ops
+    dev = _dev()
+    lists = [[_rand(3, f"sl.s{t}", (6, 512)).to(dev) for t in range(5)], [_rand(3, f"sl.a{t}", (6, 10)).to(dev) for t in range(5)],
+             [_rand(3, f"sl.l{t}", (6,)).to(dev) for t in range(5)], [torch.arange(7, dtype=torch.int32, device=dev) + t for t in range(3)]]
+    got = ops.stack_lists(lists)
+    for g, l in zip(got, lists):
+        assert g.dtype == l[0].dtype and torch.equal(g, torch.stack(l, 0))
+    halves = _rand(3, "sl.h", (12, 512)).to(dev)
+    got = ops.stack_lists([[halves[:6], halves[6:]], [halves.t()[:4], halves.t()[4:8]]])       # the second list is strided: fallback
+    assert torch.equal(got[0], halves.view(2, 6, 512)) and torch.equal(got[1], torch.stack([halves.t()[:4], halves.t()[4:8]], 0))
