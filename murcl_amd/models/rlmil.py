@@ -252,9 +252,10 @@ class ActorCritic(nn.Module):
         with torch.no_grad():
             n = flat[0].shape[0]
             if restart_batch:
+                h0 = _zero_hidden(n, self.hidden_state_dim, flat[0].device)      # read-only: the first step starts from "no hidden state"
                 for m in memories:
                     del m.hidden[:]
-                    m.hidden.append(torch.zeros(1, n, self.hidden_state_dim, device=flat[0].device))
+                    m.hidden.append(h0)
             state = ops.stack_rows([s.float() for s in flat])
             noise = (torch.randn((n * len(flat), self.action_size), device=state.device) if eps is None
                      else ops.stack_rows([e.float() for e in eps]))
@@ -286,6 +287,20 @@ class ActorCritic(nn.Module):
         k = self.action_size
         ent = 0.5 * k * (1.0 + math.log(2 * math.pi)) + k * math.log(self.action_std)
         return logp.view(T_, B), value.view(T_, B), torch.full((T_, B), ent, device=state.device)
+
+
+_ZERO_HIDDEN = {}
+
+
+def _zero_hidden(n, H, device):
+    """A shared read-only [1,n,H] zero state (rlmil.py:69-71 allocates one per rollout): no fill launch per restart."""
+    key = (n, H, str(device))
+    z = _ZERO_HIDDEN.get(key)
+    if z is None:
+        if len(_ZERO_HIDDEN) > 8:
+            _ZERO_HIDDEN.clear()
+        z = _ZERO_HIDDEN[key] = torch.zeros(1, n, H, device=device)
+    return z
 
 
 class PPO:

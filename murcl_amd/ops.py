@@ -1306,14 +1306,16 @@ DRAWS_MAX_B = 2048
 
 def step_draws(device, n_uni=0, n_nrm=0, n_views=0, B=0, alpha=0.0, seed=None):
     """Every random draw of a training step in ONE launch (``murcl_step_draws``): -> (uni [n_uni] f32 ~ U[0,1), nrm [n_nrm] f32 ~ N(0,1),
-    lam [n_views,B] f32 = alpha + U(0,1)(1 - alpha), perm [n_views,B] int32: a uniform random permutation per view).  Counter-based on
-    ``dropout_seed()`` (torch's global seed + a call counter: ``torch.manual_seed`` makes a run reproducible)."""
+    lam [n_views,B] f32 = alpha + U(0,1)(1 - alpha), perm [n_views,B] int32: a uniform random permutation per view).  Counter-based; the
+    seed is drawn from torch's CPU generator (no device work; ``torch.manual_seed`` makes a run reproducible)."""
     assert device.type == "cuda" and (n_views == 0 or 0 < B <= DRAWS_MAX_B)
     uni = torch.empty((n_uni,), dtype=torch.float32, device=device)
     nrm = torch.empty((n_nrm,), dtype=torch.float32, device=device)
     lam = torch.empty((n_views, B), dtype=torch.float32, device=device)
     perm = torch.empty((n_views, B), dtype=torch.int32, device=device)
-    check(_lib.lib().murcl_step_draws(dropout_seed() if seed is None else int(seed), ptr(uni), n_uni, ptr(nrm), n_nrm, ptr(lam), ptr(perm),
+    if seed is None:                                 # 63 bits off torch's CPU generator: host-only, reproducible under torch.manual_seed
+        seed = int(torch.empty((), dtype=torch.int64).random_())
+    check(_lib.lib().murcl_step_draws(int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(uni), n_uni, ptr(nrm), n_nrm, ptr(lam), ptr(perm),
                                       n_views, B, float(alpha), stream()), "step_draws")
     return uni, nrm, lam, perm
 
