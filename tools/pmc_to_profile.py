@@ -21,6 +21,7 @@ MAP = {
     "void panel_nt_kernel<512, 32, 8, 1, false, false>": "panel_gemm<K512,MASK>",
     "void panel_nt_kernel<128, 64, 8, 2, false, false>": "panel_gemm<K128,RANK1_MASK>",
     "adam_kernel": "adam",
+    "adam_multi_kernel": "adam",
 }
 
 
