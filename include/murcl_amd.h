@@ -265,6 +265,9 @@ int murcl_dsmil_attn(const float* Q, int ldq, int qcol0, const float* qmax, int 
                      murcl_stream_t stream);
 int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
                           murcl_stream_t stream);
+/* The same ADDED into Z (no zero fill in front: the caller cleared Z, e.g. through murcl_softmax_rows_parts). */
+int murcl_weighted_rowsum_acc(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
+                              murcl_stream_t stream);
 int murcl_rows_dot(const void* X, const float* V, float* out, int B, int N, int d, int C, int dtype,
                    murcl_stream_t stream);
 /* the same + bias[c] (may be NULL): the instance classifier's Linear(d, C) (dsmil.py:9,15) in one launch */
@@ -308,6 +311,11 @@ int murcl_gated_score_bwd_il(const void* U, const float* wc, const float* ds, vo
                              unsigned long long seed_a, unsigned long long seed_b, const void* h, const float* dM,
                              const float* Mp, const float* A, int L, int rows_per_bag, murcl_stream_t stream);
 int murcl_softmax_rows(const float* s, float* A, int B, int N, murcl_stream_t stream);
+/* The same from P partial score rows part [P][B*N] (the gate epilogues 4 / 5 of murcl_panel_gemm): s [B,N] = their column sum (written
+ * too: clam.py:144 returns the raw scores), A = soft-max_N(s) - one launch instead of murcl_colsum + murcl_softmax_rows.
+ * `zero` (may be NULL): [B, zero_n] f32 cleared by the same launch - the pooled rows murcl_weighted_rowsum_acc then adds into. */
+int murcl_softmax_rows_parts(const float* part, int P, float* s, float* A, int B, int N, float* zero, int zero_n,
+                             murcl_stream_t stream);
 int murcl_softmax_rows_bwd(const float* A, const float* dA, float* ds, int B, int N, murcl_stream_t stream);
 int murcl_topk_ids(const float* A, int B, int N, int k, int* ids, murcl_stream_t stream);
 int murcl_take_rows(const void* src, const long* rows, float* out, int R, int d, int dtype, murcl_stream_t stream);

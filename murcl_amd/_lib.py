@@ -52,6 +52,7 @@ SIGNATURES = {
     "murcl_gather_rows": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "murcl_dsmil_attn": [_P, _I, _I, _P, _I, _I, _I, _P, _P],
     "murcl_weighted_rowsum": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "murcl_weighted_rowsum_acc": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot_bias": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "murcl_rows_dot_wsum_plan": [_I, _I, _I, _I],
@@ -71,6 +72,7 @@ SIGNATURES = {
     "murcl_clam_inst_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "murcl_gated_score_bwd_il": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, _P, _P, _P, _I, _I, _P],
     "murcl_softmax_rows": [_P, _P, _I, _I, _P],
+    "murcl_softmax_rows_parts": [_P, _I, _P, _P, _I, _I, _P, _I, _P],
     "murcl_softmax_rows_bwd": [_P, _P, _P, _I, _I, _P],
     "murcl_topk_ids": [_P, _I, _I, _I, _P, _P],
     "murcl_take_rows": [_P, _P, _P, _I, _I, _I, _P],

@@ -390,6 +390,83 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     const float inv = 1.f / red[0];
     for (int n = tid; n < N; n += 256) y[n] *= inv;
 }
+// The same from P partial score rows part [P][B*N] (murcl_panel_gemm's gate epilogues leave one row per 32-column group; attention_c's
+// bias rides in row 0): s = their column sum, A = soft-max_N(s), ONE launch and one read of every partial - the column-sum launch, its
+// [B*N] round trip and two of the soft-max kernel's three passes over global memory are gone (6 + 14 us -> 8 at 64 x 4096, P = 16).
+// A thread keeps its SR_PT values of a bag in registers (N <= 256 * SR_PT; longer bags re-read s).
+#define SR_PT 16
+__global__ __launch_bounds__(256) void softmax_rows_parts_kernel(const float* __restrict__ part, int P, long M, float* __restrict__ s,
+                                                                 float* __restrict__ A, int N, float* __restrict__ zero, int zero_n) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < zero_n; i += 256) zero[(size_t)b * zero_n + i] = 0.f;      // the pooled row the next pass adds into
+    const float* x = part + (size_t)b * N;
+    float* so = s + (size_t)b * N;
+    float* y = A + (size_t)b * N;
+    const bool in_regs = N <= 256 * SR_PT;
+    float v[SR_PT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < SR_PT; ++t) v[t] = 0.f;
+    // partial row by partial row, the thread's SR_PT columns of it in flight together (column by column the P loads of a column were
+    // P dependent round trips on 64 workgroups: 115 us at 64 x 4096, P = 16)
+    int p = 0;
+    for (; p + 3 < P; p += 4) {                              // four partial rows x SR_PT columns = 64 loads in flight per thread
+        float w[4][SR_PT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < SR_PT; ++t) w[q][t] = (tid + 256 * t < N) ? x[(size_t)(p + q) * M + tid + 256 * t] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < SR_PT; ++t) v[t] += w[q][t];
+    }
+    for (; p < P; ++p) {
+        const float* xp = x + (size_t)p * M;
+        float w[SR_PT];
+#pragma unroll
+        for (int t = 0; t < SR_PT; ++t) w[t] = (tid + 256 * t < N) ? xp[tid + 256 * t] : 0.f;
+#pragma unroll
+        for (int t = 0; t < SR_PT; ++t) v[t] += w[t];
+    }
+#pragma unroll
+    for (int t = 0; t < SR_PT; ++t) {
+        const int n = tid + 256 * t;
+        if (n < N) { so[n] = v[t]; mx = fmaxf(mx, v[t]); } else v[t] = -INFINITY;
+    }
+    for (int n = tid + 256 * SR_PT; n < N; n += 256) {
+        float a = 0.f;
+        for (int p = 0; p < P; ++p) a += x[(size_t)p * M + n];
+        so[n] = a;
+        mx = fmaxf(mx, a);
+    }
+    red[tid] = mx; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < SR_PT; ++t) {
+        v[t] = (tid + 256 * t < N) ? expf(v[t] - mx) : 0.f;
+        sum += v[t];
+    }
+    for (int n = tid + 256 * SR_PT; n < N; n += 256) { const float e = expf(so[n] - mx); y[n] = e; sum += e; }
+    red[tid] = sum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.f / red[0];
+#pragma unroll
+    for (int t = 0; t < SR_PT; ++t)
+        if (tid + 256 * t < N) y[tid + 256 * t] = v[t] * inv;
+    if (!in_regs)
+        for (int n = tid + 256 * SR_PT; n < N; n += 256) y[n] *= inv;
+}
+extern "C" int murcl_softmax_rows_parts(const float* part, int P, float* s, float* A, int B, int N, float* zero, int zero_n,
+                                        hipStream_t st) {
+    if (B <= 0) return 0;
+    if (P <= 0) return -1;
+    hipLaunchKernelGGL(softmax_rows_parts_kernel, dim3(B), dim3(256), 0, st, part, P, (long)B * N, s, A, N, zero, zero ? zero_n : 0);
+    return MURCL_CHECK_LAUNCH();
+}
 // ds = A * (dA - sum_n A dA)
 __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dA,
                                                                float* __restrict__ ds, int N) {

@@ -240,12 +240,14 @@ __global__ __launch_bounds__(256) void weighted_rowsum_kernel(const T* __restric
         }
     }
 }
-extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
-                                     hipStream_t s) {
+static int weighted_rowsum_launch(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype, bool zero,
+                                  hipStream_t s) {
     if (B <= 0) return 0;
     if (C > 4 || d % 8) return -1;
-    hipError_t e = hipMemsetAsync(Z, 0, (size_t)B * C * d * 4, s);
-    if (e != hipSuccess) return (int)e;
+    if (zero) {
+        hipError_t e = hipMemsetAsync(Z, 0, (size_t)B * C * d * 4, s);
+        if (e != hipSuccess) return (int)e;
+    }
     int splits = (WR_WGS + B - 1) / B;
     if (splits > (N + 63) / 64) splits = (N + 63) / 64;
     if (splits < 1) splits = 1;
@@ -258,6 +260,15 @@ extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, in
     else
         return -1;
     return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_weighted_rowsum(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
+                                     hipStream_t s) {
+    return weighted_rowsum_launch(X, A, Z, B, N, d, C, dtype, true, s);
+}
+// the same ADDED to Z (the caller - e.g. murcl_softmax_rows_parts - has zeroed it: no fill launch in front of the pass)
+extern "C" int murcl_weighted_rowsum_acc(const void* X, const float* A, float* Z, int B, int N, int d, int C, int dtype,
+                                         hipStream_t s) {
+    return weighted_rowsum_launch(X, A, Z, B, N, d, C, dtype, false, s);
 }
 
 // out[b,n,c] = X[b,n,:] . V[b,c,:]      (dA = X dZ^T; C <= 4).  A wave walks `RPW` rows; a lane owns 8 consecutive

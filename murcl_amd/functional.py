@@ -1005,10 +1005,9 @@ class CLAMFn(torch.autograd.Function):
             # forward-only calls (validation, heat-map scoring, the frozen aggregator of stage 2): the score comes out of the gate
             # GEMM's epilogue - tanh(a_d) sigmoid(b_d) c_d summed per wave - and the [B*N, 2D] pre-activations are never written
             U = None
-            s = ops.panel_gate_score(h, views[1], views[3], views[4], bc).view(B, N)
+            s_parts = ops.panel_gate_score(h, views[1], views[3], views[4], bc, parts=True)
         elif gate_u:
-            U, s = ops.panel_gate_u(h, views[1], views[3], views[4], bc, ka, kb)
-            s = s.view(B, N)
+            U, s_parts = ops.panel_gate_u(h, views[1], views[3], views[4], bc, ka, kb, parts=True)
         else:
             wab = torch.cat([wa, wb], 0) if gated else wa
             bab = torch.cat([ba, bb], 0) if gated else ba
@@ -1018,8 +1017,14 @@ class CLAMFn(torch.autograd.Function):
                 U = ops.gemm_nt(h, c(wab), epi=ops.EPI_BIAS, bias=bab)
         if not fused_gate and not gate_u:
             s = ops.gated_score_fwd(U, wc.reshape(-1).contiguous(), bc, ka, kb, gated=gated).view(B, N)
-        A = ops.softmax_rows(s)                                                        # clam.py:144
-        M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)           # clam.py:170
+        if fused_gate or gate_u:
+            # the epilogue's partial rows summed on the way, and the pooled rows cleared for the pass below: one launch
+            M = torch.empty((B, L), dtype=torch.float32, device=x.device)
+            s, A = ops.softmax_rows_parts(s_parts, B, N, zero=M)
+            ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1), into=M)              # clam.py:170
+        else:
+            A = ops.softmax_rows(s)                                                    # clam.py:144
+            M = ops.weighted_rowsum(h.view(B, N, L), A.view(B, N, 1)).view(B, L)       # clam.py:170
         dev = x.device
         inst_loss = _zeros_const(dev, B) if inst_cfg is None else None          # (both instance branches below write their own)
         saved_inst = None

@@ -157,9 +157,10 @@ def gate_interleave(wa, ba, wb, bb, wc, dtype):
     return (W.contiguous() if dtype == torch.float32 else cast(W.contiguous(), dtype)), b, c
 
 
-def panel_gate_score(h, W_il, b_il, c_il, bc):
+def panel_gate_score(h, W_il, b_il, c_il, bc, parts=False):
     """CLAM's gated attention score straight from the gate GEMM's epilogue (``murcl_panel_gemm`` epilogue 4): h [M,512] bf16 ->
-    raw scores s [M] f32 = sum_d tanh(a_d) sigmoid(b_d) wc_d + bc, without materialising the [M, 2D] gate pre-activations."""
+    raw scores s [M] f32 = sum_d tanh(a_d) sigmoid(b_d) wc_d + bc, without materialising the [M, 2D] gate pre-activations.
+    ``parts``: the [N/32, M] partial score rows instead of their sum (``softmax_rows_parts`` sums them on its way to the soft-max)."""
     _need_cuda(h, W_il)
     h = _c(h)
     M, K = h.shape
@@ -168,10 +169,10 @@ def panel_gate_score(h, W_il, b_il, c_il, bc):
     with _span(lambda: (f"panel_gemm<K{K},GATE>", dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + (N // 32) * M * 4))):
         check(_lib.lib().murcl_panel_gemm(ptr(h), ptr(W_il), None, M, N, K, PG_GATE, ptr(b_il), None, None, ptr(_c(bc)), ptr(c_il), 0,
                                           None, 0, ptr(part), 0, stream()), "panel_gemm(gate)")
-    return colsum(part)                                                   # (attention_c's bias rides in partial row 0)
+    return part if parts else colsum(part)                                # (attention_c's bias rides in partial row 0)
 
 
-def panel_gate_u(h, W_il, b_il, c_il, bc, keep_a=None, keep_b=None):
+def panel_gate_u(h, W_il, b_il, c_il, bc, keep_a=None, keep_b=None, parts=False):
     """CLAM's gate GEMM for a call that a backward pass may follow (``murcl_panel_gemm_drop`` epilogue 5): the raw scores as in
     ``panel_gate_score`` AND the gate pre-activations U [M, 2D] bf16 in the interleaved column order of ``gate_interleave`` (read
     back by ``gated_score_bwd_il``).  ``keep_a`` / ``keep_b``: DropSeed specs of the two gate Dropouts (clam.py:47-48) or None.
@@ -186,7 +187,7 @@ def panel_gate_u(h, W_il, b_il, c_il, bc, keep_a=None, keep_b=None):
     with _span(lambda: (f"panel_gemm<K{K},GATE_U>", dict(flops=2.0 * M * N * K, bytes=M * K * 2 + N * K * 2 + M * N * 2 + (N // 32) * M * 4))):
         check(_lib.lib().murcl_panel_gemm_drop(ptr(h), ptr(W_il), ptr(U), M, N, K, PG_GATE_U, ptr(b_il), None, None, ptr(_c(bc)), ptr(c_il), 0,
                                                None, 0, ptr(part), 0, kp, sa, sb, stream()), "panel_gemm(gate_u)")
-    return U, colsum(part)                                                # (attention_c's bias rides in partial row 0)
+    return U, (part if parts else colsum(part))                           # (attention_c's bias rides in partial row 0; ``parts``: as above)
 
 
 def gated_score_bwd_il(U, wc, keep_a=None, keep_b=None, *, ds=None, h=None, dM=None, Mp=None, A=None, rows_per_bag=0):
@@ -1101,11 +1102,17 @@ def dsmil_softmax_bwd(A, dA):
     return dS
 
 
-def weighted_rowsum(X, A):
-    """Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]   X [B,N,d] (f32/bf16), A [B,N,C] f32 -> Z [B,C,d] f32."""
+def weighted_rowsum(X, A, into=None):
+    """Z[b,c,:] = sum_n A[b,n,c] X[b,n,:]   X [B,N,d] (f32/bf16), A [B,N,C] f32 -> Z [B,C,d] f32.  ``into``: a [B,C,d] f32 tensor the
+    sums are ADDED to (cleared by the caller: ``murcl_weighted_rowsum_acc``, no fill launch)."""
     X, A = _c(X), _c(A)
     B, N, d = X.shape
     C = A.shape[2]
+    if into is not None:
+        assert into.is_contiguous() and into.dtype == torch.float32 and into.numel() == B * C * d
+        with _span(lambda: (f"weighted_rowsum<{_DT_NAME[X.dtype]}>", dict(bytes=X.numel() * X.element_size(), flops=2.0 * B * N * d * C))):
+            check(_lib.lib().murcl_weighted_rowsum_acc(ptr(X), ptr(A), ptr(into), B, N, d, C, dt(X), stream()), "weighted_rowsum_acc")
+        return into.view(B, C, d)
     if B == 1 and N >= 1 << 16 and N % 64 == 0:
         # one long "bag" (a weight gradient over all patches): the kernel's row splits all add atomically into the same
         # C*d addresses - 1024 adders per address serialise at the memory side (250 us for a 537 MB pass).  Cut the rows
@@ -1200,6 +1207,19 @@ def softmax_rows(s):
     A = torch.empty_like(s)
     check(_lib.lib().murcl_softmax_rows(ptr(s), ptr(A), s.shape[0], s.shape[1], stream()), "softmax_rows")
     return A
+
+
+def softmax_rows_parts(part, B, N, zero=None):
+    """part [P, B*N] partial score rows -> (s [B,N] = their column sum, A [B,N] = soft-max over N): one launch.  ``zero``: a [B, n] f32
+    tensor cleared by the same launch (the pooled rows ``weighted_rowsum(..., into=zero)`` then adds into: no fill launch)."""
+    part = _c(part)
+    assert part.dtype == torch.float32 and part.shape[1] == B * N
+    assert zero is None or (zero.is_contiguous() and zero.dtype == torch.float32 and zero.shape[0] == B)
+    s = torch.empty((B, N), dtype=torch.float32, device=part.device)
+    A = torch.empty_like(s)
+    check(_lib.lib().murcl_softmax_rows_parts(ptr(part), part.shape[0], ptr(s), ptr(A), B, N, ptr(zero), 0 if zero is None else zero.numel() // B,
+                                              stream()), "softmax_rows_parts")
+    return s, A
 
 
 def softmax_rows_bwd(A, dA):

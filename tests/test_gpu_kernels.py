@@ -1358,3 +1358,24 @@ def test_stack_lists_is_torch_stack_in_one_launch():
     halves = _rand(3, "sl.h", (12, 512)).to(dev)
     got = ops.stack_lists([[halves[:6], halves[6:]], [halves.t()[:4], halves.t()[4:8]]])       # the second list is strided: fallback
     assert torch.equal(got[0], halves.view(2, 6, 512)) and torch.equal(got[1], torch.stack([halves.t()[:4], halves.t()[4:8]], 0))
+
+
+@pytest.mark.parametrize("B,N,P", [(64, 4096, 16), (3, 1000, 16), (2, 5000, 4), (1, 7, 1)])
+def test_softmax_rows_parts_equals_colsum_then_softmax(B, N, P):
+    """``murcl_softmax_rows_parts`` (clam.py:144 on the gate epilogue's partial score rows): s = the column sum of the P rows, A = its
+    soft-max over the N patches of each bag, against f64 (1e-6) - bags longer than the register-resident 4096 rows included."""
+    from murcl_amd import ops
+    dev = _dev()
+    part = _rand(31, f"srp.{B}.{N}.{P}", (P, B * N), 2.0).to(dev)
+    s, A = ops.softmax_rows_parts(part, B, N)
+    want_s = part.double().sum(0).view(B, N)
+    _close(s, want_s, 1e-6, 4e-6, "s")
+    _close(A, torch.softmax(want_s, 1), 2e-5, 1e-9, "A")
+    assert torch.allclose(A.sum(1).cpu(), torch.ones(B), atol=1e-5)
+    # ... and the pooled rows cleared by the same launch, the pooling pass adding into them (no fill launch in between)
+    X = _rand(31, f"srp.x{B}.{N}", (B, N, 64)).to(dev)
+    Mz = torch.full((B, 64), 7.0, device=dev)
+    s2, A2 = ops.softmax_rows_parts(part, B, N, zero=Mz)
+    assert torch.equal(s2, s) and torch.equal(A2, A) and float(Mz.abs().max()) == 0.0
+    got = ops.weighted_rowsum(X, A2.view(B, N, 1), into=Mz).view(B, 64)
+    _close(got, torch.einsum("bn,bnd->bd", A2.double().cpu(), X.double().cpu()), 1e-5, 1e-6, "pooled rows")
