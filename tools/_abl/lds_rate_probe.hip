@@ -27,12 +27,13 @@ __global__ __launch_bounds__(512) void lds_rate_kernel(int iters, unsigned long 
         f32x4 v[8];
         u32x2 w[16];
         const unsigned o = (it & 1) ? 512u : 0u;
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
+        const unsigned ab = MODE == 0 ? a128 : a128 - q4 * 16 + q4 * 256;      // MODE 3: the panel kernels' k assignment (chunk kk + 16 q4)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(a128 + o + u * 64 + h * 16 * 1040));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(ab + (MODE == 0 ? o + u * 64 : (o >> 2) + u * 16) + h * 16 * 1040));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += v[u][0];
@@ -59,6 +60,7 @@ extern "C" int murcl_debug_lds_rate(int mode, int waves, int grid, int iters, un
     const dim3 g(grid), b(64 * waves);
     const int lds = 48 * 1040;
     if (mode == 0) hipLaunchKernelGGL(lds_rate_kernel<0>, g, b, lds, s, iters, cycles, sink);
+    else if (mode == 3) hipLaunchKernelGGL(lds_rate_kernel<3>, g, b, lds, s, iters, cycles, sink);
     else if (mode == 1) hipLaunchKernelGGL(lds_rate_kernel<1>, g, b, lds, s, iters, cycles, sink);
     else hipLaunchKernelGGL(lds_rate_kernel<2>, g, b, lds, s, iters, cycles, sink);
     return (int)hipGetLastError();
