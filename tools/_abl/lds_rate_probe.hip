@@ -17,7 +17,8 @@ __global__ __launch_bounds__(512) void lds_rate_kernel(int iters, unsigned long 
     const int r16 = lane & 15, q4 = lane >> 4;
     // b128: row r16 (+16 per fragment pair), 16-byte chunk q4 + 4u of the row; b64 / tr: row 4 q4 + (r16 >> 2), 8-byte piece
     const char* p128 = smem + r16 * 1040 + q4 * 16;
-    const char* p64 = smem + (4 * q4 + (r16 >> 2)) * 1040 + (r16 & 3) * 8;
+    constexpr int ST64 = (MODE >= 4) ? 1056 : 1040;                       // MODE 4 / 5: rows 32 B apart in the bank image (16 rows = two full 256-byte lines)
+    const char* p64 = smem + (4 * q4 + (r16 >> 2)) * ST64 + (r16 & 3) * 8;
     float acc = 0.f;
     const unsigned a128 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(p128);
     const unsigned a64 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(p64);
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(512) void lds_rate_kernel(int iters, unsigned long 
         } else {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                if (MODE == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(w[u]) : "v"(a64 + (o >> 1) + (u & 7) * 32 + (u >> 3) * 16 * 1040));
-                else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(w[u]) : "v"(a64 + (o >> 1) + (u & 7) * 32 + (u >> 3) * 16 * 1040));
+                if (MODE == 1 || MODE == 4) asm volatile("ds_read_b64 %0, %1" : "=v"(w[u]) : "v"(a64 + (o >> 1) + (u & 7) * 32 + (u >> 3) * 16 * ST64));
+                else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(w[u]) : "v"(a64 + (o >> 1) + (u & 7) * 32 + (u >> 3) * 16 * ST64));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -58,9 +59,11 @@ __global__ __launch_bounds__(512) void lds_rate_kernel(int iters, unsigned long 
 // mode 0: ds_read_b128, 1: ds_read_b64, 2: ds_read_b64_tr_b16; waves = 4 or 8 per workgroup; cycles [grid][8]
 extern "C" int murcl_debug_lds_rate(int mode, int waves, int grid, int iters, unsigned long long* cycles, float* sink, hipStream_t s) {
     const dim3 g(grid), b(64 * waves);
-    const int lds = 48 * 1040;
+    const int lds = 48 * 1056;
     if (mode == 0) hipLaunchKernelGGL(lds_rate_kernel<0>, g, b, lds, s, iters, cycles, sink);
     else if (mode == 3) hipLaunchKernelGGL(lds_rate_kernel<3>, g, b, lds, s, iters, cycles, sink);
+    else if (mode == 4) hipLaunchKernelGGL(lds_rate_kernel<4>, g, b, lds, s, iters, cycles, sink);
+    else if (mode == 5) hipLaunchKernelGGL(lds_rate_kernel<5>, g, b, lds, s, iters, cycles, sink);
     else if (mode == 1) hipLaunchKernelGGL(lds_rate_kernel<1>, g, b, lds, s, iters, cycles, sink);
     else hipLaunchKernelGGL(lds_rate_kernel<2>, g, b, lds, s, iters, cycles, sink);
     return (int)hipGetLastError();
