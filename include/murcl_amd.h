@@ -137,30 +137,28 @@ int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_
 int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* bb,
                          float* scores, float* A, float* M, float* ml, float* part_ws, int B, int N, int L, int D,
                          int dtype, int exact_tanh, murcl_stream_t stream);
-/* The second launch of murcl_abmil_pool_fwd on its own (chunk partials -> A, M, ml): pass A = M = ml = NULL to
- * murcl_abmil_pool_fwd to get the partials only, e.g. to time the streaming kernel by itself. */
+/* The per-bag merge of murcl_abmil_pool_fwd on its own (chunk partials -> A, M, ml): pass A = M = ml = NULL to
+ * murcl_abmil_pool_fwd to get the partials + raw scores only (ONE launch: what a training step runs since round 6 - the merge
+ * then happens inside the decoder launch below, and the normalised attention row is formed by the backward pass or, for
+ * `last_attention`, by this entry on demand). */
 int murcl_abmil_pool_combine(const float* scores, const float* part_ws, float* A, float* M, float* ml, int B, int N,
                              int dtype, murcl_stream_t stream);
+/* K3 with K2's merge on load, abmil.py:29-32,43-44: out [B,Lout] = relu?(M Wd^T + bd) with M formed from the chunk partials
+ * part_ws of murcl_abmil_pool_fwd while the product loads its A operand; M [B,L] and ml [B,2] are written as by-products (the
+ * backward pass reads them).  f32 throughout (exact-f32 MFMA), Wd [Lout,L], L = 512, Lout a multiple of 16.  Returns -1 when the
+ * shape is outside the kernel (more than 512 chunks per bag): callers then run murcl_abmil_pool_combine + murcl_gemm_nt. */
+int murcl_abmil_pool_decoder(const float* part_ws, const float* Wd, const float* bd, float* M, float* ml, float* out, int B,
+                             int N, int L, int Lout, int dtype, int relu, murcl_stream_t stream);
 /* backward of the above w.r.t. the pre-tanh activations: dT[b,n,:] = ds_n * wb * (1 - t^2) with
  * ds_n = p_n (dM.H_n / sqrt(N) - dM.M), plus dba += sum dT, dwb += sum ds_n t_n, dbb += sum ds_n
  * (f32, ADDED to the buffers: per-workgroup partial rows in part_ws [512*(2D+1) floats] are summed by a second small
- * launch - 512 atomic adders per address cost a third of the kernel).  dH and dWa follow from dT through murcl_gemm_nt
+ * launch - 512 atomic adders per address cost a third of the kernel).  A_out (may be NULL) [B,N] receives the normalised
+ * attention row softmax(s)/sqrt(N) the pass has in registers.  dH and dWa follow from dT through murcl_panel_gemm / murcl_gemm_nt
  * (MURCL_EPI_RANK1_MASK with rowscale = A, rank1 = dM) and murcl_gemm_tn. */
 int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
                          const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
-                         float* dbb, float* part_ws, int B, int N, int L, int D, int dtype, int exact_tanh,
+                         float* dbb, float* part_ws, float* A_out, int B, int N, int L, int D, int dtype, int exact_tanh,
                          murcl_stream_t stream);
-/* The same backward pass with the attention weight gradient formed in it (abmil.py:23-27 `attention.0.weight`):
- * dWa [D,L] f32 (+)= dT^T H from the rows of H the pass is streaming anyway, instead of a second pass over H and dT by
- * murcl_gemm_tn.  bf16, L = 512, D = 128 only: murcl_abmil_pool_bwd_dwa_ws_floats returns 0 for anything else (callers then
- * use murcl_abmil_pool_bwd + murcl_gemm_tn), otherwise the number of floats of workspace `ws` (16-byte aligned) the call needs:
- * one partial dWa and one row of partial dba / dwb / dbb sums per workgroup, added up by a second launch in a fixed order
- * (bit-reproducible).  dba / dwb / dbb are ADDED to; dWa is added to when dwa_accumulate != 0, written otherwise. */
-long murcl_abmil_pool_bwd_dwa_ws_floats(int B, int N, int L, int D, int dtype);
-int murcl_abmil_pool_bwd_dwa(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
-                             const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
-                             float* dbb, float* dWa, int dwa_accumulate, float* ws, long ws_floats, int B, int N, int L,
-                             int D, int dtype, int exact_tanh, murcl_stream_t stream);
 
 /* K8/K9 -- NT_Xent.forward + its gradient + torch.cosine_similarity of the positive pairs in one
  * call (one launch for n <= 128, two for the larger global batch of a multi-GPU step; utils/losses.py:24-41;

@@ -36,9 +36,8 @@ SIGNATURES = {
     "murcl_kmeans_workspace_bytes": [_I, _I, _I],
     "murcl_kmeans_step": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "murcl_abmil_pool_combine": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "murcl_abmil_pool_bwd_dwa_ws_floats": [_I, _I, _I, _I, _I],
-    "murcl_abmil_pool_bwd_dwa": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_decoder": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_abmil_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_ntxent_workspace_bytes": [_I],
     "murcl_ntxent_fwd_bwd": [_P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
     "murcl_ntxent_fwd_bwd_batched": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -110,7 +109,7 @@ SIGNATURES = {
     "murcl_adam_multi": [_P, _I, _F, _F, _F, _F, _I, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
-_RESTYPE = {"murcl_abmil_pool_bwd_dwa_ws_floats": _L, "murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
+_RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,
             "murcl_ppo_epoch_workspace": _L}
 
 

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmurcl_amd.so")
-SOURCES = ["runtime.hip", "gemm.hip", "panel_gemm.hip", "attn_pool.hip", "attn_pool_bwd.hip", "attn_pool_bwd_dwa.hip", "ntxent.hip", "elementwise.hip", "gru.hip", "subbag.hip", "dsmil.hip", "clam.hip", "ppo.hip", "ppo_seq.hip", "kmeans.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "panel_gemm.hip", "attn_pool.hip", "attn_pool_bwd.hip", "ntxent.hip", "elementwise.hip", "gru.hip", "subbag.hip", "dsmil.hip", "clam.hip", "ppo.hip", "ppo_seq.hip", "kmeans.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -511,52 +511,61 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
 // Per bag: merge chunk partials, emit A[n] = softmax(s)_n / sqrt(N), pooled M, and (m, l).  K2C_SPLIT workgroups per bag (round 5:
 // one per bag left half the chip idle and made this launch 5.2-5.6 us of K2's 58): each takes 1 / K2C_SPLIT of the pooled columns and
 // of the rows of A; all of them read the bag's S (m, l) headers (a few hundred bytes, L2-resident).
+// Round 6: off the training step (the merge lives in abmil_pool_decoder_kernel below); what is left is the stand-alone entry point and
+// `last_attention` on demand.  Any of A / Mout may be NULL; part == NULL: (m, l) are READ from ml (the statistics a decoder launch
+// left behind) and only A is formed.
 #define K2C_SPLIT 4
 __global__ __launch_bounds__(128) void abmil_pool_combine_kernel(const float* __restrict__ scores,
                                                                  const float* __restrict__ part, float* __restrict__ A,
                                                                  float* __restrict__ Mout, float* __restrict__ ml,
                                                                  int N, int S, float inv_sqrt_n) {
     const int bag = blockIdx.x / K2C_SPLIT, q = blockIdx.x % K2C_SPLIT, tid = threadIdx.x;
-    const float* pp = part + (size_t)bag * S * (K2_L + 2);
     constexpr int CPT = K2_L / K2C_SPLIT / 128;          // pooled columns per thread: 1
     static_assert(CPT == 1, "one pooled column per thread");
     const int col = q * (K2_L / K2C_SPLIT) + tid;
-    // the chunks' (m, l) headers first, one per thread: walked one chunk after the other by every thread they were 2 S dependent
-    // round trips (9 us at S = 8)
-    __shared__ float hm[128], hl[128];
     float m = -INFINITY, l = 0.f, a0 = 0.f;
-    if (S <= 128) {
-        if (tid < S) { hm[tid] = pp[(size_t)tid * (K2_L + 2)]; hl[tid] = pp[(size_t)tid * (K2_L + 2) + 1]; }
-        __syncthreads();
-        for (int s = 0; s < S; ++s) m = fmaxf(m, hm[s]);
-        int s = 0;
-        for (; s + 3 < S; s += 4) {                          // four chunks' partial rows in flight
-            float w[4], p0[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                w[u] = (hm[s + u] == -INFINITY) ? 0.f : expf(hm[s + u] - m);
-                p0[u] = pp[(size_t)(s + u) * (K2_L + 2) + 2 + col];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; }
-        }
-        for (; s < S; ++s) {
-            const float w = (hm[s] == -INFINITY) ? 0.f : expf(hm[s] - m);
-            l += hl[s] * w;
-            a0 += pp[(size_t)s * (K2_L + 2) + 2 + col] * w;
-        }
+    if (!part) {
+        m = ml[2 * bag];
+        l = ml[2 * bag + 1];
     } else {
-        for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
-        for (int s = 0; s < S; ++s) {
-            const float* p = pp + (size_t)s * (K2_L + 2);
-            const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
-            l += p[1] * w;
-            a0 += p[2 + col] * w;
+        const float* pp = part + (size_t)bag * S * (K2_L + 2);
+        // the chunks' (m, l) headers first, one per thread: walked one chunk after the other by every thread they were 2 S dependent
+        // round trips (9 us at S = 8)
+        __shared__ float hm[128], hl[128];
+        if (S <= 128) {
+            if (tid < S) { hm[tid] = pp[(size_t)tid * (K2_L + 2)]; hl[tid] = pp[(size_t)tid * (K2_L + 2) + 1]; }
+            __syncthreads();
+            for (int s = 0; s < S; ++s) m = fmaxf(m, hm[s]);
+            int s = 0;
+            for (; s + 3 < S; s += 4) {                          // four chunks' partial rows in flight
+                float w[4], p0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w[u] = (hm[s + u] == -INFINITY) ? 0.f : expf(hm[s + u] - m);
+                    p0[u] = pp[(size_t)(s + u) * (K2_L + 2) + 2 + col];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; }
+            }
+            for (; s < S; ++s) {
+                const float w = (hm[s] == -INFINITY) ? 0.f : expf(hm[s] - m);
+                l += hl[s] * w;
+                a0 += pp[(size_t)s * (K2_L + 2) + 2 + col] * w;
+            }
+        } else {
+            for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
+            for (int s = 0; s < S; ++s) {
+                const float* p = pp + (size_t)s * (K2_L + 2);
+                const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
+                l += p[1] * w;
+                a0 += p[2 + col] * w;
+            }
         }
     }
     const float inv = inv_sqrt_n / l;
-    Mout[(size_t)bag * K2_L + col] = a0 * inv;
-    if (q == 0 && tid == 0) { ml[2 * bag] = m; ml[2 * bag + 1] = l; }
+    if (part && Mout) Mout[(size_t)bag * K2_L + col] = a0 * inv;
+    if (part && ml && q == 0 && tid == 0) { ml[2 * bag] = m; ml[2 * bag + 1] = l; }
+    if (!A) return;
     // this workgroup's quarter of the bag's rows of A
     const int per = (N + K2C_SPLIT - 1) / K2C_SPLIT, n0 = q * per, n1 = min(N, n0 + per);
     const float* sc = scores + (size_t)bag * N;
@@ -643,5 +652,154 @@ extern "C" int murcl_abmil_pool_combine(const float* scores, const float* part_w
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     hipLaunchKernelGGL(abmil_pool_combine_kernel, dim3(B * K2C_SPLIT), dim3(128), 0, stream, scores, part_ws, A, M, ml, N, S,
                        1.0f / sqrtf((float)N));
+    return MURCL_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------- K2's per-bag merge inside K3 (round 6)
+// The bag-level consumer of the pooled vector is the decoder Linear + ReLU (abmil.py:29-32,43): out = relu(M Wd^T + bd).  The
+// merge of a bag's S chunk partials (m, l, sum p.H) into M = sum_s e^{m_s - m} part_s / (l sqrt N) is a few hundred bytes of
+// arithmetic per bag, but as its own launch it cost the K2 row a second dependent launch (5 us of a 58 us row).  Here the
+// decoder product forms M while it loads its A operand: a workgroup owns a 16-bag x 16-column output tile (the tile shape of
+// gru.hip's gemm_nt_t16_f32_kernel, which ran this product before), its 16 rows of Wd arrive by LDS-DMA while the threads merge
+// the 16 bags' partial rows into the A rows of the same LDS image; the workgroups of the first column tile also write M and
+// (m, l) for the backward pass.  Exact f32 (v_mfma_f32_16x16x4_f32), single writer per element, no atomics.
+// The normalised attention row A = softmax(s) / sqrt(N) is NOT formed in the forward pass any more: nothing in the training
+// step reads it before the pooling backward, which computes p from the raw scores and (m, l) anyway and leaves A behind for
+// the rank-1 input gradient (attn_pool_bwd.hip); `last_attention` comes from murcl_abmil_pool_combine on demand.
+constexpr int PD_T = 16, PD_K = 256, PD_ROW = PD_K * 4 + 16, PD_SLOT = 2 * PD_T * PD_ROW, PD_NCH = K2_L / PD_K;
+constexpr int PD_MAXS = 512;                        // chunk headers of 16 bags in LDS: 16 * S * 8 bytes (64 KiB beside the 65 KiB image)
+static_assert(PD_NCH == 2, "two 256-k chunks: both in flight at once");
+__device__ __forceinline__ const float* pd_uniform(const float* p) {
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__global__ __launch_bounds__(256) void abmil_pool_decoder_kernel(const float* __restrict__ part, const float* __restrict__ Wd,
+                                                                 const float* __restrict__ bd, float* __restrict__ Mout,
+                                                                 float* __restrict__ ml, float* __restrict__ out, int B, int S,
+                                                                 int Lout, float inv_sqrt_n, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char pd_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int j0 = blockIdx.x * PD_T, b0 = blockIdx.y * PD_T;
+    const unsigned lds0 = lds_off(pd_smem);
+    float* hm = (float*)(pd_smem + PD_NCH * PD_SLOT);               // [16][S] chunk maxima -> merge weights
+    float* hl = hm + PD_T * S;                                       // [16][S] chunk sums
+    float* hinv = hl + PD_T * S;                                     // [16] 1 / (l sqrt N)
+    // 1. this tile's 16 rows of Wd, both k chunks: 32 row pieces of 1 KiB, eight per wave, straight into image rows 16..31
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = wave * 8 + j, row = i & 15, ch = i >> 4;
+        glds16_u(pd_uniform(Wd + (size_t)(j0 + row) * K2_L + ch * PD_K), lane * 16, lds0 + ch * PD_SLOT + (PD_T + row) * PD_ROW);
+    }
+    // 2. chunk headers of the tile's bags (bags past B: the last bag again, their rows are never stored)
+    for (int i = tid; i < PD_T * S; i += 256) {
+        const int b = i / S, s = i - b * S;
+        const float* pp = part + ((size_t)min(b0 + b, B - 1) * S + s) * (K2_L + 2);
+        hm[i] = pp[0];
+        hl[i] = pp[1];
+    }
+    __syncthreads();
+    {   // 16 lanes per bag: m = max_s m_s, l = sum_s l_s e^{m_s - m}; the weights replace the maxima
+        const int b = tid >> 4, k = tid & 15;
+        float m = -INFINITY;
+        for (int s = k; s < S; s += 16) m = fmaxf(m, hm[b * S + s]);
+        m = row16_max(m);
+        float l = 0.f;
+        for (int s = k; s < S; s += 16) {
+            const float ms = hm[b * S + s];
+            const float w = (ms == -INFINITY) ? 0.f : expf(ms - m);
+            l += hl[b * S + s] * w;
+            hm[b * S + s] = w;
+        }
+        l = row16_sum(l);
+        if (k == 0) {
+            hinv[b] = inv_sqrt_n / l;
+            if (blockIdx.x == 0 && b0 + b < B) { ml[2 * (b0 + b)] = m; ml[2 * (b0 + b) + 1] = l; }
+        }
+    }
+    __syncthreads();
+    // 3. merge: thread t owns columns 2t, 2t + 1 of every bag of the tile; four bags x four chunks of 8-byte loads in flight
+    {
+        const int c2 = 2 * tid, ch = c2 >> 8, off = (c2 & (PD_K - 1)) * 4;
+        for (int bq = 0; bq < PD_T; bq += 4) {
+            f32x2 a[4];
+            const float* pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = f32x2{0.f, 0.f};
+                pb[u] = part + (size_t)min(b0 + bq + u, B - 1) * S * (K2_L + 2) + 2 + c2;
+            }
+            int s = 0;
+            for (; s + 3 < S; s += 4) {
+                f32x2 p[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) p[u][v] = *(const f32x2*)(pb[u] + (size_t)(s + v) * (K2_L + 2));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) a[u] += p[u][v] * hm[(bq + u) * S + s + v];
+            }
+            for (; s < S; ++s)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] += *(const f32x2*)(pb[u] + (size_t)s * (K2_L + 2)) * hm[(bq + u) * S + s];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x2 mv = a[u] * hinv[bq + u];
+                *(f32x2*)(pd_smem + ch * PD_SLOT + (bq + u) * PD_ROW + off) = mv;
+                if (blockIdx.x == 0 && b0 + bq + u < B) *(f32x2*)(Mout + (size_t)(b0 + bq + u) * K2_L + c2) = mv;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the Wd rows (and this thread's loads / stores above)
+    __syncthreads();
+    // 4. the product: wave w takes k units 4w .. 4w + 3 (16 k each) of both chunks, two accumulation chains
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int c = 0; c < PD_NCH; ++c) {
+        const char* ab = pd_smem + c * PD_SLOT + r16 * PD_ROW + 16 * q4;
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+            const int u = wave * 4 + uu;
+            const f32x4 a = *(const f32x4*)(ab + 64 * u);
+            const f32x4 b = *(const f32x4*)(ab + PD_T * PD_ROW + 64 * u);
+            acc[uu & 1] = k2_mma<float>(a, b, acc[uu & 1]);
+        }
+    }
+    __syncthreads();                                                 // every wave has read the image: park the partial tiles in it
+    float* P = (float*)pd_smem;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[((wave * 2 + g) * 16 + 4 * q4 + r) * 16 + r16] = acc[g][r];
+    __syncthreads();
+    const int b = b0 + (tid >> 4), n = j0 + (tid & 15);
+    if (b >= B) return;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += P[(w * 2) * 256 + tid] + P[(w * 2 + 1) * 256 + tid];
+    v += bd ? bd[n] : 0.f;
+    if (relu) v = fmaxf(v, 0.f);
+    out[(size_t)b * Lout + n] = v;
+}
+
+// C-ABI: see include/murcl_amd.h
+extern "C" int murcl_abmil_pool_decoder(const float* part_ws, const float* Wd, const float* bd, float* M, float* ml, float* out,
+                                        int B, int N, int L, int Lout, int dtype, int relu, hipStream_t stream) {
+    if (L != K2_L || Lout <= 0 || Lout % PD_T) return -1;
+    if (B <= 0 || N <= 0) return 0;
+    int chunk, S;
+    murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
+    if (S > PD_MAXS || (B + PD_T - 1) / PD_T > 65535) return -1;     // (callers then run murcl_abmil_pool_combine + murcl_gemm_nt)
+    const int lds = PD_NCH * PD_SLOT + (2 * PD_T * S + PD_T) * 4;
+    static MurclOncePerDevice once;
+    if (once.first())
+        hipFuncSetAttribute((const void*)abmil_pool_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            PD_NCH * PD_SLOT + (2 * PD_T * PD_MAXS + PD_T) * 4);
+    hipLaunchKernelGGL(abmil_pool_decoder_kernel, dim3(Lout / PD_T, (B + PD_T - 1) / PD_T), dim3(256), lds, stream, part_ws, Wd, bd,
+                       M, ml, out, B, S, Lout, 1.0f / sqrtf((float)N), relu);
     return MURCL_CHECK_LAUNCH();
 }

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ scores, const float* __restrict__ ml, const float* __restrict__ Mp,
     const float* __restrict__ dM, T* __restrict__ dT, float* __restrict__ dba, float* __restrict__ dwb,
-    float* __restrict__ dbb, float* __restrict__ part_ws, int B, int N, int chunk_rows, int S, float inv_sqrt_n) {
+    float* __restrict__ dbb, float* __restrict__ part_ws, float* __restrict__ A_out, int B, int N, int chunk_rows, int S,
+    float inv_sqrt_n) {
     typedef K2<T> C_;
     typedef KBLds<T> L_;
     typedef typename WFrag<T>::type frag_t;
@@ -204,7 +205,12 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
         const float p = (EXACT_TANH ? __expf(sc - bag_m) : fast_exp(sc - bag_m)) * bag_invl;
         const int grow = row0 + r16;
         const float ds = (grow < N) ? p * (g - bag_c) : 0.f;
-        if (wave == 0 && q4 == 0) dbb_acc += ds;
+        if (wave == 0 && q4 == 0) {
+            dbb_acc += ds;
+            // the normalised attention row (abmil.py:40-41) for the rank-1 term of the input gradient: the forward pass no longer
+            // forms it (round 6: its per-bag merge lives in the decoder launch), this pass has p in registers
+            if (A_out && grow < N) A_out[(size_t)bag * N + grow] = p * inv_sqrt_n;
+        }
         // rows past N are redirected to the 32 spare rows after the last bag (never read)
         T* dst = dT + ((grow < N) ? ((size_t)bag * N + grow) : ((size_t)B * N + r16)) * K2_D + C_::DW * wave + 4 * q4;
         f32x4 o[C_::NJ];
@@ -288,8 +294,8 @@ extern "C" int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_ro
 // C-ABI: see include/murcl_amd.h.  dT must hold (B*N + 32) rows of D elements, part_ws 512*(2D+1) floats.
 extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* scores,
                                     const float* ml, const float* M, const float* dM, void* dT, float* dba, float* dwb,
-                                    float* dbb, float* part_ws, int B, int N, int L, int D, int dtype, int exact_tanh,
-                                    hipStream_t stream) {
+                                    float* dbb, float* part_ws, float* A_out, int B, int N, int L, int D, int dtype,
+                                    int exact_tanh, hipStream_t stream) {
     if (L != K2_L || D != K2_D || !part_ws) return -1;
     if (B <= 0 || N <= 0) return 0;
     int chunk, S;
@@ -307,7 +313,7 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
                                                                                                                   \
         }                                                                                                      \
         hipLaunchKernelGGL(k, dim3(grid), dim3(64 * K2<T>::NW), KBLds<T>::BYTES, stream, (const T*)H,         \
-                           (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, part_ws, B, N, chunk, S, isn); \
+                           (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, part_ws, A_out, B, N, chunk, S, isn); \
     }
     if (dtype == MURCL_DTYPE_BF16) {
         if (exact_tanh) KB_LAUNCH(bf16_t, true) else KB_LAUNCH(bf16_t, false)

@@ -266,7 +266,7 @@ class ABMILFn(torch.autograd.Function):
 
     x [B,N,d] in the compute dtype (f32 parity path / bf16 throughput path); parameters f32.
     Patch-level tensors (H1..H3, dZ*, dT) live in the compute dtype with f32 accumulation;
-    bag-level tensors are f32.  Returns (out [B,L], A [B,N]) - A is non-differentiable.
+    bag-level tensors are f32.  Returns (out [B,L], att, stats): ``attention_rows(att, stats)`` is A [B,N] (non-differentiable).
     """
 
     @staticmethod
@@ -329,7 +329,11 @@ class ABMILFn(torch.autograd.Function):
                 drop(h2, drops[1], False)
             h3 = ops.gemm_nt(h2, w3c, epi=ops.EPI_BIAS_RELU, bias=b3)
         if pool_fast:
-            scores, A, M, ml = ops.abmil_pool_fwd(h3.view(B, N, L), wac, ba, wb, bb)
+            # ONE launch for the K2 row (scores + chunk partials); the per-bag merge is part of the decoder launch below and the
+            # normalised attention row is formed by the backward pass (or on demand: ``attention_rows``)
+            scores, part = ops.abmil_pool_partials(h3.view(B, N, L), wac, ba, wb, bb)
+            out, M, ml = ops.abmil_pool_decoder(part, B, N, T, wd, bd)
+            A = None
         else:
             # any L / D (abmil.py:8-30 takes them as arguments): the same attention pooling as a chain of the generic kernels -
             # projection GEMM, tanh score, row soft-max, /sqrt(N) (abmil.py:40-41), weighted row sum
@@ -339,7 +343,7 @@ class ABMILFn(torch.autograd.Function):
             A = ops.mul(Asm, torch.full_like(Asm, 1.0 / (N ** 0.5)), out=torch.empty_like(Asm))
             M = ops.weighted_rowsum(h3.view(B, N, L), A.view(B, N, 1)).view(B, L)
             scores, ml = U, Asm                                                                    # what the generic backward needs
-        out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
+            out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd)
         ctx.save_for_backward(x2, h1, h2, h3, scores, A, M, ml, out, w1, w2, w3, wa, ba, wb, wd, wac, m1, m2, m3,
                               b1, b2, b3, bb, bd, wat, w3t, w2t)
         ctx.dims = (B, N, d)
@@ -349,12 +353,15 @@ class ABMILFn(torch.autograd.Function):
         ctx.drop_scale = None
         if drops is not None:
             ctx.drop_scale = tuple(1.0 / k.keep_q if isinstance(k, ops.DropSeed) else float(k.max().item()) for k in drops)
-        ctx.mark_non_differentiable(A)
+        # second / third result: what ``attention_rows`` turns into A [B,N] - (raw scores, (m, l)) from the one-pass pooling kernel,
+        # (A, None) from the generic chain
+        att, stats = (scores, ml) if pool_fast else (A, None)
+        ctx.mark_non_differentiable(*([att, stats] if pool_fast else [att]))
         ctx.set_materialize_grads(False)         # no zero-filled dA (a launch) for the attention output nobody differentiates
-        return out, A
+        return out, att, stats
 
     @staticmethod
-    def backward(ctx, dout, _dA):
+    def backward(ctx, dout, _datt, _dstats):
         if dout is None:
             return (None,) * 15
         if ctx.drop_scale is not None or not ctx.pool_fast:
@@ -380,16 +387,9 @@ class ABMILFn(torch.autograd.Function):
         budget_scope.__enter__()
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
         into_k2 = (ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None
-        if ops.abmil_pool_bwd_dwa_on(B, N, L, wac.shape[0], T):
-            # the attention weight gradient dT^T H3 comes out of the same pass over H3 (no second read of H3 and dT)
-            dT, dba, dwb, dbb, dwa = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2,
-                                                        dwa=wa.grad if _direct(wa) else "new")
-            if _direct(wa):
-                _touch(wa)
-                dwa = None
-        else:
-            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2)
-            dwa = _wgrad(dT, h3, wa)
+        # (the pass also leaves A = softmax(s)/sqrt(N) behind: the row scale of the rank-1 term below; the forward pass no longer forms it)
+        dT, dba, dwb, dbb, A = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2, want_A=True)
+        dwa = _wgrad(dT, h3, wa)
         if direct_k2:
             _touch(ba, wb, bb)
             _final(wa, ba, wb, bb, wd, bd)
@@ -469,7 +469,7 @@ class ABMILFn(torch.autograd.Function):
         dwd, dbd = ops.gemm_tn(dpre, M), ops.colsum(dpre)
         dM = ops.gemm_nt(dpre, ops.transposed(wd))
         if ctx.pool_fast:
-            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
+            dT, dba, dwb, dbb, A = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, want_A=True)
             dwb = dwb.reshape(1, -1)
         else:
             U, Asm = scores, ml
@@ -501,6 +501,13 @@ class ABMILFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwd, dbd, None
 
 
+def attention_rows(att, stats):
+    """The attention rows A [B,N] = softmax(s)/sqrt(N) of an ``ABMILFn`` / ``ABMILStepFn`` call from its second and third result:
+    the one-pass pooling kernel hands back raw scores + (m, l) and A costs one small launch HERE, when somebody asks for it
+    (``ABMIL.last_attention``); the generic chain already has A."""
+    return att if stats is None else ops.abmil_attention(att, stats)
+
+
 def abmil_fast_path(rows, N, d, L, D, dtype):
     """Does an ABMIL call of this shape take the bf16 weight-stationary encoder + one-pass pooling kernels?"""
     return (dtype == torch.bfloat16 and d == 512 and L == 512 and D == 128 and ops.panel_supported(rows, L, 512, ops.PG_BIAS_RELU)
@@ -524,7 +531,7 @@ class EncoderSession:
         self.x = e((steps, bags, N, d), dtype)
         self.h1, self.h2, self.h3 = e((R, L), dtype), e((R, L), dtype), e((R, L), dtype)
         self.m1, self.m2, self.m3 = (e((R, L // 8), torch.uint8) for _ in range(3))
-        self.scores, self.A = e((Bt, N), torch.float32), e((Bt, N), torch.float32)
+        self.scores = e((Bt, N), torch.float32)
         self.M, self.ml, self.out = e((Bt, L), torch.float32), e((Bt, 2), torch.float32), e((Bt, L), torch.float32)
         self.t, self.pending, self.dout, self.weights = 0, 0, [None] * steps, None
 
@@ -563,17 +570,17 @@ class ABMILStepFn(torch.autograd.Function):
         h3, _, _ = ops.panel_gemm(h2, w3c, ops.PG_BIAS_RELU, bias=b3, want_bitmask=True, stream_a=bool(nt & 4),
                                   out=s.rows(s.h3, t), bitmask_out=s.rows(s.m3, t))
         blk = lambda buf: s.rows(buf, t, B)                                          # noqa: E731
-        _, A, M, _ = ops.abmil_pool_fwd(h3.view(B, N, s.L), wac, ba, wb, bb, out=(blk(s.scores), blk(s.A), blk(s.M), blk(s.ml)))
-        out = ops.gemm_nt(M, wd, epi=ops.EPI_BIAS_RELU, bias=bd, out=blk(s.out))
+        scores, part = ops.abmil_pool_partials(h3.view(B, N, s.L), wac, ba, wb, bb, scores=blk(s.scores))
+        out, _, ml = ops.abmil_pool_decoder(part, B, N, T, wd, bd, out=(blk(s.out), blk(s.M), blk(s.ml)))
         s.weights = (w1, w2, w3, wa, ba, wb, wd, wac, b1, b2, b3, bb, bd, wat, w3t, w2t)
         s.t, s.pending = t + 1, s.pending + 1
         ctx.session, ctx.t = s, t
-        ctx.mark_non_differentiable(A)
+        ctx.mark_non_differentiable(scores, ml)
         ctx.set_materialize_grads(False)
-        return out, A
+        return out, scores, ml
 
     @staticmethod
-    def backward(ctx, dout, _dA):
+    def backward(ctx, dout, _datt, _dstats):
         s = ctx.session
         s.dout[ctx.t] = dout
         s.pending -= 1
@@ -586,7 +593,7 @@ class ABMILStepFn(torch.autograd.Function):
         dout_all = torch.cat([g.contiguous() if g is not None else torch.zeros_like(like) for g in s.dout[:n]], 0)
         (w1, w2, w3, wa, ba, wb, wd, wac, b1, b2, b3, bb, bd, wat, w3t, w2t) = s.weights
         R, Bt = n * s.bags * s.N, n * s.bags
-        saved = (s.x.view(-1, s.d)[:R], s.h1[:R], s.h2[:R], s.h3[:R], s.scores[:Bt], s.A[:Bt], s.M[:Bt], s.ml[:Bt], s.out[:Bt],
+        saved = (s.x.view(-1, s.d)[:R], s.h1[:R], s.h2[:R], s.h3[:R], s.scores[:Bt], None, s.M[:Bt], s.ml[:Bt], s.out[:Bt],
                  w1, w2, w3, wa, ba, wb, wd, wac, s.m1[:R], s.m2[:R], s.m3[:R], b1, b2, b3, bb, bd, wat, w3t, w2t)
         return ABMILFn._backward_default(saved, (Bt, s.N, s.d), dout_all, False) + (None,)
 

@@ -10,7 +10,7 @@ for all bags of a batch at once instead of the reference's per-bag Python loop (
 import torch
 from torch import nn
 
-from ..functional import ABMILFn, ABMILStepFn
+from ..functional import ABMILFn, ABMILStepFn, attention_rows
 
 
 def _stack(spec):
@@ -31,7 +31,7 @@ class ABMIL(nn.Module):
         self.decoder = _stack([nn.Linear(L, L), nn.ReLU()])
         self.fc = nn.Linear(L, dim_out)              # built, never applied (abmil.py:33)
         self.compute_dtype = torch.float32           # torch.bfloat16 = throughput path
-        self.last_attention = None                   # A [B,N] of the most recent call (detached)
+        self._att = None                             # most recent call: (att, stats) of ABMILFn per head (see last_attention)
         self.keep_masks = None                       # tests: (k1, k2) keep-multiplier tensors [B*N, L] replacing the dropout draws
         self.session = None                          # functional.EncoderSession of the training step in progress (deferred backward)
 
@@ -55,14 +55,32 @@ class ABMIL(nn.Module):
             return self._bags_heads(x.contiguous(), drops)
         if self.session is not None and drops is None and torch.is_grad_enabled():
             # a sequential training step keeps all its patch steps' activations in one set of buffers and runs ONE backward
-            out, A = ABMILStepFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
-                                       a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, self.session)
-            self.last_attention = A
+            out, att, stats = ABMILStepFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
+                                                a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, self.session)
+            self._att = [(att, stats)]
             return out
-        out, A = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
-                               a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops, torch.is_grad_enabled())
-        self.last_attention = A
+        out, att, stats = ABMILFn.apply(x.contiguous(), e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias,
+                                        a[0].weight, a[0].bias, a[2].weight, a[2].bias, d[0].weight, d[0].bias, drops,
+                                        torch.is_grad_enabled())
+        self._att = [(att, stats)]
         return out
+
+    @property
+    def last_attention(self):
+        """A [B,N] ([B,K,N] for K > 1 heads) of the most recent call, detached: softmax_N(scores)/sqrt(N) (abmil.py:38-41).  The
+        training step never reads it, so the one-pass pooling kernel does not form it in the forward pass: it is computed from the
+        call's raw scores and soft-max statistics on first access (one small launch) and kept.  Like the buffers of a sequential
+        training step it is only valid until the next call."""
+        if self._att is None:
+            return None
+        if not torch.is_tensor(self._att):
+            rows = [attention_rows(att, stats) for att, stats in self._att]
+            self._att = rows[0] if self.K == 1 else torch.stack(rows, 1)
+        return self._att
+
+    @last_attention.setter
+    def last_attention(self, value):
+        self._att = value
 
     def _bags_heads(self, x, drops):
         """K > 1 attention heads (abmil.py:8,23-27,38-44): ``attention.2`` has K rows, the soft-max runs over the patches of every
@@ -71,13 +89,14 @@ class ABMIL(nn.Module):
         ``attention.2`` (the heads share everything else; autograd adds their parameter gradients), i.e. K encoder passes instead
         of one.  Seeded Dropout masks are the same in every pass (one draw per call, as the reference's single encoder pass)."""
         e, a, d = self.encoder, self.attention, self.decoder
-        outs, As = [], []
+        outs, atts = [], []
         for k in range(self.K):
-            out, A = ABMILFn.apply(x, e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias, a[0].weight, a[0].bias,
-                                   a[2].weight[k:k + 1], a[2].bias[k:k + 1], d[0].weight, d[0].bias, drops, torch.is_grad_enabled())
+            out, att, stats = ABMILFn.apply(x, e[0].weight, e[0].bias, e[3].weight, e[3].bias, e[6].weight, e[6].bias, a[0].weight,
+                                            a[0].bias, a[2].weight[k:k + 1], a[2].bias[k:k + 1], d[0].weight, d[0].bias, drops,
+                                            torch.is_grad_enabled())
             outs.append(out)
-            As.append(A)
-        self.last_attention = torch.stack(As, 1)                       # [B, K, N]
+            atts.append((att, stats))
+        self._att = atts                                               # -> [B, K, N] on access
         return torch.stack(outs, 1).reshape(x.shape[0] * self.K, -1)
 
     def bag_forward(self, bag):

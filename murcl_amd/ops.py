@@ -458,9 +458,15 @@ def pool_chunks(B, N, dtype_code):
     return cr.value, nc.value
 
 
-def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
-    """H [B,N,512], Wa [128,512] (same dtype) -> scores [B,N], A [B,N], M [B,512], ml [B,2] (all f32).
-    ``out`` = (scores, A, M, ml) caller-owned contiguous buffers of those shapes."""
+def _pool_work(B, N, L, D, es):
+    # algorithmic bytes per bag (SURVEY 8(d)): H once + scores out + pooled M out; Wa amortised over the launch
+    return dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L), bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es)
+
+
+def abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh=None, scores=None):
+    """The K2 streaming pass on its own - ONE launch: H [B,N,512], Wa [128,512] (same dtype) -> raw scores [B,N] f32 and the chunk
+    partials ``part`` [B*S*(L+2)] f32 ((m, l, sum p.H) per (bag, row chunk)).  The per-bag merge belongs to the consumer:
+    ``abmil_pool_decoder`` (the training / inference path), or ``abmil_pool_combine`` for A, M, ml as tensors."""
     _need_cuda(H, Wa)
     H, Wa = _c(H), _c(Wa)
     B, N, L = H.shape
@@ -469,53 +475,98 @@ def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
         exact_tanh = H.dtype == torch.float32
     dev = H.device
     _, S = pool_chunks(B, N, dt(H))
-    if out is None:
+    if scores is None:
         scores = torch.empty((B, N), dtype=torch.float32, device=dev)
+    else:
+        assert scores.is_contiguous() and scores.dtype == torch.float32 and tuple(scores.shape) == (B, N)
+    part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
+    es = H.element_size()
+    # "row:k2_fwd" = bench.py's roofline_k2: the whole K2 row of the step, which is this one launch since round 6
+    with _span(lambda: (f"row:k2_fwd<{_DT_NAME[H.dtype]}>", _pool_work(B, N, L, D, es))):
+        with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>", _pool_work(B, N, L, D, es))):
+            check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
+                                                  None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
+                  "abmil_pool_fwd")
+    return scores, part
+
+
+def abmil_pool_combine(scores, part, dtype, out=None):
+    """scores [B,N], part (``abmil_pool_partials``) -> A [B,N] = softmax(s)/sqrt(N), M [B,512], ml [B,2] - the per-bag merge as its own
+    launch (``dtype``: the dtype H had - it fixes the chunking)."""
+    B, N = scores.shape
+    L = 512
+    dev = scores.device
+    code = F32 if dtype == torch.float32 else BF16
+    _, S = pool_chunks(B, N, code)
+    if out is None:
         A = torch.empty((B, N), dtype=torch.float32, device=dev)
         M = torch.empty((B, L), dtype=torch.float32, device=dev)
         ml = torch.empty((B, 2), dtype=torch.float32, device=dev)
     else:
-        scores, A, M, ml = out
+        A, M, ml = out
         assert all(t.is_contiguous() and t.dtype == torch.float32 for t in out)
-        assert tuple(scores.shape) == (B, N) and tuple(A.shape) == (B, N) and tuple(M.shape) == (B, L) and tuple(ml.shape) == (B, 2)
-    part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
-    es = H.element_size()
-    # algorithmic bytes per bag (SURVEY 8(d)): H once + scores out + pooled M out; Wa amortised over the launch
-    work = lambda: dict(flops=B * (2.0 * N * L * D + 2.0 * N * D + 2.0 * N * L), bytes=B * (N * L * es + N * 4 + L * 4) + L * D * es)   # noqa: E731
-    # "row:k2_fwd": ONE pair of events around BOTH launches of the K2 row (bench.py's roofline_k2: the streaming kernel and its
-    # per-bag merge; two separate pairs would add their ~2.5 us of record cost twice to a 58 us row)
-    with _span(lambda: (f"row:k2_fwd<{_DT_NAME[H.dtype]}>", work())):
-        with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>", work())):
-            # the streaming kernel alone (chunk partials): the HIP-event time of this key is the kernel rocprofv3 lists as
-            # abmil_pool_fwd_kernel
-            check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
-                                                  None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
-                  "abmil_pool_fwd")
-        with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
-            check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, dt(H), stream()),
-                  "abmil_pool_combine")
+        assert tuple(A.shape) == (B, N) and tuple(M.shape) == (B, L) and tuple(ml.shape) == (B, 2)
+    with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
+        check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, code, stream()),
+              "abmil_pool_combine")
+    return A, M, ml
+
+
+def abmil_pool_fwd(H, Wa, ba, wb, bb, exact_tanh=None, out=None):
+    """H [B,N,512], Wa [128,512] (same dtype) -> scores [B,N], A [B,N], M [B,512], ml [B,2] (all f32): the streaming pass and the
+    per-bag merge as two launches (stand-alone use; the modules run ``abmil_pool_partials`` + ``abmil_pool_decoder``).
+    ``out`` = (scores, A, M, ml) caller-owned contiguous buffers of those shapes."""
+    scores, part = abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh, scores=None if out is None else out[0])
+    A, M, ml = abmil_pool_combine(scores, part, H.dtype, out=None if out is None else out[1:])
     return scores, A, M, ml
 
 
-def abmil_pool_bwd_dwa_ok(B, N, L, D, dtype):
-    """Can ``abmil_pool_bwd(..., dwa=...)`` form the attention weight gradient inside the pooling backward pass?  (bf16, L = 512,
-    D = 128: murcl_abmil_pool_bwd_dwa.)"""
-    return dtype == torch.bfloat16 and _lib.lib().murcl_abmil_pool_bwd_dwa_ws_floats(B, N, L, D, BF16) > 0
+def abmil_pool_decoder(part, B, N, dtype, wd, bd, relu=True, out=None):
+    """The decoder layer with K2's per-bag merge on load (abmil.py:29-32,43): part (``abmil_pool_partials`` of a [B,N,512] batch in
+    ``dtype``) -> out [B,Lout] = relu(M wd^T + bd), and the by-products M [B,512], ml [B,2] the backward pass reads - ONE launch where
+    ``abmil_pool_combine`` + ``gemm_nt`` are two.  ``out`` = (out, M, ml) caller-owned buffers.  Shapes outside the kernel (more than
+    512 row chunks per bag) take those two launches."""
+    L, Lout = 512, wd.shape[0]
+    dev = part.device
+    code = F32 if dtype == torch.float32 else BF16
+    if out is None:
+        o = torch.empty((B, Lout), dtype=torch.float32, device=dev)
+        M = torch.empty((B, L), dtype=torch.float32, device=dev)
+        ml = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    else:
+        o, M, ml = out
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in out)
+        assert tuple(o.shape) == (B, Lout) and tuple(M.shape) == (B, L) and tuple(ml.shape) == (B, 2)
+    wd = _c(wd)
+    assert wd.dtype == torch.float32 and wd.shape[1] == L
+    _, S = pool_chunks(B, N, code)
+    with _span(lambda: ("abmil_pool_decoder", dict(flops=2.0 * B * L * Lout, bytes=(B * S * (L + 2) + Lout * L + B * (L + Lout)) * 4))):
+        rc = _lib.lib().murcl_abmil_pool_decoder(ptr(part), ptr(wd), ptr(bd), ptr(M), ptr(ml), ptr(o), B, N, L, Lout, code,
+                                                 int(relu), stream())
+    if rc == -1:                                  # (a HIP kernel path either way: the merge launch + the library's f32 GEMM)
+        scratch = torch.empty((1,), dtype=torch.float32, device=dev)
+        check(_lib.lib().murcl_abmil_pool_combine(ptr(scratch), ptr(part), None, ptr(M), ptr(ml), B, N, code, stream()),
+              "abmil_pool_combine")
+        gemm_nt(M, wd, epi=EPI_BIAS_RELU if relu else EPI_BIAS, bias=bd, out=o)
+    else:
+        check(rc, "abmil_pool_decoder")
+    return o, M, ml
 
 
-def abmil_pool_bwd_dwa_on(B, N, L, D, dtype):
-    """Does the ABMIL backward pass USE that form?  Off by default: measured on MI355X at the headline shape (round 5,
-    profiles/r05_d_kd_*) the one-pass kernel takes 130 + 10.5 us against 68 + 5 + 67 us for pooling backward + murcl_gemm_tn - its
-    256 KiB accumulator leaves one wave per SIMD, and nothing then covers the LDS round trips, the vector phase and the LDS-DMA
-    issue of a pair of tiles.  ``MURCL_K2B_DWA=1`` switches it on."""
-    return _K2B_DWA and abmil_pool_bwd_dwa_ok(B, N, L, D, dtype)
+def abmil_attention(scores, ml):
+    """A [B,N] = exp(s - m) / (l sqrt N) from the raw scores and the soft-max statistics of a pooling pass (abmil.py:40-41): the
+    attention row ``last_attention`` shows, formed on demand (no training-step launch needs it in the forward pass)."""
+    B, N = scores.shape
+    A = torch.empty_like(scores)
+    check(_lib.lib().murcl_abmil_pool_combine(ptr(_c(scores)), None, ptr(A), None, ptr(_c(ml)), B, N, F32, stream()),
+          "abmil_pool_combine")
+    return A
 
 
-def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None, dwa=None):
-    """-> dT [B*N,128] (dtype of H; 32 spare rows allocated behind it), dba[128], dwb[128], dbb[1].
-    ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros.
-    ``dwa``: None - the attention weight gradient is the caller's business (``gemm_tn(dT, H)``); "new" - a fifth result dWa [D,L]
-    f32 = dT^T H, formed in the same pass over H (``abmil_pool_bwd_dwa_ok`` must hold); a [D,L] f32 tensor - ADDED to in place."""
+def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None, want_A=False):
+    """-> dT [B*N,128] (dtype of H; 32 spare rows allocated behind it), dba[128], dwb[128], dbb[1] (, A [B,N] with ``want_A``: the
+    normalised attention row softmax(s)/sqrt(N), which the pass has in registers - the rank-1 input gradient's row scale).
+    ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros."""
     _need_cuda(H, Wa, dM)
     H, Wa, dM = _c(H), _c(Wa), _c(dM)
     B, N, L = H.shape
@@ -531,31 +582,18 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None,
         z = torch.zeros((2 * D + 1,), dtype=torch.float32, device=dev)          # one fill for the three accumulators
         dba, dwb, dbb = z[:D], z[D:2 * D], z[2 * D:]
     es = H.element_size()
-    if dwa is not None:
-        wsf = _lib.lib().murcl_abmil_pool_bwd_dwa_ws_floats(B, N, L, D, dt(H))
-        if not wsf:
-            raise ValueError("abmil_pool_bwd(dwa=...): bf16, L = 512, D = 128 only (abmil_pool_bwd_dwa_ok)")
-        acc = not isinstance(dwa, str)
-        dWa = dwa if acc else torch.empty((D, L), dtype=torch.float32, device=dev)
-        assert dWa.dtype == torch.float32 and dWa.is_contiguous() and tuple(dWa.shape) == (D, L)
-        ws = torch.empty((wsf,), dtype=torch.float32, device=dev)
-        # algorithmic bytes: H once, dT out, the saved scores (SURVEY 8(d) K2 backward) - the partial dWa rows are the kernel's own
-        with _span(lambda: (f"abmil_pool_bwd_dwa<{_DT_NAME[H.dtype]}>",
-                   dict(flops=B * (4.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
-            check(_lib.lib().murcl_abmil_pool_bwd_dwa(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
-                                                      ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(dWa), int(acc), ptr(ws), wsf,
-                                                      B, N, L, D, dt(H), int(exact_tanh), stream()), "abmil_pool_bwd_dwa")
-        return dT_full[:B * N], dba, dwb, dbb, dWa
+    A = torch.empty((B, N), dtype=torch.float32, device=dev) if want_A else None
     part = torch.empty((512 * (2 * D + 1),), dtype=torch.float32, device=dev)      # per-workgroup parameter-gradient rows
     with _span(lambda: (f"abmil_pool_bwd<{_DT_NAME[H.dtype]}>",
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
         check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
-                                              ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(part), B, N, L, D, dt(H),
+                                              ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(part), ptr(A), B, N, L, D, dt(H),
                                               int(exact_tanh), stream()), "abmil_pool_bwd")
+    if want_A:
+        return dT_full[:B * N], dba, dwb, dbb, A
     return dT_full[:B * N], dba, dwb, dbb
 
 
-_K2B_DWA = _os.environ.get("MURCL_K2B_DWA", "0") == "1"       # dev A/B switch, OFF: dWa inside the pooling backward pass (abmil_pool_bwd_dwa_on)
 _NTX_XCHG = True          # test hook: n <= 128, P = 128 through the one-exchange kernel (False: the recompute kernel other P take)
 _NTX_BUF = {}
 

@@ -670,23 +670,93 @@ def test_abmil_pool_bwd(dtype, B, N):
     assert abs(dbb.item()) < 1e-3 * max(1.0, wbr.grad.abs().max().item())      # softmax shift invariance
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,Lout", [(4, 256, 512), (128, 2048, 512), (2, 300, 512), (1, 1, 512), (19, 700, 64), (33, 96, 16), (3, 9000, 512)])
+def test_abmil_pool_decoder_merges_the_chunk_partials_on_load(dtype, B, N, Lout):
+    """murcl_abmil_pool_decoder (round 6: K2's per-bag merge inside the decoder launch, abmil.py:29-32,43) against the two launches
+    it replaces - murcl_abmil_pool_combine for M / (m, l), then relu(M Wd^T + bd) in float64: M, ml to 1e-6, out to 1e-4 (exact-f32
+    MFMA, only the summation order differs); bags that are not a multiple of the 16-bag tile, one to many chunks per bag."""
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(21, B, N)
+    wd = _rand(21, f"wd{Lout}", (Lout, 512), 1 / math.sqrt(512)).to(dev)
+    bd = _rand(21, f"bd{Lout}", (Lout,), 0.1).to(dev)
+    Hd, Wad = H.to(dtype).to(dev), Wa.to(dtype).to(dev)
+    sc, part = ops.abmil_pool_partials(Hd, Wad, ba.to(dev), wb.to(dev), bb.to(dev))
+    A0, M0, ml0 = ops.abmil_pool_combine(sc, part, dtype)
+    for relu in (True, False):
+        out, M, ml = ops.abmil_pool_decoder(part, B, N, dtype, wd, bd, relu=relu)
+        _close(M, M0, rtol=1e-6, atol=1e-6 * M0.abs().max().item(), msg="M")
+        _close(ml, ml0, rtol=1e-6, atol=0, msg="ml")
+        ref = M0.double().cpu() @ wd.double().cpu().t() + bd.double().cpu()
+        ref = torch.relu(ref) if relu else ref
+        _close(out, ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item(), msg="out")
+    # the attention rows on demand = what the combine launch writes
+    _close(ops.abmil_attention(sc, ml), A0, rtol=1e-6, atol=0, msg="A on demand")
+    # run-to-run bit-reproducibility (single writer per element, fixed summation order)
+    out2, M2, _ = ops.abmil_pool_decoder(part, B, N, dtype, wd, bd)
+    out3, M3, _ = ops.abmil_pool_decoder(part, B, N, dtype, wd, bd)
+    assert torch.equal(out2, out3) and torch.equal(M2, M3)
+
+
+def test_abmil_pool_decoder_beyond_the_kernels_chunk_count_takes_the_two_launch_form():
+    """One bag of 100 000 rows is cut into more than 512 chunks: murcl_abmil_pool_decoder returns -1 and the wrapper runs the merge
+    launch + the library GEMM (both HIP): same numbers."""
+    from murcl_amd import ops, _lib
+    dev = _dev()
+    B, N = 1, 100000
+    assert ops.pool_chunks(B, N, _lib.BF16)[1] > 512
+    H, Wa, ba, wb, bb = _k2_inputs(22, B, N)
+    wd, bd = _rand(22, "wd", (512, 512), 1 / math.sqrt(512)).to(dev), _rand(22, "bd", (512,), 0.1).to(dev)
+    sc, part = ops.abmil_pool_partials(H.bfloat16().to(dev), Wa.bfloat16().to(dev), ba.to(dev), wb.to(dev), bb.to(dev))
+    _, M0, ml0 = ops.abmil_pool_combine(sc, part, torch.bfloat16)
+    out, M, ml = ops.abmil_pool_decoder(part, B, N, torch.bfloat16, wd, bd)
+    assert torch.equal(M, M0) and torch.equal(ml, ml0)
+    ref = torch.relu(M0.double().cpu() @ wd.double().cpu().t() + bd.double().cpu())
+    _close(out, ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item(), msg="out")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (16, 2048), (1, 1)])
+def test_abmil_pool_bwd_leaves_the_attention_rows_behind(dtype, B, N):
+    """``want_A``: A = softmax(s)/sqrt(N) out of the backward pass (the rank-1 input gradient's row scale) = the rows the merge launch
+    writes, to 1e-6 (f32: __expf vs expf) / 1e-5 (bf16 path: the fast exp2 form); the other results unchanged bit for bit."""
+    from murcl_amd import ops
+    dev = _dev()
+    H, Wa, ba, wb, bb = _k2_inputs(23, B, N)
+    Hd, Wad, bad, wbd, bbd = H.to(dtype).to(dev), Wa.to(dtype).to(dev), ba.to(dev), wb.to(dev), bb.to(dev)
+    dM = _rand(23, "dM", (B, 512)).to(dev)
+    sc, A0, M, ml = ops.abmil_pool_fwd(Hd, Wad, bad, wbd, bbd)
+    r0 = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M, dM)
+    r1 = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M, dM, want_A=True)
+    assert all(torch.equal(a, b) for a, b in zip(r0, r1[:4]))
+    _close(r1[4], A0, rtol=1e-6 if dtype == torch.float32 else 1e-5, atol=1e-12, msg="A")
+
+
 @pytest.mark.parametrize("B,N", [(4, 256), (2, 300), (3, 40), (1, 1), (16, 2048), (300, 96), (128, 2048)])
 def test_abmil_pool_bwd_with_the_attention_weight_gradient_in_the_same_pass(B, N):
-    """murcl_abmil_pool_bwd_dwa (bf16): dT / dba / dwb / dbb as the two-launch form leaves them, dWa = dT^T H against
+    """The PARKED one-pass pooling backward (tools/_abl/attn_pool_bwd_dwa.hip, built by tools/_abl/build_kd.py into its own library -
+    it lost its A/B in round 5 and left the product library in round 6; this keeps it honest for the next attempt).
+    murcl_abmil_pool_bwd_dwa (bf16): dT / dba / dwb / dbb as the two-launch form leaves them, dWa = dT^T H against
     (a) the product of the STORED (bf16) dT with H in float64 - what murcl_gemm_tn forms, to 1e-4 of the largest entry -
     and (b) the oracle's autograd of models/abmil.py:38-42 w.r.t. attention.0.weight on the bf16-rounded inputs;
     accumulation into an existing gradient; run-to-run bit-reproducibility.  Ragged N (not a multiple of 32), single-row bags,
     fewer / more items than workgroups."""
+    import os
+    import sys
     from murcl_amd import ops
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_abl"))
+    import kd
+    if not kd.available():
+        pytest.skip("tools/_abl/lib/kd.so not built (python tools/_abl/build_kd.py)")
     dev = _dev()
     H, Wa, ba, wb, bb = _k2_inputs(12, B, N)
     H, Wa = H.bfloat16(), Wa.bfloat16()
     dM = _rand(12, "dM", (B, 512))
     Hd, Wad, bad, wbd, bbd, dMd = (t.to(dev) for t in (H, Wa, ba, wb, bb, dM))
-    assert ops.abmil_pool_bwd_dwa_ok(B, N, 512, 128, torch.bfloat16)
     sc, A_g, M_g, ml = ops.abmil_pool_fwd(Hd, Wad, bad, wbd, bbd)
     dT0, dba0, dwb0, dbb0 = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd)
-    dT, dba, dwb, dbb, dWa = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")
+    dT, dba, dwb, dbb, dWa = kd.pool_bwd_dwa(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")
     # the same formulas on the same inputs: the stored dT differs at most by the last bf16 bit (MFMA operand order)
     # (a single-row bag has p = 1 and g = c: ds is the rounding noise of g - c, so every comparison gets a floor of the size of
     #  that noise - fl for an entry of dT, flw for an entry of dWa)
@@ -712,10 +782,10 @@ def test_abmil_pool_bwd_with_the_attention_weight_gradient_in_the_same_pass(B, N
     # accumulation + reproducibility
     base = _rand(12, "base", (128, 512)).to(dev)
     acc = base.clone()
-    out = ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa=acc)
+    out = kd.pool_bwd_dwa(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa=acc)
     assert out[4] is acc
     assert torch.equal(acc, base + dWa)
-    assert torch.equal(ops.abmil_pool_bwd(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")[4], dWa)
+    assert torch.equal(kd.pool_bwd_dwa(Hd, Wad, bad, wbd, sc, ml, M_g, dMd, dwa="new")[4], dWa)
     assert torch.equal(out[0], dT)
 
 

@@ -56,7 +56,7 @@ def main():
         "copy_bf16": (lambda: H.copy_(X), 2 * M * 512 * 2, 0),
         "k2_fwd": (lambda: ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
         "k2_bwd": (lambda: ops.abmil_pool_bwd(H.view(B, N, 512), Wa, ba, wb, sc, ml, Mp, dM), M * 640 * 2, 2.0 * M * 512 * 128),
-        "k2_bwd_dwa": (lambda: ops.abmil_pool_bwd(H.view(B, N, 512), Wa, ba, wb, sc, ml, Mp, dM, dwa="new"), M * 640 * 2, 4.0 * M * 512 * 128),
+        "k2_part": (lambda: ops.abmil_pool_partials(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
         "panel_fwd": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
         "panel_fwd_nobm": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
         "panel_mask": (lambda: ops.panel_gemm(X, W, ops.PG_MASK, bitmask=bm, colsum=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),

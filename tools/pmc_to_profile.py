@@ -15,7 +15,7 @@ MAP = {
     "void abmil_pool_fwd_kernel<unsigned short, false>": "abmil_pool_fwd<bf16>",
     "abmil_pool_combine_kernel": "abmil_pool_combine",
     "void abmil_pool_bwd_kernel<unsigned short, false>": "abmil_pool_bwd<bf16>",
-    "void abmil_pool_bwd_dwa_kernel<false>": "abmil_pool_bwd_dwa<bf16>",
+    "abmil_pool_decoder_kernel": "abmil_pool_decoder",
     "void gemm_tn_kernel<unsigned short, 4, false>": "gemm_tn<bf16>",
     "void panel_nt_kernel<512, 32, 8, 0, true, false>": "panel_gemm<K512,BIAS_RELU>",
     "void panel_nt_kernel<512, 32, 8, 1, false, false>": "panel_gemm<K512,MASK>",

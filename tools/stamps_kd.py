@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Dev tool: where a pair iteration of the fused pooling backward (attn_pool_bwd_dwa.hip) spends its cycles
-(needs a -DKD_STAMPS build: python tools/ab_build.py kd_stamps attn_pool_bwd_dwa.hip:-DKD_STAMPS).
+- the kernel is parked under tools/_abl since round 6; needs its library built with stamps:
 
-    MURCL_AMD_LIB=tools/_abl/lib/kd_stamps.so python tools/stamps_kd.py
+    python tools/_abl/build_kd.py -DKD_STAMPS && python tools/stamps_kd.py
 """
 import ctypes
 import math
@@ -13,7 +13,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from murcl_amd import _lib, ops  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_abl"))
+from murcl_amd import _lib, ops  # noqa: E402,F401
+import kd  # noqa: E402
 
 WG, IT, EV = 16, 40, 12
 
@@ -30,7 +32,7 @@ def main():
     bb = torch.zeros((1,), device=dev)
     dM = torch.randn((B, 512), generator=g, device=dev)
     sc, A, Mp, ml = ops.abmil_pool_fwd(H, Wa, ba, wb, bb)
-    fn = lambda: ops.abmil_pool_bwd(H, Wa, ba, wb, sc, ml, Mp, dM, dwa="new")   # noqa: E731
+    fn = lambda: kd.pool_bwd_dwa(H, Wa, ba, wb, sc, ml, Mp, dM, dwa="new")   # noqa: E731
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -40,7 +42,7 @@ def main():
     b.record()
     torch.cuda.synchronize()
     print(f"fused pooling backward (+reduce): {a.elapsed_time(b) * 1e3:.1f} us (instrumented build)")
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib = ctypes.CDLL(kd.LIB)
     buf = np.zeros((WG, 2, IT, EV), dtype=np.uint32)
     rc = lib.murcl_debug_kd_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(buf.nbytes))
     assert rc == 0, rc
