@@ -89,7 +89,9 @@ int murcl_gemm_tn_grouped(const murcl_tn_problem* probs, int n, int dtype, float
  * ReLU' taken from a 1-bit-per-element mask ([M,N/8] bytes; bit e of byte c <=> column 8c+e of the forward
  * output was > 0) that the forward epilogue (epilogue 0) can emit through bitmask_out.
  * epilogue: 0 = relu(.+bias) (K=512), 1 = . * mask (K=512), 2 = (. + rowscale[m]*rank1[m/rows_per_bag][n]) * mask
- * (K=128 with N=512, or K=512), 3 = . + bias (K=512), 4 = CLAM's gated attention score without the pre-activations
+ * (K=128 with N=512, or K=512; with bias != NULL - the [M/rows_per_bag][2] soft-max statistics (m, l) of murcl_abmil_pool_decoder /
+ * _combine - rowscale holds the RAW attention scores and the row scale is exp(rowscale[m] - m_bag) / (l_bag sqrt(rows_per_bag)),
+ * i.e. abmil.py:40-41's A formed in the epilogue), 3 = . + bias (K=512), 4 = CLAM's gated attention score without the pre-activations
  * (clam.py:55-60; K=512, forward-only calls): W / bias hold attention_a and attention_b interleaved in 16-row blocks (rows
  * 32g..32g+15 = attention_a[16g..], rows 32g+16..32g+31 = attention_b[16g..]), rank1 = attention_c's weight at the a-rows ([N]
  * f32), and the ONLY output is colsum_ws = [N/32][M] f32 partial scores, partial[g][m] = sum over d in 16g..16g+15 of
@@ -131,7 +133,7 @@ int murcl_set_cu_budget(int cus);
 
 /* K2 -- ABMIL attention pooling, abmil.py:38-42:  scores[b,n] = wb.tanh(Wa H[b,n]+ba)+bb,
  * A = softmax_N(scores)/sqrt(N), M[b] = A[b].H[b];  ml[b] = (max, sum exp) of the soft-max.
- * H [B,N,L] and Wa [D,L] in `dtype`; L = 512, D = 128.  part_ws: B*n_chunks*(L+2) floats with
+ * H [B,N,L] and Wa [D,L] in `dtype`; L = 512, D = 128.  part_ws: B*n_chunks*(L+4) floats with
  * n_chunks from murcl_abmil_pool_workspace. */
 int murcl_abmil_pool_workspace(int B, int N, int dtype, int* chunk_rows, int* n_chunks);
 int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* ba, const float* wb, const float* bb,

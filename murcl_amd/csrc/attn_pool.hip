@@ -356,14 +356,14 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
                 }
             }
             if (tin + 1 == tiles_per_item - 1) {    // ---- end of item: publish partial + raw scores
-                float* pp = part + ((size_t)cp.bag * S + cp.ch) * (K2_L + 2);
+                float* pp = part + ((size_t)cp.bag * S + cp.ch) * K2_PSTRIDE;
                 if (q4 == 0) {
 #pragma unroll
-                    for (int j = 0; j < C_::NPJ; ++j) pp[2 + C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
+                    for (int j = 0; j < C_::NPJ; ++j) pp[C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
                 }
                 {
                     const float l_tot = fixed_ref ? half_wave_sum(lane < 2 * C_::TR ? l_run : 0.f) : l_run;
-                    if (tid == 0) { pp[0] = fixed_ref ? smax : m_run; pp[1] = l_tot; }
+                    if (tid == 0) { pp[K2_L] = fixed_ref ? smax : m_run; pp[K2_L + 1] = l_tot; }
                 }
                 m_run = -INFINITY; l_run = 0.f;
 #pragma unroll
@@ -486,14 +486,14 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
         }
 
         if (tin == tiles_per_item - 1) {        // ---- end of item: publish partial + raw scores
-            float* pp = part + ((size_t)cp.bag * S + cp.ch) * (K2_L + 2);
+            float* pp = part + ((size_t)cp.bag * S + cp.ch) * K2_PSTRIDE;
             if (q4 == 0) {                      // rows 0 (+1) of the accumulator tiles live in lane quarter 0
 #pragma unroll
-                for (int j = 0; j < C_::NPJ; ++j) pp[2 + C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
+                for (int j = 0; j < C_::NPJ; ++j) pp[C_::PC * wave + 16 * j + r16] = macc[j][0] + macc[j][1];
             }
             {
                 const float l_tot = fixed_ref ? rdlane(row16_sum(lane < 16 ? l_run : 0.f), 0) : l_run;
-                if (tid == 0) { pp[0] = fixed_ref ? smax : m_run; pp[1] = l_tot; }
+                if (tid == 0) { pp[K2_L] = fixed_ref ? smax : m_run; pp[K2_L + 1] = l_tot; }
             }
             __syncthreads();                    // sbuf complete
             const int rbeg = cp.ch * chunk_rows;
@@ -528,12 +528,12 @@ __global__ __launch_bounds__(128) void abmil_pool_combine_kernel(const float* __
         m = ml[2 * bag];
         l = ml[2 * bag + 1];
     } else {
-        const float* pp = part + (size_t)bag * S * (K2_L + 2);
+        const float* pp = part + (size_t)bag * S * K2_PSTRIDE;
         // the chunks' (m, l) headers first, one per thread: walked one chunk after the other by every thread they were 2 S dependent
         // round trips (9 us at S = 8)
         __shared__ float hm[128], hl[128];
         if (S <= 128) {
-            if (tid < S) { hm[tid] = pp[(size_t)tid * (K2_L + 2)]; hl[tid] = pp[(size_t)tid * (K2_L + 2) + 1]; }
+            if (tid < S) { hm[tid] = pp[(size_t)tid * K2_PSTRIDE + K2_L]; hl[tid] = pp[(size_t)tid * K2_PSTRIDE + K2_L + 1]; }
             __syncthreads();
             for (int s = 0; s < S; ++s) m = fmaxf(m, hm[s]);
             int s = 0;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(128) void abmil_pool_combine_kernel(const float* __
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     w[u] = (hm[s + u] == -INFINITY) ? 0.f : expf(hm[s + u] - m);
-                    p0[u] = pp[(size_t)(s + u) * (K2_L + 2) + 2 + col];
+                    p0[u] = pp[(size_t)(s + u) * K2_PSTRIDE + col];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { l += hl[s + u] * w[u]; a0 += p0[u] * w[u]; }
@@ -550,15 +550,15 @@ __global__ __launch_bounds__(128) void abmil_pool_combine_kernel(const float* __
             for (; s < S; ++s) {
                 const float w = (hm[s] == -INFINITY) ? 0.f : expf(hm[s] - m);
                 l += hl[s] * w;
-                a0 += pp[(size_t)s * (K2_L + 2) + 2 + col] * w;
+                a0 += pp[(size_t)s * K2_PSTRIDE + col] * w;
             }
         } else {
-            for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * (K2_L + 2)]);
+            for (int s = 0; s < S; ++s) m = fmaxf(m, pp[(size_t)s * K2_PSTRIDE + K2_L]);
             for (int s = 0; s < S; ++s) {
-                const float* p = pp + (size_t)s * (K2_L + 2);
-                const float w = (p[0] == -INFINITY) ? 0.f : expf(p[0] - m);
-                l += p[1] * w;
-                a0 += p[2 + col] * w;
+                const float* p = pp + (size_t)s * K2_PSTRIDE;
+                const float w = (p[K2_L] == -INFINITY) ? 0.f : expf(p[K2_L] - m);
+                l += p[K2_L + 1] * w;
+                a0 += p[col] * w;
             }
         }
     }
@@ -686,72 +686,68 @@ __global__ __launch_bounds__(256) void abmil_pool_decoder_kernel(const float* __
     const unsigned lds0 = lds_off(pd_smem);
     float* hm = (float*)(pd_smem + PD_NCH * PD_SLOT);               // [16][S] chunk maxima -> merge weights
     float* hl = hm + PD_T * S;                                       // [16][S] chunk sums
-    float* hinv = hl + PD_T * S;                                     // [16] 1 / (l sqrt N)
     // 1. this tile's 16 rows of Wd, both k chunks: 32 row pieces of 1 KiB, eight per wave, straight into image rows 16..31
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int i = wave * 8 + j, row = i & 15, ch = i >> 4;
         glds16_u(pd_uniform(Wd + (size_t)(j0 + row) * K2_L + ch * PD_K), lane * 16, lds0 + ch * PD_SLOT + (PD_T + row) * PD_ROW);
     }
-    // 2. chunk headers of the tile's bags (bags past B: the last bag again, their rows are never stored)
-    for (int i = tid; i < PD_T * S; i += 256) {
-        const int b = i / S, s = i - b * S;
-        const float* pp = part + ((size_t)min(b0 + b, B - 1) * S + s) * (K2_L + 2);
-        hm[i] = pp[0];
-        hl[i] = pp[1];
-    }
-    __syncthreads();
-    {   // 16 lanes per bag: m = max_s m_s, l = sum_s l_s e^{m_s - m}; the weights replace the maxima
+    // 2. + 3. the merge.  16 threads per bag: thread (b, k) owns the eight 4-column groups 4 (k + 16 i) of bag b, so that a bag's
+    // partial row is read as 256-byte segments.  The partial rows do not depend on the headers: the first PD_SB chunks' loads go out
+    // together with the header loads - one memory round trip for headers + half the rows at S = 8, one more for the rest (walking
+    // them bag after bag behind the weights was eight dependent round trips: 11 us for the launch).
+    {
+        constexpr int PD_SB = 4;
         const int b = tid >> 4, k = tid & 15;
+        const int bag = min(b0 + b, B - 1);                           // bags past B: the last bag again, their rows are never stored
+        const float* pp = part + (size_t)bag * S * K2_PSTRIDE;
+        f32x4 a[8], p[PD_SB][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load = [&](int s0) {
+#pragma unroll
+            for (int v = 0; v < PD_SB; ++v) {
+                const float* row = pp + (size_t)min(s0 + v, S - 1) * K2_PSTRIDE + 4 * k;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p[v][i] = *(const f32x4*)(row + 64 * i);      // (rows are 16-byte aligned: K2_PSTRIDE)
+            }
+        };
+        load(0);
+        // headers: thread k of the bag's 16 takes chunks k, k + 16, ...
         float m = -INFINITY;
-        for (int s = k; s < S; s += 16) m = fmaxf(m, hm[b * S + s]);
+        for (int s = k; s < S; s += 16) {
+            const float ms = pp[(size_t)s * K2_PSTRIDE + K2_L];
+            hm[b * S + s] = ms;
+            hl[b * S + s] = pp[(size_t)s * K2_PSTRIDE + K2_L + 1];
+            m = fmaxf(m, ms);
+        }
         m = row16_max(m);
         float l = 0.f;
         for (int s = k; s < S; s += 16) {
             const float ms = hm[b * S + s];
             const float w = (ms == -INFINITY) ? 0.f : expf(ms - m);
             l += hl[b * S + s] * w;
-            hm[b * S + s] = w;
+            hm[b * S + s] = w;                                        // the merge weights replace the maxima
         }
         l = row16_sum(l);
-        if (k == 0) {
-            hinv[b] = inv_sqrt_n / l;
-            if (blockIdx.x == 0 && b0 + b < B) { ml[2 * (b0 + b)] = m; ml[2 * (b0 + b) + 1] = l; }
+        const float inv = inv_sqrt_n / l;
+        if (k == 0 && blockIdx.x == 0 && b0 + b < B) { ml[2 * (b0 + b)] = m; ml[2 * (b0 + b) + 1] = l; }
+        __syncthreads();                                              // (a bag's 16 threads share a wave; the barrier is the simple fence)
+        for (int s0 = 0; s0 < S; s0 += PD_SB) {
+#pragma unroll
+            for (int v = 0; v < PD_SB; ++v) {
+                const float w = (s0 + v < S) ? hm[b * S + s0 + v] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] += p[v][i] * w;
+            }
+            if (s0 + PD_SB < S) load(s0 + PD_SB);
         }
-    }
-    __syncthreads();
-    // 3. merge: thread t owns columns 2t, 2t + 1 of every bag of the tile; four bags x four chunks of 8-byte loads in flight
-    {
-        const int c2 = 2 * tid, ch = c2 >> 8, off = (c2 & (PD_K - 1)) * 4;
-        for (int bq = 0; bq < PD_T; bq += 4) {
-            f32x2 a[4];
-            const float* pb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = f32x2{0.f, 0.f};
-                pb[u] = part + (size_t)min(b0 + bq + u, B - 1) * S * (K2_L + 2) + 2 + c2;
-            }
-            int s = 0;
-            for (; s + 3 < S; s += 4) {
-                f32x2 p[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) p[u][v] = *(const f32x2*)(pb[u] + (size_t)(s + v) * (K2_L + 2));
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) a[u] += p[u][v] * hm[(bq + u) * S + s + v];
-            }
-            for (; s < S; ++s)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] += *(const f32x2*)(pb[u] + (size_t)s * (K2_L + 2)) * hm[(bq + u) * S + s];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x2 mv = a[u] * hinv[bq + u];
-                *(f32x2*)(pd_smem + ch * PD_SLOT + (bq + u) * PD_ROW + off) = mv;
-                if (blockIdx.x == 0 && b0 + bq + u < B) *(f32x2*)(Mout + (size_t)(b0 + bq + u) * K2_L + c2) = mv;
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int col = 4 * (k + 16 * i);
+            const f32x4 mv = a[i] * inv;
+            *(f32x4*)(pd_smem + (col >> 8) * PD_SLOT + b * PD_ROW + (col & (PD_K - 1)) * 4) = mv;
+            if (blockIdx.x == 0 && b0 + b < B) *(f32x4*)(Mout + (size_t)(b0 + b) * K2_L + col) = mv;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the Wd rows (and this thread's loads / stores above)

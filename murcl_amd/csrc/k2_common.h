@@ -7,6 +7,7 @@
 #define K2_D 128
 #define K2_TR 16                  // rows per tile (one MFMA row tile)
 #define K2_NSLOT 4                // ring slots per workgroup; three tiles in flight while one is consumed
+#define K2_PSTRIDE (K2_L + 4)      // floats per chunk partial in the forward workspace: [L] sum p.H, then (m, l), 2 spare - rows 16-byte aligned
 
 // NW waves per workgroup, each owning a DW = 128/NW column slice of Wa in registers:
 //   bf16: NW = 4 (DW = 32, 128 VGPRs of weights), TWO workgroups per CU - they desynchronise naturally, so

@@ -387,6 +387,10 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     }
     float gsc[2] = {0.f, 0.f};                       // PG_GATE: the tile's two 16-row partial scores, until they are stored together
     float rk[(EPI == PG_RANK1_MASK) ? NJ : 1][4];
+    // PG_RANK1_MASK with `bias` = the [bags][2] soft-max statistics (m, l) of the pooling pass: `rowscale` then holds the RAW scores
+    // and the row scale A = exp(s - m) / (l sqrt(rows_per_bag)) is formed here (abmil.py:40-41) - two v_exp per lane and tile - so
+    // that no pass has to write and re-read the normalised attention rows (round 6)
+    float bag_m = 0.f, bag_inv = 1.f;
     int cur_bag = -1;
     float csum[NJ][4];                       // column sums in accumulator layout: column 16j + 4q4 + r, over this lane's rows
 #pragma unroll
@@ -552,13 +556,17 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) rk[j][r] = rank1[(size_t)bag * N + n0 + 16 * j + 4 * q4 + r];
+                if (bias) {
+                    bag_m = bias[2 * bag];
+                    bag_inv = 1.0f / (sqrtf((float)rows_per_bag) * bias[2 * bag + 1]);
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (part >= 0 && part != i && (part < 10 || (part - 10) / NJ != i)) continue;
             const int row = 16 * i + r16;
-            const float a_m = am[i];
+            const float a_m = (EPI == PG_RANK1_MASK && bias) ? fast_exp(am[i] - bag_m) * bag_inv : am[i];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (part >= 10 && (part - 10) % NJ != j) continue;       // 10 + NJ*i + j: one 16x16 block of the tile

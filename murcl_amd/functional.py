@@ -387,8 +387,12 @@ class ABMILFn(torch.autograd.Function):
         budget_scope.__enter__()
         direct_k2 = _direct(ba) and _direct(wb) and _direct(bb)      # the kernel's atomics add straight into the grads
         into_k2 = (ba.grad, wb.grad.view(-1), bb.grad) if direct_k2 else None
-        # (the pass also leaves A = softmax(s)/sqrt(N) behind: the row scale of the rank-1 term below; the forward pass no longer forms it)
-        dT, dba, dwb, dbb, A = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2, want_A=True)
+        # The row scale of the rank-1 term below is A = softmax(s)/sqrt(N), which the forward pass no longer forms: the bf16 panel
+        # kernel makes it from the raw scores and (m, l) in its epilogue; the f32 GEMM takes the rows this pass leaves behind
+        if m3 is not None:
+            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2)
+        else:
+            dT, dba, dwb, dbb, A = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, into=into_k2, want_A=True)
         dwa = _wgrad(dT, h3, wa)
         if direct_k2:
             _touch(ba, wb, bb)
@@ -407,8 +411,8 @@ class ABMILFn(torch.autograd.Function):
             # the three weight gradients wait until the last input gradient exists and run as ONE grouped launch (one round of
             # workgroups, one reduce launch: ops.gemm_tn_grouped) unless a data-parallel reducer asked for per-layer milestones
             grouped = _GROUP_WGRAD and _MILESTONE is None
-            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N,
-                                         colsum=True, colsum_into=None if f3 else into(b3), colsum_defer=f3)
+            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=scores.view(-1), bias=ml, rank1=dM,
+                                         rows_per_bag=N, colsum=True, colsum_into=None if f3 else into(b3), colsum_defer=f3)
             if not grouped:
                 dw3 = _wgrad(dz3, h2, w3, b3, db3 if f3 else None)
                 _final(w3, b3)
@@ -468,7 +472,10 @@ class ABMILFn(torch.autograd.Function):
         dpre = ops.relu_bwd(dout.contiguous(), out)
         dwd, dbd = ops.gemm_tn(dpre, M), ops.colsum(dpre)
         dM = ops.gemm_nt(dpre, ops.transposed(wd))
-        if ctx.pool_fast:
+        if ctx.pool_fast and m3 is not None:
+            dT, dba, dwb, dbb = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM)
+            dwb = dwb.reshape(1, -1)
+        elif ctx.pool_fast:
             dT, dba, dwb, dbb, A = ops.abmil_pool_bwd(h3.view(B, N, L), wac, ba, wb, scores, ml, M, dM, want_A=True)
             dwb = dwb.reshape(1, -1)
         else:
@@ -480,7 +487,11 @@ class ABMILFn(torch.autograd.Function):
             dwb, dba = dwb.view(1, -1), dba.contiguous()
         dwa = ops.gemm_tn(dT, h3)
         if m3 is not None:
-            dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
+            if ctx.pool_fast:
+                dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=scores.view(-1), bias=ml, rank1=dM,
+                                             rows_per_bag=N, colsum=True)
+            else:
+                dz3, _, db3 = ops.panel_gemm(dT, wat, ops.PG_RANK1_MASK, bitmask=m3, rowscale=A.view(-1), rank1=dM, rows_per_bag=N, colsum=True)
             dz2, _, db2 = ops.panel_gemm(dz3, w3t, ops.PG_MASK, bitmask=m2, colsum=True)
             dz1, _, db1 = ops.panel_gemm(dz2, w2t, ops.PG_MASK, bitmask=m1, colsum=True)
         else:

@@ -465,7 +465,7 @@ def _pool_work(B, N, L, D, es):
 
 def abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh=None, scores=None):
     """The K2 streaming pass on its own - ONE launch: H [B,N,512], Wa [128,512] (same dtype) -> raw scores [B,N] f32 and the chunk
-    partials ``part`` [B*S*(L+2)] f32 ((m, l, sum p.H) per (bag, row chunk)).  The per-bag merge belongs to the consumer:
+    partials ``part`` [B*S*(L+4)] f32 ((sum p.H, m, l) per (bag, row chunk)).  The per-bag merge belongs to the consumer:
     ``abmil_pool_decoder`` (the training / inference path), or ``abmil_pool_combine`` for A, M, ml as tensors."""
     _need_cuda(H, Wa)
     H, Wa = _c(H), _c(Wa)
@@ -479,7 +479,7 @@ def abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh=None, scores=None):
         scores = torch.empty((B, N), dtype=torch.float32, device=dev)
     else:
         assert scores.is_contiguous() and scores.dtype == torch.float32 and tuple(scores.shape) == (B, N)
-    part = torch.empty((B * S * (L + 2),), dtype=torch.float32, device=dev)
+    part = torch.empty((B * S * (L + 4),), dtype=torch.float32, device=dev)
     es = H.element_size()
     # "row:k2_fwd" = bench.py's roofline_k2: the whole K2 row of the step, which is this one launch since round 6
     with _span(lambda: (f"row:k2_fwd<{_DT_NAME[H.dtype]}>", _pool_work(B, N, L, D, es))):
@@ -506,7 +506,7 @@ def abmil_pool_combine(scores, part, dtype, out=None):
         A, M, ml = out
         assert all(t.is_contiguous() and t.dtype == torch.float32 for t in out)
         assert tuple(A.shape) == (B, N) and tuple(M.shape) == (B, L) and tuple(ml.shape) == (B, 2)
-    with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 2) * 4 + L * 4)))):
+    with _span(lambda: ("abmil_pool_combine", dict(flops=0.0, bytes=B * (2 * N * 4 + S * (L + 4) * 4 + L * 4)))):
         check(_lib.lib().murcl_abmil_pool_combine(ptr(scores), ptr(part), ptr(A), ptr(M), ptr(ml), B, N, code, stream()),
               "abmil_pool_combine")
     return A, M, ml
@@ -540,7 +540,7 @@ def abmil_pool_decoder(part, B, N, dtype, wd, bd, relu=True, out=None):
     wd = _c(wd)
     assert wd.dtype == torch.float32 and wd.shape[1] == L
     _, S = pool_chunks(B, N, code)
-    with _span(lambda: ("abmil_pool_decoder", dict(flops=2.0 * B * L * Lout, bytes=(B * S * (L + 2) + Lout * L + B * (L + Lout)) * 4))):
+    with _span(lambda: ("abmil_pool_decoder", dict(flops=2.0 * B * L * Lout, bytes=(B * S * (L + 4) + Lout * L + B * (L + Lout)) * 4))):
         rc = _lib.lib().murcl_abmil_pool_decoder(ptr(part), ptr(wd), ptr(bd), ptr(M), ptr(ml), ptr(o), B, N, L, Lout, code,
                                                  int(relu), stream())
     if rc == -1:                                  # (a HIP kernel path either way: the merge launch + the library's f32 GEMM)

@@ -1189,6 +1189,34 @@ def test_panel_gemm_rank1_mask(bags, n):
     _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
 
 
+@pytest.mark.parametrize("bags,n", [(2, 64), (8, 1024), (5, 96)])
+def test_panel_gemm_rank1_mask_forms_the_attention_rows_from_raw_scores(bags, n):
+    """PG_RANK1_MASK with ``bias`` = the [bags,2] soft-max statistics (round 6): ``rowscale`` holds RAW scores and the row scale is
+    exp(s - m) / (l sqrt n) = softmax(s)/sqrt(n) (abmil.py:40-41), formed in the epilogue - against the explicit-A form of the same
+    kernel (the fast exp2 form differs from expf by ~1e-7 relative: far below the bf16 output) and float64."""
+    from murcl_amd import ops
+    dev = _dev()
+    M = bags * n
+    dT = _rand(24, f"dT{M}", (M, 128), 0.05).bfloat16()
+    WaT = _rand(24, "WaT", (512, 128), 0.1).bfloat16()
+    H = _rand(24, f"H{M}", (M, 512))
+    sc = _rand(24, f"s{M}", (bags, n), 2.0)
+    dM = _rand(24, f"dM{bags}", (bags, 512))
+    m = sc.max(1).values - torch.from_numpy(detrand.uniform(24, f"sh{bags}", (bags,)))        # any reference >= ... the kernel only needs exp(s - m) / l consistent
+    l = torch.exp(sc.double() - m.double()[:, None]).sum(1).float()
+    ml = torch.stack([m, l], 1).contiguous()
+    A = torch.softmax(sc.double(), 1) / math.sqrt(n)
+    bits = _bits(H > 0).to(dev)
+    C, _, cs = ops.panel_gemm(dT.to(dev), WaT.to(dev), ops.PG_RANK1_MASK, bitmask=bits, rowscale=sc.reshape(-1).to(dev),
+                              bias=ml.to(dev), rank1=dM.to(dev), rows_per_bag=n, colsum=True)
+    ref = (dT.double() @ WaT.double().t() + A.reshape(-1)[:, None] * dM.double().repeat_interleave(n, 0)) * (H.double() > 0)
+    _close(C.float(), ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item(), msg="C")
+    C2, _, _ = ops.panel_gemm(dT.to(dev), WaT.to(dev), ops.PG_RANK1_MASK, bitmask=bits, rowscale=A.float().reshape(-1).to(dev),
+                              rank1=dM.to(dev), rows_per_bag=n, colsum=True)
+    assert (C.float() - C2.float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item()        # one bf16 ulp of the largest entry
+    _close(cs, C.double().sum(0).float(), rtol=1e-3, atol=1e-2 * math.sqrt(M), msg="colsum")
+
+
 def test_panel_gemm_unsupported_shapes_fall_back():
     from murcl_amd import ops
     assert not ops.panel_supported(100, 512, 512, ops.PG_BIAS_RELU)      # M % 32

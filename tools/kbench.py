@@ -52,11 +52,18 @@ def main():
     Asc = torch.rand((M,), generator=g, device=dev)
     H, bm, _ = ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True)
     sc, Aw, Mp, ml = ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb)
+    _, part0 = ops.abmil_pool_partials(H.view(B, N, 512), Wa, ba, wb, bb)
+    Wd = torch.randn((512, 512), generator=g, device=dev) / math.sqrt(512)
+    bd = torch.randn((512,), generator=g, device=dev) * 0.1
     cases = {
         "copy_bf16": (lambda: H.copy_(X), 2 * M * 512 * 2, 0),
         "k2_fwd": (lambda: ops.abmil_pool_fwd(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
         "k2_bwd": (lambda: ops.abmil_pool_bwd(H.view(B, N, 512), Wa, ba, wb, sc, ml, Mp, dM), M * 640 * 2, 2.0 * M * 512 * 128),
         "k2_part": (lambda: ops.abmil_pool_partials(H.view(B, N, 512), Wa, ba, wb, bb), M * 512 * 2, 2.0 * M * 512 * 128),
+        "k2_bwd_wantA": (lambda: ops.abmil_pool_bwd(H.view(B, N, 512), Wa, ba, wb, sc, ml, Mp, dM, want_A=True), M * 640 * 2, 2.0 * M * 512 * 128),
+        "k2_decoder": (lambda: ops.abmil_pool_decoder(part0, B, N, torch.bfloat16, Wd, bd), 0, 0),
+        "k2_combine": (lambda: ops.abmil_pool_combine(sc, part0, torch.bfloat16), 0, 0),
+        "k2_dec_gemm": (lambda: ops.gemm_nt(Mp, Wd, epi=ops.EPI_BIAS_RELU, bias=bd), 0, 0),
         "panel_fwd": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias, want_bitmask=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
         "panel_fwd_nobm": (lambda: ops.panel_gemm(X, W, ops.PG_BIAS_RELU, bias=bias), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
         "panel_mask": (lambda: ops.panel_gemm(X, W, ops.PG_MASK, bitmask=bm, colsum=True), 2 * M * 512 * 2, 2.0 * M * 512 * 512),
