@@ -210,6 +210,30 @@ def m_full(device, dtype, bags=64, raw=8192, steps=30):
     return out
 
 
+def headline_f32(device, B, N, D, steps=8):
+    """The headline step on the PARITY path (f32 everywhere, exact-f32 MFMA: the kernels held to 1e-4 against the reference's outputs)
+    - the throughput line of the path that carries the parity claim (only `--dtype f32` by hand measured it)."""
+    model, fc, opt, crit = build(torch.float32, device, B)
+    views = synth_views(B, N, D, torch.float32, device, 0)
+    step = make_step(model, fc, opt, crit, views, 1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        loss = step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    flops = 2 * B * 9.41e9 * (N / 2048.0)
+    return dict(workload=f"the headline step with f32 patch tensors (parity path): {B} bags x {N} x {D} per view", ms_per_step=round(ms, 4),
+                bags_per_s=round(B / ms * 1e3, 1), steps=steps, loss=round(float(loss.item()), 6),
+                frac_of_f32_mfma_peak=round(flops / (ms * 1e-3) / 1e12 / PEAK["mfma_f32_TFLOPs"], 4),
+                note="exact-f32 v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 matrix rate: this path exists for parity (<= 1e-4 vs the "
+                     "reference), the bf16 storage path above for throughput")
+
+
 def _timed_ms(fn, reps=10, warm=3):
     for _ in range(warm):
         fn()
@@ -353,6 +377,46 @@ def other_rows(device):
     out["dsmil_c5_share_fwd_bwd_bf16"] = dict(workload=f"DSMIL {B} bags x {N} x {d} bf16 storage", ms=round(ms, 4),
                                               bags_per_s=round(B / ms * 1e3, 1), chain_traffic_GB=round(nbytes / 1e9, 3),
                                               chain_traffic_frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 4))
+    return out
+
+
+def box_calibration(device):
+    """What THIS box delivers, measured in this process before the timed region (the same tree read 45.2 k and
+    42.7 k bags/s on two boxes of the pool and nothing in the line could tell a slow box from a regression): a streaming copy of one
+    [B*N,512] bf16 activation tensor (268 MB in, 268 MB out = the traffic of one encoder launch) and a register-only bf16 MFMA loop on
+    non-trivial operands, both own kernels behind the C-ABI (csrc/runtime.hip), HIP-event medians; plus the clocks sysfs shows."""
+    from murcl_amd import _lib
+    L = _lib.lib()
+    nbytes = 128 * 2048 * 512 * 2
+    src = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=device).normal_()
+    dst = torch.empty_like(src)
+    copy_ms = _timed_ms(lambda: _lib.check(L.murcl_calib_copy(src.data_ptr(), dst.data_ptr(), nbytes, _lib.stream()), "calib_copy"), reps=15)
+    del src, dst
+    buf = torch.empty((256 * 512,), dtype=torch.float32, device=device)
+    iters = 16000
+    mfma_ms = _timed_ms(lambda: _lib.check(L.murcl_calib_mfma_bf16(buf.data_ptr(), iters, _lib.stream()), "calib_mfma"), reps=7)
+    flops = 256.0 * 8 * iters * 4 * 16384
+    out = dict(copy_GBps=round(2 * nbytes / copy_ms / 1e6, 1), copy_ms=round(copy_ms, 4), copy_bytes_moved=2 * nbytes,
+               mfma_bf16_TFLOPs=round(flops / mfma_ms / 1e9, 1), mfma_ms=round(mfma_ms, 4),
+               mfma_clock_MHz_if_4096_flop_per_clk_per_cu=round(flops / (mfma_ms * 1e-3) / (256 * 4096.0) / 1e6, 1),
+               note="own kernels (murcl_calib_copy: 16-byte streaming copy of one activation tensor; murcl_calib_mfma_bf16: 8 waves per CU of "
+                    "back-to-back v_mfma_f32_16x16x32_bf16 on register operands), measured in this process before the timed region")
+    clocks = {}
+    try:
+        import glob
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            for name in ("pp_dpm_sclk", "pp_dpm_mclk"):
+                fn = os.path.join(card, name)
+                if os.path.exists(fn):
+                    with open(fn) as f:
+                        cur = [ln.split(":")[1].strip().rstrip("*").strip() for ln in f if ln.strip().endswith("*")]
+                    if cur:
+                        clocks.setdefault(os.path.basename(os.path.dirname(card)), {})[name] = cur[0]
+            if clocks:
+                break
+    except Exception:                                                          # noqa: BLE001
+        pass
+    out["sysfs_clocks_idle"] = clocks or None
     return out
 
 
@@ -576,6 +640,12 @@ def main():
     # with the driver's --warmup 5 those steps used to fall into the timed region.
     gc.collect()
     gc.freeze()
+    box = None
+    if rank == 0:
+        try:
+            box = box_calibration(device)
+        except Exception as e:                                                 # noqa: BLE001  (a diagnostic must not take the line with it)
+            box = {"error": f"{type(e).__name__}: {e}"[:300]}
     for _ in range(max(0, args.warmup - 1)):
         step()
 
@@ -683,8 +753,12 @@ def main():
         traffic, src = _pmc_traffic(key)
         if key.startswith("row:k2_fwd"):
             traffic, src = _pmc_traffic(f"abmil_pool_fwd<{args.dtype}>")
+        box_copy = (box or {}).get("copy_GBps")
+        box_mfma = (box or {}).get("mfma_bf16_TFLOPs")
         out = dict(kernel=key, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(frac, 4),
                    frac_flops=round(frac_flops, 4), frac_layer_bytes=round(frac_bytes, 4),
+                   frac_of_box_copy=round(by / sec_avg / 1e9 / box_copy, 4) if box_copy else None,
+                   frac_of_box_mfma=round(fl / sec_avg / 1e12 / box_mfma, 4) if (box_mfma and mfma_peak == PEAK["mfma_bf16_TFLOPs"]) else None,
                    bound_source="SURVEY.md 8(d): K1 (encoder GEMMs) MFMA-bound, K2 / streaming passes HBM-bound",
                    traffic=traffic, traffic_source=src, launches=r["calls"], avg_launch_ms=round(sec_avg * 1e3, 4),
                    algorithmic_bytes_per_launch=int(by), algorithmic_flops_per_launch=int(fl))
@@ -738,6 +812,7 @@ def main():
                                f"per GPU, {args.dtype} patch tensors / f32 accumulate (BASELINE configs[1])",
                    "bags_per_gpu": B, "patches": N, "feat_dim": D, "global_bags": B * world,
                    "sharding": "bags by WSI; all-gather of z + grad all-reduce" if world > 1 else "single GPU"},
+        "box": box,
         "roofline": dict(roof(dominant), step=step_roof()),
         "roofline_k2": dict(roof(k2row_key), kernel=k2_key, launches_of_the_row=[k2_key],
                             avg_ms_each_untimed_pass=[round(breakdown[k]["ms_avg"], 4) for k in (k2_key,) if k in breakdown],
@@ -772,6 +847,7 @@ def main():
                 print(f"bench.py: extra '{name}' failed: {e!r}", file=sys.stderr, flush=True)
             gc.collect()
             torch.cuda.empty_cache()
+        extra("abmil_c2_f32", lambda: headline_f32(device, B, N, D))
         extra("m_full", lambda: m_full(device, dtype))
         extra("rows", lambda: other_rows(device))
         extra("cpu_baseline", lambda: cpu_baseline(B, N, D))

@@ -131,6 +131,12 @@ int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int M, int N, i
 int murcl_cu_budget(void);
 int murcl_set_cu_budget(int cus);
 
+/* Box calibration for bench.py (csrc/runtime.hip; not on the product path, no reference counterpart): a streaming copy of `bytes`
+ * (multiple of 16) with 16-byte accesses, and a register-only loop of 256 CUs x 8 waves x iters x 4 v_mfma_f32_16x16x32_bf16 (16384 FLOP
+ * each) writing 256*512 floats - timed by the caller, they say what HBM rate and matrix clock THIS box sustains. */
+int murcl_calib_copy(const void* src, void* dst, long bytes, murcl_stream_t stream);
+int murcl_calib_mfma_bf16(float* out_256x512, int iters, murcl_stream_t stream);
+
 /* K2 -- ABMIL attention pooling, abmil.py:38-42:  scores[b,n] = wb.tanh(Wa H[b,n]+ba)+bb,
  * A = softmax_N(scores)/sqrt(N), M[b] = A[b].H[b];  ml[b] = (max, sum exp) of the soft-max.
  * H [B,N,L] and Wa [D,L] in `dtype`; L = 512, D = 128.  part_ws: B*n_chunks*(L+4) floats with

@@ -30,6 +30,8 @@ SIGNATURES = {
     "murcl_panel_gemm_drop": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _F, ctypes.c_ulonglong, ctypes.c_ulonglong, _P],
     "murcl_cu_budget": [],
     "murcl_set_cu_budget": [_I],
+    "murcl_calib_copy": [_P, _P, _L, _P],
+    "murcl_calib_mfma_bf16": [_P, _I, _P],
     "murcl_abmil_pool_workspace": [_I, _I, _I, _c.POINTER(_I), _c.POINTER(_I)],
     "murcl_abmil_pool_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "murcl_dropout_mask": [_P, _L, _F, _F, ctypes.c_ulonglong, _I, _P],

@@ -125,6 +125,11 @@ def test_gpus_1_through_the_spawn_path_prints_the_contract_line():
     assert st["flops"] == pytest.approx(2 * 64 * 9.41e9) and 0 < st["frac_of_mfma"] < 1
     assert st["fused_min_bytes"] == 2 * 64 * 2048 * 512 * 2
     assert st["hbm_bytes_pmc"] is None or (st["ratio_vs_fused_min"] > 1 and st["pmc_source"])
+    # round 6: the box is calibrated in the same process (copy rate + bf16 MFMA rate of THIS box), fractions against it beside the
+    # fractions against the data-sheet peaks
+    box = out["box"]
+    assert 2000 < box["copy_GBps"] < 8000 and 800 < box["mfma_bf16_TFLOPs"] < 2600, box
+    assert 0 < r["frac_of_box_copy"] < 1.5 and 0 < k2["frac_of_box_copy"] < 1.2
     # round 6: the K2 row is ONE launch - its per-bag merge runs inside the decoder launch (no abmil_pool_combine in the step)
     assert k2["bound"] == "hbm" and k2["launches_of_the_row"] == ["abmil_pool_fwd<bf16>"]
     assert len(k2["avg_ms_each_untimed_pass"]) == 1 and k2["avg_launch_ms"] > 0
