@@ -122,6 +122,26 @@ def cap_rccl_channels(world):
     return os.environ["NCCL_MAX_NCHANNELS"]
 
 
+def budget_for_channels(budget, max_channels):
+    """The CU budget that leaves RCCL's channel workgroups their CUs: ``budget`` (what MURCL_CU_BUDGET asks for) lowered until the
+    reserve 256 - budget covers ``max_channels`` (NCCL_MAX_NCHANNELS; None = not set: RCCL picks its own count, 32 is assumed), in steps
+    of 8 (one per XCD), never below 64.  -> (budget, note or None); the note says what was overridden and why - callers print it,
+    because a reserve smaller than the channel count puts every overlapped launch into a second round (+ 50 % step time on one GPU,
+    profiles/r05_f_cu_thief.txt) without any other symptom."""
+    budget = max(64, min(256, int(budget))) & ~7
+    if budget >= 256:
+        return 256, None                                      # the reserve was switched off on purpose
+    channels = 32 if max_channels is None else max(1, int(max_channels))
+    need = min(192, (channels + 7) // 8 * 8)
+    if 256 - budget >= need:
+        return budget, None
+    fitted = 256 - need
+    why = ("NCCL_MAX_NCHANNELS is not set (dist.cap_rccl_channels was not called before init_process_group): RCCL may run up to 32 "
+           "channel workgroups") if max_channels is None else f"NCCL_MAX_NCHANNELS={channels}"
+    return fitted, (f"murcl_amd.dist: {why}, more than the {256 - budget} CUs MURCL_CU_BUDGET={budget} leaves free - the overlapped launches "
+                    f"are sized for {fitted} CUs instead (set NCCL_MAX_NCHANNELS <= {256 - budget} or lower MURCL_CU_BUDGET to silence this)")
+
+
 def reserve_cus_for_collectives(group=None):
     """Collectives that overlap the backward pass run RCCL's channel workgroups beside the persistent kernels of the step.  Those
     kernels are ONE round of workgroups with a static share each (one per CU): with even 4 CUs held by somebody else a launch runs
@@ -136,7 +156,13 @@ def reserve_cus_for_collectives(group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2 or dist.get_backend(group) != "nccl":
         return None
     from . import functional, ops
-    budget = max(64, min(256, int(os.environ.get("MURCL_CU_BUDGET", "248")))) & ~7
+    # (round 6) the environment may have said NCCL_MAX_NCHANNELS before cap_rccl_channels could (it only sets a default), or nobody
+    # called it: the reserve follows the channel cap that is actually in force, and says so loudly
+    cap = os.environ.get("NCCL_MAX_NCHANNELS")
+    budget, note = budget_for_channels(os.environ.get("MURCL_CU_BUDGET", "248"), int(cap) if cap and cap.isdigit() else None)
+    if note and dist.get_rank(group) == 0:
+        import warnings
+        warnings.warn(note, RuntimeWarning, stacklevel=2)
     if os.environ.get("MURCL_CU_BUDGET_SCOPE", "backward") == "all":
         return ops.set_cu_budget(budget)
     functional.set_overlap_cu_budget(budget)

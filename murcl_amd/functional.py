@@ -1054,13 +1054,14 @@ class CLAMFn(torch.autograd.Function):
             # one grouped cross-entropy launch replace the per-class / per-bag loops; pairs differ only in their targets:
             #   class == label      -> 2k rows, targets [1]*k + [0]*k            (inst_eval,     clam.py:105-119)
             #   class != label      -> k top rows with target 0 if subtyping    (inst_eval_out, clam.py:122-132), else none
-            labels, k, subtyping = inst_cfg
+            labels, k, subtyping = inst_cfg[:3]
+            custom_loss = inst_cfg[3] if len(inst_cfg) > 3 else None          # a caller-supplied instance_loss_fn (clam.py:64-65,118,131)
             n_cls = inst_w.shape[0]
             ids = ops.topk_ids(A, k)                                                   # [B, 2k]
             lab = labels.to(device=dev, dtype=torch.int64) if isinstance(labels, torch.Tensor) else \
                 torch.as_tensor([int(v) for v in labels], dtype=torch.int64).to(dev)
             w_st = inst_w.reshape(n_cls * 2, -1).contiguous()
-            if _FUSED_INST and 2 * n_cls <= 16 and k <= 32 and L % 8 == 0:
+            if custom_loss is None and _FUSED_INST and 2 * n_cls <= 16 and k <= 32 and L % 8 == 0:
                 # one launch: gather the 2k rows, all 2 n_cls instance logits, the cross-entropies and their gradients
                 inst_loss, dl, inst_pt = ops.clam_inst_fwd(h, ids, lab, w_st, inst_b.reshape(-1), B, N, k, n_cls, subtyping)
                 saved_inst = ("fused", ids, dl, w_st, k, n_cls)
@@ -1073,6 +1074,27 @@ class CLAMFn(torch.autograd.Function):
                 same = lab.view(B, 1) == cls_ids                                                            # [B, n_cls]
                 targets = torch.where(same.unsqueeze(2), t_in, t_out).contiguous()                          # [B, n_cls, 2k]
                 loss_g, dl_g, preds_g = ops.cross_entropy(logits_g.view(-1, 2), targets.view(-1), 2 * k)
+                if custom_loss is not None:
+                    # The reference hands (logits [rows,2], targets [rows]) of every evaluated (bag, class) pair to whatever loss it was
+                    # constructed with (clam.py:118,131).  The gather, the classifier product and the predictions above are the HIP
+                    # kernels; the caller's loss runs on the pair's few logits as given (rows with target -1 do not exist for that pair)
+                    # and its gradient w.r.t. them - taken here with autograd on that [rows,2] leaf - takes the place of the
+                    # cross-entropy gradient in the backward pass below.  A loss with parameters of its own gets no gradient for them.
+                    with torch.enable_grad():
+                        leaf = logits_g.detach().requires_grad_()
+                        tg = targets.view(B, n_cls, 2 * k)
+                        pair = []
+                        for b_ in range(B):
+                            for c_ in range(n_cls):
+                                keep_rows = tg[b_, c_] >= 0
+                                if bool(keep_rows.any()):
+                                    pair.append(custom_loss(leaf[b_, c_][keep_rows], tg[b_, c_][keep_rows]))
+                                else:
+                                    pair.append(leaf.new_zeros(()))
+                        loss_pairs = torch.stack(pair).view(B, n_cls)
+                        dl_g, = torch.autograd.grad(loss_pairs.sum(), leaf, allow_unused=True)
+                    loss_g = loss_pairs.detach().reshape(-1)
+                    dl_g = (torch.zeros_like(logits_g) if dl_g is None else dl_g).reshape(-1, 2).contiguous()
                 scale = 1.0 / n_cls if subtyping else 1.0                                  # clam.py:167-168
                 inst_loss = loss_g.view(B, n_cls).sum(1) * scale
                 inst_pt = torch.stack([preds_g.view(B, n_cls, 2 * k), targets], 0)         # -1 where a pair has no such row

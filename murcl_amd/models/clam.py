@@ -49,20 +49,11 @@ import types as _types
 _EMPTY_RESULT = _types.MappingProxyType({})
 
 
-def _checked_instance_loss(fn):
-    """The reference calls the loss it was given on (logits [2k,2], targets [2k]) of every evaluated class (clam.py:64-65,118,131).
-    The instance branch here is one HIP launch each way that evaluates exactly ``nn.CrossEntropyLoss()`` - mean reduction, no class
-    weights, no label smoothing (the only loss the reference's scripts pass: its constructor default).  ``None`` means that
-    default; any other callable would silently produce other numbers, so it is refused."""
-    if fn is None:
-        return nn.CrossEntropyLoss()
-    plain = (type(fn) is nn.CrossEntropyLoss and fn.reduction == "mean" and fn.weight is None
-             and float(getattr(fn, "label_smoothing", 0.0)) == 0.0 and fn.ignore_index == -100)
-    if not plain:
-        raise NotImplementedError(
-            "murcl_amd CLAM_SB: instance_loss_fn must be None or a default nn.CrossEntropyLoss() - the fused instance branch "
-            f"(csrc/clam.hip) evaluates mean cross-entropy and nothing else; got {fn!r}")
-    return fn
+def _is_default_ce(fn):
+    """Is ``fn`` the loss the fused instance branch (csrc/clam.hip) evaluates - ``nn.CrossEntropyLoss()`` with mean reduction, no class
+    weights, no label smoothing (the reference's constructor default and the only loss its scripts pass, clam.py:64-65)?"""
+    return (type(fn) is nn.CrossEntropyLoss and fn.reduction == "mean" and fn.weight is None
+            and float(getattr(fn, "label_smoothing", 0.0)) == 0.0 and fn.ignore_index == -100)
 
 
 class CLAM_SB(nn.Module):
@@ -79,7 +70,13 @@ class CLAM_SB(nn.Module):
         self.classifiers = nn.Linear(size[1], n_classes)
         self.instance_classifiers = nn.ModuleList([nn.Linear(size[1], 2) for _ in range(n_classes)])
         self.k_sample, self.n_classes, self.subtyping, self.dropout = k_sample, n_classes, subtyping, dropout
-        self.instance_loss_fn = _checked_instance_loss(instance_loss_fn)      # clam.py:64-65; CE itself runs in the HIP kernel
+        # clam.py:64-65,118,131: the reference calls the loss it was given on (logits [rows,2], targets [rows]) of every evaluated
+        # class.  The default CE runs inside the one-launch instance branch; any other callable gets the same logits / targets (formed
+        # by the HIP kernels) and its own gradient w.r.t. them goes back through the instance backward (functional.CLAMFn) - round 6:
+        # such a loss used to be refused
+        self.instance_loss_fn = nn.CrossEntropyLoss() if instance_loss_fn is None else instance_loss_fn
+        if not callable(self.instance_loss_fn):
+            raise TypeError(f"instance_loss_fn must be callable, got {type(instance_loss_fn).__name__}")
         self.compute_dtype = torch.float32
         self.last_attention = None
         self._empty_results = None                   # cached per-bag result dicts of calls that report nothing (batch_forward)
@@ -121,7 +118,8 @@ class CLAM_SB(nn.Module):
             # labels stay where they are: a device tensor goes to the kernels as it is (no .tolist() round trip, which would
             # stall the host on everything queued so far)
             lab = labels.reshape(-1) if isinstance(labels, torch.Tensor) else [int(l) for l in labels]
-            cfg = (lab, self.k_sample, self.subtyping)
+            cfg = (lab, self.k_sample, self.subtyping) if _is_default_ce(self.instance_loss_fn) else \
+                (lab, self.k_sample, self.subtyping, self.instance_loss_fn)
         M, A, s, inst_loss, ids, inst_out = CLAMFn.apply(x.contiguous(), net[0].weight, net[0].bias, wa, ba, wb, bb, wc, bc,
                                                          inst_w, inst_b, keeps, cfg, torch.is_grad_enabled())
         self.last_attention = A

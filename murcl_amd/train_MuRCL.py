@@ -84,8 +84,10 @@ def get_scheduler(args, optimizer):
     return make_scheduler(optimizer, args.scheduler, args.epochs, args.warmup)
 
 
-_DEFERRED_ENCODER = os.environ.get("MURCL_DEFERRED_ENCODER", "1") == "1"     # dev A/B switch: one aggregator backward per sequential step
-_BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/B switch: the recurrent head over all patch steps at once
+# Which of two BUILT forms a sequential step takes (test hooks flipped through monkeypatch - tests/test_gpu_step.py - not environment
+# switches: the per-step forms are what other shapes / stages run anyway, so both stay tested):
+_DEFERRED_ENCODER = True       # one aggregator backward for all T patch steps of a sequential step (functional.EncoderSession)
+_BATCHED_HEAD = True           # the recurrent head over all patch steps at once (Full_layer.forward_view_sequence)
 
 
 # ------------------------------------------------------------------------------------------------ the hot step

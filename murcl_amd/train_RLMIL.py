@@ -36,7 +36,7 @@ def create_model(arch, dim_patch, num_classes, device, model_dim=512, D=128, siz
     return model.to(device), fc.to(device)
 
 
-_BATCHED_HEAD = os.environ.get("MURCL_BATCHED_HEAD", "1") == "1"        # dev A/B switch
+_BATCHED_HEAD = True           # test hook (monkeypatch), not an environment switch: the recurrent head over all patch steps at once
 
 
 def _confidence(logits, labels):

@@ -791,6 +791,66 @@ def g20_abmil_full_grads():
     np.savez_compressed(os.path.join(OUT, "g20_abmil_full_grads.npz"), **res)
 
 
+def g21_full_layer_cascade():
+    """Full_layer(fc_rnn=False), the cascaded head (rlmil.py:201-206,222-239), driven the way the training loops drive the head - both
+    views through ONE module, restart at patch step 0 (train_MuRCL.py:243,272): view 0 and view 1 of step 0 each restart (None, None),
+    then the shared concatenation grows by one block per call: fc_2 (step 1 view 0), fc_3 (step 1 view 1), fc_4, fc_5.  Outputs,
+    the gradients of all four classifiers (in full) and of the inputs for a weighted sum of the logits."""
+    seed, B, F_, C = 21, 4, 512, 16
+    fc = r_rlmil.Full_layer(F_, 1024, False, C)
+    fc.load_state_dict(P.to_torch(P.full_layer_cascade(seed, F_, C)))
+    res, xs, loss = {}, {}, 0.0
+    for t in range(3):
+        for v in range(2):
+            x = T(detrand.normal(seed, f"g21.x.{t}.{v}", (B, F_))).requires_grad_()
+            xs[(t, v)] = x
+            z = fc(x, restart=(t == 0))
+            res[f"none.{t}.{v}"] = np.array(z is None)
+            res[f"width.{t}.{v}"] = np.array(fc.hidden.shape[1])
+            if z is not None:
+                res[f"z.{t}.{v}"] = z.detach().numpy()
+                loss = loss + (z * T(detrand.normal(seed, f"g21.w.{t}.{v}", (B, C)))).sum()
+    loss.backward()
+    for k, p_ in fc.named_parameters():
+        res["grad." + k] = p_.grad.numpy().astype(np.float32)
+    for (t, v), x in xs.items():
+        res[f"dx.{t}.{v}"] = (x.grad if x.grad is not None else torch.zeros_like(x)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g21_full_layer_cascade.npz"), **res)
+
+
+def instance_losses():
+    """The non-default instance losses of G22 (shared with the tests: the SAME callables go to the reference and to murcl_amd)."""
+    return {"ce_weighted_sum": torch.nn.CrossEntropyLoss(weight=torch.tensor([0.7, 1.3]), reduction="sum"),
+            "multi_margin": torch.nn.MultiMarginLoss(),
+            "lambda_logit_gap": lambda lg, tg: ((lg[:, 1] - lg[:, 0]) * (1.0 - 2.0 * tg.float())).exp().mean()}
+
+
+def g22_clam_custom_instance_loss():
+    """CLAM_SB(instance_loss_fn=<callable>) - clam.py:64-65,118,131 call whatever loss the constructor was given: G4's inputs through
+    three non-default losses (weighted / summed CE, multi-margin, a plain lambda), subtyping on (both inst_eval and inst_eval_out
+    run), labels 0 and 1: per-bag instance losses and the parameter gradients (small ones in full) of bag + instance objective."""
+    seed, B, N, d = 11, 3, 300, 512
+    x = T(P.bags(seed, "g4.x", B, N, d))
+    res = {}
+    for name, fn in instance_losses().items():
+        for label in (0, 1):
+            m = r_clam.CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, instance_loss_fn=fn,
+                               subtyping=True, in_dim=d)
+            m.load_state_dict(P.to_torch(P.clam_sb(seed)), strict=False)      # (a weighted CE module adds its own "instance_loss_fn.weight" key)
+            m.eval()
+            tot, losses = 0, []
+            for b in range(B):
+                Mb, rdb = m.bag_forward(x[b], label=torch.tensor([label]), instance_eval=True)
+                losses.append(float(rdb["instance_loss"]))
+                tot = tot + Mb.sum() + rdb["instance_loss"]
+            tot.backward()
+            res[f"{name}.l{label}.inst_loss"] = np.array(losses)
+            for k, v in m.named_parameters():
+                if v.grad is not None:
+                    res[f"{name}.l{label}.grad.{k}"] = _grad_entry(v.grad)
+    np.savez_compressed(os.path.join(OUT, "g22_clam_custom_instance_loss.npz"), **res)
+
+
 def g17_rl_two_steps():
     """G12 with a second optimizer step (Adam's first step is sign-like, a second one makes the comparison bite):
     TWO consecutive batches through the reference's own ``train()`` (train_MuRCL.py:189-343) at train_stage 2 and 3, T = 3,
@@ -1018,7 +1078,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
     for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general, g17_rl_two_steps,
-               g18_clam_big, g19_abmil_heads, g20_abmil_full_grads):
+               g18_clam_big, g19_abmil_heads, g20_abmil_full_grads, g21_full_layer_cascade, g22_clam_custom_instance_loss):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

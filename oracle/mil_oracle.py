@@ -94,7 +94,7 @@ def clam_sb_forward(p, x, drop_mask=None):
     return M, A, s, h
 
 
-def clam_instance_eval(p, A, h, label, n_classes, k_sample, subtyping):
+def clam_instance_eval(p, A, h, label, n_classes, k_sample, subtyping, loss_fn=None):
     """CLAM_SB.inst_eval / inst_eval_out for ONE bag (clam.py:103-132,146-168).
 
     A [N] post-softmax, h [N,512], label int.  Returns (loss, preds int64, targets
@@ -118,7 +118,7 @@ def clam_instance_eval(p, A, h, label, n_classes, k_sample, subtyping):
         else:
             continue
         logits = F.linear(h[ids], w, b)                       # clam.py:116,129
-        total = total + F.cross_entropy(logits, tgt)          # clam.py:118,131
+        total = total + (F.cross_entropy(logits, tgt) if loss_fn is None else loss_fn(logits, tgt))   # clam.py:118,131 (instance_loss_fn)
         preds.append(logits.argmax(1))
         targets.append(tgt)
         ids_all.append(ids)
@@ -193,6 +193,19 @@ def full_layer_step(p, x, hidden):
     h = gru_cell(x, hidden, p["rnn.weight_ih_l0"], p["rnn.weight_hh_l0"],
                  p["rnn.bias_ih_l0"], p["rnn.bias_hh_l0"])
     return _lin(h, p, "fc"), h
+
+
+def full_layer_cascade_step(p, x, hidden, feature_num):
+    """Full_layer.forward, fc_rnn=False (models/rlmil.py:222-239): ``hidden`` is the running concatenation of the inputs (None ==
+    restart=True); the classifier of the current width k * feature_num (k = 2..5) is applied, a single block gives None.
+    Returns (logits or None, hidden').  As with the recurrent head the caller carries ONE ``hidden`` for both views."""
+    hidden = x if hidden is None else torch.cat([hidden, x], 1)
+    k = hidden.shape[1] // feature_num
+    if k == 1:
+        return None, hidden
+    if k not in (2, 3, 4, 5):
+        raise RuntimeError("cascade wider than fc_5 (the reference prints the size and exits)")
+    return _lin(hidden, p, f"fc_{k}"), hidden
 
 
 # ----------------------------------------------------------------------------- PPO

@@ -84,6 +84,14 @@ def full_layer(seed, feature_num=512, hidden=1024, class_num=128):
     return d
 
 
+def full_layer_cascade(seed, feature_num=512, class_num=16):
+    """models/rlmil.py:201-206 (fc_rnn=False): the cascaded classifiers fc_2 .. fc_5."""
+    d = {}
+    for k in (2, 3, 4, 5):
+        _linear(seed, f"fc_{k}", class_num, feature_num * k, d)
+    return d
+
+
 def actor_critic(seed, state_dim=512, hidden=512, action_size=10):
     """models/rlmil.py:40-54."""
     d = {}

@@ -267,6 +267,39 @@ def test_full_layer_interleaved_hidden_golden(golden):
                 np.testing.assert_allclose(fc.hidden[0].cpu().numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
 
 
+def test_full_layer_cascade_golden(golden):
+    """G21: ``Full_layer(fc_rnn=False)`` (rlmil.py:201-206,222-239; a constructor argument of the boundary, ``--fc_rnn`` defaults to
+    True in both scripts) on the HIP kernels against the reference's outputs: the two restarts return None, the shared concatenation
+    grows through fc_2 .. fc_5; logits, every classifier gradient entry and the input gradients at 1e-4; a sixth block raises."""
+    from murcl_amd.models.rlmil import Full_layer
+    g = golden("g21_full_layer_cascade")
+    dev = _dev()
+    fc = Full_layer(512, 1024, False, 16)
+    fc.load_state_dict(P.to_torch(P.full_layer_cascade(21, 512, 16)))
+    fc = fc.to(dev)
+    assert sorted(fc.state_dict()) == sorted(f"fc_{k}.{n}" for k in (2, 3, 4, 5) for n in ("weight", "bias"))
+    xs, loss = {}, 0.0
+    for t in range(3):
+        for v in range(2):
+            x = T(detrand.normal(21, f"g21.x.{t}.{v}", (4, 512))).to(dev).requires_grad_()
+            xs[(t, v)] = x
+            z = fc(x, restart=(t == 0))
+            assert (z is None) == bool(g[f"none.{t}.{v}"]) and fc.hidden.shape[1] == int(g[f"width.{t}.{v}"])
+            if z is not None:
+                np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"z.{t}.{v}"], rtol=1e-4, atol=2e-6)
+                loss = loss + (z * T(detrand.normal(21, f"g21.w.{t}.{v}", (4, 16))).to(dev)).sum()
+    loss.backward()
+    for k, p_ in fc.named_parameters():
+        want = g["grad." + k]
+        np.testing.assert_allclose(p_.grad.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max(), err_msg=k)
+    for (t, v), x in xs.items():
+        want = g[f"dx.{t}.{v}"]
+        got = x.grad.cpu().numpy() if x.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * max(1e-30, np.abs(want).max()), err_msg=f"dx {t} {v}")
+    with pytest.raises(RuntimeError):
+        fc(T(detrand.normal(21, "g21.x.3.0", (4, 512))).to(dev))
+
+
 def test_full_layer_forward_views_equals_the_per_view_loop():
     """forward_views(restart=True) batches the independent views: same outputs, hidden state and gradients as
     the reference's `[fc(o, restart) for o in outputs]` loop (train_MuRCL.py:243); restart=False stays sequential."""
@@ -500,6 +533,29 @@ def test_clam_vs_reference_golden(golden, subtyping):
     ids = ops.topk_ids(m.last_attention, 8).cpu().numpy()
     np.testing.assert_array_equal(ids[:, :8], g[f"{tag}.top_p"])
     np.testing.assert_array_equal(ids[:, 8:], g[f"{tag}.top_n"])
+
+
+@pytest.mark.parametrize("name", ["ce_weighted_sum", "multi_margin", "lambda_logit_gap"])
+@pytest.mark.parametrize("label", [0, 1])
+def test_clam_custom_instance_loss_vs_reference_golden(golden, name, label):
+    """G22: ``CLAM_SB(instance_loss_fn=<callable>)`` (clam.py:64-65,118,131 call whatever loss the constructor was given; rounds 4-5
+    refused anything but the default CE): the HIP kernels gather the top / bottom rows and form logits, targets and predictions, the
+    caller's loss runs on each evaluated (bag, class) pair's [rows,2] logits and its own gradient goes back through the instance
+    backward - per-bag instance losses at 2e-4 and every stored gradient against the reference's, three non-default losses."""
+    from murcl_amd.models.clam import CLAM_SB
+    g = golden("g22_clam_custom_instance_loss")
+    losses = {"ce_weighted_sum": torch.nn.CrossEntropyLoss(weight=torch.tensor([0.7, 1.3]), reduction="sum"),
+              "multi_margin": torch.nn.MultiMarginLoss(),
+              "lambda_logit_gap": lambda lg, tg: ((lg[:, 1] - lg[:, 0]) * (1.0 - 2.0 * tg.float())).exp().mean()}
+    m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, instance_loss_fn=losses[name], subtyping=True, in_dim=512)
+    m.load_state_dict(P.to_torch(P.clam_sb(11)), strict=False)      # (a weighted CE module carries its own "instance_loss_fn.weight")
+    m = m.to(_dev()).eval()
+    x = T(P.bags(11, "g4.x", 3, 300, 512)).to(_dev())
+    M, _, res = m(x, label=[label] * 3, instance_eval=True)
+    for b in range(3):
+        np.testing.assert_allclose(float(res[b]["instance_loss"].detach()), g[f"{name}.l{label}.inst_loss"][b], rtol=2e-4)
+    (M.sum() + sum(r["instance_loss"] for r in res)).backward()
+    _check_grad_entries(m.named_parameters(), g, f"{name}.l{label}.grad.", 3e-4, zero_keys=("attention_net.3.attention_c.bias",))
 
 
 def test_clam_grads_golden(golden):

@@ -122,17 +122,36 @@ def test_stack_rows_is_a_view_when_the_blocks_are_consecutive():
     assert torch.equal(s, x[:, :2])
 
 
-def test_clam_sb_refuses_an_instance_loss_it_would_not_evaluate():
-    """clam.py:64-65,118,131 call the loss they were given; the fused instance branch evaluates mean cross-entropy only: None and a
-    default nn.CrossEntropyLoss() are accepted, anything else raises instead of silently producing other numbers."""
+def test_clam_sb_takes_any_callable_instance_loss():
+    """clam.py:64-65,118,131 call the loss they were given: None means the default nn.CrossEntropyLoss() (which runs inside the fused
+    instance branch); any other callable is kept and handed the logits / targets of every evaluated class (round 6: G22 pins the
+    numbers on the GPU); a non-callable raises."""
     import pytest
     from torch import nn
-    from murcl_amd.models.clam import CLAM_SB
-    assert isinstance(CLAM_SB().instance_loss_fn, nn.CrossEntropyLoss)
-    assert isinstance(CLAM_SB(instance_loss_fn=nn.CrossEntropyLoss()).instance_loss_fn, nn.CrossEntropyLoss)
-    for bad in (nn.CrossEntropyLoss(reduction="sum"), nn.CrossEntropyLoss(label_smoothing=0.1), nn.MultiMarginLoss(),
-                nn.CrossEntropyLoss(weight=torch.tensor([1.0, 2.0])), lambda a, b: (a.sum() + b.sum())):
-        with pytest.raises(NotImplementedError):
-            CLAM_SB(instance_loss_fn=bad)
+    from murcl_amd.models.clam import CLAM_SB, _is_default_ce
+    assert isinstance(CLAM_SB().instance_loss_fn, nn.CrossEntropyLoss) and _is_default_ce(CLAM_SB().instance_loss_fn)
+    assert _is_default_ce(CLAM_SB(instance_loss_fn=nn.CrossEntropyLoss()).instance_loss_fn)
+    for other in (nn.CrossEntropyLoss(reduction="sum"), nn.CrossEntropyLoss(label_smoothing=0.1), nn.MultiMarginLoss(),
+                  nn.CrossEntropyLoss(weight=torch.tensor([1.0, 2.0])), lambda a, b: (a.sum() + b.sum())):
+        m = CLAM_SB(instance_loss_fn=other)
+        assert m.instance_loss_fn is other and not _is_default_ce(other)
+    with pytest.raises(TypeError):
+        CLAM_SB(instance_loss_fn=3)
     m = CLAM_SB(size_arg="big", dropout=True)                     # clam.py:66-67: a 384-wide attention net (index 3 with the Dropout)
     assert m.attention_net[3].attention_a[0].weight.shape == (384, 512) and m.attention_net[3].attention_c.weight.shape == (1, 384)
+
+
+def test_cu_reserve_follows_the_rccl_channel_cap():
+    """dist.budget_for_channels (round 6): the CU budget of the launches a collective overlaps leaves RCCL one CU per channel it MAY
+    run - a user-set NCCL_MAX_NCHANNELS above the reserve, or no cap at all, lowers the budget (with a note that is printed) instead
+    of silently re-creating the second-round cliff; a fitting cap or a switched-off reserve (256) changes nothing."""
+    from murcl_amd.dist import budget_for_channels as f
+    assert f("248", 8) == (248, None)
+    assert f(248, 4) == (248, None)
+    assert f(256, 64) == (256, None)                    # reserve switched off on purpose
+    b, note = f("248", 16)
+    assert b == 240 and "NCCL_MAX_NCHANNELS=16" in note and "240" in note
+    b, note = f("248", None)
+    assert b == 224 and "not set" in note
+    assert f(240, 12) == (240, None) and f(200, 56)[0] == 200 and f(248, 1000)[0] == 64
+    assert f("251", 8) == (248, None)                   # multiples of 8: one step per XCD

@@ -232,6 +232,32 @@ def test_g9_full_layer_interleaved_hidden(golden):
             np.testing.assert_allclose(hidden.numpy(), g[f"h.{t}.{v}"], rtol=1e-4, atol=2e-6)
 
 
+def test_g21_full_layer_cascade(golden):
+    """G21: Full_layer(fc_rnn=False) - the cascaded classifiers over the shared, growing concatenation (rlmil.py:201-206,222-239):
+    None for the two restarts, then fc_2 .. fc_5; logits, classifier gradients (in full) and input gradients of the reference."""
+    g = golden("g21_full_layer_cascade")
+    p = {k: v.clone().requires_grad_() for k, v in P.to_torch(P.full_layer_cascade(21, 512, 16)).items()}
+    hidden, xs, loss = None, {}, 0.0
+    for t in range(3):
+        for v in range(2):
+            x = T(detrand.normal(21, f"g21.x.{t}.{v}", (4, 512))).requires_grad_()
+            xs[(t, v)] = x
+            z, hidden = O.full_layer_cascade_step(p, x, None if t == 0 else hidden, 512)
+            assert (z is None) == bool(g[f"none.{t}.{v}"]) and hidden.shape[1] == int(g[f"width.{t}.{v}"])
+            if z is not None:
+                np.testing.assert_allclose(z.detach().numpy(), g[f"z.{t}.{v}"], rtol=1e-4, atol=2e-6)
+                loss = loss + (z * T(detrand.normal(21, f"g21.w.{t}.{v}", (4, 16)))).sum()
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["grad." + k], rtol=1e-4, atol=1e-5 * np.abs(g["grad." + k]).max(), err_msg=k)
+    for (t, v), x in xs.items():
+        want = g[f"dx.{t}.{v}"]
+        got = x.grad.numpy() if x.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(1e-30, np.abs(want).max()), err_msg=f"dx {t} {v}")
+    with pytest.raises(RuntimeError):
+        O.full_layer_cascade_step(p, T(detrand.normal(21, "g21.x.3.0", (4, 512))), hidden, 512)      # a sixth block: the reference exits
+
+
 # ------------------------------------------------------------------ G12: BASELINE config 4's body (PPO sampler in the loop)
 def _fp(x):
     return _summ(x if torch.is_tensor(x) else torch.as_tensor(x))
@@ -504,3 +530,30 @@ def test_g20_abmil_every_gradient_entry(golden):
     np.testing.assert_allclose(out.detach().numpy(), g["out"], **TOL)
     out.sum().backward()
     _check_grad_entries(g, "grad.", p, rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["ce_weighted_sum", "multi_margin", "lambda_logit_gap"])
+@pytest.mark.parametrize("label", [0, 1])
+def test_g22_clam_custom_instance_loss(golden, name, label):
+    """G22: CLAM_SB(instance_loss_fn=<callable>) - the reference calls whatever loss it was constructed with on every evaluated
+    class (clam.py:64-65,118,131): per-bag instance losses and the gradients of bag + instance objective for three non-default
+    losses (the same callables the generator handed to the reference: oracle/gen_goldens.instance_losses is re-stated here)."""
+    g = golden("g22_clam_custom_instance_loss")
+    fn = _instance_losses()[name]
+    p = _leaf(P.clam_sb(11))
+    x = T(P.bags(11, "g4.x", 3, 300, 512))
+    M, A, s, h = O.clam_sb_forward(p, x)
+    tot = M.sum()
+    for b in range(3):
+        loss = O.clam_instance_eval(p, A[b], h[b], label, 2, 8, True, loss_fn=fn)[0]
+        np.testing.assert_allclose(loss.item(), g[f"{name}.l{label}.inst_loss"][b], rtol=1e-5)
+        tot = tot + loss
+    tot.backward()
+    _check_grad_entries(g, f"{name}.l{label}.grad.", p)
+
+
+def _instance_losses():
+    return {"ce_weighted_sum": torch.nn.CrossEntropyLoss(weight=torch.tensor([0.7, 1.3]), reduction="sum"),
+            "multi_margin": torch.nn.MultiMarginLoss(),
+            "lambda_logit_gap": lambda lg, tg: ((lg[:, 1] - lg[:, 0]) * (1.0 - 2.0 * tg.float())).exp().mean()}
+
