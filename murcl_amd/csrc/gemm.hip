@@ -911,8 +911,17 @@ struct TnGroupArgs {
     int M[TN_MAXG], N1[TN_MAXG], N2[TN_MAXG], lda[TN_MAXG], ldb[TN_MAXG], mps[TN_MAXG];
     unsigned map[TN_MAXWG];          // workgroup -> (g << 28) | (tile << 16) | split; 0xFFFFFFFF: no work
 };
-__global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, float* __restrict__ ws) {
+// NWV waves per workgroup: 8 = 2 (n1) x 4 (n2) wave tiles of 128 x 64, two waves per SIMD (rounds 3-5); 4 = 2 x 2 wave tiles of
+// 128 x 128, ONE wave per SIMD with a 256-register accumulator (round 6 A/B, -DTN_SQ_WAVES=4): a slab's A half is read from LDS by
+// two waves instead of four - 64 KiB of fragment reads per slab where the 8-wave form reads 96 - for the same MFMA count per CU.
+#ifndef TN_SQ_WAVES
+#define TN_SQ_WAVES 8
+#endif
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void gemm_tn_sq_kernel(const TnGroupArgs ga, float* __restrict__ ws) {
     constexpr int ROWS = 32, PITCH = 512, A_BYTES = ROWS * PITCH, SLOT = 2 * A_BYTES, NSLOT = TN_SQ_NSLOT;   // 32 KiB slots
+    constexpr int NTH = 64 * NWV, NT = 1024 / NTH;          // threads; 16-byte chunks of a slab half per thread: 2 / 4
+    constexpr int WCN = NWV / 2, NJ = 16 / WCN;             // wave columns: 4 / 2; 16-column MFMA tiles per wave along n2: 4 / 8
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned code = ga.map[blockIdx.x];
     if (code == 0xFFFFFFFFu) return;
@@ -933,12 +942,12 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
 
     // LDS-DMA chunk maps: a slab half = 32 rows x 32 chunks of 16 B = 1024 chunks, two per thread; linear LDS image,
     // swizzle applied to the global source chunk.  Row pointers advance by a constant per slab (no per-load 64-bit math).
-    const bf16_t* ap[2];
-    const bf16_t* bp[2];
-    int srow[2];
+    const bf16_t* ap[NT];
+    const bf16_t* bp[NT];
+    int srow[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ci = t * 512 + tid, row = ci >> 5;
+    for (int t = 0; t < NT; ++t) {
+        const int ci = t * NTH + tid, row = ci >> 5;
         srow[t] = row;
         ap[t] = A + (size_t)n10 + (((ci & 31) ^ swz(row)) << 3);
         bp[t] = B + (size_t)n20 + (((ci & 31) ^ swz(row)) << 3);
@@ -947,19 +956,19 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
         const int mrow0 = mbeg + (nslab - 1 - s) * ROWS;                 // slabs are walked from the high rows down
         const unsigned la = lds0 + (s % NSLOT) * SLOT, lb = la + A_BYTES;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const size_t r = (size_t)min(mrow0 + srow[t], M - 1);
-            glds16(ap[t] + r * lda, la + (t * 512 + wave * 64) * 16);
-            glds16(bp[t] + r * ldb, lb + (t * 512 + wave * 64) * 16);
+            glds16(ap[t] + r * lda, la + (t * NTH + wave * 64) * 16);
+            glds16(bp[t] + r * ldb, lb + (t * NTH + wave * 64) * 16);
         }
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int wr = wave >> 2, wc = wave & 3;
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wr = wave / WCN, wc = wave % WCN;
 
     // transposed-read offsets (lane constants): rows 8g + rq (+4), 16-column group t -> chunks 2t, 2t+1; tile index i
     // (j) -> offset ^ (i << 5) as in the kernel above
@@ -967,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
     {
         const int gq = lane >> 4, u = lane & 15, rq = u >> 2, p4 = u & 3;
         const int row = 8 * gq + rq;
-        const int ca = 2 * (wr * 8) + (p4 >> 1), cb = 2 * (wc * 4) + (p4 >> 1);
+        const int ca = 2 * (wr * 8) + (p4 >> 1), cb = 2 * (wc * NJ) + (p4 >> 1);
         abase = row * PITCH + ((ca ^ swz(row)) << 4) + ((p4 & 1) << 3);
         bbase = A_BYTES + row * PITCH + ((cb ^ swz(row)) << 4) + ((p4 & 1) << 3);
     }
@@ -981,40 +990,41 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
     const int pre = min(NSLOT - 1, nslab);
     for (int s = 0; s < pre; ++s) stage(s);
     for (int s = 0; s < nslab; ++s) {
-        // slab s landed (up to NSLOT - 2 younger slabs stay in flight: 4 LDS-DMA ops per thread and slab), visible to all waves;
+        // slab s landed (up to NSLOT - 2 younger slabs stay in flight: 2 NT LDS-DMA ops per thread and slab), visible to all waves;
         // then the slot of slab s-1 - every wave has its fragments in registers - takes slab s + NSLOT - 1
-        if (NSLOT >= 5 && s + 3 < nslab) { WAIT_VMCNT(12); }
-        else if (s + 2 < nslab) { WAIT_VMCNT(8); } else if (s + 1 < nslab) { WAIT_VMCNT(4); } else { WAIT_VMCNT(0); }
+        if (NSLOT >= 5 && s + 3 < nslab) { if (NT == 2) { WAIT_VMCNT(12); } else { WAIT_VMCNT(24); } }
+        else if (s + 2 < nslab) { if (NT == 2) { WAIT_VMCNT(8); } else { WAIT_VMCNT(16); } }
+        else if (s + 1 < nslab) { if (NT == 2) { WAIT_VMCNT(4); } else { WAIT_VMCNT(8); } } else { WAIT_VMCNT(0); }
         LDS_BARRIER();
         if (s + NSLOT - 1 < nslab) stage(s + NSLOT - 1);
         char* slab = smem + (s % NSLOT) * SLOT;
         const int rows_here = min(ROWS, mend - (mbeg + (nslab - 1 - s) * ROWS));
         if (rows_here < ROWS) {                                              // ragged tail of the split: zero the missing rows
-            for (int idx = tid; idx < (ROWS - rows_here) * 32; idx += 512) {
+            for (int idx = tid; idx < (ROWS - rows_here) * 32; idx += NTH) {
                 *(u32x4*)(slab + (rows_here + (idx >> 5)) * PITCH + (idx & 31) * 16) = u32x4{0, 0, 0, 0};
                 *(u32x4*)(slab + A_BYTES + (rows_here + (idx >> 5)) * PITCH + (idx & 31) * 16) = u32x4{0, 0, 0, 0};
             }
             LDS_BARRIER();
         }
-        bf16x8 bfr[4], af[8];
+        bf16x8 bfr[NJ], af[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(slab, bbase ^ (j << 5));
+        for (int j = 0; j < NJ; ++j) bfr[j] = tr_frag(slab, bbase ^ (j << 5));
 #pragma unroll
         for (int i = 0; i < 8; ++i) af[i] = tr_frag(slab, abase ^ (i << 5));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);          // B (8 reads) + A0, A1 (4 reads)
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NJ + 4, 0);  // B (2 NJ reads) + A0, A1 (4 reads)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {                                // MFMAs of A_i with the reads of A_{i+2} between them
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NJ / 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NJ / 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NJ / 2, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
     }
     // ---- this split's partial tile -> the workspace in the matrix's own row-major layout: part[sp][n1][n2] (the accumulator-
     // layout alternative - 32 whole-KiB stores per wave instead of 128 four-byte ones - measured neutral in round 3)
@@ -1023,8 +1033,8 @@ __global__ __launch_bounds__(512) void gemm_tn_sq_kernel(const TnGroupArgs ga, f
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n2 = n20 + wc * 64 + j * 16 + r16;
+        for (int j = 0; j < NJ; ++j) {
+            const int n2 = n20 + wc * (16 * NJ) + j * 16 + r16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n10 + wr * 128 + i * 16 + 4 * q4 + r;
@@ -1413,11 +1423,11 @@ static int tn_sq_launch(const TnProblem* pr, int n, float* ws, hipStream_t strea
         }
     }
     for (int g = n; g <= TN_MAXG; ++g) { ra.blk0[g] = blk; ra.cs_blk0[g] = csb; }
-    auto k = gemm_tn_sq_kernel;
+    auto k = gemm_tn_sq_kernel<TN_SQ_WAVES>;
     constexpr int LDS = TN_SQ_NSLOT * 32768;
     static MurclOncePerDevice once;
     if (once.first()) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
-    hipLaunchKernelGGL(k, dim3(TN_MAXWG), dim3(512), LDS, stream, ga, ws);
+    hipLaunchKernelGGL(k, dim3(TN_MAXWG), dim3(64 * TN_SQ_WAVES), LDS, stream, ga, ws);
     int rc = MURCL_CHECK_LAUNCH();
     if (rc) return rc;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blk + csb)), dim3(256), 0, stream, (const float*)ws, ra);
