@@ -100,7 +100,11 @@ int murcl_gemm_tn_grouped(const murcl_tn_problem* probs, int n, int dtype, float
  * colsum_ws (256*N floats, required with colsum_out) and a second small launch adds them up.  walk_reverse bit 0: the
  * row tiles are visited from the last to the first (same result; use it when the kernel that has just produced A
  * walked forward, so that this pass starts on the rows that are still in the Infinity Cache); bit 1 (K=512): A is
- * loaded with the non-temporal cache policy (read once: it should not displace the output from the Infinity Cache).
+ * loaded with the non-temporal cache policy (read once: it should not displace the output from the Infinity Cache); bit 2 (K=512,
+ * epilogues 0 / 1 without Dropout): W is in FRAGMENT ORDER - a 16-row block stored as 16 k-steps x 64 lanes x 8 elements, lane
+ * (q4, r16) of k-step kk holding elements [(kk + 16 q4) * 8, +8) of row r16 (what murcl_cast_batch writes for a job with transpose
+ * bit 1) - so that the kernel's weight slice is one coalesced 1-KiB load per k-step beside its first tiles.  murcl_abmil_pool_fwd /
+ * _bwd take Wa the same way with bit 1 of their exact_tanh argument (bf16).
  * murcl_panel_gemm_supported tells whether a shape is covered (else use murcl_gemm_nt). */
 int murcl_panel_gemm_supported(int M, int N, int K, int epilogue, int rows_per_bag);
 /* colsum_ws given WITHOUT colsum_out: the partial rows stay in colsum_ws ([murcl_panel_gemm_colsum_rows][N] f32) and no second

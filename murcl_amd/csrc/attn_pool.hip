@@ -66,12 +66,13 @@ extern "C" int murcl_debug_k2_stamps(void* host, long bytes) {
 #define K2_STAMP(ev)
 #endif
 
-template <typename T, bool EXACT_TANH>
+template <typename T, bool EXACT_TANH, bool WFRAG = false>
 __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::MIN_WAVES)) void abmil_pool_fwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ bb_p, float* __restrict__ scores, float* __restrict__ part, int B, int N,
     int chunk_rows, int S) {
     typedef K2<T, K2F_NWO(T)> C_;
+    constexpr bool wfrag = WFRAG && sizeof(T) == 2;      // (a template parameter: as a run-time branch the two prologues' fragment registers met in phi nodes and spilled)
     typedef K2Lds<T, K2F_NWO(T)> L_;
     typedef typename WFrag<T>::type frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,7 +106,14 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     // instruction: 32 such instructions per wave pull each line of the slice through the CU's memory pipe up to eight times -
     // about as many bytes as the workgroup's whole share of H.  WPRO: the wave's 16 rows per column block travel as 16 whole-row
     // LDS-DMA pieces into its private quarter of the (still empty) tile ring and come back as conflict-free ds_read_b128 fragments.
-    constexpr bool WPRO = K2_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+#ifndef K2_ABL_NOWEIGHTS
+#define K2_ABL_NOWEIGHTS 0       // dev ablation (tools/ab_build.py): 1 = no weight prologue at all (constant fragments, wrong results): its time is
+#endif                           // the upper bound of what any faster prologue can buy
+    constexpr bool WPRO_C = !K2_ABL_NOWEIGHTS && K2_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+    // FRAGMENT-ORDER weights (round 6; `wfrag`, bf16): Wa arrives pre-arranged as the fragments themselves (csrc/elementwise.hip
+    // frag_index, written by the weight-view launch that follows every optimizer step), so a k-step's fragment is ONE coalesced 1-KiB
+    // load straight into registers and the first tiles are requested BEFORE the weights instead of after the staging round trips
+    constexpr bool WPRO = WPRO_C && !wfrag;
     if (!WPRO)
         for (int s = 0; s < pre; ++s) issue(s);
 
@@ -116,7 +124,11 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
 #pragma unroll
     for (int j = 0; j < C_::NJ; ++j) {
         const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
-        if (WPRO) {
+        if constexpr (wfrag) {
+            const char* fblk = (const char*)Wa + ((size_t)((C_::DW * wave) / 16 + j) * C_::NKK) * 1024 + lane * 16;
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)(fblk + kk * 1024);
+        } else if (WPRO) {
             const char* wblk = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j) * K2_L);
             const unsigned stage = lds0 + wave * 16 * C_::PADB;
 #pragma unroll
@@ -131,7 +143,12 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next block's pieces overwrite these rows
         }
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK && !WPRO; ++kk) {
+        for (int kk = 0; kk < C_::NKK && !WPRO && !wfrag; ++kk) {
+            if (K2_ABL_NOWEIGHTS) {
+                wa[j][kk] = frag_t{};
+                asm volatile("" : "+v"(wa[j][kk]));
+                continue;
+            }
             wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
             asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
         }
@@ -149,6 +166,12 @@ __global__ __launch_bounds__((64 * K2<T, K2F_NWO(T)>::NW), (K2<T, K2F_NWO(T)>::M
     const bool fixed_ref = smax < 30.f;
     // retire the compiler-counted loads above; from here on the only VMEM ops in flight are LDS-DMA tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (wfrag) {
+#pragma unroll
+        for (int j = 0; j < C_::NJ; ++j)
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) asm volatile("" : "+v"(wa[j][kk]));      // resident from here on: never re-loaded in the loop
+    }
     if (WPRO) {
         LDS_BARRIER();                          // every wave has read its fragments back: the ring is free for tiles
         for (int s = 0; s < pre; ++s) issue(s);
@@ -610,17 +633,20 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
                                     float* scores, float* A, float* M, float* ml, float* part_ws, int B, int N, int L,
                                     int D, int dtype, int exact_tanh, hipStream_t stream) {
     if (L != K2_L || D != K2_D) return -1;
+    const int wfrag = (exact_tanh >> 1) & 1;         // flags: bit 0 = exact tanh, bit 1 = Wa in fragment order (bf16 only)
+    exact_tanh &= 1;
+    if (wfrag && dtype != MURCL_DTYPE_BF16) return -1;
     if (B <= 0 || N <= 0) return 0;
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
     const int items = B * S;
     const int max_grid = murcl_cu_budget() * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
     const int grid = items < max_grid ? items : max_grid;
-#define K2_LAUNCH(T, EX)                                                                                        \
+#define K2_LAUNCH(T, EX, WF)                                                                                      \
     {                                                                                                           \
         typedef K2<T, K2F_NWO(T)> CL_;                                                                          \
         typedef K2Lds<T, K2F_NWO(T)> LL_;                                                                       \
-        auto k = abmil_pool_fwd_kernel<T, EX>;                                                                  \
+        auto k = abmil_pool_fwd_kernel<T, EX, WF>;                                                              \
         static MurclOncePerDevice once;                                                                                     \
         if (once.first()) {                                                                                            \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LL_::BYTES);        \
@@ -630,9 +656,10 @@ extern "C" int murcl_abmil_pool_fwd(const void* H, const void* Wa, const float* 
                            ba, wb, bb, scores, part_ws, B, N, chunk, S);                                        \
     }
     if (dtype == MURCL_DTYPE_BF16) {
-        if (exact_tanh) K2_LAUNCH(bf16_t, true) else K2_LAUNCH(bf16_t, false)
+        if (exact_tanh) { if (wfrag) K2_LAUNCH(bf16_t, true, true) else K2_LAUNCH(bf16_t, true, false) }
+        else { if (wfrag) K2_LAUNCH(bf16_t, false, true) else K2_LAUNCH(bf16_t, false, false) }
     } else if (dtype == MURCL_DTYPE_F32) {
-        if (exact_tanh) K2_LAUNCH(float, true) else K2_LAUNCH(float, false)
+        if (exact_tanh) K2_LAUNCH(float, true, false) else K2_LAUNCH(float, false, false)
     } else {
         return -1;
     }

@@ -28,13 +28,14 @@ template <typename T> struct KBLds {
 #ifndef K2B_WPRO
 #define K2B_WPRO 1
 #endif
-template <typename T, bool EXACT_TANH>
+template <typename T, bool EXACT_TANH, bool WFRAG = false>
 __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const T* __restrict__ H, const T* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ wb,
     const float* __restrict__ scores, const float* __restrict__ ml, const float* __restrict__ Mp,
     const float* __restrict__ dM, T* __restrict__ dT, float* __restrict__ dba, float* __restrict__ dwb,
     float* __restrict__ dbb, float* __restrict__ part_ws, float* __restrict__ A_out, int B, int N, int chunk_rows, int S,
     float inv_sqrt_n) {
+    constexpr bool wfrag = WFRAG && sizeof(T) == 2;      // Wa in fragment order (a template parameter: attn_pool.hip)
     typedef K2<T> C_;
     typedef KBLds<T> L_;
     typedef typename WFrag<T>::type frag_t;
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     const int pre = min(3, my_tiles);
     // weight prologue as in the forward kernel (attn_pool.hip): whole-row LDS-DMA pieces through the still empty tile ring
     // instead of fragment-shaped global loads that touch 64 cache lines per instruction
-    constexpr bool WPRO = K2B_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+    constexpr bool WPRO_C = K2B_WPRO && sizeof(T) == 2 && C_::NW * 16 * C_::PADB <= K2_NSLOT * C_::SLOT;
+    constexpr bool WPRO = WPRO_C && !wfrag;             // `wfrag`: Wa in fragment order, loaded straight into registers beside the first tiles (attn_pool.hip)
     if (!WPRO)
         for (int s = 0; s < pre; ++s) issue(s);
 
@@ -77,7 +79,11 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < C_::NJ; ++j) {
         const char* wrow = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j + r16) * K2_L);
-        if (WPRO) {
+        if constexpr (wfrag) {
+            const char* fblk = (const char*)Wa + ((size_t)((C_::DW * wave) / 16 + j) * C_::NKK) * 1024 + lane * 16;
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) wa[j][kk] = *(const frag_t*)(fblk + kk * 1024);
+        } else if (WPRO) {
             const char* wblk = (const char*)(Wa + (size_t)(C_::DW * wave + 16 * j) * K2_L);
             const unsigned stage = lds0 + wave * 16 * C_::PADB;
 #pragma unroll
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next block's pieces overwrite these rows
         }
 #pragma unroll
-        for (int kk = 0; kk < C_::NKK && !WPRO; ++kk) {
+        for (int kk = 0; kk < C_::NKK && !WPRO && !wfrag; ++kk) {
             wa[j][kk] = *(const frag_t*)(wrow + (kk + C_::NKK * q4) * 16);
             asm volatile("" : "+v"(wa[j][kk]));      // keep resident: never re-load inside the tile loop
         }
@@ -109,6 +115,12 @@ __global__ __launch_bounds__(64 * K2<T>::NW, 2) void abmil_pool_bwd_kernel(
     float bag_m = 0.f, bag_invl = 0.f, bag_c = 0.f;
     int cur_bag = -1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (wfrag) {
+#pragma unroll
+        for (int j = 0; j < C_::NJ; ++j)
+#pragma unroll
+            for (int kk = 0; kk < C_::NKK; ++kk) asm volatile("" : "+v"(wa[j][kk]));
+    }
     if (WPRO) {
         LDS_BARRIER();                          // every wave has read its fragments back: the ring is free for tiles
         for (int s = 0; s < pre; ++s) issue(s);
@@ -297,6 +309,9 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
                                     float* dbb, float* part_ws, float* A_out, int B, int N, int L, int D, int dtype,
                                     int exact_tanh, hipStream_t stream) {
     if (L != K2_L || D != K2_D || !part_ws) return -1;
+    const int wfrag = (exact_tanh >> 1) & 1;         // flags: bit 0 = exact tanh, bit 1 = Wa in fragment order (bf16 only)
+    exact_tanh &= 1;
+    if (wfrag && dtype != MURCL_DTYPE_BF16) return -1;
     if (B <= 0 || N <= 0) return 0;
     int chunk, S;
     murcl_abmil_pool_workspace(B, N, dtype, &chunk, &S);
@@ -304,9 +319,9 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
     const int max_grid = murcl_cu_budget() * (dtype == MURCL_DTYPE_BF16 ? 2 : 1);
     const int grid = items < max_grid ? items : max_grid;
     const float isn = 1.0f / sqrtf((float)N);
-#define KB_LAUNCH(T, EX)                                                                                       \
+#define KB_LAUNCH(T, EX, WF)                                                                                      \
     {                                                                                                          \
-        auto k = abmil_pool_bwd_kernel<T, EX>;                                                                 \
+        auto k = abmil_pool_bwd_kernel<T, EX, WF>;                                                                \
         static MurclOncePerDevice once;                                                                                    \
         if (once.first()) {                                                                                           \
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, KBLds<T>::BYTES);  \
@@ -316,9 +331,10 @@ extern "C" int murcl_abmil_pool_bwd(const void* H, const void* Wa, const float* 
                            (const T*)Wa, ba, wb, scores, ml, M, dM, (T*)dT, dba, dwb, dbb, part_ws, A_out, B, N, chunk, S, isn); \
     }
     if (dtype == MURCL_DTYPE_BF16) {
-        if (exact_tanh) KB_LAUNCH(bf16_t, true) else KB_LAUNCH(bf16_t, false)
+        if (exact_tanh) { if (wfrag) KB_LAUNCH(bf16_t, true, true) else KB_LAUNCH(bf16_t, true, false) }
+        else { if (wfrag) KB_LAUNCH(bf16_t, false, true) else KB_LAUNCH(bf16_t, false, false) }
     } else if (dtype == MURCL_DTYPE_F32) {
-        if (exact_tanh) KB_LAUNCH(float, true) else KB_LAUNCH(float, false)
+        if (exact_tanh) KB_LAUNCH(float, true, false) else KB_LAUNCH(float, false, false)
     } else {
         return -1;
     }

@@ -60,25 +60,36 @@ struct MurclCastJob {           // 32 bytes, mirrored by murcl_amd/ops.py
     int rows, cols;
     int transpose;              // bit 0: transpose; bits 8..: leading dimension of dst in elements (0: cols, or rows when transposed) -
     int dtype_out;              //   a job may fill a row / column block of a larger matrix (CLAM's interleaved gate weights)
+                                // bit 1 (round 6): FRAGMENT ORDER - the destination [R, 512] (R % 16 == 0, contiguous) is written as the
+                                //   persistent kernels' MFMA weight fragments instead of rows: frag_index() below
 };
+// Fragment order of a [R, 512] weight matrix (panel_gemm.hip / attn_pool*.hip, K = 512): a 16-row block is 16 k-steps x 64 lanes x 8
+// elements - lane (q4, r16) of k-step kk holds elements [(kk + 16 q4) * 8, +8) of row r16 - so that a wave fetches a whole fragment with
+// ONE fully coalesced 1-KiB load per k-step, straight into registers, while its first tiles are already in flight.
+__device__ __forceinline__ size_t frag_index(int row, int col) {
+    const int chunk = col >> 3, q4 = chunk >> 4, kk = chunk & 15;
+    return (size_t)(row >> 4) * (16 * 512) + (size_t)((kk * 64 + q4 * 16 + (row & 15)) * 8 + (col & 7));
+}
 template <typename T>
 __device__ __forceinline__ void cast_job_tile(const MurclCastJob& j, int tile, float (*t)[33]) {
     const int tc = (j.cols + 31) / 32;
     const int c0 = (tile % tc) * 32, r0 = (tile / tc) * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     T* y = (T*)j.dst;
     const int ldd = j.transpose >> 8;
+    const bool frag = (j.transpose & 2) != 0;                    // (destination width 512: checked by the host side)
     if (j.transpose & 1) {
         const size_t ld = ldd ? ldd : j.rows;
         for (int k = ty; k < 32; k += 8)
             if (r0 + k < j.rows && c0 + tx < j.cols) t[k][tx] = j.src[(size_t)(r0 + k) * j.cols + c0 + tx];
         __syncthreads();
         for (int k = ty; k < 32; k += 8)
-            if (c0 + k < j.cols && r0 + tx < j.rows) y[(size_t)(c0 + k) * ld + r0 + tx] = from_f<T>(t[tx][k]);
+            if (c0 + k < j.cols && r0 + tx < j.rows)
+                y[frag ? frag_index(c0 + k, r0 + tx) : (size_t)(c0 + k) * ld + r0 + tx] = from_f<T>(t[tx][k]);
     } else {
         const size_t ld = ldd ? ldd : j.cols;
         for (int k = ty; k < 32; k += 8)
             if (r0 + k < j.rows && c0 + tx < j.cols)
-                y[(size_t)(r0 + k) * ld + c0 + tx] = from_f<T>(j.src[(size_t)(r0 + k) * j.cols + c0 + tx]);
+                y[frag ? frag_index(r0 + k, c0 + tx) : (size_t)(r0 + k) * ld + c0 + tx] = from_f<T>(j.src[(size_t)(r0 + k) * j.cols + c0 + tx]);
     }
 }
 __global__ __launch_bounds__(256) void cast_batch_kernel(const MurclCastJob* __restrict__ jobs) {

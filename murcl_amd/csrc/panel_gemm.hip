@@ -181,7 +181,7 @@ __device__ __forceinline__ unsigned pg_pos_flags_nonneg(unsigned w, unsigned one
     return t;
 }
 
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false>
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false, bool WFRAG = false>
 __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
     const float* __restrict__ bias, uint8_t* __restrict__ bm_out, const uint8_t* __restrict__ bm_in,
@@ -327,7 +327,11 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
     // eight times.  Instead each 16-row block of the slice travels as 16 whole-row LDS-DMA pieces into the wave's private 1/NW of
     // the tile ring (not yet in use: the first tiles are requested after the fragments have been read back).  Measured on the K2
     // forward, which has the same prologue: 62.8 -> 55.1 us per launch (profiles/r03_m).
-    constexpr bool WPRO = PG_WPRO != 0 && PAD && !RS && PG_NW * 16 * PADB <= PG_NSLOT * SLOT;
+    constexpr bool WPRO_C = PG_WPRO != 0 && PAD && !RS && PG_NW * 16 * PADB <= PG_NSLOT * SLOT;
+    // FRAGMENT-ORDER weights (round 6; walk_reverse bit 2, K = 512): W arrives as the fragments themselves (csrc/elementwise.hip
+    // frag_index): one coalesced 1-KiB load per k-step straight into registers, the first tiles requested BEFORE them
+    constexpr bool wfrag = PAD && WFRAG;                 // (a template parameter: as a run-time branch the two prologues' fragment registers spilled)
+    constexpr bool WPRO = WPRO_C && !wfrag;
     const int pre = (RS || WPRO) ? 0 : min(3, my_tiles);
     for (int s = 0; s < pre; ++s) issue(s);
     if (RS) rs_load(std::integral_constant<int, 0>{}, 0);
@@ -337,6 +341,12 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const bf16_t* wrow = W + (size_t)(n0 + 16 * j + r16) * K;
+        if constexpr (wfrag) {
+            const char* fblk = (const char*)W + ((size_t)((n0 >> 4) + j) * NKK) * 1024 + lane * 16;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) wf[j][kk] = *(const bf16x8*)(fblk + kk * 1024);
+            continue;
+        }
         if (WPRO) {
             const char* wblk = (const char*)(W + (size_t)(n0 + 16 * j) * K);
             const unsigned stage = lds0 + wave * 16 * PADB;
@@ -398,6 +408,12 @@ __global__ __launch_bounds__(64 * PG_NW) void panel_nt_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (wfrag) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(wf[j][kk]));      // resident from here on: never re-loaded in the loop
+    }
     if (WPRO) {
         LDS_BARRIER();                           // every wave has read its fragments back: the ring is free for tiles
         const int pre_w = min(3, my_tiles);
@@ -792,7 +808,7 @@ static int pg_grid(int M, int panels) {
     return grid;
 }
 
-template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false>
+template <int K, int WN, int PG_NW, int EPI, bool BM_OUT, bool DROP = false, bool WFRAG = false>
 static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, uint8_t* bm_out,
                      const uint8_t* bm_in, const float* rowscale, const float* rank1, int rows_per_bag,
                      float* colsum_part, int* streams_out, int walk_reverse, hipStream_t s, PgDrop drop = PgDrop{0ull, 0ull, 0u, 1.f}) {
@@ -802,7 +818,7 @@ static int pg_launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
                         ((EPI == PG_MASK || EPI == PG_RANK1_MASK) ? PG_NSLOT * PG_NW * 256 : 0) +
                         (EPI == PG_RANK1_MASK ? PG_NSLOT * 256 : 0) + PG_STAMP_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT, DROP>;
+    auto k = panel_nt_kernel<K, WN, PG_NW, EPI, BM_OUT, DROP, WFRAG>;
     static MurclOncePerDevice once;      
     if (once.first()) {
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -866,6 +882,9 @@ extern "C" int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int 
         if (K != 512 || !((epilogue == PG_BIAS_RELU && bitmask_out) || epilogue == PG_GATE_U)) return -1;
     }
     if (colsum_out && !colsum_ws) return -1;
+    // walk_reverse bit 2: W is in fragment order (csrc/elementwise.hip frag_index) - the plain K = 512 epilogues without Dropout only
+    const bool wfrag = (walk_reverse & 4) != 0;
+    if (wfrag && (K != 512 || dropping || !(epilogue == PG_BIAS_RELU || epilogue == PG_MASK))) return -1;
     float* part = colsum_ws;                 // without colsum_out: the partial rows are the result (the caller adds them up)
     int streams = 0, rc = -1;
     const bf16_t* a = (const bf16_t*)A;
@@ -883,11 +902,16 @@ extern "C" int murcl_panel_gemm_drop(const void* A, const void* W, void* C, int 
                       : pg_launch<512, 32, 8, PG_GATE_U, false, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_BIAS_RELU) {
         if (!bias) return -1;
+        if (wfrag)
+            rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true, false, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream)
+                    : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false, false, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
+        else
         rc = bo ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream)
                 : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_BIAS_RELU, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_MASK) {
         if (!bi) return -1;
-        rc = pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
+        rc = wfrag ? pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false, false, true>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream)
+                   : pg_launch<512, PG_WIDE ? 64 : 32, PG_WIDE ? 4 : 8, PG_MASK, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);
     } else if (K == 512 && epilogue == PG_BIAS) {
         if (!bias) return -1;
         rc = pg_launch<512, 32, 8, PG_BIAS, false>(a, w, c, M, N, bias, bo, bi, rowscale, rank1, rows_per_bag, part, &streams, walk_reverse, stream);

@@ -47,6 +47,14 @@ _DSMIL_QV = True          # ... and the [B*C]-row algebra around them as three l
 _DSMIL_X3 = True          # DSMIL's long f32 GEMMs (the literal-order chain) as a 3-term bf16 split
 _GROUP_WGRAD = True       # the encoder weight gradients of a backward pass as one grouped launch
 _FOLD_BIAS = True         # encoder bias gradients folded into the wgrad reduce
+_FRAG_WEIGHTS = True      # ABMIL bf16 fast path: the K = 512 weight operands as FRAGMENT-ORDER views (ops.is_frag; round 6)
+
+
+def _frag_specs(w1, w2, w3, wa, T):
+    """The seven weight views of the bf16 ABMIL chain with every K = 512 operand in fragment order: W1..W3, Wa (forward, pooling) and
+    W3^T, W2^T (the masked input gradients); Wa^T [512,128] (the rank-1 input gradient, K = 128) stays row-major."""
+    return [(w1, False, T, "frag"), (w2, False, T, "frag"), (w3, False, T, "frag"), (wa, False, T, "frag"),
+            (wa, True, T), (w3, True, T, "frag"), (w2, True, T, "frag")]
 
 
 # CUs the launches of the aggregator's backward pass - pooling backward up to the last input gradient - are sized for while a
@@ -284,19 +292,21 @@ class ABMILFn(torch.autograd.Function):
         # compute-dtype copies of W1..W3, Wa for this pass and W2^T, W3^T, Wa^T for the dgrads of the backward pass: one
         # launch, and only when a parameter changed since they were last built (ops.weight_views)
         wmats = (w1, w2, w3, wa)
+        # bf16 + panel-friendly shapes: weight-stationary GEMMs that also emit 1-bit ReLU masks
+        fast = (T == torch.bfloat16 and d == 512 and pool_fast and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
+                and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
         if all(w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() for w in wmats):
             tr = [(wa, True, T), (w3, True, T), (w2, True, T)]
             if T == torch.float32:
                 w1c, w2c, w3c, wac = wmats
                 wat, w3t, w2t = ops.weight_views(tr)
+            elif fast and _FRAG_WEIGHTS:
+                w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views(_frag_specs(w1, w2, w3, wa, T))
             else:
                 w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views([(w, False, T) for w in wmats] + tr)
         else:
             w1c, w2c, w3c, wac = (ops.cast(w.contiguous(), T) for w in wmats)
             wat, w3t, w2t = (ops.transpose_cast(w, T) for w in (wa, w3, w2))
-        # bf16 + panel-friendly shapes: weight-stationary GEMMs that also emit 1-bit ReLU masks
-        fast = (T == torch.bfloat16 and d == 512 and pool_fast and ops.panel_supported(B * N, L, 512, ops.PG_BIAS_RELU)
-                and ops.panel_supported(B * N, L, 128, ops.PG_RANK1_MASK, N))
         seeded = drops is not None and isinstance(drops[0], ops.DropSeed)
 
         def drop(h, k, bits):
@@ -571,8 +581,9 @@ class ABMILStepFn(torch.autograd.Function):
         x2 = s.x[t].view(B * N, d)
         if x.data_ptr() != x2.data_ptr():
             x2.copy_(x.reshape(B * N, d))
-        w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views([(w, False, T) for w in (w1, w2, w3, wa)] +
-                                                              [(wa, True, T), (w3, True, T), (w2, True, T)])
+        w1c, w2c, w3c, wac, wat, w3t, w2t = ops.weight_views(_frag_specs(w1, w2, w3, wa, T) if _FRAG_WEIGHTS else
+                                                             [(w, False, T) for w in (w1, w2, w3, wa)] +
+                                                             [(wa, True, T), (w3, True, T), (w2, True, T)])
         nt = _STREAM_A
         h1, _, _ = ops.panel_gemm(x2, w1c, ops.PG_BIAS_RELU, bias=b1, want_bitmask=True, stream_a=bool(nt & 1),
                                   out=s.rows(s.h1, t), bitmask_out=s.rows(s.m1, t))

@@ -106,6 +106,7 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     ``x3`` (f32 operands, more than 1024 rows): the products run as a 3-term bf16 split on the bf16 matrix pipe - f32-level
     accuracy (relative error ~1e-7 against the exact-f32 MFMA path) at a fraction of its time."""
     _need_cuda(A, B)
+    assert not is_frag(B), "gemm_nt takes row-major operands (a fragment-order weight view belongs to panel_gemm / the K2 passes)"
     A, B = _c(A), _c(B)
     M, K = A.shape
     N = B.shape[0]
@@ -239,10 +240,12 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
     ``drop`` (a DropSeed; PG_BIAS_RELU with ``want_bitmask``, K = 512): Dropout behind the ReLU inside the epilogue, the mask
     never materialised; the bit mask records what survives (= ``dropout_relu_bitmask`` on the output, without that pass)."""
     _need_cuda(A, W)
-    A, W = _c(A), _c(W)
+    wfrag = 4 if is_frag(W) else 0                          # (W in fragment order: walk_reverse bit 2 of the C-ABI)
+    A, W = _c(A), (W if wfrag else _c(W))
     M, K = A.shape
     N = W.shape[0]
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[1] == K
+    assert not wfrag or (K == 512 and epi in (PG_BIAS_RELU, PG_MASK) and drop is None), "fragment-order weights: K = 512, BIAS_RELU / MASK"
     # ``out`` / ``bitmask_out``: caller-owned result buffers (row blocks of a larger tensor: functional.EncoderSession)
     C = torch.empty((M, N), dtype=torch.bfloat16, device=A.device) if out is None else out
     assert C.is_contiguous() and C.dtype == torch.bfloat16 and tuple(C.shape) == (M, N)
@@ -262,13 +265,13 @@ def panel_gemm(A, W, epi, *, bias=None, want_bitmask=False, bitmask=None, rowsca
             check(_lib.lib().murcl_panel_gemm_drop(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                                    ptr(rowscale), ptr(rank1), rows_per_bag,
                                                    ptr(colsum_into if colsum_into is not None else cs),
-                                                   int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0),
+                                                   int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0) | wfrag,
                                                    drop.keep_p, drop.seed, 0, stream()), "panel_gemm(drop)")
         else:
             check(_lib.lib().murcl_panel_gemm(ptr(A), ptr(W), ptr(C), M, N, K, epi, ptr(bias), ptr(bm), ptr(bitmask),
                                               ptr(rowscale), ptr(rank1), rows_per_bag,
                                               ptr(colsum_into if colsum_into is not None else cs),
-                                              int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0), stream()),
+                                              int(colsum_into is not None), ptr(ws), int(reverse) | (2 if stream_a else 0) | wfrag, stream()),
                   "panel_gemm")
     if colsum_defer:
         return C, bm, (ws, _lib.lib().murcl_panel_gemm_colsum_rows(M, N, K, epi))
@@ -468,7 +471,8 @@ def abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh=None, scores=None):
     partials ``part`` [B*S*(L+4)] f32 ((sum p.H, m, l) per (bag, row chunk)).  The per-bag merge belongs to the consumer:
     ``abmil_pool_decoder`` (the training / inference path), or ``abmil_pool_combine`` for A, M, ml as tensors."""
     _need_cuda(H, Wa)
-    H, Wa = _c(H), _c(Wa)
+    wfrag = 2 if is_frag(Wa) else 0                         # (Wa in fragment order: bit 1 of the C-ABI's exact_tanh / flags argument)
+    H, Wa = _c(H), (Wa if wfrag else _c(Wa))
     B, N, L = H.shape
     D = Wa.shape[0]
     if exact_tanh is None:
@@ -485,7 +489,7 @@ def abmil_pool_partials(H, Wa, ba, wb, bb, exact_tanh=None, scores=None):
     with _span(lambda: (f"row:k2_fwd<{_DT_NAME[H.dtype]}>", _pool_work(B, N, L, D, es))):
         with _span(lambda: (f"abmil_pool_fwd<{_DT_NAME[H.dtype]}>", _pool_work(B, N, L, D, es))):
             check(_lib.lib().murcl_abmil_pool_fwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(bb), ptr(scores), None, None,
-                                                  None, ptr(part), B, N, L, D, dt(H), int(exact_tanh), stream()),
+                                                  None, ptr(part), B, N, L, D, dt(H), int(exact_tanh) | wfrag, stream()),
                   "abmil_pool_fwd")
     return scores, part
 
@@ -568,7 +572,8 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None,
     normalised attention row softmax(s)/sqrt(N), which the pass has in registers - the rank-1 input gradient's row scale).
     ``into`` = (dba, dwb, dbb) f32 buffers: the kernel ADDS to them (gradient accumulation) instead of fresh zeros."""
     _need_cuda(H, Wa, dM)
-    H, Wa, dM = _c(H), _c(Wa), _c(dM)
+    wfrag = 2 if is_frag(Wa) else 0
+    H, Wa, dM = _c(H), (Wa if wfrag else _c(Wa)), _c(dM)
     B, N, L = H.shape
     D = Wa.shape[0]
     if exact_tanh is None:
@@ -588,7 +593,7 @@ def abmil_pool_bwd(H, Wa, ba, wb, scores, ml, M, dM, exact_tanh=None, into=None,
                dict(flops=B * (2.0 * N * L * D + 2.0 * N * L), bytes=B * (N * L * es + N * D * es + N * 4) + L * D * es))):
         check(_lib.lib().murcl_abmil_pool_bwd(ptr(H), ptr(Wa), ptr(ba), ptr(wb), ptr(scores), ptr(ml), ptr(M), ptr(dM),
                                               ptr(dT_full), ptr(dba), ptr(dwb), ptr(dbb), ptr(part), ptr(A), B, N, L, D, dt(H),
-                                              int(exact_tanh), stream()), "abmil_pool_bwd")
+                                              int(exact_tanh) | wfrag, stream()), "abmil_pool_bwd")
     if want_A:
         return dT_full[:B * N], dba, dwb, dbb, A
     return dT_full[:B * N], dba, dwb, dbb
@@ -689,12 +694,22 @@ def is_managed(p):
     return r is not None and r() is p
 
 
+def is_frag(w):
+    """Is ``w`` a FRAGMENT-ORDER weight view (``weight_views`` spec with a fourth element "frag")?  Such a [R,512] bf16 tensor holds the
+    persistent kernels' MFMA weight fragments, not rows (csrc/elementwise.hip frag_index): only ``panel_gemm`` (K = 512) and the K2
+    pooling passes take it - they then fetch their weight slice with coalesced 1-KiB loads beside their first tiles instead of staging
+    it through the still empty tile ring first."""
+    return getattr(w, "_murcl_frag", False)
+
+
 def weight_views(specs):
-    """specs: sequence of (param [R,C] f32 contiguous, transpose: bool, dtype).  Returns the prepared tensors (read
-    only; they persist and are refreshed lazily)."""
+    """specs: sequence of (param [R,C] f32 contiguous, transpose: bool, dtype[, "frag"]).  Returns the prepared tensors (read
+    only; they persist and are refreshed lazily).  "frag": the view ([.., 512] after the optional transpose, rows % 16 == 0, bf16) in
+    fragment order (``is_frag``)."""
     import numpy as np
-    key = tuple((p.data_ptr(), p.shape[0], p.shape[1], bool(tr), d) for p, tr, d in specs)
-    ver = (PARAM_EPOCH, tuple(p._version for p, _, _ in specs))
+    specs = [(sp[0], sp[1], sp[2], len(sp) > 3 and sp[3] == "frag") for sp in specs]
+    key = tuple((p.data_ptr(), p.shape[0], p.shape[1], bool(tr), d, fr) for p, tr, d, fr in specs)
+    ver = (PARAM_EPOCH, tuple(p._version for p, _, _, _ in specs))
     st = _VIEWS.get(key)
     if st is None:
         if len(_VIEWS) >= 64:
@@ -702,21 +717,24 @@ def weight_views(specs):
             _MERGED.clear()
         dev = specs[0][0].device
         outs, rec, max_tiles = [], [], 0
-        for p, tr, d in specs:
+        for p, tr, d, fr in specs:
             _need_cuda(p)
             assert p.dtype == torch.float32 and p.dim() == 2 and p.is_contiguous()
             R, C = p.shape
             o = torch.empty((C, R) if tr else (R, C), dtype=d, device=dev)
+            if fr:
+                assert d == torch.bfloat16 and o.shape[1] == 512 and o.shape[0] % 16 == 0, "fragment-order views: [16k, 512] bf16"
+                o._murcl_frag = True
             outs.append(o)
-            rec.append((p.data_ptr(), o.data_ptr(), R, C, int(tr), _lib.BF16 if d == torch.bfloat16 else _lib.F32))
+            rec.append((p.data_ptr(), o.data_ptr(), R, C, int(tr) | (2 if fr else 0), _lib.BF16 if d == torch.bfloat16 else _lib.F32))
             max_tiles = max(max_tiles, ((R + 31) // 32) * ((C + 31) // 32))
         jobs = np.array(rec, dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"),
                                              ("tr", "<i4"), ("dt", "<i4")]))
         table = torch.from_numpy(jobs.view(np.uint8).copy()).to(dev)
         st = _VIEWS[key] = dict(outs=outs, table=table, n=len(rec), max_tiles=max_tiles, ver=None,
-                                keep=[p for p, _, _ in specs], managed=False,
+                                keep=[p for p, _, _, _ in specs], managed=False,
                                 tiles=[((r[2] + 31) // 32) * ((r[3] + 31) // 32) for r in rec])
-    st["managed"] = all(is_managed(p) for p, _, _ in specs)
+    st["managed"] = all(is_managed(p) for p, _, _, _ in specs)
     if st["ver"] != ver or not st["managed"]:
         check(_lib.lib().murcl_cast_batch(ptr(st["table"]), st["n"], st["max_tiles"], stream()), "cast_batch")
         st["ver"] = ver

@@ -1224,6 +1224,62 @@ def test_panel_gemm_unsupported_shapes_fall_back():
     assert not ops.panel_supported(64, 512, 128, ops.PG_RANK1_MASK, 48)  # bag not a whole number of tiles
 
 
+# ------------------------------------------------------------------ fragment-order weight views (round 6)
+def _frag_perm(w):
+    """The fragment order of a [R,512] matrix in plain index arithmetic (csrc/elementwise.hip frag_index): a 16-row block is 16 k-steps
+    x 64 lanes x 8 elements, lane (q4, r16) of k-step kk holds elements [(kk + 16 q4) * 8, +8) of row r16."""
+    R = w.shape[0]
+    blk = w.reshape(R // 16, 16, 4, 16, 8)                 # [block, r16, q4, kk, e]
+    return blk.permute(0, 3, 2, 1, 4).reshape(R, 512).contiguous()      # [block, kk, q4, r16, e]
+
+
+def test_fragment_order_views_and_the_kernels_that_take_them():
+    """``weight_views`` specs with "frag": the bf16 view equals the row-major view pushed through the fragment permutation (plain and
+    transposed sources); ``panel_gemm`` (K = 512: BIAS_RELU with bit mask, MASK) and the K2 pooling passes compute BIT-IDENTICAL results
+    from the fragment-order operand (same fragments in the same registers - only the prologue's loads differ); ``gemm_nt`` refuses it."""
+    from murcl_amd import ops
+    dev = _dev()
+    W = _rand(31, "W", (512, 512), 1 / math.sqrt(512)).to(dev)
+    Wa = _rand(31, "Wa", (128, 512), 2 / math.sqrt(512)).to(dev)
+    Wt_src = _rand(31, "Wt", (512, 512), 1 / math.sqrt(512)).to(dev)
+    bf = torch.bfloat16
+    plain = ops.weight_views([(W, False, bf), (Wa, False, bf), (Wt_src, True, bf)])
+    frag = ops.weight_views([(W, False, bf, "frag"), (Wa, False, bf, "frag"), (Wt_src, True, bf, "frag")])
+    for p_, f_ in zip(plain, frag):
+        assert ops.is_frag(f_) and not ops.is_frag(p_) and f_.shape == p_.shape
+        assert torch.equal(f_.view(torch.int16), _frag_perm(p_).view(torch.int16))
+    M = 4096
+    X = _rand(31, "X", (M, 512)).bfloat16().to(dev)
+    bias = _rand(31, "b", (512,), 0.1).to(dev)
+    h0, m0, _ = ops.panel_gemm(X, plain[0], ops.PG_BIAS_RELU, bias=bias, want_bitmask=True)
+    h1, m1, _ = ops.panel_gemm(X, frag[0], ops.PG_BIAS_RELU, bias=bias, want_bitmask=True)
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16)) and torch.equal(m0, m1)
+    dZ = _rand(31, "dZ", (M, 512), 0.05).bfloat16().to(dev)
+    z0, _, c0 = ops.panel_gemm(dZ, plain[2], ops.PG_MASK, bitmask=m0, colsum=True)
+    z1, _, c1 = ops.panel_gemm(dZ, frag[2], ops.PG_MASK, bitmask=m0, colsum=True)
+    assert torch.equal(z0.view(torch.int16), z1.view(torch.int16))
+    _close(c1, c0, rtol=1e-5, atol=1e-5 * c0.abs().max().item(), msg="colsum")        # (its partial rows meet through float atomics)
+    with pytest.raises(AssertionError):
+        ops.gemm_nt(X, frag[0])
+    # K2 forward / backward with Wa in fragment order
+    B, N = 16, 2048
+    H, _, ba, wb, bb = _k2_inputs(31, B, N)
+    Hd, bad, wbd, bbd = H.bfloat16().to(dev), ba.to(dev), wb.to(dev), bb.to(dev)
+    dM = _rand(31, "dM", (B, 512)).to(dev)
+    r0 = ops.abmil_pool_fwd(Hd, plain[1], bad, wbd, bbd)
+    r1 = ops.abmil_pool_fwd(Hd, frag[1], bad, wbd, bbd)
+    assert all(torch.equal(a, b) for a, b in zip(r0, r1))
+    g0 = ops.abmil_pool_bwd(Hd, plain[1], bad, wbd, r0[0], r0[3], r0[2], dM)
+    g1 = ops.abmil_pool_bwd(Hd, frag[1], bad, wbd, r0[0], r0[3], r0[2], dM)
+    assert torch.equal(g0[0].view(torch.int16), g1[0].view(torch.int16)) and all(torch.equal(a, b) for a, b in zip(g0[1:], g1[1:]))
+    # ragged / tiny launches take the same prologue
+    for B2, N2 in ((1, 1), (3, 40), (2, 300)):
+        H2 = _k2_inputs(32, B2, N2)[0].bfloat16().to(dev)
+        a = ops.abmil_pool_fwd(H2, plain[1], bad, wbd, bbd)
+        b = ops.abmil_pool_fwd(H2, frag[1], bad, wbd, bbd)
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 # ------------------------------------------------------------------ cached weight views (one batched cast/transpose launch)
 def test_weight_views_follow_parameter_updates():
     from murcl_amd import ops
