@@ -471,6 +471,12 @@ int murcl_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
 typedef struct { float *p, *g, *m, *v; long n; float lr; int step; } MurclAdamJob;
 int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                      int zero_grad, murcl_stream_t stream);
+/* The same launch for a step that is CAPTURED into a hipGraph and replayed: replays_dev (device int[2], zeroed by the caller before
+ * the first replay; NULL = murcl_adam_multi) counts the steps the replays have taken - the kernel's bias corrections use
+ * job.step + replays_dev[0] and its last workgroup advances the counter, so that every replay is the NEXT optimizer step, not the
+ * captured one again (torch.optim.Adam's state['step'], train_MuRCL.py:165-171, kept on the device). */
+int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                          int zero_grad, int* replays_dev, murcl_stream_t stream);
 /* torch.optim.SGD.step for one flat tensor (train_MuRCL.py:158-163, train_RLMIL.py:258-263): L2 weight decay, momentum
  * buffer (first != 0: the buffer is initialised with the gradient), dampening 0, optional Nesterov. */
 int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov, float weight_decay,

@@ -484,14 +484,39 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
     const float denom = sqrtf(v) / bc2_sqrt + eps;
     p = p - lr_bc1 * (m / denom);
 }
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float wd, int zero_grad) {
+// `replays` (may be NULL; int[2] = {steps taken by replays so far, arrival ticket}): the step counts of the table are those of the
+// launch that was CAPTURED into a hipGraph, and every replay of that graph is one more optimizer step - the bias corrections then use
+// step + replays[0], read by every workgroup at its start, and the workgroup that finishes LAST (arrival ticket) advances the
+// counter for the next replay: a replayed step is a real training step, not the captured one again (bench.py's graph-timed region).
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float wd, int zero_grad,
+                                                         int* __restrict__ replays) {
     int j = 0;
     while (j + 1 < t.n_jobs && (int)blockIdx.x >= t.first_chunk[j + 1]) ++j;
     const MurclAdamJob jb = t.job[j];
     const long base = (long)((int)blockIdx.x - t.first_chunk[j]) * AM_CHUNK;
     const long n = jb.n - base < AM_CHUNK ? jb.n - base : AM_CHUNK;
     float* p = jb.p + base; float* g = jb.g + base; float* m = jb.m + base; float* v = jb.v + base;
-    const float lr_bc1 = jb.lr / t.bc1[j], bc2s = t.bc2s[j];
+    float bc1 = t.bc1[j], bc2s = t.bc2s[j];
+    if (replays) {
+        const int extra = __hip_atomic_load(replays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (extra) {                                         // (the same expressions as the host side of murcl_adam_multi)
+            const float st = (float)(jb.step + extra);
+            bc1 = 1.f - powf(b1, st);
+            bc2s = sqrtf(1.f - powf(b2, st));
+        }
+    }
+    const float lr_bc1 = jb.lr / bc1;
+    struct Arrive {                                          // runs when the workgroup leaves the kernel, whichever return it takes
+        int* r;
+        __device__ ~Arrive() {
+            if (!r) return;
+            __syncthreads();
+            if (threadIdx.x == 0 && __hip_atomic_fetch_add(r + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+                __hip_atomic_store(r + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } arrive{replays};
     const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
     if (vec && n == AM_CHUNK) {
         f32x4 P[4], G[4], M[4], V[4];
@@ -521,8 +546,14 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable t, float b1, 
         if (zero_grad) g[i] = 0.f;
     }
 }
+extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                                     int zero_grad, int* replays_dev, hipStream_t s);
 extern "C" int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                                 int zero_grad, hipStream_t s) {
+    return murcl_adam_multi_live(jobs_host, n_jobs, beta1, beta2, eps, weight_decay, zero_grad, nullptr, s);
+}
+extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                                     int zero_grad, int* replays_dev, hipStream_t s) {
     if (n_jobs <= 0) return 0;
     if (n_jobs > MURCL_ADAM_MAX_JOBS) return -1;
     AdamTable t;
@@ -540,7 +571,8 @@ extern "C" int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float
     if (!t.n_jobs) return 0;
     if (chunks > 0x7fffffffL) return -1;
     t.first_chunk[t.n_jobs] = (int)chunks;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, weight_decay, zero_grad);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, weight_decay, zero_grad,
+                       replays_dev);
     return MURCL_CHECK_LAUNCH();
 }
 

@@ -1015,15 +1015,22 @@ class _AdamJob(_lib.ctypes.Structure):                 # MurclAdamJob (include/m
 ADAM_MAX_JOBS = 8
 
 
-def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False):
+def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False, replays=None):
     """torch.optim.Adam.step over several flat runs in ONE launch.  ``jobs``: up to ``ADAM_MAX_JOBS`` tuples (p, g, m, v, lr, step) of
-    equally long contiguous f32 tensors (each run with its own learning rate and step count)."""
+    equally long contiguous f32 tensors (each run with its own learning rate and step count).  ``replays``: None, or a device int32[2]
+    (zeros) when the launch is being captured into a hipGraph - the step counts then advance on the device with every replay
+    (murcl_adam_multi_live)."""
     assert 0 < len(jobs) <= ADAM_MAX_JOBS
     arr = (_AdamJob * len(jobs))()
     for a, (p, g, m, v, lr, step) in zip(arr, jobs):
         _need_cuda(p)
         assert all(t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel() for t in (p, g, m, v))
         a.p, a.g, a.m, a.v, a.n, a.lr, a.step = ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step)
+    if replays is not None:
+        assert replays.dtype == torch.int32 and replays.numel() >= 2 and replays.is_contiguous()
+        check(_lib.lib().murcl_adam_multi_live(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
+                                               float(weight_decay), int(bool(zero_grad)), ptr(replays), stream()), "adam_multi_live")
+        return
     check(_lib.lib().murcl_adam_multi(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
                                       float(weight_decay), int(bool(zero_grad)), stream()), "adam_multi")
 

@@ -130,7 +130,29 @@ class FlatAdam(_FlatOptimizer):
 
     def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, direct_grad=True, fused_zero=True):
         self.betas, self.eps = betas, eps
+        self.replays = None                                     # device int32[2] while a captured step is being replayed (live_graph)
         super().__init__(param_groups, weight_decay, direct_grad, fused_zero)
+
+    def live_graph(self, on=True):
+        """Capture mode for a step that will be REPLAYED as a hipGraph: ``step()`` launches murcl_adam_multi_live, whose step counts
+        advance on the device with every replay (a replay is the next optimizer step, not the captured one again).  Call with
+        ``on=True`` before capturing (the counter is zeroed), replay, then ``after_replays(k)`` to bring the host-side counts up to
+        date and leave the mode."""
+        if on:
+            dev = self.groups[0]["p"].device
+            self.replays = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._live_captured, self._live_ids = 0, []
+        else:
+            self.replays = None
+
+    def after_replays(self, steps):
+        """``steps`` optimizer steps have run as replays of the captured step(s) (replays x captured steps per graph): bring the
+        host-side counts up to date and leave capture mode.  The capture itself executed nothing but was counted on the host."""
+        extra = steps - self._live_captured
+        for pid in set(self._live_ids):
+            self._pstep[pid] += extra
+        self.step_count += extra
+        self.replays = None
 
     def _launch(self, g, lo, hi, n):
         ops.adam_step(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], self.betas, self.eps,
@@ -138,13 +160,20 @@ class FlatAdam(_FlatOptimizer):
 
     def step(self):
         """All groups' runs in ONE launch when there are few of them (the usual step: one run per group); the general walk otherwise."""
-        runs = [(g, lo, hi, n) for g in self.groups for lo, hi, n in self._runs(g)]
+        live = 0
+        if self.replays is not None:
+            # every captured launch carries the step count of the FIRST captured step: the device counter advances once per launch
+            self._live_ids += [pid for g in self.groups for pid, _, _ in g["segs"] if pid in self._fn._TOUCHED]
+            live, self._live_captured = self._live_captured, self._live_captured + 1
+        runs = [(g, lo, hi, n - live) for g in self.groups for lo, hi, n in self._runs(g)]
         if not 0 < len(runs) <= ops.ADAM_MAX_JOBS:
+            if self.replays is not None:
+                raise RuntimeError("FlatAdam.live_graph: the captured step must fit one adam_multi launch")
             for g, lo, hi, n in runs:
                 self._launch(g, lo, hi, n)
         else:
             ops.adam_multi([(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], n) for g, lo, hi, n in runs],
-                           self.betas, self.eps, self.weight_decay, zero_grad=self.fused_zero)
+                           self.betas, self.eps, self.weight_decay, zero_grad=self.fused_zero, replays=self.replays)
         self._finish_step()
 
 

@@ -347,3 +347,62 @@ def test_early_stop_with_deferred_boundaries_discards_the_extra_steps(tmp_path, 
     assert d_last["epoch"] == s_last["epoch"] == 2
     assert len(list(csv.reader(open(d_run / "losses.csv")))) == len(list(csv.reader(open(s_run / "losses.csv")))) == 3
     assert capsys.readouterr().out.count("Loss: ") == 4
+
+
+@pytest.mark.parametrize("G", [1, 5])
+def test_hipgraph_replayed_steps_are_the_next_training_steps(G):
+    """bench.py's graph region (round 6): G steps captured ONCE with the optimizer in live-graph mode - Adam's step counts advance on
+    the device (murcl_adam_multi_live) - and replayed: after the same number of steps the parameters, Adam moments and host-side step
+    counts equal those of the step-by-step eager loop up to the run-to-run noise of the loop itself (the attention weight gradient's
+    split sums meet through float atomics; measured here as eager vs eager), while a replay with FROZEN step counts (no live mode: the
+    captured bias correction again and again) lands clearly outside it."""
+    import bench
+    dev = torch.device("cuda:0")
+
+    def run(mode):
+        model, fc, opt, crit = bench.build(torch.bfloat16, dev, 8)
+        views = bench.synth_views(8, 512, 512, torch.bfloat16, dev, 0)
+        step = bench.make_step(model, fc, opt, crit, views, 1)
+        for _ in range(2):
+            step()
+        total = 10
+        if mode != "eager":
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()                                            # (step 3: per-stream state exists before the capture)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            if mode == "live":
+                opt.live_graph(True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(G):
+                    step()
+            for _ in range(total // G):
+                g.replay()
+            torch.cuda.synchronize()
+            if mode == "live":
+                opt.after_replays(total)
+                step()                                            # and the eager loop carries on from the right step count
+        else:
+            for _ in range(total + 2):
+                step()
+        torch.cuda.synchronize()
+        return ([p.detach().float().clone() for grp in opt.groups for p in (grp["p"], grp["m"], grp["v"])], opt.step_count,
+                sorted(opt._pstep.values()))
+
+    def dist(x, y, which):
+        """largest difference of the parameters (which = 0) / first moments (1) / second moments (2), relative to the tensor's largest entry"""
+        return max(((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item() for a, b in zip(x[which::3], y[which::3]))
+    (pe, ce, se), (pe2, _, _), (pg, cg, sg) = run("eager"), run("eager"), run("live")
+    assert ce == cg == 14 and se == sg
+    for which in range(3):
+        noise = dist(pe, pe2, which)
+        assert dist(pe, pg, which) <= max(4 * noise, 1e-6), (which, dist(pe, pg, which), noise)
+    if G == 1:
+        pf = run("frozen")[0]                                     # 10 replays of step 4's bias correction: the wrong steps
+        # (measured: noise p / m / v = 6e-4 / 7e-3 / 9e-3 of the largest entry after 14 steps - Adam amplifies the last bits of the
+        #  atomically summed attention weight gradient; live replays 6e-4 / 9e-3 / 1.3e-2; frozen replays 2e-3 / 0.11 / 0.08)
+        assert dist(pe, pf, 0) > 2 * max(dist(pe, pe2, 0), 1e-6) and dist(pe, pf, 1) > 5 * max(dist(pe, pe2, 1), 1e-6), \
+            ([dist(pe, pf, w) for w in range(3)], [dist(pe, pe2, w) for w in range(3)])
