@@ -304,6 +304,7 @@ def other_rows(device):
     once forward and twice backward against 8 TB/s), and `chain_traffic_*` = the bytes the un-fused operator chain as built
     moves (14 passes over [B*N,512] for CLAM: 5 forward + 9 backward; for the reassociated DSMIL chain the two accountings coincide: 3 passes over X) - the second says how well the passes stream, not how close
     the row is to its algorithmic floor."""
+    from murcl_amd import ops
     from murcl_amd.models.clam import CLAM_SB
     from murcl_amd.models.dsmil import build_dsmil
     g = torch.Generator(device=device)
@@ -313,6 +314,10 @@ def other_rows(device):
     m = CLAM_SB(gate=True, size_arg="small", dropout=True, k_sample=8, n_classes=2, subtyping=True, in_dim=512).to(device)
     m.compute_dtype = torch.bfloat16
     m.eval()
+    # as under the training scripts' optimizers, the parameters are "managed": their compute-dtype / transposed / interleaved views are
+    # cached between optimizer steps instead of being rebuilt by a launch on every call (nothing updates them inside these rows)
+    for p_ in m.parameters():
+        ops.manage_param(p_)
     x = (torch.randn((B, N, 512), generator=g, device=device).abs() * 0.5).bfloat16()
     labels = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(1)).to(device)    # a device tensor, as in training
 
@@ -345,6 +350,8 @@ def other_rows(device):
     del m, x
     B, N, d = 16, 8192, 1024
     md = build_dsmil(d, 2).to(device)
+    for p_ in md.parameters():
+        ops.manage_param(p_)
     xd = torch.randn((B, N, d), generator=g, device=device).abs() * 0.5
 
     def dsmil_fb():
@@ -858,6 +865,14 @@ def main():
         "timed_region_host_enqueue_ms": {"median": round(sorted(host_ms)[len(host_ms) // 2], 3), "max": round(max(host_ms), 3),
                                          "drain_after_last_enqueue": round((elapsed - (host_t[-1] - t0)) * 1e3, 3)},
         "bags_per_s_at_median": round(B * world / (stats["median_ms"] * 1e-3), 1) if stats else None,
+        "kernels_vs_box": {k: dict(us=round(v["ms_avg"] * 1e3, 1), layer_GBps=round(v["bytes"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e9, 1),
+                                   frac_of_box_copy=round(v["bytes"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e9 / box["copy_GBps"], 3),
+                                   TFLOPs=round(v["flops"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e12, 1),
+                                   frac_of_box_mfma=round(v["flops"] / v["calls"] / (v["ms_avg"] * 1e-3) / 1e12 / box["mfma_bf16_TFLOPs"], 3))
+                           for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])
+                           if v["bytes"] and v["ms_avg"] > 0.03 and box and box.get("copy_GBps")} or None,
+        "kernels_vs_box_note": "every encoder-sized launch of the step (untimed breakdown pass, one HIP-event pair each): its layer-wise bytes and FLOPs "
+                               "against what a plain copy / a register-only MFMA loop reach on THIS box (`box`), not against the data-sheet peaks",
         "kernel_ms_per_step_note": "untimed 2-step pass with EVERY launch bracketed by HIP events (~2-3 us each): sums above ms_per_step",
         "kernel_ms_per_step": {k: round(v["ms_total"] / 2, 4) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms_total"])},
     }

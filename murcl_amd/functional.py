@@ -841,8 +841,7 @@ class DSMILFn(torch.autograd.Function):
         dev = x.device
         x2 = x.reshape(B * N, d)
         dbag2 = (dbag if dbag is not None else torch.zeros((B, C, d), device=dev)).reshape(B * C, d).contiguous()
-        dwv = ops.gemm_tn(dbag2, Z.view(B * C, d))
-        dbv = ops.colsum(dbag2)
+        dwv, dbv = ops.gemm_tn_with_colsum(dbag2, Z.view(B * C, d))           # (dWv, dbv) of the value projection: one launch
         dZ = ops.gemm_nt(dbag2, ops.transposed(wv)).view(B, C, d)
         xm = None if qv else ops.gather_rows(x2, m, B, C, N, 0, d)                          # critical instances
         dcls = dclasses.reshape(B, N, C).float().contiguous() if dclasses is not None else None

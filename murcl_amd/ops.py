@@ -292,6 +292,23 @@ import os as _os
 _TN_SQ = True             # test hook: False keeps the 256 x 128 atomics kernel (the form shapes without a workspace take)
 
 
+def gemm_tn_with_colsum(A, B):
+    """(A^T B, column sums of A) for a fresh bag-level f32 gradient pair - a Linear's (dW, db) from (dy, x) - in ONE launch where the
+    single-writer 32 x 32 kernel takes the shape (its workgroups of the first column tile form the sums with one more MFMA per
+    step), else as ``gemm_tn`` + ``colsum``."""
+    _need_cuda(A, B)
+    A, B = _c(A), _c(B)
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    if A.dtype == torch.float32 and B.dtype == torch.float32 and M <= 512 and _TN_SMALL_GROUP and N1 % 4 == 0 and N2 % 4 == 0:
+        C = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+        cs = torch.empty((N1,), dtype=torch.float32, device=A.device)
+        arr = (_lib.TnProblem * 1)(_lib.TnProblem(ptr(A), ptr(B), ptr(C), None, ptr(cs), M, N1, N2, N1, N2, N2, 0, _lib.TN_OVERWRITE, 1.0))
+        if _lib.lib().murcl_gemm_tn_grouped(arr, 1, F32, None, 0, stream()) == 0:
+            return C, cs
+    return gemm_tn(A, B), colsum(A)
+
+
 def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3=False):
     """C[N1,N2] (f32) = A[M,N1]^T @ B[M,N2]  (adds into ``out`` when given).  ``colsum_into`` [N1] f32: the column sums
     of A are ADDED to it in the same launch (the bias gradient that goes with this weight gradient); with

@@ -1224,6 +1224,19 @@ def test_panel_gemm_unsupported_shapes_fall_back():
     assert not ops.panel_supported(64, 512, 128, ops.PG_RANK1_MASK, 48)  # bag not a whole number of tiles
 
 
+@pytest.mark.parametrize("M,N1,N2", [(32, 1024, 1024), (128, 128, 1024), (300, 52, 512), (512, 3072, 512), (1000, 64, 64)])
+def test_gemm_tn_with_colsum_is_one_launch_for_bag_level_gradients(M, N1, N2):
+    """(dW, db) = (dy^T x, column sums of dy) of a bag-level Linear from one launch of the single-writer small-tile kernel (fresh
+    outputs, no zero fill; M <= 512), two launches beyond it: float64 reference at 1e-5."""
+    from murcl_amd import ops
+    dev = _dev()
+    A, B = _rand(41, f"A{M}{N1}", (M, N1)).to(dev), _rand(41, f"B{M}{N2}", (M, N2)).to(dev)
+    C, cs = ops.gemm_tn_with_colsum(A, B)
+    ref = A.double().t().cpu() @ B.double().cpu()
+    _close(C, ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item(), msg="C")
+    _close(cs, A.double().sum(0).cpu(), rtol=1e-5, atol=1e-5 * math.sqrt(M), msg="colsum")
+
+
 # ------------------------------------------------------------------ fragment-order weight views (round 6)
 def _frag_perm(w):
     """The fragment order of a [R,512] matrix in plain index arithmetic (csrc/elementwise.hip frag_index): a 16-row block is 16 k-steps
