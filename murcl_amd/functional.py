@@ -787,8 +787,13 @@ class DSMILFn(torch.autograd.Function):
     QD = 128
 
     @staticmethod
-    def forward(ctx, x, wc, bc, wq, bq, wv, bv, want_max=False):
-        """``want_max``: also return cmax [B,C] = the max-instance class scores (train_RLMIL.py:516, ``torch.max(outputs_ins, 0)``) as a
+    def forward(ctx, x, wc, bc, wq, bq, wv, bv, want_max=False, keep_v=None):
+        """``keep_v`` (BClassifier(dropout_v > 0) in training mode, dsmil.py:53-59: ``v = Linear(Dropout(feats))``): None, or a keep
+        multiplier for the VALUE branch's input - an ``ops.DropSeed`` (its mask is materialised here: a path no script takes) or a
+        [B,N,d] tensor of 0 / 1/keep (parity tests).  The attention logits see the un-dropped features (``q = Linear(feats)``), so the
+        pooled operand is X * keep while scores and logits use X: the explicit chain (soft-max, then a weighted row sum over the
+        dropped copy) instead of the one-pass kernels.
+        ``want_max``: also return cmax [B,C] = the max-instance class scores (train_RLMIL.py:516, ``torch.max(outputs_ins, 0)``) as a
         differentiable output - the arg-max launch has them in hand, and their gradient reaches the instance classifier through the
         B*C critical rows only (no dense [B,N,C] gradient, no ATen max / scatter / fill launches)."""
         B, N, d = x.shape
@@ -797,6 +802,11 @@ class DSMILFn(torch.autograd.Function):
         QD = DSMILFn.QD
         LD = QD + ((C + 7) // 8) * 8
         x2 = x.reshape(B * N, d)
+        xv = x                                                                          # the value branch's input (dsmil.py:66)
+        if keep_v is not None:
+            km = ops.dropout_mask((B, N, d), T, keep_v.keep_p, x.device, seed=keep_v.seed) if isinstance(keep_v, ops.DropSeed) else \
+                keep_v.to(T).reshape(B, N, d).contiguous()
+            xv = ops.mul(x, km, out=torch.empty_like(x))
         cls = ops.rows_dot(x2.view(1, B * N, d), wc.view(1, C, d), bias=bc).view(B * N, C)    # instance scores (dsmil.py:9-16)
         m, cmax = ops.dsmil_argmax(cls, B, N, C, want_max=True)                         # critical instances (:71-73) and their scores
         reassoc = _DSMIL_REASSOC and C <= 4
@@ -811,7 +821,7 @@ class DSMILFn(torch.autograd.Function):
         if reassoc:
             Y = v
             # attention + pooling from one pass over X: A = soft-max_n(X v_c / sqrt(128)) (:76-77), Z = A^T X (:78)
-            one = ops.dsmil_attn_pool(x, v.view(B, C, d), 1.0 / math.sqrt(QD)) if _DSMIL_ONEPASS else None
+            one = ops.dsmil_attn_pool(x, v.view(B, C, d), 1.0 / math.sqrt(QD)) if (_DSMIL_ONEPASS and keep_v is None) else None
             if one is None:
                 v *= 1.0 / math.sqrt(QD)
                 A = ops.dsmil_softmax_(ops.rows_dot(x, v.view(B, C, d)))
@@ -822,11 +832,11 @@ class DSMILFn(torch.autograd.Function):
             qmax = ops.gather_rows(Y, m, B, C, N, 0, QD)
             A = ops.dsmil_attn(Y, 0, qmax, B, N, C)
             one = None
-        A, Z = one if one is not None else (A, ops.weighted_rowsum(x, A))               # Z = A^T X  (:78)
+        A, Z = one if one is not None else (A, ops.weighted_rowsum(xv, A))              # Z = A^T X  (:78; X * keep with dropout_v)
         bag = ops.gemm_nt(Z.view(B * C, d), wv, epi=ops.EPI_BIAS, bias=bv).view(B, C, d)
         classes = cls.view(B, N, C)
-        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else _placeholder(x))
-        ctx.meta = (B, N, d, C, LD, reassoc, qv)
+        ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else _placeholder(x), xv if keep_v is not None else _placeholder(x))
+        ctx.meta = (B, N, d, C, LD, reassoc, qv, keep_v is not None)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
         if not want_max:
@@ -835,8 +845,10 @@ class DSMILFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dclasses, dbag, _dm, dcmax=None):
-        x, Y, m, qmax, A, Z, wv, wq, xm_saved = ctx.saved_tensors
-        B, N, d, C, LD, reassoc, qv = ctx.meta
+        x, Y, m, qmax, A, Z, wv, wq, xm_saved, xv = ctx.saved_tensors
+        B, N, d, C, LD, reassoc, qv, dropped = ctx.meta
+        if not dropped:
+            xv = x                                                                          # the pooled operand (X * keep under dropout_v)
         T, QD = x.dtype, DSMILFn.QD
         dev = x.device
         x2 = x.reshape(B * N, d)
@@ -846,13 +858,13 @@ class DSMILFn(torch.autograd.Function):
         xm = None if qv else ops.gather_rows(x2, m, B, C, N, 0, d)                          # critical instances
         dcls = dclasses.reshape(B, N, C).float().contiguous() if dclasses is not None else None
         # reassociated: ONE pass over X gives R (below) and dWc - neither dA nor dS is stored
-        one = ops.dsmil_attn_pool_bwd(x, dZ, A, Z, dcls, 1.0 / math.sqrt(QD)) if (reassoc and _DSMIL_ONEPASS) else None
+        one = ops.dsmil_attn_pool_bwd(x, dZ, A, Z, dcls, 1.0 / math.sqrt(QD)) if (reassoc and _DSMIL_ONEPASS and not dropped) else None
         # otherwise dA = X dZ^T and, when the instance scores carry a gradient, dWc = dcls^T X from the SAME pass over X
         fused = None
         if one is None:
-            if dclasses is not None:
+            if dclasses is not None and not dropped:
                 fused = ops.rows_dot_wsum(x, dZ, dcls)
-            dA = fused[0] if fused is not None else ops.rows_dot(x, dZ)
+            dA = fused[0] if fused is not None else ops.rows_dot(xv, dZ)                      # dA = (X * keep) dZ^T
         dwc = dbc = None
         cmax_done = False
         if one is not None and qv and dcmax is not None:
@@ -908,7 +920,7 @@ class DSMILFn(torch.autograd.Function):
             dwc_m, dbc_m = (g * xm_f).sum(0), g.view(B, C).sum(0)
             dwc = dwc_m if dwc is None else dwc + dwc_m
             dbc = dbc_m if dbc is None else dbc + dbc_m
-        return None, dwc, dbc, dwq, dbq, dwv, dbv, None
+        return None, dwc, dbc, dwq, dbq, dwv, dbv, None, None
 
 
 _INST_CONST = {}

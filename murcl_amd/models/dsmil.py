@@ -21,8 +21,11 @@ class FCLayer(nn.Module):
 class BClassifier(nn.Module):
     def __init__(self, input_size, output_class, dropout_v=0.0):
         super().__init__()
-        if dropout_v != 0.0:
-            raise NotImplementedError("dropout_v must be 0 (the reference never sets it, dsmil.py:118)")
+        if not 0.0 <= dropout_v < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout_v}")
+        # dropout_v > 0 (no reference script sets it, dsmil.py:118): Dropout on the value branch's input while training - built for
+        # the constructor's contract (round 6), on the explicit chain of DSMILFn instead of its one-pass kernels
+        self.dropout_v = float(dropout_v)
         self.q = nn.Linear(input_size, 128)
         self.v = nn.Sequential(nn.Dropout(dropout_v), nn.Linear(input_size, input_size))
         self.fcc = nn.Conv1d(output_class, output_class, kernel_size=input_size)     # unused, kept for checkpoints
@@ -35,6 +38,7 @@ class MILNet(nn.Module):
         self.b_classifier = b_classifier
         self.compute_dtype = torch.float32
         self.last_critical = None          # m [B,C]: arg-max patch per class of the latest call
+        self.keep_mask_v = None            # tests: a [B,N,d] keep multiplier (0 or 1/keep) replacing the value branch's dropout draw
 
     def _run(self, x, want_max=False):
         """-> (classes [B,N,C], bag [B,C,d]); with ``want_max`` also the max-instance class scores [B,C] = classes.max(1)[0]
@@ -43,8 +47,11 @@ class MILNet(nn.Module):
         if x.dtype != self.compute_dtype:
             x = ops.cast(x.float().contiguous(), self.compute_dtype)
         fc, b = self.i_classifier.fc[0], self.b_classifier
+        keep_v = self.keep_mask_v
+        if keep_v is None and self.training and getattr(b, "dropout_v", 0.0) > 0.0:
+            keep_v = ops.DropSeed(1.0 - b.dropout_v)                          # nn.Dropout(dropout_v) in front of v's Linear (dsmil.py:55-58)
         classes, bag, m, cmax = DSMILFn.apply(x.contiguous(), fc.weight, fc.bias, b.q.weight, b.q.bias, b.v[1].weight, b.v[1].bias,
-                                              bool(want_max))
+                                              bool(want_max), keep_v)
         self.last_critical = m
         return (classes, bag, cmax) if want_max else (classes, bag)
 

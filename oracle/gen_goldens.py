@@ -851,6 +851,45 @@ def g22_clam_custom_instance_loss():
     np.savez_compressed(os.path.join(OUT, "g22_clam_custom_instance_loss.npz"), **res)
 
 
+def dsmil_keep_mask(seed, B, N, d, p_drop):
+    """The injected keep multiplier of G23 (0 where dropped, 1/(1-p) where kept), as a [B,N,d] float32 array (shared with the tests)."""
+    return ((detrand.uniform(seed, "g23.keep", (B, N, d)) >= p_drop).astype(np.float32) / np.float32(1.0 - p_drop)).astype(np.float32)
+
+
+def g23_dsmil_dropout_v():
+    """BClassifier(dropout_v=0.25) in TRAINING mode (dsmil.py:53-59,66: ``v = Sequential(Dropout(dropout_v), Linear)``; build_dsmil never
+    sets it).  torch's dropout draw cannot be reproduced elsewhere, so the Dropout module in front of v's Linear is swapped for one that
+    multiplies by an injected keep mask - everything else is the reference's own forward: instance scores, critical instances,
+    attention from the UN-dropped features, bag = A^T V with V from the dropped ones; plus the gradients of a weighted objective."""
+    seed, B, N, d, C, p_drop = 23, 3, 200, 512, 2, 0.25
+    fcl = r_dsmil.FCLayer(d, C)
+    bcl = r_dsmil.BClassifier(input_size=d, output_class=C, dropout_v=p_drop)
+    m = r_dsmil.MILNet(fcl, bcl)
+    m.load_state_dict(P.to_torch(P.dsmil(seed, d, C)))
+    m.train()
+    keep = T(dsmil_keep_mask(seed, B, N, d, p_drop))
+
+    class Injected(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.b = 0
+
+        def forward(self, feats):                               # called once per bag, in batch order (dsmil.py:85-88)
+            out = feats * keep[self.b]
+            self.b += 1
+            return out
+    bcl.v[0] = Injected()
+    x = T(P.bags(seed, "g23.x", B, N, d))
+    classes, bag, _ = m(x)
+    res = {"classes": torch.stack(classes).detach().numpy(), "bag": bag.detach().numpy()}
+    wb_, wc_ = T(detrand.normal(seed, "g23.wb", (B, C, d))), T(detrand.normal(seed, "g23.wc", (B, N, C)))
+    ((bag * wb_).sum() + (torch.stack(classes) * wc_).sum()).backward()
+    for k, v in m.named_parameters():
+        if v.grad is not None:
+            res["grad." + k] = _grad_entry(v.grad)
+    np.savez_compressed(os.path.join(OUT, "g23_dsmil_dropout_v.npz"), **res)
+
+
 def g17_rl_two_steps():
     """G12 with a second optimizer step (Adam's first step is sign-like, a second one makes the comparison bite):
     TWO consecutive batches through the reference's own ``train()`` (train_MuRCL.py:189-343) at train_stage 2 and 3, T = 3,
@@ -1078,7 +1117,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
     for fn in (g1_abmil, g2_ntxent, g3_pretrain, g4_clam, g5_dsmil, g6_get_feats, g7_mixup, g8_ppo, g9_full_layer, g10_eval, g11_manifest, g12_rl_step, g13_cli_flags, g14_clam_plain, g15_supervised_steps, g16_abmil_general, g17_rl_two_steps,
-               g18_clam_big, g19_abmil_heads, g20_abmil_full_grads, g21_full_layer_cascade, g22_clam_custom_instance_loss):
+               g18_clam_big, g19_abmil_heads, g20_abmil_full_grads, g21_full_layer_cascade, g22_clam_custom_instance_loss, g23_dsmil_dropout_v):
         if not only or fn.__name__ in only:
             fn()
             print("wrote", fn.__name__)

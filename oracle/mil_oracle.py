@@ -128,13 +128,15 @@ def clam_instance_eval(p, A, h, label, n_classes, k_sample, subtyping, loss_fn=N
 
 
 # ----------------------------------------------------------------------------- DSMIL
-def dsmil_forward(p, x):
+def dsmil_forward(p, x, keep_v=None):
     """MILNet.forward for a batch (models/dsmil.py:9-16,64-81,104-113).
 
     x [B,N,d] -> classes [B,N,C], bag [B,C,d], A [B,N,C], m [B,C] critical-instance ids.
+    ``keep_v`` [B,N,d] (0 or 1/keep): the value branch's nn.Dropout(dropout_v) in training mode (dsmil.py:55-58,66) with its mask
+    injected; None = dropout_v 0 / eval mode.
     """
     c = _lin(x, p, "i_classifier.fc.0")                         # dsmil.py:15
-    V = _lin(x, p, "b_classifier.v.1")                          # dsmil.py:66 (dropout_v=0)
+    V = _lin(x if keep_v is None else x * keep_v, p, "b_classifier.v.1")      # dsmil.py:66 (Dropout, then Linear)
     Q = _lin(x, p, "b_classifier.q")                            # dsmil.py:67
     m = c.argmax(dim=1)                                         # dsmil.py:71-73 (sort desc, row 0)
     m_feats = torch.gather(x, 1, m.unsqueeze(-1).expand(-1, -1, x.shape[-1]))

@@ -557,3 +557,23 @@ def _instance_losses():
             "multi_margin": torch.nn.MultiMarginLoss(),
             "lambda_logit_gap": lambda lg, tg: ((lg[:, 1] - lg[:, 0]) * (1.0 - 2.0 * tg.float())).exp().mean()}
 
+
+def _dsmil_keep_mask(seed, B, N, d, p_drop):
+    return T(((detrand.uniform(seed, "g23.keep", (B, N, d)) >= p_drop).astype(np.float32) / np.float32(1.0 - p_drop)).astype(np.float32))
+
+
+def test_g23_dsmil_dropout_v(golden):
+    """G23: BClassifier(dropout_v = 0.25) in training mode with an injected keep mask (dsmil.py:53-59,66): the value branch sees the
+    dropped features, scores and attention the un-dropped ones - outputs and gradients of the reference's own forward."""
+    g = golden("g23_dsmil_dropout_v")
+    p = _leaf(P.dsmil(23, 512, 2))
+    x = T(P.bags(23, "g23.x", 3, 200, 512))
+    c, bag, A, m = O.dsmil_forward(p, x, keep_v=_dsmil_keep_mask(23, 3, 200, 512, 0.25))
+    np.testing.assert_allclose(c.detach().numpy(), g["classes"], **TOL)
+    np.testing.assert_allclose(bag.detach().numpy(), g["bag"], rtol=1e-4, atol=1e-5)
+    wb_, wc_ = T(detrand.normal(23, "g23.wb", (3, 2, 512))), T(detrand.normal(23, "g23.wc", (3, 200, 2)))
+    ((bag * wb_).sum() + (c * wc_).sum()).backward()
+    _check_grad_entries(g, "grad.", p)
+    # and it is not the un-dropped forward
+    assert (O.dsmil_forward(p, x)[1] - bag).abs().max().item() > 1e-3
+
