@@ -212,6 +212,12 @@ int murcl_subbag_select(const int* cluster_ids, const int* cluster_off, const in
 int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
                             const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in, int dtype_out,
                             murcl_stream_t stream);
+/* The same, writing only the bags [bag_lo, bag_lo + n_out) of every view (out [views][n_out][feat_size][d]) while idx / lam / perm /
+ * bag_row_off cover all B bags: the mix-up partner of a rank's bag may be ANY bag of the global batch (utils/datasets.py:267-269
+ * permutes over the whole batch) - a data-parallel rank that keeps the whole cohort resident gathers it locally (round 6). */
+int murcl_subbag_gather_mix_rows(const void* feats, const long* bag_row_off, const int* idx, const float* lam, const int* perm,
+                                 void* out, int views, int B, int feat_size, int d, int bag_lo, int n_out, int dtype_in,
+                                 int dtype_out, murcl_stream_t stream);
 
 /* Every random draw of one training step in ONE launch (train_MuRCL.py:235,256-258 window positions ~ U[0,1); utils/datasets.py:265-267
  * mix-up lambda = alpha + U(0,1)(1 - alpha) [n_views, B] and a uniform random permutation of the bags perm [n_views, B] int32 per

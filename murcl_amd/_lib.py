@@ -47,6 +47,7 @@ SIGNATURES = {
     "murcl_ntxent_small_xchg": [_P, _I, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P, _P],
     "murcl_subbag_select": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "murcl_subbag_gather_mix": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "murcl_subbag_gather_mix_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "murcl_mixup": [_P, _P, _P, _P, _I, _L, _I, _P],
     "murcl_dsmil_argmax": [_P, _I, _I, _I, _I, _P, _P],
     "murcl_dsmil_argmax_max": [_P, _I, _I, _I, _I, _P, _P, _P],

@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
                                                                 const int* __restrict__ idx,
                                                                 const float* __restrict__ lam,
                                                                 const int* __restrict__ perm, TO* __restrict__ out,
-                                                                int VB, int B, int feat_size, int d) {
+                                                                int VB, int B, int feat_size, int d, int bag_lo, int n_out) {
+    // bag_lo / n_out (round 6, batch-global mix-up of a sharded step): only the bags [bag_lo, bag_lo + n_out) of every view are
+    // WRITTEN (out [views][n_out][feat_size][d]); idx / lam / perm / bag_row_off cover all B bags of the batch - a partner may be any
+    // bag of the global batch, gathered from the replicated store (VB here = views * n_out output bags)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long total = (long)VB * feat_size;
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
     for (int u = 0; u < SG_ROWS; ++u) {
         const long row = min(row0 + u, total - 1);
         live[u] = row0 + u < total;
-        const int vb = (int)(row / feat_size), r = (int)(row - (long)vb * feat_size);
-        const int b = vb % B, v0 = vb - b;                          // the bag's rows by b; its view's block of idx / lam / perm by v0
+        const int ob = (int)(row / feat_size), r = (int)(row - (long)ob * feat_size);       // output bag (view * n_out + local bag)
+        const int b = bag_lo + ob % n_out, v0 = (ob / n_out) * B, vb = v0 + b;             // the bag's rows by b; its view's block of idx / lam / perm by v0
         const int i0 = idx[(size_t)vb * feat_size + r];
         const int pb = mix ? perm[vb] : b;                          // mix-up partner: a bag of the same view
         const int i1 = mix ? idx[(size_t)(v0 + pb) * feat_size + r] : -1;
@@ -174,16 +177,24 @@ __global__ __launch_bounds__(256) void subbag_gather_mix_kernel(const TI* __rest
         }
     }
 }
+extern "C" int murcl_subbag_gather_mix_rows(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
+                                            const int* perm, void* out, int views, int B, int feat_size, int d, int bag_lo, int n_out,
+                                            int dtype_in, int dtype_out, hipStream_t stream);
 extern "C" int murcl_subbag_gather_mix(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
                                        const int* perm, void* out, int views, int B, int feat_size, int d, int dtype_in,
                                        int dtype_out, hipStream_t stream) {
-    if (B <= 0 || feat_size <= 0 || views <= 0) return 0;
-    if (d % 8) return -1;
+    return murcl_subbag_gather_mix_rows(feats, bag_row_off, idx, lam, perm, out, views, B, feat_size, d, 0, B, dtype_in, dtype_out, stream);
+}
+extern "C" int murcl_subbag_gather_mix_rows(const void* feats, const long* bag_row_off, const int* idx, const float* lam,
+                                            const int* perm, void* out, int views, int B, int feat_size, int d, int bag_lo, int n_out,
+                                            int dtype_in, int dtype_out, hipStream_t stream) {
+    if (B <= 0 || feat_size <= 0 || views <= 0 || n_out <= 0) return 0;
+    if (d % 8 || bag_lo < 0 || bag_lo + n_out > B) return -1;
     if ((lam == nullptr) != (perm == nullptr)) return -1;
-    const long rows = (long)views * B * feat_size;
+    const long rows = (long)views * n_out * feat_size;
     dim3 grid((unsigned)((rows + 4 * SG_ROWS - 1) / (4 * SG_ROWS)));
 #define GM(TI, TO) hipLaunchKernelGGL((subbag_gather_mix_kernel<TI, TO>), grid, dim3(256), 0, stream, (const TI*)feats, \
-                                      bag_row_off, idx, lam, perm, (TO*)out, views * B, B, feat_size, d)
+                                      bag_row_off, idx, lam, perm, (TO*)out, views * n_out, B, feat_size, d, bag_lo, n_out)
     if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_F32) GM(float, float);
     else if (dtype_in == MURCL_DTYPE_F32 && dtype_out == MURCL_DTYPE_BF16) GM(float, bf16_t);
     else if (dtype_in == MURCL_DTYPE_BF16 && dtype_out == MURCL_DTYPE_BF16) GM(bf16_t, bf16_t);

@@ -91,19 +91,43 @@ _BATCHED_HEAD = True           # the recurrent head over all patch steps at once
 
 
 # ------------------------------------------------------------------------------------------------ the hot step
-def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world=1, injected=None):
+def _shared_seed(args):
+    """The next 63-bit seed of the run's SHARED random stream (``--global_mixup``): a CPU generator that every rank seeds with
+    ``--seed`` and advances once per optimizer step, so that draws which must agree across ranks - the window positions and mix-up
+    draws of the GLOBAL batch - come out identical everywhere without a collective."""
+    gen = getattr(args, "_shared_gen", None)
+    if gen is None:
+        gen = args._shared_gen = torch.Generator().manual_seed(int(getattr(args, "seed", 985)) + 104729)
+    return int(torch.empty((), dtype=torch.int64).random_(generator=gen))
+
+
+def _gather_actions(acts, world):
+    """[2] x [B_local, K] sampler actions of this rank -> [2] x [world * B_local, K] in rank order (one all-gather of both views):
+    under batch-global mix-up a bag's partner may sit on another rank, and its sub-bag is cut by THAT bag's actions."""
+    both = torch.stack([a.detach().float() for a in acts], 0).contiguous()            # [2, B, K]
+    out = torch.empty((world,) + tuple(both.shape), dtype=torch.float32, device=both.device)
+    mdist.all_gather_rows(out.view(world * both.shape[0] * both.shape[1], -1), both.view(both.shape[0] * both.shape[1], -1))
+    g = out.permute(1, 0, 2, 3).reshape(2, world * both.shape[1], both.shape[2])        # [2, world * B, K]
+    return [g[0].contiguous(), g[1].contiguous()]
+
+
+def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world=1, injected=None, local=None):
     """One optimizer step on a batch of raw bags (train_MuRCL.py:233-304).
 
-    ``pack``: BagPack of this rank's bags.  ``injected`` (tests): dict replacing the random draws - 'actions'
+    ``pack``: BagPack of this rank's bags.  ``local`` = (lo, n) (``--global_mixup``, world > 1): ``pack`` is the GLOBAL batch - every
+    rank keeps the whole cohort resident - and this rank trains on its bags [lo, lo + n) of it; window positions and mix-up draws are
+    made for the global batch from the run's shared random stream (identical on every rank), the sampler's actions of stages 2 / 3
+    are all-gathered, and a bag's mix-up partner is any bag of the global batch exactly as utils/datasets.py:263-271 permutes it.  ``injected`` (tests): dict replacing the random draws - 'actions'
     [T][2][B,K] (stage 1: every patch step; stages 2/3: only entry 0 is read, the later window positions come from the
     PPO sampler), 'draws' [T][2](lambda [B,1], perm [B]), and for stages 2/3 'eps' [T-1][2][B,K] ~ N(0,1), the sampler's
     Gaussian noise (rlmil.py:85-86); an optional 'trace' list receives the action tensors of every patch step.
     Returns (loss, losses[T], rewards[T-1])."""
-    B, K, dev = pack.B, pack.K, pack.feats.device
+    gB, K, dev = pack.B, pack.K, pack.feats.device            # gB: bags the draws / actions are made for (the global batch under ``local``)
+    B = gB if local is None else int(local[1])                # bags this rank trains on
     dt_ = model.encoder.compute_dtype
     train_enc = args.train_stage != 2
     if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
-        return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world)
+        return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world, local)
     losses, rewards, sim_last, states, loss_vec = [], [], None, None, None
     late_head, agg_outs = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), []
     # stage 3: the T aggregator passes stay sequential (the sampler needs step t's states for step t+1's windows) but share ONE
@@ -117,20 +141,26 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         # every random number of the step in four launches (uniform window positions, mix-up draws, the sampler's Gaussian
         # noise) instead of ~10 tiny launches per view and patch step; none of them depends on anything computed in the step
         rl = args.train_stage != 1
-        acts_u, noise, mix = draw_step(dev, (1 if rl else args.T, 2, B, K),                  # :235,256-258
-                                       (args.T - 1, 2, B, K) if rl and args.T > 1 else None,  # rlmil.py:85-86
-                                       2 * args.T, B, args.alpha)                             # datasets.py:265-267
+        if local is None:
+            acts_u, noise, mix = draw_step(dev, (1 if rl else args.T, 2, B, K),                  # :235,256-258
+                                           (args.T - 1, 2, B, K) if rl and args.T > 1 else None,  # rlmil.py:85-86
+                                           2 * args.T, B, args.alpha)                             # datasets.py:265-267
+        else:           # global batch: positions + mix-up draws from the shared stream, the sampler's noise (this rank's rows) from its own
+            acts_u, _, mix = draw_step(dev, (1 if rl else args.T, 2, gB, K), None, 2 * args.T, gB, args.alpha, seed=_shared_seed(args))
+            noise = draw_step(dev, None, (args.T - 1, 2, B, K), 0, 0, args.alpha)[1] if rl and args.T > 1 else None
     for t in range(args.T):
         if t == 0 or args.train_stage == 1:
             acts = [a.to(dev) for a in injected["actions"][t]] if injected is not None else acts_u[t]      # [2,B,K]: one launch each
         else:
             eps = [noise[t - 1, 0], noise[t - 1, 1]] if injected is None else [e.to(dev) for e in injected["eps"][t - 1]]
             acts = ppo.select_actions(states, memory_list, restart_batch=(t == 1), eps=eps)  # :259-265, both views in one policy step
+            if local is not None:
+                acts = _gather_actions(acts, world)                                          # the partners' windows: their ranks' actions
         if injected is not None and injected.get("trace") is not None:
             injected["trace"].append([a.detach().clone() for a in acts])
         views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=dt_,
                                 draws=mix[2 * t:2 * t + 2] if injected is None else injected["draws"][t],
-                                out=None if session is None else session.views(t))                        # :237-239,266-269
+                                out=None if session is None else session.views(t), local=local)           # :237-239,266-269
         with torch.set_grad_enabled(train_enc):
             outputs, states = model(views)                                                   # :242,271
             if late_head:
@@ -197,22 +227,24 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     return loss.detach(), [l.detach() for l in losses], rewards
 
 
-def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected=None, world=1):
+def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected=None, world=1, local=None):
     """Stage 1 draws every patch step's window positions at random (train_MuRCL.py:235,256-258): no step depends on the
     aggregator states of the step before, so the sub-bags of all T steps are built into ONE buffer and the aggregator
     runs ONCE over 2*T*B bags - each weight-stationary / wgrad kernel is launched once at full size instead of T times
     at a fraction of it (a launch costs ~15 us before its first tile).  Only the recurrent head and the T NT-Xent
     launches stay sequential.  The random draws of the whole step are made up front in a few launches
     (``datasets.draw_mixups``); injected draws keep the reference's per-step order."""
-    B, K, dev, T_ = pack.B, pack.K, pack.feats.device, args.T
+    gB, K, dev, T_ = pack.B, pack.K, pack.feats.device, args.T
+    B = gB if local is None else int(local[1])
     acts, draws = [], []
     if injected is not None:
         for t in range(T_):
             acts += [a.to(dev) for a in injected["actions"][t]]
             draws += list(injected["draws"][t])
     else:
-        acts, _, draws = draw_step(dev, (2 * T_, B, K), None, 2 * T_, B, args.alpha)         # :235,256-258; datasets.py:265-267
-    views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws)
+        acts, _, draws = draw_step(dev, (2 * T_, gB, K), None, 2 * T_, gB, args.alpha,       # :235,256-258; datasets.py:265-267
+                                   seed=None if local is None else _shared_seed(args))
+    views, _ = subbag_views(pack, acts, args.feat_size, alpha=args.alpha, out_dtype=model.encoder.compute_dtype, draws=draws, local=local)
     outputs, _ = model(views)                                                                # 2*T*B bags, one batch
     losses, rewards, sim_last = [], [], None
     z_all = fc.forward_view_sequence(outputs).view(T_, 2, B, -1) if _BATCHED_HEAD and fc.fc_rnn else None   # :243,272, all steps
@@ -323,7 +355,19 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
     early_stop = G.EarlyStop(args.patience) if args.patience is not None else None
     mine = shard_slides(len(train_set), rank, world)
     store = None
-    if not args.no_resident:
+    # --global_mixup (world > 1): every rank keeps the WHOLE split resident (C4's 512 slides are 4.3 GB in bf16 of 288), the epoch
+    # order is one shared permutation, step s takes the global batch order[s * world * B : (s + 1) * world * B] and this rank trains
+    # on its B bags of it - so that a bag's mix-up partner is any bag of the global batch, as the reference's one-process
+    # DataParallel step permutes it (utils/datasets.py:263-271, train_MuRCL.py:145); default: rank-local partners
+    global_mix = bool(getattr(args, "global_mixup", False)) and world > 1
+    if global_mix and args.no_resident:
+        raise ValueError("--global_mixup needs the resident slide store (drop --no_resident)")
+    if global_mix:
+        store = DeviceSlideStore.from_dataset(train_set, device, dtype=model.encoder.compute_dtype)
+        if rank == 0:
+            print(f"resident slide store (whole split on every rank, --global_mixup): {len(store)} slides, "
+                  f"{store.bytes() / 2 ** 30:.2f} GiB on {device}", flush=True)
+    elif not args.no_resident:
         # this rank's slides, uploaded once and kept in HBM for the whole run (SURVEY 8(e),(f)): a batch is an index list.
         # (--preload asks the reference to keep the split in host memory; the resident store subsumes it.)
         store = DeviceSlideStore.from_dataset(train_set, device, dtype=model.encoder.compute_dtype, indices=mine)
@@ -367,7 +411,17 @@ def train(args, train_set, model, fc, ppo, criterion, optimizer, scheduler, devi
         last_step = []                                                        # loss of patch step T-1, one entry per batch
         if rank == 0 and optimizer is not None:
             print(f"Training Stage: {args.train_stage}, lr: " + ", ".join(f"group[{k}]: {g['lr']}" for k, g in enumerate(optimizer.param_groups)), flush=True)
-        if store is not None:
+        if global_mix:
+            order = np.random.default_rng(int(args.seed) * 7919 + epoch).permutation(len(store))       # the same on every rank
+            gbs = args.batch_size * world
+            for it in range(steps_per_epoch):
+                pack = store.pack(order[np.arange(it * gbs, (it + 1) * gbs) % len(store)])             # the GLOBAL batch
+                _, ls, _ = pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list, world,
+                                         local=(rank * args.batch_size, args.batch_size))
+                last_step.append(ls[-1])
+                if drain_snapshots():
+                    break
+        elif store is not None:
             order = np.random.permutation(len(store))
             for it in range(steps_per_epoch):
                 s = it * args.batch_size
@@ -490,6 +544,12 @@ def build_parser():
                    help="stage 1: run the aggregator once per patch step like the reference instead of once per optimizer step")
     x.add_argument("--no_resident", action="store_true",
                    help="re-read and upload every slide on every step like the reference, instead of keeping the split in HBM")
+    x.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="several ranks: nccl (= RCCL over xGMI, one GPU per rank) or gloo (debugging: ranks may share a GPU, "
+                        "collectives are staged through host memory)")
+    x.add_argument("--global_mixup", action="store_true",
+                   help="several ranks: mix-up partners from the whole GLOBAL batch, as the reference's one-process step permutes it "
+                        "(every rank then keeps the whole split resident; default: partners from the rank's own bags)")
     return p
 
 
@@ -505,7 +565,10 @@ def run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         from . import dist as mdist
         mdist.cap_rccl_channels(world)                     # RCCL's channel workgroups must fit the CUs the step leaves free
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:                                                  # gloo: several ranks on ONE device (tests); collectives staged through the host
+            dist.init_process_group(args.dist_backend)
         box = [args.save_dir]
         dist.broadcast_object_list(box, src=0)                 # rank 0 resolved (and possibly incremented) the directory
         args.save_dir = box[0]

@@ -144,12 +144,15 @@ def select_indices(pack, action_sequence, feat_size):
     return idx, cnt
 
 
-def _gather(pack, idx, feat_size, out, lam=None, perm=None, views=1):
-    """idx [views*B, feat_size], lam / perm [views*B] (perm: partner bag 0..B-1 inside the view), out [views*B, feat_size, d]."""
+def _gather(pack, idx, feat_size, out, lam=None, perm=None, views=1, local=None):
+    """idx [views*B, feat_size], lam / perm [views*B] (perm: partner bag 0..B-1 inside the view), out [views*B, feat_size, d].
+    ``local`` = (lo, n): only the bags [lo, lo + n) of every view are written - out [views*n, feat_size, d] - while idx / lam / perm
+    cover all B bags (a sharded step whose mix-up partners come from the whole global batch)."""
     d = pack.feats.shape[1]
-    check(_lib.lib().murcl_subbag_gather_mix(ptr(pack.feats), ptr(pack.row_off), ptr(idx), ptr(lam), ptr(perm),
-                                             ptr(out), views, pack.B, feat_size, d, dt(pack.feats), dt(out), stream()),
-          "subbag_gather_mix")
+    lo, n = (0, pack.B) if local is None else local
+    check(_lib.lib().murcl_subbag_gather_mix_rows(ptr(pack.feats), ptr(pack.row_off), ptr(idx), ptr(lam), ptr(perm),
+                                                  ptr(out), views, pack.B, feat_size, d, int(lo), int(n), dt(pack.feats), dt(out),
+                                                  stream()), "subbag_gather_mix")
     return out
 
 
@@ -210,7 +213,7 @@ def draw_mixups(n_views, B, alpha, device):
     return draw_step(device, None, None, n_views, B, alpha)[2]
 
 
-def draw_step(device, uni_shape, nrm_shape, n_views, B, alpha):
+def draw_step(device, uni_shape, nrm_shape, n_views, B, alpha, seed=None):
     """Every random draw of one training step: (u ~ U[0,1) of ``uni_shape`` or None - the window positions, train_MuRCL.py:235,256-258;
     n ~ N(0,1) of ``nrm_shape`` or None - the sampler's noise, rlmil.py:85-86; the ``draw_mixups`` of ``n_views`` views).  On the GPU
     ONE launch (``ops.step_draws``: counter-based generator seeded from torch's global seed) instead of ~12 (two ``torch.rand``, two
@@ -221,9 +224,11 @@ def draw_step(device, uni_shape, nrm_shape, n_views, B, alpha):
     if torch.device(device).type == "cuda":
         from .. import ops
         if B <= ops.DRAWS_MAX_B:
-            uni, nrm, lam, perm = ops.step_draws(torch.device(device), nu, nn_, n_views, B, alpha)
+            uni, nrm, lam, perm = ops.step_draws(torch.device(device), nu, nn_, n_views, B, alpha, seed=seed)
             return (None if uni_shape is None else uni.view(uni_shape), None if nrm_shape is None else nrm.view(nrm_shape),
                     MixDraws(lam.unsqueeze(-1), perm))
+    if seed is not None:
+        raise NotImplementedError("a seeded draw_step needs the counter-based launch (GPU, B <= ops.DRAWS_MAX_B)")
     u = torch.rand((2, n_views, B), device=device)
     lam = u[0].mul(1 - alpha).add_(alpha).unsqueeze(-1)
     perm = u[1].argsort(dim=1).to(torch.int32)
@@ -245,12 +250,17 @@ class MixDraws(list):
         return super().__getitem__(i)
 
 
-def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None, out=None):
+def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, draws=None, out=None, local=None):
     """Fused K12+K13 for V views: returns (views: list of [B,feat_size,d] slices of ONE buffer, draws).
 
     ``draws`` = list of (lambda_ [B,1], rand_idx [B]) per view (generated like ``mixup`` when None and
-    alpha is given; alpha None disables mix-up)."""
+    alpha is given; alpha None disables mix-up).
+    ``local`` = (lo, n) (round 6, batch-global mix-up under data parallelism): ``pack`` / actions / draws describe the GLOBAL batch
+    of B bags - the partner ``rand_idx[b]`` is any of them, as datasets.py:267-269 permutes over the whole batch - and only the views
+    of this rank's bags [lo, lo + n) are built: -> V views of [n, feat_size, d]."""
     dev, B = pack.feats.device, pack.B
+    lo_n = (0, B) if local is None else (int(local[0]), int(local[1]))
+    nB = lo_n[1]
     d = pack.feats.shape[1]
     # all V views through ONE selection launch and ONE gather (+ mix-up) launch: the views differ only in their rows of
     # actions / lambda / perm (12 views per stage-1 step: 24 launches before)
@@ -266,10 +276,10 @@ def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, 
         else:
             acts = torch.stack([a.to(torch.float32) for a in action_sequences], 0)
     if out is None:
-        buf = torch.empty((V * B, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
+        buf = torch.empty((V * nB, feat_size, d), dtype=out_dtype or pack.feats.dtype, device=dev)
     else:                                   # a caller-owned [V*B, feat_size, d] block (functional.EncoderSession keeps all patch steps' views)
         buf = out
-        assert buf.is_contiguous() and tuple(buf.shape) == (V * B, feat_size, d) and buf.dtype == (out_dtype or pack.feats.dtype)
+        assert buf.is_contiguous() and tuple(buf.shape) == (V * nB, feat_size, d) and buf.dtype == (out_dtype or pack.feats.dtype)
     idx, _ = select_indices(pack, acts.reshape(V, B, pack.K), feat_size)
     used, lam, perm = [], None, None
     if alpha is not None or draws is not None:
@@ -282,5 +292,5 @@ def subbag_views(pack, action_sequences, feat_size, alpha=None, out_dtype=None, 
             perm = torch.stack([dr[1].to(torch.int32) for dr in draws[:V]], 0).reshape(-1)
         used = [(draws[v][0], draws[v][1]) for v in range(V)]
         lam, perm = lam.to(torch.float32).contiguous(), perm.to(torch.int32).contiguous()
-    _gather(pack, idx.view(V * B, feat_size), feat_size, buf, lam, perm, views=V)
-    return [buf[v * B:(v + 1) * B] for v in range(V)], used
+    _gather(pack, idx.view(V * B, feat_size), feat_size, buf, lam, perm, views=V, local=local)
+    return [buf[v * nB:(v + 1) * nB] for v in range(V)], used

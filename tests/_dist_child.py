@@ -8,6 +8,11 @@ flat gradient all-reduce, PPO collectives) - and stores both results.
 mode "gloo2": rank ``rank`` of ``world`` processes that share cuda:0, backend gloo (RCCL refuses two ranks on one
 device; gloo collectives are staged through the host by murcl_amd.dist) - the real kernels on B/world bags per rank.
 mode "single": no process group, all B bags: the reference result for "gloo2".
+modes "gloo2g" / "singleg" (round 6, --global_mixup): the same with mix-up permutations over the WHOLE batch - every rank holds all B
+raw bags (the replicated store), trains on its half (``pretrain_step(local=...)``) and all-gathers the sampler's actions; the
+single-process run with the same global permutations is its reference.
+mode "cli2g": rank ``rank`` of ``world`` processes running the ENTRY SCRIPT itself (``train_MuRCL.main``, stages 1-3 in turn) with
+``--global_mixup --dist_backend gloo`` and its own random draws; stores the parameters each rank holds after each stage.
 """
 import os
 import sys
@@ -21,15 +26,28 @@ sys.path.insert(0, ROOT)
 SEED, B, K, FS, TN = 41, 4, 6, 96, 3
 
 
-def scenario(lo, hi):
-    """Bags [lo, hi) of the fixed B-bag batch with their draws; mix-up partners stay inside each half (rank-local)."""
+def scenario(lo, hi, global_mix=False):
+    """Bags [lo, hi) of the fixed B-bag batch with their draws; mix-up partners stay inside each half (rank-local).
+    ``global_mix``: ALL B bags with actions / draws for all of them (only the sampler's noise is cut to [lo, hi)) and permutations
+    over the whole batch."""
     from oracle import detrand, params as P
     Ns = [420 + 29 * b for b in range(B)]
-    feats = [P.bags(SEED, f"f{b}", 1, Ns[b], 512)[0] for b in range(lo, hi)]
-    cls = [P.cluster_lists(SEED, f"c{b}", Ns[b], K) for b in range(lo, hi)]
+    blo, bhi = (0, B) if global_mix else (lo, hi)
+    feats = [P.bags(SEED, f"f{b}", 1, Ns[b], 512)[0] for b in range(blo, bhi)]
+    cls = [P.cluster_lists(SEED, f"c{b}", Ns[b], K) for b in range(blo, bhi)]
     half = B // 2
     perms = [[np.concatenate([detrand.permutation(SEED, f"p{t}{v}{h}", half) + h * half for h in range(2)]) for v in range(2)]
              for t in range(TN)]
+    if global_mix:
+        perms = [[detrand.permutation(SEED, f"gp{t}{v}", B) for v in range(2)] for t in range(TN)]
+        assert any((np.asarray(perms[t][v])[:half] >= half).any() for t in range(TN) for v in range(2)), "no cross-rank partner drawn"
+        full = lambda a: np.ascontiguousarray(a)                      # noqa: E731
+        cut_ = lambda a: np.ascontiguousarray(a[lo:hi])               # noqa: E731
+        inj = {"actions": [[full(detrand.uniform(SEED, f"a{t}{v}", (B, K)).astype(np.float32)) for v in range(2)] for t in range(TN)],
+               "draws": [[(full(detrand.uniform(SEED, f"l{t}{v}", (B, 1), 0.9, 1.0).astype(np.float32)), full(np.asarray(perms[t][v])))
+                          for v in range(2)] for t in range(TN)],
+               "eps": [[cut_(detrand.normal(SEED, f"e{t}{v}", (B, K)).astype(np.float32)) for v in range(2)] for t in range(TN - 1)]}
+        return feats, cls, inj
 
     def cut(a):
         return np.ascontiguousarray(a[lo:hi])
@@ -51,7 +69,7 @@ def write_prev_stage(workdir, stage):
                     "policy": P.to_torch(P.actor_critic(SEED, 512, 512, K))}, path)
 
 
-def run_step(workdir, stage, lo, hi, dist_path):
+def run_step(workdir, stage, lo, hi, dist_path, global_mix=False):
     from oracle import params as P
     from murcl_amd.models import rlmil
     from murcl_amd.train_MuRCL import build_parser, create_model, get_optimizer, pretrain_step
@@ -74,13 +92,14 @@ def run_step(workdir, stage, lo, hi, dist_path):
         ppo.policy_old.load_state_dict(pol)
         ppo.data_parallel = True if dist_path else False
     opt = get_optimizer(args, model, fc)
-    feats, cls, inj = scenario(lo, hi)
+    feats, cls, inj = scenario(lo, hi, global_mix)
     pack = BagPack.from_lists([T(f).to(dev) for f in feats], cls)
     dinj = {"actions": [[T(a).to(dev) for a in row] for row in inj["actions"]],
             "draws": [[(T(l).to(dev), T(p).to(dev)) for l, p in row] for row in inj["draws"]],
             "eps": [[T(e).to(dev) for e in row] for row in inj["eps"]]}
     loss, losses, rewards = pretrain_step(args, model, fc, ppo, NT_Xent(hi - lo, 1.0), opt, pack,
-                                          [rlmil.Memory(), rlmil.Memory()], world=2 if dist_path else 1, injected=dinj)
+                                          [rlmil.Memory(), rlmil.Memory()], world=2 if dist_path else 1, injected=dinj,
+                                          local=(lo, hi - lo) if (global_mix and dist_path) else None)
     assert not any(r.requires_grad for r in rewards)
     out = {"losses": torch.stack(losses).cpu(), "rewards": torch.cat(rewards).cpu(),
            "model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
@@ -90,9 +109,31 @@ def run_step(workdir, stage, lo, hi, dist_path):
     return out
 
 
+def run_cli(rank, world, port, workdir):
+    from murcl_amd import train_MuRCL
+    kept, inner = {}, train_MuRCL.train
+
+    def train_and_keep(args, train_set, model, fc, ppo, *rest):
+        out = inner(args, train_set, model, fc, ppo, *rest)
+        kept[f"s{args.train_stage}"] = {"model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                                        "fc": {k: v.detach().cpu().clone() for k, v in fc.state_dict().items()},
+                                        "policy": None if ppo is None else {k: v.detach().cpu().clone() for k, v in ppo.policy.state_dict().items()}}
+        return out
+    train_MuRCL.train = train_and_keep
+    for stage in (1, 2, 3):
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port) + stage), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        train_MuRCL.main(["--synthetic", "12,360", "--num_clusters", "4", "--feat_size", "64", "--T", "3", "--batch_size", "3",
+                          "--data_repeat", "2", "--arch", "ABMIL", "--device", "0", "--exist_ok", "--dtype", "f32", "--epochs", "2",
+                          "--ppo_epochs", "2", "--train_stage", str(stage), "--global_mixup", "--dist_backend", "gloo",
+                          "--save_dir", os.path.join(workdir, "cli", f"stage_{stage}")])
+    torch.save(kept, os.path.join(workdir, f"cli2g_{rank}.pt"))
+
+
 def main():
     mode, rank, world, port, workdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
-    if mode != "single":
+    if mode == "cli2g":
+        return run_cli(rank, world, port, workdir)
+    if mode not in ("single", "singleg"):
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
         if mode == "nccl1":
@@ -103,19 +144,19 @@ def main():
     for stage in (1, 2, 3):
         if stage > 1:
             write_prev_stage(workdir, stage) if rank == 0 else None
-            if mode == "gloo2":
+            if mode in ("gloo2", "gloo2g"):
                 import torch.distributed as dist
                 dist.barrier()
         if mode == "nccl1":
             res[f"s{stage}.plain"] = run_step(workdir, stage, 0, B, False)
             res[f"s{stage}.dist"] = run_step(workdir, stage, 0, B, True)
-        elif mode == "gloo2":
+        elif mode in ("gloo2", "gloo2g"):
             per = B // world
-            res[f"s{stage}"] = run_step(workdir, stage, rank * per, (rank + 1) * per, True)
+            res[f"s{stage}"] = run_step(workdir, stage, rank * per, (rank + 1) * per, True, global_mix=(mode == "gloo2g"))
         else:
-            res[f"s{stage}"] = run_step(workdir, stage, 0, B, False)
+            res[f"s{stage}"] = run_step(workdir, stage, 0, B, False, global_mix=(mode == "singleg"))
     torch.save(res, os.path.join(workdir, f"{mode}_{rank}.pt"))
-    if mode != "single":
+    if mode not in ("single", "singleg"):
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -37,7 +37,7 @@ def test_every_reference_flag_exists_with_same_type_default_choices(g13, entry):
         assert (list(a.choices) if a.choices is not None else None) == row["choices"], row["dest"]
         assert type(a).__name__ == row["action"] and a.nargs == row["nargs"], row["dest"]
     extras = set(mine) - {r["dest"] for r in g13["flags"][entry]} - {"help"}
-    assert extras <= {"synthetic", "num_clusters", "dtype", "no_batched_stage1", "no_resident"}, extras
+    assert extras <= {"synthetic", "num_clusters", "dtype", "no_batched_stage1", "no_resident", "global_mixup", "dist_backend"}, extras
 
 
 @pytest.mark.parametrize("script", ["pretrain.sh", "scratch.sh", "finetune.sh", "linear.sh"])

@@ -85,3 +85,50 @@ def test_two_ranks_equal_one_process_and_stay_identical(tmp_path):
             for k in a[part]:
                 assert torch.equal(a[part][k], b[part][k]), f"stage {stage}: ranks diverged on {part}.{k}"
                 _same_update(a[part][k], w[part][k], pre[part][k], f"stage {stage} {part}.{k}")
+
+
+def test_two_ranks_with_batch_global_mixup_equal_one_process(tmp_path):
+    """--global_mixup (round 6; utils/datasets.py:263-271 permutes over the WHOLE batch, which the default rank-local form changes at
+    W > 1): two ranks that each hold all B raw bags, train on their half (``pretrain_step(local=...)``) with mix-up partners drawn over
+    the whole batch - at least one partner sits on the other rank - and all-gather the sampler's actions == ONE process with the same
+    global draws: same global loss at every patch step, same rewards, the same update (stages 1-3), ranks bit-identical."""
+    port = 30250 + os.getpid() % 300
+    _wait([_spawn("gloo2g", r, 2, port, tmp_path) for r in range(2)])
+    _wait([_spawn("singleg", 0, 1, 0, tmp_path)])
+    r0, r1, one = (torch.load(tmp_path / f) for f in ("gloo2g_0.pt", "gloo2g_1.pt", "singleg_0.pt"))
+    from oracle import params as P
+    pre = {"model": {"encoder." + k: v for k, v in P.to_torch(P.abmil(41)).items()}, "fc": P.to_torch(P.full_layer(41)),
+           "policy": P.to_torch(P.actor_critic(41, 512, 512, 6))}
+    for stage in (1, 2, 3):
+        a, b, w = r0[f"s{stage}"], r1[f"s{stage}"], one[f"s{stage}"]
+        np.testing.assert_allclose(a["losses"].numpy(), w["losses"].numpy(), rtol=1e-5)
+        assert torch.equal(a["losses"], b["losses"])
+        np.testing.assert_allclose(torch.cat([a["rewards"], b["rewards"]], 1).numpy(), w["rewards"].numpy(), rtol=2e-3, atol=2e-6)
+        trained = ("policy",) if stage == 2 else ("model", "fc")
+        for part in trained:
+            for k in a[part]:
+                assert torch.equal(a[part][k], b[part][k]), f"stage {stage}: ranks diverged on {part}.{k}"
+                _same_update(a[part][k], w[part][k], pre[part][k], f"stage {stage} {part}.{k}")
+
+
+def test_entry_script_on_two_ranks_with_global_mixup_keeps_the_ranks_identical(tmp_path):
+    """``train_MuRCL.main --global_mixup --dist_backend gloo`` on two ranks sharing this GPU, stages 1-3 with the script's OWN random
+    draws: the shared stream (window positions, mix-up draws, epoch order) needs no collective, the sampler's noise is per rank and its
+    actions are all-gathered - every stage trains (parameters move), stays finite, and the two ranks end each stage with bit-identical
+    parameters; rank 0 reports the whole split resident."""
+    port = 31250 + os.getpid() % 300
+    procs = [_spawn("cli2g", r, 2, port, tmp_path) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out[-4000:]
+        outs.append(out)
+    assert "whole split on every rank, --global_mixup): 12 slides" in outs[0] and "whole split" not in outs[1]
+    r0, r1 = (torch.load(tmp_path / f"cli2g_{r}.pt") for r in range(2))
+    for stage, parts in ((1, ("model", "fc")), (2, ("policy",)), (3, ("model", "fc"))):
+        a, b = r0[f"s{stage}"], r1[f"s{stage}"]
+        for part in parts:
+            for k in a[part]:
+                assert torch.isfinite(a[part][k]).all(), (stage, part, k)
+                assert torch.equal(a[part][k], b[part][k]), f"stage {stage}: ranks diverged on {part}.{k}"
+    assert not torch.equal(r0["s1"]["model"]["encoder.encoder.0.weight"], r0["s3"]["model"]["encoder.encoder.0.weight"])

@@ -171,3 +171,47 @@ def test_get_feats_with_empty_and_singleton_clusters():
         assert cnt[b] == len(want), (b, cnt[b], len(want))
         np.testing.assert_array_equal(idx[b, :len(want)], np.asarray(want, dtype=np.int64))
         assert (idx[b, len(want):] == -1).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_subbag_views_of_a_shard_with_global_partners_equal_the_rows_of_the_global_call(dtype):
+    """``subbag_views(local=(lo, n))`` (round 6, --global_mixup): actions, lambdas and permutations describe the GLOBAL batch - the
+    partner of a rank's bag may be any of its bags (utils/datasets.py:267-269) - and only the rank's bags are built: for every
+    shard of a 12-bag batch the V views are bit-for-bit the corresponding rows of the one global call, into caller-owned buffers too."""
+    from murcl_amd.utils.datasets import BagPack, subbag_views
+    dev = _dev()
+    B, K, fs, V = 12, 5, 128, 3
+    Ns = [700 + 41 * b for b in range(B)]
+    cls = [P.cluster_lists(61, f"c{b}", Ns[b], K) for b in range(B)]
+    feats = [T(P.bags(61, f"f{b}", 1, Ns[b], 64)[0]).to(dev) for b in range(B)]
+    pack = BagPack.from_lists(feats, cls, dtype=dtype)
+    acts = T(detrand.uniform(61, "act", (V, B, K)).astype(np.float32)).to(dev)
+    draws = [(T(detrand.uniform(61, f"l{v}", (B, 1), 0.5, 1.0).astype(np.float32)).to(dev),
+              T(np.asarray(detrand.permutation(61, f"p{v}", B)).astype(np.int32)).to(dev)) for v in range(V)]
+    whole, _ = subbag_views(pack, acts, fs, alpha=0.9, draws=draws)
+    for lo, n in ((0, 4), (4, 4), (8, 4), (0, 12), (5, 1), (9, 3)):
+        part, _ = subbag_views(pack, acts, fs, alpha=0.9, draws=draws, local=(lo, n))
+        assert len(part) == V and all(tuple(p.shape) == (n, fs, 64) for p in part)
+        for v in range(V):
+            assert torch.equal(part[v], whole[v][lo:lo + n]), (lo, n, v)
+    buf = torch.empty((V * 4, fs, 64), dtype=dtype, device=dev)
+    part, _ = subbag_views(pack, acts, fs, alpha=0.9, draws=draws, out=buf, local=(4, 4))
+    assert part[0].data_ptr() == buf.data_ptr() and torch.equal(part[2], whole[2][4:8])
+
+
+def test_seeded_step_draws_repeat_and_unseeded_ones_do_not():
+    """``draw_step(seed=s)`` (the shared stream of --global_mixup: every rank calls it with the same seed and needs no collective):
+    the same seed gives the same window positions, lambdas and permutations bit for bit, another seed or no seed gives others; the
+    permutations are permutations and lambda lies in [alpha, 1)."""
+    from murcl_amd.utils.datasets import draw_step
+    dev = _dev()
+    a = draw_step(dev, (2, 2, 12, 5), None, 4, 12, 0.9, seed=1234567)
+    b = draw_step(dev, (2, 2, 12, 5), None, 4, 12, 0.9, seed=1234567)
+    c = draw_step(dev, (2, 2, 12, 5), None, 4, 12, 0.9, seed=1234568)
+    d = draw_step(dev, (2, 2, 12, 5), None, 4, 12, 0.9)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2].lam, b[2].lam) and torch.equal(a[2].perm, b[2].perm) and a[1] is None
+    assert not torch.equal(a[0], c[0]) and not torch.equal(a[0], d[0]) and not torch.equal(a[2].lam, c[2].lam)
+    assert (a[2].perm.sort(1)[0] == torch.arange(12, device=dev, dtype=torch.int32)).all()
+    assert (a[2].lam >= 0.9).all() and (a[2].lam < 1.0).all()
+    only_noise = draw_step(dev, None, (2, 2, 3, 5), 0, 0, 0.9)                       # a rank's own sampler noise under --global_mixup
+    assert only_noise[0] is None and tuple(only_noise[1].shape) == (2, 2, 3, 5) and torch.isfinite(only_noise[1]).all()

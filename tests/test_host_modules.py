@@ -155,3 +155,17 @@ def test_cu_reserve_follows_the_rccl_channel_cap():
     assert b == 224 and "not set" in note
     assert f(240, 12) == (240, None) and f(200, 56)[0] == 200 and f(248, 1000)[0] == 64
     assert f("251", 8) == (248, None)                   # multiples of 8: one step per XCD
+
+
+def test_shared_seed_stream_is_the_same_on_every_rank_and_independent_of_the_global_generator():
+    """train_MuRCL._shared_seed (--global_mixup): a function of --seed and the number of steps taken only - two 'ranks' with different
+    torch global seeds (main() offsets them per rank) draw the same sequence; another --seed gives another."""
+    import types
+    from murcl_amd.train_MuRCL import _shared_seed
+    r0, r1, other = (types.SimpleNamespace(seed=s) for s in (985, 985, 986))
+    torch.manual_seed(1)
+    a = [_shared_seed(r0) for _ in range(5)]
+    torch.manual_seed(2)
+    b = [_shared_seed(r1) for _ in range(5)]
+    assert a == b and len(set(a)) == 5 and all(0 <= v < 2 ** 63 for v in a)
+    assert [_shared_seed(other) for _ in range(5)] != a
