@@ -479,7 +479,7 @@ int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, flo
                      int zero_grad, murcl_stream_t stream);
 /* The same launch for a step that is CAPTURED into a hipGraph and replayed: replays_dev (device int[2], zeroed by the caller before
  * the first replay; NULL = murcl_adam_multi) counts the steps the replays have taken - the kernel's bias corrections use
- * job.step + replays_dev[0] and its last workgroup advances the counter, so that every replay is the NEXT optimizer step, not the
+ * job.step + replays_dev[0] and a one-thread launch queued behind it advances the counter, so that every replay is the NEXT optimizer step, not the
  * captured one again (torch.optim.Adam's state['step'], train_MuRCL.py:165-171, kept on the device). */
 int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                           int zero_grad, int* replays_dev, murcl_stream_t stream);

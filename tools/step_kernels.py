@@ -1,7 +1,8 @@
 """Per-kernel totals of ONE step out of a rocprofv3 --kernel-trace csv: the kernels between the last two launches of a marker
 kernel (one that runs once per step), grouped by name: launches, total time, idle gap before them.
 
-usage: python tools/step_kernels.py <trace dir> <marker substring> [occurrences per step, default 1]
+usage: python tools/step_kernels.py <trace dir> <marker substring> [occurrences per step, default 1] [seq]
+("seq": the launch sequence itself - start, duration, gap before - after the totals)
 """
 import csv
 import glob
@@ -31,6 +32,11 @@ def main():
     print(f"# kernels {len(seq)}  span {(rows[b][0] - seq[0][0]) / 1e3:.1f} us  busy {busy / 1e3:.1f} us")
     for k, (n, t, g) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{n:4d} x  dur {t / 1e3:8.1f} us  avg {t / n / 1e3:6.1f}  gap-before {g / 1e3:7.1f}  {k}")
+    if len(sys.argv) > 4 and sys.argv[4] == "seq":
+        prev = rows[a - 1][1] if a else seq[0][0]
+        for s, e, name in seq:
+            print("%9.1f us  dur %7.1f  gap %6.1f  %s" % ((s - seq[0][0]) / 1e3, (e - s) / 1e3, max(0, s - prev) / 1e3, name.split("(")[0][:90]))
+            prev = max(prev, e)
 
 
 if __name__ == "__main__":
