@@ -483,6 +483,15 @@ int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, flo
  * captured one again (torch.optim.Adam's state['step'], train_MuRCL.py:165-171, kept on the device). */
 int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                           int zero_grad, int* replays_dev, murcl_stream_t stream);
+/* out = a x + b y over n floats: the rewards of a contrastive step, cosine of patch step t-1 minus that of step t
+ * (train_MuRCL.py:282-283), for all T-1 steps in one launch. */
+int murcl_axpby(const float* x, const float* y, float a, float b, float* out, long n, murcl_stream_t stream);
+/* out[0] = mean of n floats in a fixed order (one workgroup): the step loss, mean of the T patch-step losses (train_MuRCL.py:291),
+ * where nothing differentiates it (frozen-aggregator stage 2). */
+int murcl_mean_small(const float* x, int n, float* out, murcl_stream_t stream);
+/* dst <- src (both 16-byte aligned, any byte count): `policy_old.load_state_dict(policy.state_dict())` after a PPO update
+ * (models/rlmil.py:183) on the two flat parameter buffers, as a launch of this library.  -1: a pointer is not 16-byte aligned. */
+int murcl_copy_bytes(const void* src, void* dst, long bytes, murcl_stream_t stream);
 /* torch.optim.SGD.step for one flat tensor (train_MuRCL.py:158-163, train_RLMIL.py:258-263): L2 weight decay, momentum
  * buffer (first != 0: the buffer is initialised with the gradient), dampening 0, optional Nesterov. */
 int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov, float weight_decay,

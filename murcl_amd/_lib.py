@@ -81,6 +81,9 @@ SIGNATURES = {
     "murcl_scatter_add_rows_masked": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "murcl_cross_entropy": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "murcl_mul": [_P, _P, _P, _L, _I, _P],
+    "murcl_axpby": [_P, _P, _F, _F, _P, _L, _P],
+    "murcl_mean_small": [_P, _I, _P, _P],
+    "murcl_copy_bytes": [_P, _P, _L, _P],
     "murcl_policy_head_fwd": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "murcl_policy_head_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
     "murcl_ppo_returns": [_P, _F, _I, _I, _P, _P],

@@ -569,6 +569,64 @@ extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, 
     return MURCL_CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------- bag-level odds and ends of the training step
+// out = a x + b y over n floats (the rewards of a contrastive step: cosine of step t-1 minus cosine of step t, train_MuRCL.py:282-283)
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a * x[i] + b * y[i];
+}
+extern "C" int murcl_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, y, a, b, out, n);
+    return MURCL_CHECK_LAUNCH();
+}
+// out[0] = mean of n floats, one workgroup, a fixed summation order (the step loss = mean of the T patch-step losses, train_MuRCL.py:291)
+__global__ __launch_bounds__(256) void mean_small_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / (float)n;
+}
+extern "C" int murcl_mean_small(const float* x, int n, float* out, hipStream_t s) {
+    if (n <= 0 || n > (1 << 20)) return -1;
+    hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(256), 0, s, x, n, out);
+    return MURCL_CHECK_LAUNCH();
+}
+
+// dst <- src, `bytes` bytes, both 16-byte aligned (flat parameter buffers: policy -> policy_old after a PPO update, rlmil.py:183): a
+// streaming copy of 16-byte pieces, the last 1..15 bytes by one lane - a launch of this library in the step's sequence instead of a
+// runtime blit
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long n16, int tail) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = (long)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * 256 < n16) v[u] = src[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i + u * 256 < n16) dst[i + u * 256] = v[u];
+    }
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned char* s = (const unsigned char*)(src + n16);
+        unsigned char* d = (unsigned char*)(dst + n16);
+        for (int k = 0; k < tail; ++k) d[k] = s[k];
+    }
+}
+extern "C" int murcl_copy_bytes(const void* src, void* dst, long bytes, hipStream_t stream) {
+    if (bytes <= 0) return 0;
+    if ((((size_t)src | (size_t)dst) & 15) != 0) return -1;
+    const long n16 = bytes / 16;
+    const long want = (n16 + 1023) / 1024;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, stream,
+                       (const u32x4*)src, (u32x4*)dst, n16, (int)(bytes & 15));
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- SGD (torch.optim.SGD semantics: L2 decay, momentum
 // buffer initialised with the first gradient, dampening 0, optional Nesterov; train_MuRCL.py:158-163)
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, long n, float lr,

@@ -679,16 +679,16 @@ class GRUSeqFn(torch.autograd.Function):
         gh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=x.device)
         gates = torch.empty_like(gh)
         hs = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
-        gh[0] = b_hh                                                     # W_hh . 0 + b_hh
         fused = ops.gru_step_ok(B, H)                                    # h W_hh^T and the gate math of a step in one launch
         whh, bhh = w_hh.detach(), b_hh.detach()
+        gh0 = bhh.view(1, -1)                                            # W_hh . 0 + b_hh: ONE row that every batch row of step 0 reads (gh[0] stays unwritten)
         for t in range(T):
             if t and fused:
                 ops.gru_step_fwd(gi[t], hs[t - 1], whh, bhh, hnew=hs[t], gates=gates[t], gh=gh[t])
                 continue
             if t:
                 ops.gemm_nt(hs[t - 1], w_hh, epi=ops.EPI_BIAS, bias=b_hh, out=gh[t])
-            ops.gru_gates_fwd(gi[t], gh[t], hs[t - 1] if t else None, hnew=hs[t], gates=gates[t])
+            ops.gru_gates_fwd(gi[t], gh[t] if t else gh0, hs[t - 1] if t else None, hnew=hs[t], gates=gates[t])
         ctx.save_for_backward(x2, w_ih, w_hh, gates, gh, hs, b_ih, b_hh)
         return hs
 
@@ -699,19 +699,20 @@ class GRUSeqFn(torch.autograd.Function):
         dhs = dhs.contiguous()
         dgi, dgh = torch.empty_like(gh), torch.empty_like(gh)
         w_hh_t = ops.transposed(w_hh)
+        gh0 = b_hh.detach().view(1, -1)                                  # step 0's gh (see forward)
         if T > 1 and ops.gru_step_ok(B, H):
             # back through time, one launch per step: dh_{t-1} += dgh_t W_hh, then step t-1's gate backward on the finished rows;
             # the working copy of the upstream gradients also collects the direct path dh_t * z_t of every step
             work = dhs.clone()
             ops.gru_gates_bwd_into(work[T - 1], gates[T - 1], gh[T - 1], hs[T - 2], dgi[T - 1], dgh[T - 1], work[T - 2], accumulate=True)
             for t in range(T - 1, 0, -1):
-                ops.gru_step_bwd(dgh[t], w_hh_t, work[t - 1], gates[t - 1], gh[t - 1], hs[t - 2] if t > 1 else None, dgi[t - 1],
+                ops.gru_step_bwd(dgh[t], w_hh_t, work[t - 1], gates[t - 1], gh[t - 1] if t > 1 else gh0, hs[t - 2] if t > 1 else None, dgi[t - 1],
                                  dgh[t - 1], work[t - 2] if t > 1 else None, accumulate=True)
         else:
             carry = None
             for t in range(T - 1, -1, -1):
                 dh = dhs[t] if carry is None else dhs[t] + carry
-                _, _, dhp = ops.gru_gates_bwd(dh, gates[t], gh[t], hs[t - 1] if t else None, dgi=dgi[t], dgh=dgh[t])
+                _, _, dhp = ops.gru_gates_bwd(dh, gates[t], gh[t] if t else gh0, hs[t - 1] if t else None, dgi=dgi[t], dgh=dgh[t])
                 if t:
                     carry = ops.gemm_nt(dgh[t], w_hh_t, out=dhp, accumulate=True)
         dgi2, dgh2 = dgi.view(T * B, 3 * H), dgh.view(T * B, 3 * H)

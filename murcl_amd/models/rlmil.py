@@ -112,9 +112,28 @@ class Full_layer(nn.Module):
         xs = list(xs)
         n2, B = len(xs), xs[0].shape[0]
         x = _whole(xs) if n2 > 1 else xs[0]
+        r = self.rnn
+        if (not torch.is_grad_enabled() and xs[0].is_cuda and xs[0].dtype == torch.float32 and xs[0].dim() == 2 and n2 > 1
+                and len({tuple(t.shape) for t in xs}) == 1):
+            from .. import ops
+            H = r.weight_hh_l0.shape[1]
+            if ops.gru_step_ok(B, H, xs[0].shape[1]) and ops.gru_step_ok(B, H):
+                # nobody differentiates this pass (frozen-aggregator stage 2, validation): the same kernels in the same order, every
+                # hidden state written straight into the rows of ONE buffer - no concatenations, no saved gate tensors
+                if x is None:
+                    x = ops.stack_lists([xs])[0].view(n2 * B, -1)
+                wih, whh, bih, bhh = (t.detach() for t in (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0))
+                h_all = torch.empty((n2 * B, H), dtype=torch.float32, device=x.device)
+                ops.gru_step_fwd(bih, None, whh, bhh, hnew=h_all[:B], x=x[:B], w_ih=wih, want_backward=False)
+                gi = ops.gemm_nt(x[B:], wih, epi=ops.EPI_BIAS, bias=bih)
+                ops.gru_gates_fwd(gi[:B], bhh.view(1, -1), None, hnew=h_all[B:2 * B])
+                for t in range(1, n2 - 1):
+                    ops.gru_step_fwd(gi[t * B:(t + 1) * B], h_all[t * B:(t + 1) * B], whh, bhh, hnew=h_all[(t + 1) * B:(t + 2) * B],
+                                     want_backward=False)
+                self.hidden = h_all[-B:].unsqueeze(0)
+                return ops.gemm_nt(h_all, self.fc.weight.detach(), epi=ops.EPI_BIAS, bias=self.fc.bias.detach())
         if x is None:
             x = torch.cat(xs, 0)
-        r = self.rnn
         x = x.float()
         h00 = GRUStepFn.apply(x[:B], None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         hs = GRUSeqFn.apply(x[B:].view(n2 - 1, B, -1), r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
@@ -429,6 +448,7 @@ class _HipPolicyKernels:
     @staticmethod
     def sync_old(ppo):
         if ppo._old_flat is not None and ppo._old_flat.data_ptr() == ppo.policy_old._plist()[0].data_ptr():
-            ppo._old_flat.copy_(ppo.optimizer.groups[0]["p"])
+            from .. import ops
+            ops.copy_flat(ppo._old_flat, ppo.optimizer.groups[0]["p"])
         else:                                                      # someone re-seated policy_old's tensors (e.g. .to()): generic path
             ppo.policy_old.load_state_dict(ppo.policy.state_dict())

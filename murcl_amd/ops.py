@@ -1449,6 +1449,34 @@ def mul(x, k, out=None):
     return out
 
 
+def axpby(x, y, a, b):
+    """a x + b y for equally shaped contiguous f32 tensors, one launch (murcl_axpby)."""
+    _need_cuda(x, y)
+    assert x.shape == y.shape and x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().murcl_axpby(ptr(x), ptr(y), float(a), float(b), ptr(out), x.numel(), stream()), "axpby")
+    return out
+
+
+def mean_small(x):
+    """Mean of a small contiguous f32 tensor -> a 0-dim tensor, one launch in a fixed order (murcl_mean_small); not differentiable."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(_lib.lib().murcl_mean_small(ptr(x), x.numel(), ptr(out), stream()), "mean_small")
+    return out
+
+
+def copy_flat(dst, src):
+    """dst <- src for two equally long contiguous buffers with 16-byte aligned bases (flat parameter buffers) as ONE launch of this
+    library (murcl_copy_bytes; no runtime blit in the step's launch sequence); anything else goes through ``copy_``."""
+    if (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype and src.numel() == dst.numel()
+            and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+        check(_lib.lib().murcl_copy_bytes(ptr(src), ptr(dst), src.numel() * src.element_size(), stream()), "copy_bytes")
+        return dst
+    return dst.copy_(src)
+
+
 # ------------------------------------------------------------------------------------------ PPO (K10/K11)
 def policy_head_fwd(z, std, eps=None, actions=None):
     """z [R,K] -> (mu [R,K], action [R,K], logp [R]); sample with eps or evaluate given actions."""

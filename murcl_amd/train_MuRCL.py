@@ -187,7 +187,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
             if world == 1 and 2 * B <= 128:
                 loss_t, sims = criterion.forward_steps(z_all.view(args.T, 2 * B, -1))        # :249,277: one launch
                 loss_vec, losses = loss_t, list(loss_t.unbind(0))
-                rewards = list((sims[:-1] - sims[1:]).unsqueeze(1).unbind(0))                # :282-283
+                rewards = list(ops.axpby(sims[:-1], sims[1:], 1.0, -1.0).unsqueeze(1).unbind(0))   # :282-283, all steps in one launch
                 for m in memory_list:
                     m.rewards.extend(rewards)
             for t in range(args.T if not losses else 0):
@@ -204,7 +204,10 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                         m.rewards.append(reward)
                 sim_last = sim
     # :291 - the mean of the [T] loss vector is one launch (and one in the backward); sum(list) / T was T + 1 (and T + 1 back)
-    loss = loss_vec.mean() if loss_vec is not None else sum(losses) / args.T
+    if loss_vec is not None and not loss_vec.requires_grad and loss_vec.is_cuda:
+        loss = ops.mean_small(loss_vec)                       # (stage 2: nothing differentiates it)
+    else:
+        loss = loss_vec.mean() if loss_vec is not None else sum(losses) / args.T
     enc.session = None
     if train_enc:
         optimizer.zero_grad()
@@ -255,7 +258,7 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
         with functional.deferred_wgrads():
             loss.backward(ops.unit_grad(loss))
         optimizer.step()                                                                      # :293-295
-        return loss.detach(), list(loss_t.detach().unbind(0)), list((sims[:-1] - sims[1:]).unsqueeze(1).unbind(0))   # :282-283
+        return loss.detach(), list(loss_t.detach().unbind(0)), list(ops.axpby(sims[:-1], sims[1:], 1.0, -1.0).unsqueeze(1).unbind(0))   # :282-283
     for t in range(T_):
         z = (z_all[t, 0], z_all[t, 1]) if z_all is not None else fc.forward_views(outputs[2 * t:2 * t + 2], restart=(t == 0))
         if world > 1:

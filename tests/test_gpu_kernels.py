@@ -1546,3 +1546,28 @@ def test_softmax_rows_parts_equals_colsum_then_softmax(B, N, P):
     assert torch.equal(s2, s) and torch.equal(A2, A) and float(Mz.abs().max()) == 0.0
     got = ops.weighted_rowsum(X, A2.view(B, N, 1), into=Mz).view(B, 64)
     _close(got, torch.einsum("bn,bnd->bd", A2.double().cpu(), X.double().cpu()), 1e-5, 1e-6, "pooled rows")
+
+
+def test_axpby_mean_small_and_copy_flat():
+    """The bag-level odds and ends of the training step as own launches (round 6: no ATen kernel left in the stage-2 step):
+    rewards = cos(t-1) - cos(t) (train_MuRCL.py:282-283), the mean of the T step losses (:291), the flat copy policy -> policy_old
+    (rlmil.py:183) - against torch."""
+    from murcl_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    sims = torch.randn((6, 64), generator=g, device=dev)
+    r = ops.axpby(sims[:-1], sims[1:], 1.0, -1.0)
+    assert torch.equal(r, sims[:-1] - sims[1:])
+    np.testing.assert_allclose(ops.axpby(sims, sims, 0.25, 0.5).cpu().numpy(), (0.75 * sims).cpu().numpy(), rtol=1e-6)
+    for n in (1, 6, 255, 256, 1000):
+        x = torch.randn((n,), generator=g, device=dev)
+        m = ops.mean_small(x)
+        assert m.shape == () and abs(m.item() - x.double().mean().item()) <= 1e-6 * max(1.0, x.abs().max().item())
+    for n in (3_681_291, 4, 3, 1_048_576):                                         # (the sampler's 3,681,291 parameters: a 12-byte tail)
+        src = torch.randn((n,), generator=g, device=dev)
+        dst = torch.zeros((n + 8,), device=dev)
+        assert ops.copy_flat(dst[:n], src).data_ptr() == dst.data_ptr() and torch.equal(dst[:n], src) and (dst[n:] == 0).all()
+    odd_s, odd_d = src[1:1000], torch.zeros((999,), device=dev)                     # a base that is not 16-byte aligned: the generic path
+    ops.copy_flat(odd_d, odd_s)
+    assert torch.equal(odd_d, odd_s)

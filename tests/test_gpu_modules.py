@@ -356,6 +356,35 @@ def test_full_layer_forward_views_on_row_blocks_of_one_tensor():
         np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=2e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-7, err_msg=k)
 
 
+def test_full_layer_view_sequence_without_grad_equals_the_per_step_loop_and_the_grad_path():
+    """forward_view_sequence over T = 4 patch steps x 2 views: under no_grad (frozen-aggregator stage 2: one own stacking launch, every
+    hidden state written into one buffer, no saved gate tensors) == the reference's loop `[fc(x, restart=(t == 0)) for x in views]`
+    step by step (train_MuRCL.py:243,272, shared hidden state included) == the autograd path, for separately allocated inputs and for
+    row blocks of one tensor; the hidden state ends the same."""
+    from murcl_amd.models.rlmil import Full_layer
+    dev = _dev()
+    fc = Full_layer(512, 1024, True, 128)
+    fc.load_state_dict(P.to_torch(P.full_layer(985)))
+    fc = fc.to(dev)
+    Tn, B = 4, 8
+    xs = [T(detrand.normal(33, f"fvs.x.{i}", (B, 512))).to(dev) for i in range(2 * Tn)]
+    with torch.no_grad():
+        loop = torch.cat([torch.cat(fc.forward_views(xs[2 * t:2 * t + 2], restart=(t == 0)), 0) for t in range(Tn)], 0)
+        h_loop = fc.hidden.clone()
+        fast = fc.forward_view_sequence(xs)
+        h_fast = fc.hidden.clone()
+        whole = torch.cat(xs, 0)
+        fast_blocks = fc.forward_view_sequence(list(whole.split(B, 0)))
+    grad = fc.forward_view_sequence([x.clone().requires_grad_() for x in xs])
+    h_grad = fc.hidden.detach().clone()
+    assert fast.shape == (2 * Tn * B, 128) and not fast.requires_grad and grad.requires_grad
+    np.testing.assert_allclose(fast.cpu().numpy(), loop.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(fast, fast_blocks)
+    np.testing.assert_allclose(fast.cpu().numpy(), grad.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(h_fast.cpu().numpy(), h_loop.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(h_fast.cpu().numpy(), h_grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
 def test_flat_adam_refreshes_cached_weight_views_in_its_step():
     """Transposed f32 / compute-dtype views of optimizer-owned weights are rebuilt by FlatAdam.step (one launch for all
     of them); views of another optimizer's weights stay valid and untouched."""
