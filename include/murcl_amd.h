@@ -484,7 +484,8 @@ int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, flo
 int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                           int zero_grad, int* replays_dev, murcl_stream_t stream);
 /* out = a x + b y over n floats: the rewards of a contrastive step, cosine of patch step t-1 minus that of step t
- * (train_MuRCL.py:282-283), for all T-1 steps in one launch. */
+ * (train_MuRCL.py:282-283), for all T-1 steps in one launch; b == 0: out = a x, y is not read (the 1/T of the step loss's mean on
+ * the stored NT-Xent gradients, :291). */
 int murcl_axpby(const float* x, const float* y, float a, float b, float* out, long n, murcl_stream_t stream);
 /* out[0] = mean of n floats in a fixed order (one workgroup): the step loss, mean of the T patch-step losses (train_MuRCL.py:291),
  * where nothing differentiates it (frozen-aggregator stage 2). */

@@ -572,6 +572,10 @@ extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, 
 // ---------------------------------------------------------------- bag-level odds and ends of the training step
 // out = a x + b y over n floats (the rewards of a contrastive step: cosine of step t-1 minus cosine of step t, train_MuRCL.py:282-283)
 __global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out, long n) {
+    if (b == 0.f) {                          // a plain scaling: y is not read (0 * inf would turn an overflow into a NaN)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a * x[i];
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a * x[i] + b * y[i];
 }
 extern "C" int murcl_axpby(const float* x, const float* y, float a, float b, float* out, long n, hipStream_t s) {

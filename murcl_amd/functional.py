@@ -612,12 +612,51 @@ class ABMILStepFn(torch.autograd.Function):
         if all(g is None for g in s.dout[:n]):
             return (None,) * 14
         like = next(g for g in s.dout[:n] if g is not None)
-        dout_all = torch.cat([g.contiguous() if g is not None else torch.zeros_like(like) for g in s.dout[:n]], 0)
+        from .utils.views import adjacent as _adjacent, as_one as _as_one       # (module level would be a circular import)
+        douts = [g if g is not None else torch.zeros_like(like) for g in s.dout[:n]]
+        if all(g is not None for g in s.dout[:n]) and _adjacent(douts):
+            dout_all = _as_one(douts)                                                # row blocks of one gradient (SessionOutFn): a re-view
+        else:
+            dout_all = torch.cat([g.contiguous() for g in douts], 0)
         (w1, w2, w3, wa, ba, wb, wd, wac, b1, b2, b3, bb, bd, wat, w3t, w2t) = s.weights
         R, Bt = n * s.bags * s.N, n * s.bags
         saved = (s.x.view(-1, s.d)[:R], s.h1[:R], s.h2[:R], s.h3[:R], s.scores[:Bt], None, s.M[:Bt], s.ml[:Bt], s.out[:Bt],
                  w1, w2, w3, wa, ba, wb, wd, wac, s.m1[:R], s.m2[:R], s.m3[:R], b1, b2, b3, bb, bd, wat, w3t, w2t)
         return ABMILFn._backward_default(saved, (Bt, s.N, s.d), dout_all, False) + (None,)
+
+
+class SessionOutFn(torch.autograd.Function):
+    """The aggregator outputs of all patch steps of an ``EncoderSession`` as ONE tensor [steps * bags, L] without a copy: the steps
+    wrote them into consecutive row blocks of ``session.out``, so the forward is a view of that buffer and the backward hands every
+    step the row block of the ONE upstream gradient that belongs to it (views again: ``ABMILStepFn.backward`` then finds its T
+    upstream gradients adjacent in one buffer).  Replaces a concatenation of 2T tensors in the forward pass and, in the backward pass,
+    T concatenations of the two views' gradients plus one of the T steps' (stage 3 of train_MuRCL.py: 8 ATen launches)."""
+
+    @staticmethod
+    def forward(ctx, session, *hs):
+        ctx.n, ctx.rows = len(hs), session.bags
+        ctx.set_materialize_grads(False)
+        return session.out[:len(hs) * session.bags].view(len(hs) * session.bags, -1)
+
+    @staticmethod
+    def backward(ctx, d):
+        if d is None:
+            return (None,) * (1 + ctx.n)
+        d = d.contiguous()
+        return (None,) + tuple(d[t * ctx.rows:(t + 1) * ctx.rows] for t in range(ctx.n))
+
+
+def session_whole(session, hs):
+    """``hs`` = the per-step aggregator outputs [bags, L] of ``session`` in step order -> the [steps * bags, L] tensor that equals
+    ``torch.cat(hs)`` (a view of the session's buffer, differentiable), or None when they are not the session's row blocks."""
+    if session is None or not hs or len(hs) > session.steps:
+        return None
+    row = session.out.shape[1] * session.out.element_size()
+    for t, h in enumerate(hs):
+        if not (torch.is_tensor(h) and h.dtype == session.out.dtype and tuple(h.shape) == (session.bags, session.out.shape[1])
+                and h.is_contiguous() and h.data_ptr() == session.out.data_ptr() + t * session.bags * row):
+            return None
+    return SessionOutFn.apply(session, *hs)
 
 
 class GRUStepFn(torch.autograd.Function):
@@ -728,24 +767,85 @@ class GRUSeqFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, _bgrad(dgi2, b_ih), _bgrad(dgh2, b_hh)
 
 
+class GRUViewSeqFn(torch.autograd.Function):
+    """The recurrent head over the n = 2T aggregator outputs of a contrastive step as ONE node (Full_layer.forward_view_sequence;
+    train_MuRCL.py:243,272 with the reference's one shared hidden state): x [n*B, F] = the blocks x_00, x_01, x_10, x_11, ... of B rows;
+    blocks 0 and 1 start from the zero state (``restart`` at patch step 0), block k >= 2 continues from block k-1 -> every hidden
+    state [n*B, H] in one buffer.  The input projection, the input gradient and each weight / bias gradient are ONE launch over all
+    n*B rows; no slice of x enters the graph (slicing x into a single step and a sequence cost two zero-fills, two copies and an
+    add in the backward pass, and a concatenation of the two results in the forward pass).  Needs n >= 3 and the one-launch step
+    kernels (``ops.gru_step_ok``)."""
+
+    @staticmethod
+    def forward(ctx, x, B, w_ih, w_hh, b_ih, b_hh):
+        x2 = x.contiguous()
+        R, H = x2.shape[0], w_hh.shape[1]
+        n = R // B
+        assert R == n * B and n >= 3 and ops.gru_step_ok(B, H)
+        gi = ops.gemm_nt(x2, w_ih, epi=ops.EPI_BIAS, bias=b_ih)                      # [R, 3H]
+        gh = torch.empty((R, 3 * H), dtype=torch.float32, device=x.device)          # (blocks 0 and 1 stay unwritten: they read the bias row)
+        gates = torch.empty_like(gh)
+        hs = torch.empty((R, H), dtype=torch.float32, device=x.device)
+        whh, bhh = w_hh.detach(), b_hh.detach()
+        ops.gru_gates_fwd(gi[:2 * B], bhh.view(1, -1), None, hnew=hs[:2 * B], gates=gates[:2 * B])     # both zero-state blocks: one launch
+        for k in range(2, n):
+            lo, hi = k * B, (k + 1) * B
+            ops.gru_step_fwd(gi[lo:hi], hs[lo - B:lo], whh, bhh, hnew=hs[lo:hi], gates=gates[lo:hi], gh=gh[lo:hi])
+        ctx.save_for_backward(x2, w_ih, w_hh, gates, gh, hs, b_ih, b_hh)
+        ctx.B = B
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        x2, w_ih, w_hh, gates, gh, hs, b_ih, b_hh = ctx.saved_tensors
+        B = ctx.B
+        R, H = hs.shape
+        n = R // B
+        blk = lambda t, k: t[k * B:(k + 1) * B]                                       # noqa: E731
+        dgi, dgh = torch.empty_like(gh), torch.empty_like(gh)
+        w_hh_t = ops.transposed(w_hh)
+        gh0 = b_hh.detach().view(1, -1)
+        # back through time on a working copy of the upstream gradients (it collects dh_t * z_t and dgh_{t+1} W_hh of every step)
+        work = ops.copy_flat(torch.empty((R, H), dtype=torch.float32, device=hs.device), dhs.contiguous())
+        ops.gru_gates_bwd_into(blk(work, n - 1), blk(gates, n - 1), blk(gh, n - 1), blk(hs, n - 2), blk(dgi, n - 1), blk(dgh, n - 1),
+                               blk(work, n - 2), accumulate=True)
+        for k in range(n - 1, 1, -1):             # block k's dgh is complete: dh_{k-1} += dgh_k W_hh, then block k-1's gate backward
+            first = k - 1 == 1                    # block 1 started from the zero state: bias row, no previous state to pass a gradient to
+            ops.gru_step_bwd(blk(dgh, k), w_hh_t, blk(work, k - 1), blk(gates, k - 1), gh0 if first else blk(gh, k - 1),
+                             None if first else blk(hs, k - 2), blk(dgi, k - 1), blk(dgh, k - 1), None if first else blk(work, k - 2),
+                             accumulate=True)
+        ops.gru_gates_bwd_into(blk(work, 0), blk(gates, 0), gh0, None, blk(dgi, 0), blk(dgh, 0))      # block 0: a single step beside the chain
+        dx = ops.gemm_nt(dgi, ops.transposed(w_ih)) if ctx.needs_input_grad[0] else None
+        dw_ih, db_ih = _wbgrad(dgi, x2, w_ih, b_ih)
+        dw_hh = _wgrad(dgh[2 * B:], hs[B:R - B], w_hh)                                 # blocks k >= 2 against the state of block k-1
+        return dx, None, dw_ih, dw_hh, db_ih, _bgrad(dgh, b_hh)
+
+
 class NTXentSeqFn(torch.autograd.Function):
     """NT_Xent of T independent (view 0, view 1) batches at once: z [T,2B,P] -> (loss [T], cos(z_i, z_j) [T,B]); one launch
     computes all losses, gradients and cosines (the T patch steps of a pre-training step, train_MuRCL.py:249,277)."""
 
     @staticmethod
     def forward(ctx, z, temperature):
+        """-> (loss [T], sim [T,B], mean of the T losses): the step loss of train_MuRCL.py:291 comes out of this node as its own
+        launch (``ops.mean_small``), so that its gradient - 1/T on every step - is ONE scaling of the stored dz instead of a mean
+        node's reduce, expand and multiply."""
         loss, dz, sim = ops.ntxent_batched(z, temperature, want_grad=True)
         ctx.save_for_backward(dz)
         ctx.mark_non_differentiable(sim)
         ctx.set_materialize_grads(False)
-        return loss, sim
+        return loss, sim, ops.mean_small(loss)
 
     @staticmethod
-    def backward(ctx, dloss, _dsim):
+    def backward(ctx, dloss, _dsim, dmean):
         (dz,) = ctx.saved_tensors
-        if dloss is None:
+        if dloss is None and dmean is None:
             return None, None
-        return dz * dloss.view(-1, 1, 1), None
+        T_ = dz.shape[0]
+        if dloss is None and ops.is_unit_grad(dmean):
+            return ops.axpby(dz, dz, 1.0 / T_, 0.0), None                                # (b = 0: y is not read)
+        w = dloss if dmean is None else (dmean / T_).expand(T_) if dloss is None else dloss + dmean / T_
+        return dz * w.reshape(-1, 1, 1), None
 
 
 class NTXentFn(torch.autograd.Function):

@@ -15,13 +15,16 @@ class CL(nn.Module):
         self.encoder = encoder
         self.projection_dim = projection_dim      # stored, unused - as in the reference (cl.py:5-10)
         self.n_features = n_features
+        self.last_whole = None                    # the latest call's views as one tensor [V*B, F] (batched path), else None
 
     def forward(self, x_views):
         assert isinstance(x_views, list), "CL expects a list of views"
         same = all(isinstance(v, torch.Tensor) and v.shape == x_views[0].shape for v in x_views)
+        self.last_whole = None
         if same and x_views[0].dim() == 3:
             h = self.encoder(as_one(x_views))[0]
             h_views = list(h.split(x_views[0].shape[0], 0))
+            self.last_whole = h                      # the views' rows as ONE tensor (a consumer of all of them needs no concatenation)
         else:
             h_views = [self.encoder(v)[0] for v in x_views]
         return h_views, [h.detach() for h in h_views]

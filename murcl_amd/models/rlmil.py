@@ -99,7 +99,7 @@ class Full_layer(nn.Module):
         self.hidden = hs[-1].unsqueeze(0)
         return LinearFn.apply(hs.reshape(x.shape[0] * x.shape[1], -1), self.fc.weight, self.fc.bias, False)
 
-    def forward_view_sequence(self, xs):
+    def forward_view_sequence(self, xs, whole=None):
         """The head over ALL patch steps of a contrastive step: ``xs`` = the aggregator outputs [x_t0, x_t1 for t in range(T)]
         (2T tensors [B,F]) -> z [2T*B, class_num] in the same order, as if
         ``forward_views([x_t0, x_t1], restart=(t == 0))`` had been called step by step (train_MuRCL.py:243,272).  With the one
@@ -111,30 +111,38 @@ class Full_layer(nn.Module):
         from ..functional import GRUSeqFn
         xs = list(xs)
         n2, B = len(xs), xs[0].shape[0]
-        x = _whole(xs) if n2 > 1 else xs[0]
+        x = whole if whole is not None else (_whole(xs) if n2 > 1 else xs[0])        # ``whole``: torch.cat(xs, 0), already in one tensor
+        assert whole is None or (whole.dim() == 2 and whole.shape[0] == n2 * B)
         r = self.rnn
         if (not torch.is_grad_enabled() and xs[0].is_cuda and xs[0].dtype == torch.float32 and xs[0].dim() == 2 and n2 > 1
                 and len({tuple(t.shape) for t in xs}) == 1):
             from .. import ops
             H = r.weight_hh_l0.shape[1]
-            if ops.gru_step_ok(B, H, xs[0].shape[1]) and ops.gru_step_ok(B, H):
-                # nobody differentiates this pass (frozen-aggregator stage 2, validation): the same kernels in the same order, every
-                # hidden state written straight into the rows of ONE buffer - no concatenations, no saved gate tensors
+            if ops.gru_step_ok(B, H) and n2 >= 3:
+                # nobody differentiates this pass (frozen-aggregator stage 2, validation): the launches of GRUViewSeqFn.forward without
+                # the tensors its backward pass would need - one stacking launch, one input product over all rows, every hidden state
+                # written straight into the rows of ONE buffer
                 if x is None:
                     x = ops.stack_lists([xs])[0].view(n2 * B, -1)
                 wih, whh, bih, bhh = (t.detach() for t in (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0))
                 h_all = torch.empty((n2 * B, H), dtype=torch.float32, device=x.device)
-                ops.gru_step_fwd(bih, None, whh, bhh, hnew=h_all[:B], x=x[:B], w_ih=wih, want_backward=False)
-                gi = ops.gemm_nt(x[B:], wih, epi=ops.EPI_BIAS, bias=bih)
-                ops.gru_gates_fwd(gi[:B], bhh.view(1, -1), None, hnew=h_all[B:2 * B])
-                for t in range(1, n2 - 1):
-                    ops.gru_step_fwd(gi[t * B:(t + 1) * B], h_all[t * B:(t + 1) * B], whh, bhh, hnew=h_all[(t + 1) * B:(t + 2) * B],
+                gi = ops.gemm_nt(x, wih, epi=ops.EPI_BIAS, bias=bih)
+                ops.gru_gates_fwd(gi[:2 * B], bhh.view(1, -1), None, hnew=h_all[:2 * B])          # blocks 0 and 1: from the zero state
+                for k in range(2, n2):
+                    ops.gru_step_fwd(gi[k * B:(k + 1) * B], h_all[(k - 1) * B:k * B], whh, bhh, hnew=h_all[k * B:(k + 1) * B],
                                      want_backward=False)
                 self.hidden = h_all[-B:].unsqueeze(0)
                 return ops.gemm_nt(h_all, self.fc.weight.detach(), epi=ops.EPI_BIAS, bias=self.fc.bias.detach())
         if x is None:
             x = torch.cat(xs, 0)
         x = x.float()
+        if n2 >= 3 and x.is_cuda and x.dim() == 2:
+            from .. import ops
+            from ..functional import GRUViewSeqFn
+            if ops.gru_step_ok(B, r.weight_hh_l0.shape[1]):
+                h_all = GRUViewSeqFn.apply(x, B, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)      # one node, one buffer
+                self.hidden = h_all[-B:].unsqueeze(0)
+                return LinearFn.apply(h_all, self.fc.weight, self.fc.bias, False)
         h00 = GRUStepFn.apply(x[:B], None, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         hs = GRUSeqFn.apply(x[B:].view(n2 - 1, B, -1), r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
         self.hidden = hs[-1].unsqueeze(0)

@@ -128,8 +128,8 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
     train_enc = args.train_stage != 2
     if args.train_stage == 1 and args.T > 1 and not getattr(args, "no_batched_stage1", False):
         return _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer, pack, injected, world, local)
-    losses, rewards, sim_last, states, loss_vec = [], [], None, None, None
-    late_head, agg_outs = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), []
+    losses, rewards, sim_last, states, loss_vec, loss_mean = [], [], None, None, None, None
+    late_head, agg_outs, agg_whole = _BATCHED_HEAD and getattr(fc, "fc_rnn", False), [], []
     # stage 3: the T aggregator passes stay sequential (the sampler needs step t's states for step t+1's windows) but share ONE
     # backward over all T * 2B bags (functional.EncoderSession); ABMIL's default shape in bf16 only
     enc, session = model.encoder, None
@@ -167,6 +167,7 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                 # the sampler picks the next windows from the aggregator's states; what the head and the loss produce (the
                 # loss itself, the rewards) is needed after the last patch step only: they run once, below
                 agg_outs += list(outputs)
+                agg_whole.append(getattr(model, "last_whole", None))
                 continue
             outputs = fc.forward_views(outputs, restart=(t == 0))                            # :243,272
             if world > 1:
@@ -183,10 +184,12 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
         sim_last = sim
     if late_head:
         with torch.set_grad_enabled(train_enc):
-            z_all = fc.forward_view_sequence(agg_outs).view(args.T, 2, B, -1)                # :243,272 for every step at once
+            # (a training session keeps every step's aggregator output in one buffer: the head reads that buffer, no concatenation)
+            x_whole = functional.session_whole(session, agg_whole) if session is not None and all(h is not None for h in agg_whole) else None
+            z_all = fc.forward_view_sequence(agg_outs, whole=x_whole).view(args.T, 2, B, -1)   # :243,272 for every step at once
             if world == 1 and 2 * B <= 128:
                 loss_t, sims = criterion.forward_steps(z_all.view(args.T, 2 * B, -1))        # :249,277: one launch
-                loss_vec, losses = loss_t, list(loss_t.unbind(0))
+                loss_vec, losses, loss_mean = loss_t, list(loss_t.unbind(0)), criterion.last_mean
                 rewards = list(ops.axpby(sims[:-1], sims[1:], 1.0, -1.0).unsqueeze(1).unbind(0))   # :282-283, all steps in one launch
                 for m in memory_list:
                     m.rewards.extend(rewards)
@@ -204,11 +207,15 @@ def pretrain_step(args, model, fc, ppo, criterion, optimizer, pack, memory_list,
                         m.rewards.append(reward)
                 sim_last = sim
     # :291 - the mean of the [T] loss vector is one launch (and one in the backward); sum(list) / T was T + 1 (and T + 1 back)
-    if loss_vec is not None and not loss_vec.requires_grad and loss_vec.is_cuda:
+    if loss_vec is not None and loss_mean is not None:
+        loss = loss_mean                                      # (the mean came out of the NT-Xent node: no mean node in the graph)
+    elif loss_vec is not None and not loss_vec.requires_grad and loss_vec.is_cuda:
         loss = ops.mean_small(loss_vec)                       # (stage 2: nothing differentiates it)
     else:
         loss = loss_vec.mean() if loss_vec is not None else sum(losses) / args.T
     enc.session = None
+    if hasattr(model, "last_whole"):
+        model.last_whole = None                               # (do not keep the last patch step's graph alive past the step)
     if train_enc:
         optimizer.zero_grad()
         with functional.deferred_wgrads():          # the head's T weight gradients per parameter as one product each
@@ -253,7 +260,7 @@ def _pretrain_step_all_patch_steps_at_once(args, model, fc, criterion, optimizer
     z_all = fc.forward_view_sequence(outputs).view(T_, 2, B, -1) if _BATCHED_HEAD and fc.fc_rnn else None   # :243,272, all steps
     if z_all is not None and world == 1 and 2 * B <= 128:
         loss_t, sims = criterion.forward_steps(z_all.view(T_, 2 * B, -1))                     # :249,277 for all steps: one launch
-        loss = loss_t.mean()                                                                  # :291
+        loss = criterion.last_mean if criterion.last_mean is not None else loss_t.mean()      # :291 (an output of the NT-Xent node)
         optimizer.zero_grad()
         with functional.deferred_wgrads():
             loss.backward(ops.unit_grad(loss))

@@ -19,6 +19,7 @@ class NT_Xent(nn.Module):
         self.temperature = temperature
         self._shard = None
         self.last_similarity = None          # cos(z_i[b], z_j[b]) of the latest call (K9)
+        self.last_mean = None                # forward_steps under grad: the mean of the T step losses, differentiable
 
     def set_shard(self, lo, hi):
         self._shard = (int(lo), int(hi))
@@ -35,8 +36,9 @@ class NT_Xent(nn.Module):
         if not torch.is_grad_enabled() or not z.requires_grad:
             from .. import ops
             loss, _, sim = ops.ntxent_batched(z, float(self.temperature), want_grad=False)
+            self.last_mean = None
         else:
-            loss, sim = NTXentSeqFn.apply(z, float(self.temperature))
+            loss, sim, self.last_mean = NTXentSeqFn.apply(z, float(self.temperature))     # last_mean: loss.mean() as an output of the node
         self.last_similarity = sim[-1]
         return loss, sim
 

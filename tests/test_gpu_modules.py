@@ -385,6 +385,56 @@ def test_full_layer_view_sequence_without_grad_equals_the_per_step_loop_and_the_
     np.testing.assert_allclose(h_fast.cpu().numpy(), h_grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("whole", [True, False])
+def test_full_layer_view_sequence_node_equals_the_per_step_loop_with_gradients(whole):
+    """forward_view_sequence under grad = ONE recurrent node over the 2T blocks (functional.GRUViewSeqFn: one input product, one input
+    gradient, one weight / bias gradient launch each over all rows; blocks 0 and 1 from the zero state): outputs, the gradient that
+    reaches every aggregator output and every parameter gradient equal the reference's per-step loop
+    `[fc(x, restart=(t == 0)) for x in views]` (train_MuRCL.py:243,272), for row blocks of one tensor and for separate tensors; the step
+    loss mean that comes out of the NT-Xent node back-propagates like `.mean()`."""
+    from murcl_amd.models.rlmil import Full_layer
+    from murcl_amd.utils.losses import NT_Xent
+    from murcl_amd import ops
+    dev = _dev()
+    Tn, B = 3, 8
+    x0 = T(detrand.normal(34, "fvn.x", (2 * Tn * B, 512))).to(dev)
+
+    def run(seq):
+        fc = Full_layer(512, 1024, True, 128)
+        fc.load_state_dict(P.to_torch(P.full_layer(985)))
+        fc = fc.to(dev)
+        crit = NT_Xent(B, 1.0)
+        if whole:
+            leaf = x0.clone().requires_grad_()
+            xs = list((leaf * 1.0).split(B, 0))
+        else:
+            leafs = [x0[i * B:(i + 1) * B].clone().requires_grad_() for i in range(2 * Tn)]
+            xs = [l * 1.0 for l in leafs]
+        if seq:
+            z = fc.forward_view_sequence(xs).view(Tn, 2 * B, -1)
+            loss_t, _ = crit.forward_steps(z)
+            loss = crit.last_mean
+            assert loss is not None and loss.requires_grad
+            np.testing.assert_allclose(loss.item(), loss_t.mean().item(), rtol=1e-6)
+            loss.backward(ops.unit_grad(loss))
+        else:
+            zs = [fc(x, restart=(i < 2)) for i, x in enumerate(xs)]
+            z = torch.cat(zs, 0).view(Tn, 2 * B, -1)
+            loss_t = torch.stack([crit(z[t, :B], z[t, B:]) for t in range(Tn)])
+            loss_t.mean().backward()
+        dx = leaf.grad if whole else torch.cat([l.grad for l in leafs], 0)
+        return z.detach().cpu(), loss_t.detach().cpu(), fc.hidden.detach().cpu(), dx.cpu(), {k: v.grad.cpu() for k, v in fc.named_parameters()}
+
+    za, la, ha, da, ga = run(True)
+    zb, lb, hb, db, gb = run(False)
+    np.testing.assert_allclose(za.numpy(), zb.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(la.numpy(), lb.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ha.numpy(), hb.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(da.numpy(), db.numpy(), rtol=2e-4, atol=1e-5 * float(db.abs().max()))
+    for k in ga:
+        np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=2e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-9, err_msg=k)
+
+
 def test_flat_adam_refreshes_cached_weight_views_in_its_step():
     """Transposed f32 / compute-dtype views of optimizer-owned weights are rebuilt by FlatAdam.step (one launch for all
     of them); views of another optimizer's weights stay valid and untouched."""
