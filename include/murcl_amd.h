@@ -493,6 +493,12 @@ int murcl_mean_small(const float* x, int n, float* out, murcl_stream_t stream);
 /* dst <- src (both 16-byte aligned, any byte count): `policy_old.load_state_dict(policy.state_dict())` after a PPO update
  * (models/rlmil.py:183) on the two flat parameter buffers, as a launch of this library.  -1: a pointer is not 16-byte aligned. */
 int murcl_copy_bytes(const void* src, void* dst, long bytes, murcl_stream_t stream);
+/* C[M,N] (+)= A[M,K] B[N,K]^T, f32, K <= 16: the input gradient dX = dY W of a classifier head with a handful of outputs
+ * (train_RLMIL.py:316,502,709: nn.Linear(hidden, num_classes)) without zero-padding k to the matrix-core kernels' step.  -1: K > 16. */
+int murcl_gemm_nt_smallk(const float* A, const float* B, float* C, int M, int N, int K, int accumulate, murcl_stream_t stream);
+/* dst[R,Cp] = [src[R,C] | 0] (elem_size 2 or 4): the zero-padded operand of a product whose extent is not a multiple of the kernels'
+ * step, one launch instead of a fill and a strided copy. */
+int murcl_pad_cols(const void* src, void* dst, long R, int C, int Cp, int elem_size, murcl_stream_t stream);
 /* torch.optim.SGD.step for one flat tensor (train_MuRCL.py:158-163, train_RLMIL.py:258-263): L2 weight decay, momentum
  * buffer (first != 0: the buffer is initialised with the gradient), dampening 0, optional Nesterov. */
 int murcl_sgd_step(float* p, float* g, float* buf, long n, float lr, float momentum, int nesterov, float weight_decay,

@@ -84,6 +84,8 @@ SIGNATURES = {
     "murcl_axpby": [_P, _P, _F, _F, _P, _L, _P],
     "murcl_mean_small": [_P, _I, _P, _P],
     "murcl_copy_bytes": [_P, _P, _L, _P],
+    "murcl_gemm_nt_smallk": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "murcl_pad_cols": [_P, _P, _L, _I, _I, _I, _P],
     "murcl_policy_head_fwd": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "murcl_policy_head_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
     "murcl_ppo_returns": [_P, _F, _I, _I, _P, _P],

@@ -631,6 +631,47 @@ extern "C" int murcl_copy_bytes(const void* src, void* dst, long bytes, hipStrea
     return MURCL_CHECK_LAUNCH();
 }
 
+// C[M,N] (+)= A[M,K] B[N,K]^T for a handful of k (K <= 16, f32): the input gradient of a classifier with two or ten outputs
+// (dX = dY W, K = the class count; train_RLMIL.py's heads) as one small launch - the matrix-core GEMMs step k by 32 and would need
+// both operands zero-padded to 32 columns first (two fills and two copies per call)
+__global__ __launch_bounds__(256) void smallk_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                        int M, int N, int K, int accumulate) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += A[(long)m * K + k] * B[(long)n * K + k];
+        C[i] = accumulate ? C[i] + acc : acc;
+    }
+}
+extern "C" int murcl_gemm_nt_smallk(const float* A, const float* B, float* C, int M, int N, int K, int accumulate, hipStream_t s) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || K > 16) return -1;
+    const long blocks = ((long)M * N + 255) / 256;
+    hipLaunchKernelGGL(smallk_nt_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, A, B, C, M, N, K, accumulate);
+    return MURCL_CHECK_LAUNCH();
+}
+// dst[R, Cp] = [src[R, C] | 0]: zero-padded columns in one launch (f32 / bf16 by element size) for the operands of products whose
+// inner or outer extent is not a multiple of what the matrix-core kernels step by
+__global__ __launch_bounds__(256) void pad_cols_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long R, int C,
+                                                       int Cp, int es) {
+    const long total = R * Cp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / Cp;
+        const int c = (int)(i % Cp);
+        if (es == 4) ((unsigned*)dst)[i] = c < C ? ((const unsigned*)src)[r * C + c] : 0u;
+        else ((unsigned short*)dst)[i] = c < C ? ((const unsigned short*)src)[r * C + c] : (unsigned short)0;
+    }
+}
+extern "C" int murcl_pad_cols(const void* src, void* dst, long R, int C, int Cp, int elem_size, hipStream_t s) {
+    if (R <= 0 || Cp <= 0) return 0;
+    if (C > Cp || (elem_size != 2 && elem_size != 4)) return -1;
+    const long blocks = (R * Cp + 255) / 256;
+    hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, (const unsigned char*)src,
+                       (unsigned char*)dst, R, C, Cp, elem_size);
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- SGD (torch.optim.SGD semantics: L2 decay, momentum
 // buffer initialised with the first gradient, dampening 0, optional Nesterov; train_MuRCL.py:158-163)
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, long n, float lr,

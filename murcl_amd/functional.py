@@ -742,7 +742,7 @@ class GRUSeqFn(torch.autograd.Function):
         if T > 1 and ops.gru_step_ok(B, H):
             # back through time, one launch per step: dh_{t-1} += dgh_t W_hh, then step t-1's gate backward on the finished rows;
             # the working copy of the upstream gradients also collects the direct path dh_t * z_t of every step
-            work = dhs.clone()
+            work = ops.copy_flat(torch.empty_like(dhs), dhs)
             ops.gru_gates_bwd_into(work[T - 1], gates[T - 1], gh[T - 1], hs[T - 2], dgi[T - 1], dgh[T - 1], work[T - 2], accumulate=True)
             for t in range(T - 1, 0, -1):
                 ops.gru_step_bwd(dgh[t], w_hh_t, work[t - 1], gates[t - 1], gh[t - 1] if t > 1 else gh0, hs[t - 2] if t > 1 else None, dgi[t - 1],
@@ -1383,6 +1383,33 @@ class GroupedCrossEntropyFn(torch.autograd.Function):
     def backward(ctx, g, _gconf=None):
         (dl,) = ctx.saved_tensors
         return dl * g.reshape(-1, 1).repeat_interleave(ctx.group, 0), None, None, None
+
+
+class StepCEMeanFn(torch.autograd.Function):
+    """The loss of a supervised RL-MIL step whose T x B head rows were computed together (train_RLMIL.py:316,502,709 per patch step,
+    their mean over the T steps as the step loss): logits [T*B, C], targets [T*B] -> (mean_t loss_t, loss_t [T], conf [T*B]) with
+    loss_t = nn.CrossEntropyLoss() of step t's B rows and conf the soft-max confidence of each row's true class (the rewards are its
+    differences between steps, :345,369-371).  One cross-entropy launch + one mean launch forward, ONE scaling of the stored
+    d(loss_t)/d(logits) backward; loss_t and conf are not differentiable (a sum / division node over loss_t, a repeat_interleave and a
+    multiply in the backward pass were ~10 ATen launches per step)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, group):
+        loss_t, dl, _, conf = ops.cross_entropy(logits.float().contiguous(), targets.to(torch.int64).contiguous(), int(group), want_conf=True)
+        ctx.save_for_backward(dl)
+        ctx.T = loss_t.numel()
+        ctx.mark_non_differentiable(loss_t, conf)
+        ctx.set_materialize_grads(False)
+        return ops.mean_small(loss_t), loss_t, conf
+
+    @staticmethod
+    def backward(ctx, g, _gl=None, _gc=None):
+        (dl,) = ctx.saved_tensors
+        if g is None:
+            return None, None, None
+        if ops.is_unit_grad(g):
+            return ops.axpby(dl, dl, 1.0 / ctx.T, 0.0), None, None
+        return dl * (g / ctx.T), None, None
 
 
 class CrossEntropyFn(torch.autograd.Function):

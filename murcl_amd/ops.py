@@ -112,11 +112,15 @@ def gemm_nt(A, B, *, epi=EPI_NONE, bias=None, mask=None, rowscale=None, rank1=No
     N = B.shape[0]
     assert B.shape[1] == K and A.dtype == B.dtype
     kq = 32 if A.dtype == torch.float32 else 64
-    if K % kq:                      # head layers with a handful of outputs (dgrad K = 1, 2, 10): zero-pad K
-        Kp = ((K + kq - 1) // kq) * kq
-        Ap, Bp = A.new_zeros((M, Kp)), B.new_zeros((N, Kp))
-        Ap[:, :K], Bp[:, :K] = A, B
-        A, B, K = Ap, Bp, Kp
+    if K % kq:                      # head layers with a handful of outputs (dgrad K = 1, 2, 10)
+        if (K <= 16 and A.dtype == torch.float32 and epi == EPI_NONE and mask is None and not colsum and not x3
+                and (out_dtype or A.dtype) == torch.float32):
+            C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)      # one small launch, no padding
+            assert C.is_contiguous() and C.dtype == torch.float32 and tuple(C.shape) == (M, N)
+            check(_lib.lib().murcl_gemm_nt_smallk(ptr(A), ptr(B), ptr(C), M, N, K, int(accumulate), stream()), "gemm_nt_smallk")
+            return C
+        Kp = ((K + kq - 1) // kq) * kq                                                   # zero-pad K: one launch per operand
+        A, B, K = pad_cols(A, Kp), pad_cols(B, Kp), Kp
     odt = out_dtype or A.dtype
     C = out if out is not None else torch.empty((M, N), dtype=odt, device=A.device)
     ws = torch.empty(((M + 127) // 128, N), dtype=torch.float32, device=A.device) if colsum else None
@@ -322,12 +326,14 @@ def gemm_tn(A, B, *, splits=0, out=None, colsum_into=None, colsum_parts=None, x3
     if colsum_parts is not None and (colsum_into is None or N1 % 4):
         raise ValueError("colsum_parts needs colsum_into and N1 % 4 == 0")
     if N1 % epc:                    # tiny head gradients (N1 = 1, 2, 10): zero-pad the columns of A, slice the result
-        Ap = A.new_zeros((M, ((N1 + epc - 1) // epc) * epc))
-        Ap[:, :N1] = A
-        res = gemm_tn(Ap, B, splits=splits)[:N1]
+        res = gemm_tn(pad_cols(A, ((N1 + epc - 1) // epc) * epc), B, splits=splits)[:N1]      # (the first N1 rows: contiguous)
         if colsum_into is not None:
             colsum(A, out=colsum_into, accumulate=True)
-        return out.add_(res) if out is not None else res.contiguous()
+        if out is None:
+            return res.contiguous()
+        if out.is_contiguous() and out.dtype == torch.float32:
+            return axpby(out, res, 1.0, 1.0, out=out)
+        return out.add_(res)
     if colsum_into is not None:
         assert colsum_into.dtype == torch.float32 and colsum_into.is_contiguous() and colsum_into.numel() == N1
     if (out is None and colsum_into is None and A.dtype == torch.float32 and M <= 512 and splits <= 0 and not x3 and _TN_SMALL_GROUP
@@ -1449,11 +1455,23 @@ def mul(x, k, out=None):
     return out
 
 
-def axpby(x, y, a, b):
-    """a x + b y for equally shaped contiguous f32 tensors, one launch (murcl_axpby)."""
+def pad_cols(x, Cp):
+    """[R,C] -> [R,Cp] = [x | 0] (contiguous f32 / bf16), one launch (murcl_pad_cols)."""
+    _need_cuda(x)
+    x = _c(x)
+    R, C = x.shape
+    assert Cp >= C and x.element_size() in (2, 4)
+    out = torch.empty((R, Cp), dtype=x.dtype, device=x.device)
+    check(_lib.lib().murcl_pad_cols(ptr(x), ptr(out), R, C, Cp, x.element_size(), stream()), "pad_cols")
+    return out
+
+
+def axpby(x, y, a, b, out=None):
+    """a x + b y for equally shaped contiguous f32 tensors, one launch (murcl_axpby); ``out`` may be x or y (elementwise)."""
     _need_cuda(x, y)
     assert x.shape == y.shape and x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else out
+    assert out.shape == x.shape and out.dtype == torch.float32 and out.is_contiguous()
     check(_lib.lib().murcl_axpby(ptr(x), ptr(y), float(a), float(b), ptr(out), x.numel(), stream()), "axpby")
     return out
 
@@ -1521,15 +1539,15 @@ STACK_MAX_JOBS = 96
 
 def stack_lists(lists):
     """``[torch.stack(l, 0) for l in lists]`` in ONE launch (``murcl_stack_lists``): every list holds equally shaped contiguous CUDA
-    tensors of a 4-byte dtype; anything else (or more than ``STACK_MAX_JOBS`` tensors in all) goes through ``torch.stack``."""
+    tensors of a 4- or 8-byte dtype; anything else (or more than ``STACK_MAX_JOBS`` tensors in all) goes through ``torch.stack``."""
     flat = [t for l in lists for t in l]
-    if (not flat or len(flat) > STACK_MAX_JOBS or not all(t.is_cuda and t.is_contiguous() and t.element_size() == 4 for t in flat)
+    if (not flat or len(flat) > STACK_MAX_JOBS or not all(t.is_cuda and t.is_contiguous() and t.element_size() in (4, 8) for t in flat)
             or any(t.shape != l[0].shape or t.dtype != l[0].dtype for l in lists for t in l)):
         return [torch.stack(l, 0) for l in lists]
     outs = [torch.empty((len(l),) + tuple(l[0].shape), dtype=l[0].dtype, device=l[0].device) for l in lists]
     arr, i = (_CopyJob * len(flat))(), 0
     for l, o in zip(lists, outs):
-        nb = l[0].numel() * 4
+        nb = l[0].numel() * l[0].element_size()
         for k, t in enumerate(l):
             arr[i].src, arr[i].dst, arr[i].bytes = t.data_ptr(), o.data_ptr() + k * nb, nb
             i += 1

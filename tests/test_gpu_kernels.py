@@ -1571,3 +1571,39 @@ def test_axpby_mean_small_and_copy_flat():
     odd_s, odd_d = src[1:1000], torch.zeros((999,), device=dev)                     # a base that is not 16-byte aligned: the generic path
     ops.copy_flat(odd_d, odd_s)
     assert torch.equal(odd_d, odd_s)
+
+
+def test_small_extent_products_without_aten_padding():
+    """Classifier heads with a handful of outputs (train_RLMIL.py:316,502,709: nn.Linear(hidden, num_classes)): the input gradient
+    dX = dY W (inner extent = the class count) runs as ONE small launch (murcl_gemm_nt_smallk), other awkward inner extents are
+    zero-padded by ONE own launch per operand (murcl_pad_cols), the weight gradient dW = dY^T X adds into its buffer with an own
+    launch - against float64 matmuls."""
+    from murcl_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    for M, N, K in ((384, 1024, 2), (64, 512, 10), (7, 33, 1), (130, 96, 16), (96, 128, 40)):
+        A = torch.randn((M, K), generator=g, device=dev)
+        Bm = torch.randn((N, K), generator=g, device=dev)
+        want = (A.double() @ Bm.double().t())
+        C = ops.gemm_nt(A, Bm)
+        _close(C, want, 1e-5, 1e-5 * float(want.abs().max()), f"gemm_nt {M}x{N}x{K}")
+        base = torch.randn((M, N), generator=g, device=dev)
+        C2 = ops.gemm_nt(A, Bm, out=base.clone(), accumulate=True)
+        _close(C2, want + base.double(), 1e-5, 1e-5 * float(want.abs().max()), f"gemm_nt accumulate {M}x{N}x{K}")
+    p = ops.pad_cols(torch.arange(12, device=dev, dtype=torch.float32).view(3, 4), 6)
+    assert p.shape == (3, 6) and torch.equal(p[:, :4], torch.arange(12, device=dev, dtype=torch.float32).view(3, 4)) and (p[:, 4:] == 0).all()
+    pb = ops.pad_cols(torch.ones((5, 3), device=dev).bfloat16(), 8)
+    assert pb.dtype == torch.bfloat16 and (pb[:, :3] == 1).all() and (pb[:, 3:] == 0).all()
+    for M, N1, N2 in ((384, 2, 1024), (64, 10, 512), (100, 1, 64)):
+        dy = torch.randn((M, N1), generator=g, device=dev)
+        x = torch.randn((M, N2), generator=g, device=dev)
+        want = dy.double().t() @ x.double()
+        _close(ops.gemm_tn(dy, x), want, 1e-5, 1e-5 * float(want.abs().max()), f"gemm_tn {M}x{N1}x{N2}")
+        acc = torch.randn((N1, N2), generator=g, device=dev)
+        cs = torch.randn((N1,), generator=g, device=dev)
+        acc0, cs0 = acc.clone(), cs.clone()
+        r = ops.gemm_tn(dy, x, out=acc, colsum_into=cs)
+        assert r.data_ptr() == acc.data_ptr()
+        _close(acc, want + acc0.double(), 1e-5, 1e-5 * float(want.abs().max()), f"gemm_tn into {M}x{N1}x{N2}")
+        _close(cs, cs0.double() + dy.double().sum(0), 1e-5, 1e-4, "colsum_into")
