@@ -466,6 +466,9 @@ int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n
 #define MURCL_STACK_MAX_JOBS 96
 typedef struct { const void* src; void* dst; long bytes; } MurclCopyJob;
 int murcl_stack_lists(const MurclCopyJob* jobs_host, int n_jobs, murcl_stream_t stream);
+/* dst += src (f32, `bytes` a multiple of 4) for every job, ONE launch: the gradients a backward node returns as its own tensors added
+ * into the parameters' gradient buffers - autograd's AccumulateGrad (`loss.backward()`, train_MuRCL.py:293; one add per parameter). */
+int murcl_add_lists(const MurclCopyJob* jobs_host, int n_jobs, murcl_stream_t stream);
 
 /* torch.optim.Adam.step for one flat tensor (train_MuRCL.py:165,295; rlmil.py:141,182).  zero_grad != 0 also clears g
  * (the optimizer.zero_grad() that precedes the next backward pass, train_MuRCL.py:293) in the same pass. */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "murcl_ppo_epoch_wt": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _L, _F, _F, _F, _P, _P, _P],
     "murcl_step_draws": [ctypes.c_ulonglong, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P],
     "murcl_stack_lists": [_P, _I, _P],
+    "murcl_add_lists": [_P, _I, _P],
     "murcl_cast_batch": [_P, _I, _I, _P],
     "murcl_cast_batch_flat": [_P, _P, _I, _I, _P],
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],

@@ -155,6 +155,30 @@ extern "C" int murcl_stack_lists(const MurclCopyJob* jobs_host, int n_jobs, hipS
     return MURCL_CHECK_LAUNCH();
 }
 
+// dst += src (f32) for several (src, dst, bytes) jobs in ONE launch: the gradients a backward node produced as its own tensors added
+// to the parameters' pre-seated gradient views (what autograd's AccumulateGrad does with one ATen add per parameter - eight for CLAM-SB)
+__global__ __launch_bounds__(256) void add_lists_kernel(StackTable t) {
+    const MurclCopyJob j = t.job[blockIdx.y];
+    const long w0 = (long)blockIdx.x * 1024, n = j.bytes >> 2;
+    const float* s = (const float*)j.src;
+    float* d = (float*)j.dst;
+    for (long w = w0 + threadIdx.x; w < w0 + 1024 && w < n; w += 256) d[w] += s[w];
+}
+extern "C" int murcl_add_lists(const MurclCopyJob* jobs_host, int n_jobs, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    if (n_jobs > MURCL_STACK_MAX_JOBS) return -1;
+    StackTable t;
+    long mx = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (jobs_host[i].bytes < 0 || (jobs_host[i].bytes & 3)) return -1;
+        t.job[i] = jobs_host[i];
+        mx = jobs_host[i].bytes > mx ? jobs_host[i].bytes : mx;
+    }
+    if (mx == 0) return 0;
+    hipLaunchKernelGGL(add_lists_kernel, dim3((unsigned)((mx + 4095) / 4096), n_jobs), dim3(256), 0, s, t);
+    return MURCL_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- column sums: out[n] (+)= sum_r x[r][n]
 // grid = (column groups of 16*CPT, row splits); a thread owns CPT = 16/sizeof(T) consecutive columns (16-byte loads)
 // for one of 16 row lanes; each block adds its partial sums atomically.  Row splits are capped at 64: float atomics

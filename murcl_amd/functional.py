@@ -229,6 +229,18 @@ def _bgrad(dy, b):
     return ops.colsum(dy)
 
 
+def _pgrads(*pairs):
+    """``[(gradient tensor or None, parameter)]`` -> the list of what autograd should still see: parameters that accumulate directly
+    get their gradients added to the pre-seated buffers by ONE launch for all of them (and None here), the others get theirs back."""
+    direct = [(g, p) for g, p in pairs if g is not None and _direct(p)]
+    if len(direct) > 1:
+        ops.add_lists([(g.reshape(p.grad.shape) if g.shape != p.grad.shape else g, p.grad) for g, p in direct])
+        _touch(*(p for _, p in direct))
+        done = {id(p) for _, p in direct}
+        return [None if (g is None or id(p) in done) else g for g, p in pairs]
+    return [g for g, _ in pairs]
+
+
 def _pgrad(g, p):
     """A gradient that a kernel already produced as its own tensor."""
     if _direct(p):
@@ -1225,6 +1237,7 @@ class CLAMFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h, U if U is not None else _placeholder(x2), A, M, w1, wa, wb, wc,
                               inst_w if inst_w is not None else _placeholder(x2), m1)
         ctx.gated, ctx.gate_u = gated, gate_u
+        ctx.bias_params = (b1, ba, bb, bc)               # (the parameters themselves: the backward pass adds into their gradient buffers)
         ctx.wab_t = views[2] if gate_u else None         # (a cached view: parameters do not change between a forward and its backward)
         ctx.keeps, ctx.saved_inst, ctx.dims = keeps, saved_inst, (B, N, d, L, D)
         if ids is None:
@@ -1245,6 +1258,7 @@ class CLAMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dM, _dA, _ds, dinst, _dids, _dpt):
         x2, h, U, A, M, w1, wa, wb, wc, inst_w, m1 = ctx.saved_tensors
+        b1, ba, bb, bc = ctx.bias_params
         B, N, d, L, D = ctx.dims
         T = x2.dtype
         f32 = T == torch.float32
@@ -1326,10 +1340,14 @@ class CLAMFn(torch.autograd.Function):
                 db1 = ops.colsum(dz1)
             if kp is not None:
                 dw1, db1 = dw1 / kp, db1 / kp
+        # the eight (six without the gate) parameter gradients: added to the optimizer's pre-seated buffers by ONE launch (autograd's
+        # AccumulateGrad would run one ATen add per parameter); parameters without such a buffer get their tensors back
         if not gated:
-            return (None, dw1, db1, dwab, dbab.contiguous(), None, None, dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None, None)
-        return (None, dw1, db1, dwab[:D].contiguous(), dbab[:D].contiguous(), dwab[D:].contiguous(), dbab[D:].contiguous(),
-                dwc.view(1, -1), dbc, dinst_w, dinst_b, None, None, None)
+            dw1, db1, dwab, dbab_, dwc_, dbc = _pgrads((dw1, w1), (db1, b1), (dwab, wa), (dbab.contiguous(), ba), (dwc.view(1, -1), wc), (dbc, bc))
+            return (None, dw1, db1, dwab, dbab_, None, None, dwc_, dbc, dinst_w, dinst_b, None, None, None)
+        dw1, db1, dwa_, dba_, dwb_, dbb_, dwc_, dbc = _pgrads((dw1, w1), (db1, b1), (dwab[:D].contiguous(), wa), (dbab[:D].contiguous(), ba),
+                                                              (dwab[D:].contiguous(), wb), (dbab[D:].contiguous(), bb), (dwc.view(1, -1), wc), (dbc, bc))
+        return (None, dw1, db1, dwa_, dba_, dwb_, dbb_, dwc_, dbc, dinst_w, dinst_b, None, None, None)
 
 
 class PolicyHeadFn(torch.autograd.Function):

@@ -1555,6 +1555,23 @@ def stack_lists(lists):
     return outs
 
 
+def add_lists(pairs):
+    """``dst += src`` for every (src, dst) pair of equally sized contiguous f32 CUDA tensors in ONE launch (murcl_add_lists)."""
+    pairs = [(s_, d_) for s_, d_ in pairs if s_ is not None]
+    if not pairs:
+        return
+    assert len(pairs) <= STACK_MAX_JOBS
+    arr = (_CopyJob * len(pairs))()
+    keep = []
+    for i, (s_, d_) in enumerate(pairs):
+        s_ = _c(s_)
+        assert (s_.is_cuda and d_.is_cuda and s_.dtype == torch.float32 and d_.dtype == torch.float32 and d_.is_contiguous()
+                and s_.numel() == d_.numel())
+        keep.append(s_)
+        arr[i].src, arr[i].dst, arr[i].bytes = s_.data_ptr(), d_.data_ptr(), s_.numel() * 4
+    check(_lib.lib().murcl_add_lists(ctypes.addressof(arr), len(pairs), stream()), "add_lists")
+
+
 def pointer_table(tensors):
     """Host array of device pointers (the ``const float* const*`` arguments of the sequence entry points)."""
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])

@@ -1607,3 +1607,21 @@ def test_small_extent_products_without_aten_padding():
         assert r.data_ptr() == acc.data_ptr()
         _close(acc, want + acc0.double(), 1e-5, 1e-5 * float(want.abs().max()), f"gemm_tn into {M}x{N1}x{N2}")
         _close(cs, cs0.double() + dy.double().sum(0), 1e-5, 1e-4, "colsum_into")
+
+
+def test_add_lists_accumulates_every_pair_in_one_launch():
+    """murcl_add_lists: dst += src for a table of (src, dst) pairs of different lengths (the gradients a backward node returns, added to
+    the optimizer's pre-seated gradient views: autograd's AccumulateGrad, one ATen add per parameter otherwise)."""
+    from murcl_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev)
+    g.manual_seed(13)
+    flat = torch.randn((9000,), generator=g, device=dev)
+    views = [flat[:5], flat[5:5 + 4096].view(8, 512), flat[4101:4101 + 4097], flat[8198:8199]]
+    before = [v.clone() for v in views]
+    srcs = [torch.randn(v.shape, generator=g, device=dev) for v in views]
+    rest = flat[8199:].clone()
+    ops.add_lists(list(zip(srcs, views)) + [(None, flat[:1])])
+    for v, b, s_ in zip(views, before, srcs):
+        assert torch.equal(v, b + s_)
+    assert torch.equal(flat[8199:], rest)
