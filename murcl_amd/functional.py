@@ -950,6 +950,7 @@ class DSMILFn(torch.autograd.Function):
         classes = cls.view(B, N, C)
         ctx.save_for_backward(x, Y, m, qmax, A, Z, wv, wq, xm if qv else _placeholder(x), xv if keep_v is not None else _placeholder(x))
         ctx.meta = (B, N, d, C, LD, reassoc, qv, keep_v is not None)
+        ctx.params = (wc, bc, wq, bq, wv, bv)             # (the parameters themselves: the backward pass adds into their gradient buffers)
         ctx.mark_non_differentiable(m)
         ctx.set_materialize_grads(False)
         if not want_max:
@@ -1033,6 +1034,8 @@ class DSMILFn(torch.autograd.Function):
             dwc_m, dbc_m = (g * xm_f).sum(0), g.view(B, C).sum(0)
             dwc = dwc_m if dwc is None else dwc + dwc_m
             dbc = dbc_m if dbc is None else dbc + dbc_m
+        # six parameter gradients: ONE launch adds them to the optimizer's pre-seated buffers (no AccumulateGrad add per parameter)
+        dwc, dbc, dwq, dbq, dwv, dbv = _pgrads(*zip((dwc, dbc, dwq, dbq, dwv, dbv), ctx.params))
         return None, dwc, dbc, dwq, dbq, dwv, dbv, None, None
 
 
