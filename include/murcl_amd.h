@@ -493,6 +493,9 @@ int murcl_axpby(const float* x, const float* y, float a, float b, float* out, lo
 /* out[0] = mean of n floats in a fixed order (one workgroup): the step loss, mean of the T patch-step losses (train_MuRCL.py:291),
  * where nothing differentiates it (frozen-aggregator stage 2). */
 int murcl_mean_small(const float* x, int n, float* out, murcl_stream_t stream);
+/* out[g] = mean of x[g * group .. (g + 1) * group), g < groups: CLAM-SB's instance loss per bag -> per patch step (train_RLMIL.py:336,
+ * `instance_loss` averaged over the batch of every step) when the T x B bags of a step were computed together. */
+int murcl_group_mean(const float* x, int groups, int group, float* out, murcl_stream_t stream);
 /* dst <- src (both 16-byte aligned, any byte count): `policy_old.load_state_dict(policy.state_dict())` after a PPO update
  * (models/rlmil.py:183) on the two flat parameter buffers, as a launch of this library.  -1: a pointer is not 16-byte aligned. */
 int murcl_copy_bytes(const void* src, void* dst, long bytes, murcl_stream_t stream);

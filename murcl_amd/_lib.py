@@ -83,6 +83,7 @@ SIGNATURES = {
     "murcl_mul": [_P, _P, _P, _L, _I, _P],
     "murcl_axpby": [_P, _P, _F, _F, _P, _L, _P],
     "murcl_mean_small": [_P, _I, _P, _P],
+    "murcl_group_mean": [_P, _I, _I, _P, _P],
     "murcl_copy_bytes": [_P, _P, _L, _P],
     "murcl_gemm_nt_smallk": [_P, _P, _P, _I, _I, _I, _I, _P],
     "murcl_pad_cols": [_P, _P, _L, _I, _I, _I, _P],

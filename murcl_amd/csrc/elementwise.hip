@@ -621,6 +621,26 @@ __global__ __launch_bounds__(256) void mean_small_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) out[0] = part[0] / (float)n;
 }
+// out[g] = mean of x[g * group .. (g + 1) * group): one workgroup per group, a fixed summation order (CLAM-SB's instance loss per bag
+// -> per patch step, train_RLMIL.py:336)
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ x, int group, float* __restrict__ out) {
+    __shared__ float part[256];
+    const float* xg = x + (long)blockIdx.x * group;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < group; i += 256) acc += xg[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] / (float)group;
+}
+extern "C" int murcl_group_mean(const float* x, int groups, int group, float* out, hipStream_t s) {
+    if (groups <= 0 || group <= 0) return groups == 0 ? 0 : -1;
+    hipLaunchKernelGGL(group_mean_kernel, dim3(groups), dim3(256), 0, s, x, group, out);
+    return MURCL_CHECK_LAUNCH();
+}
 extern "C" int murcl_mean_small(const float* x, int n, float* out, hipStream_t s) {
     if (n <= 0 || n > (1 << 20)) return -1;
     hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(256), 0, s, x, n, out);

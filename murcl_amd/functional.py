@@ -1433,6 +1433,50 @@ class StepCEMeanFn(torch.autograd.Function):
         return dl * (g / ctx.T), None, None
 
 
+class StepLossFn(torch.autograd.Function):
+    """``StepCEMeanFn`` for the two architectures whose step loss mixes a second term into the head's cross-entropy
+    (train_RLMIL.py:336 CLAM-SB: ``bag_weight * ce + (1 - bag_weight) * instance_loss``, the instance loss averaged over the B bags of
+    the step; :527-529 DSMIL: ``0.5 * ce + 0.5 * ce(max-instance scores)``): logits [T*B, C], targets [T*B], ``extra`` = the per-bag
+    instance losses [T*B] (``extra_is_logits`` False) or the second logits [T*B, C'] -> (mean_t loss_t, loss_t [T], conf [T*B]).
+    Forward: the cross-entropy launch(es), a grouped mean, one mixing launch, one mean launch; backward: one scaling per input (the
+    instance-loss gradient is a constant).  ``loss_t`` and ``conf`` are not differentiable."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, group, w_ce, extra, w_x, extra_is_logits):
+        tg = targets.to(torch.int64).contiguous()
+        ce_t, dl, _, conf = ops.cross_entropy(logits.float().contiguous(), tg, int(group), want_conf=True)
+        T_ = ce_t.numel()
+        if extra_is_logits:
+            x_t, dlx, _ = ops.cross_entropy(extra.float().contiguous(), tg, int(group))
+            ctx.save_for_backward(dl, dlx)
+        else:
+            x_t = ops.group_mean(extra.float().contiguous().view(-1), T_, int(group))
+            ctx.save_for_backward(dl)
+        loss_t = ops.axpby(ce_t, x_t, float(w_ce), float(w_x))
+        ctx.meta = (T_, int(group), float(w_ce), float(w_x), bool(extra_is_logits), tuple(extra.shape))
+        ctx.mark_non_differentiable(loss_t, conf)
+        ctx.set_materialize_grads(False)
+        return ops.mean_small(loss_t), loss_t, conf
+
+    @staticmethod
+    def backward(ctx, g, _gl=None, _gc=None):
+        if g is None:
+            return (None,) * 7
+        T_, group, w_ce, w_x, is_logits, xshape = ctx.meta
+        dl = ctx.saved_tensors[0]
+        if ops.is_unit_grad(g):
+            dlogits = ops.axpby(dl, dl, w_ce / T_, 0.0)
+            if is_logits:
+                dlx = ctx.saved_tensors[1]
+                dextra = ops.axpby(dlx, dlx, w_x / T_, 0.0)
+            else:
+                dextra = ops.filled(xshape, w_x / (T_ * group), dl.device)
+        else:
+            dlogits = dl * (g * (w_ce / T_))
+            dextra = ctx.saved_tensors[1] * (g * (w_x / T_)) if is_logits else (g * (w_x / (T_ * group))).expand(xshape).contiguous()
+        return dlogits, None, None, None, dextra, None, None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """nn.CrossEntropyLoss() (mean) over [R,C] logits (train_RLMIL.py:316,502,709)."""
 

@@ -1485,6 +1485,29 @@ def mean_small(x):
     return out
 
 
+def group_mean(x, groups, group):
+    """x [groups * group] contiguous f32 -> [groups]: the mean of every run of ``group`` values, one launch (murcl_group_mean)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == groups * group
+    out = torch.empty((groups,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().murcl_group_mean(ptr(x), int(groups), int(group), ptr(out), stream()), "group_mean")
+    return out
+
+
+_ONES = {}
+
+
+def filled(shape, value, device):
+    """A FRESH f32 tensor of ``shape`` filled with ``value`` by an own launch (a scaling of a cached, never handed-out ones tensor)."""
+    import math as _m
+    n = _m.prod(shape)
+    key = (torch.device(device), n)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((n,), dtype=torch.float32, device=device)
+    return axpby(one, one, float(value), 0.0).view(shape)
+
+
 def copy_flat(dst, src):
     """dst <- src for two equally long contiguous buffers with 16-byte aligned bases (flat parameter buffers) as ONE launch of this
     library (murcl_copy_bytes; no runtime blit in the step's launch sequence); anything else goes through ``copy_``."""

@@ -11,7 +11,7 @@ import os
 import torch
 
 from murcl_amd import functional, ops
-from murcl_amd.functional import CrossEntropyFn, GroupedCrossEntropyFn, StepCEMeanFn
+from murcl_amd.functional import CrossEntropyFn, GroupedCrossEntropyFn, StepCEMeanFn, StepLossFn
 from murcl_amd.models import abmil, clam, dsmil, rlmil
 from murcl_amd.utils.datasets import draw_step, subbag_views
 from murcl_amd.utils.views import as_one
@@ -98,6 +98,15 @@ def _head_all_steps(arch, fc, head_in_all, extra_all, labels, T, B, bag_weight, 
     if arch == "ABMIL":                                                                    # :727: the step loss is the mean of the T CE values
         total, loss_t, conf = StepCEMeanFn.apply(logits_all, lab_all, B)
         rewards = list(ops.axpby(conf[B:], conf[:-B], 1.0, -1.0).view(T - 1, 1, B).unbind(0)) if T > 1 else []   # :369-371, one launch
+        memory.rewards.extend(rewards)
+        return total, list(loss_t.unbind(0)), rewards, logits_all[-B:]
+    if logits_all.is_cuda and arch in ("CLAM_SB", "DSMIL") and extra_all is not None:
+        # :336 / :527-529: the two-term step losses, their mean over the T steps and its gradient in one node (functional.StepLossFn)
+        if arch == "CLAM_SB":
+            total, loss_t, conf = StepLossFn.apply(logits_all, lab_all, B, bag_weight, extra_all, 1.0 - bag_weight, False)
+        else:
+            total, loss_t, conf = StepLossFn.apply(logits_all, lab_all, B, 0.5, extra_all, 0.5, True)
+        rewards = list(ops.axpby(conf[B:], conf[:-B], 1.0, -1.0).view(T - 1, 1, B).unbind(0)) if T > 1 else []   # :369-371,569-571
         memory.rewards.extend(rewards)
         return total, list(loss_t.unbind(0)), rewards, logits_all[-B:]
     ce, conf = GroupedCrossEntropyFn.apply(logits_all, lab_all, B, True)                # conf: soft-max confidence of the true class (:345,537,735)

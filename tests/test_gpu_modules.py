@@ -1213,3 +1213,59 @@ def test_clam_size_big_vs_reference_golden(golden, dtype):
     M2, _, res = m(x, label=[1, 1, 1], instance_eval=True)
     (M2.sum() + sum(r["instance_loss"] for r in res)).backward()
     _check_grad_entries(m.named_parameters(), g, "grad.", 3e-4, zero_keys=("attention_net.3.attention_c.bias",))
+
+
+@pytest.mark.parametrize("mode", ["clam", "dsmil", "abmil"])
+def test_step_loss_nodes_equal_the_tensor_op_composition(mode):
+    """functional.StepLossFn / StepCEMeanFn (the supervised step's loss of T patch steps as one node: train_RLMIL.py:336 CLAM-SB,
+    :527-529 DSMIL, :727 ABMIL) against the same formulas written with torch ops on the same logits: the step loss, the per-step
+    losses, the confidences and the gradients that reach the logits and the second term."""
+    import torch.nn.functional as F
+    from murcl_amd import ops
+    from murcl_amd.functional import StepCEMeanFn, StepLossFn
+    dev = _dev()
+    Tn, B, C = 6, 8, 2
+    lg0 = T(detrand.normal(35, f"sl.{mode}.lg", (Tn * B, C))).to(dev)
+    ex0 = T(detrand.normal(35, f"sl.{mode}.ex", (Tn * B, C) if mode == "dsmil" else (Tn * B,))).to(dev)
+    labels = T(np.asarray(detrand.permutation(35, "sl.lab", B)) % C).to(dev).long()
+    lab_all = labels.repeat(Tn)
+    bw = 0.7
+
+    def ref():
+        lg, ex = lg0.clone().requires_grad_(), ex0.clone().requires_grad_()
+        ce = torch.stack([F.cross_entropy(lg[t * B:(t + 1) * B], labels) for t in range(Tn)])
+        if mode == "clam":
+            lt = bw * ce + (1 - bw) * ex.view(Tn, B).mean(1)
+        elif mode == "dsmil":
+            lt = 0.5 * ce + 0.5 * torch.stack([F.cross_entropy(ex[t * B:(t + 1) * B], labels) for t in range(Tn)])
+        else:
+            lt = ce
+        total = lt.sum() / Tn
+        total.backward()
+        conf = torch.softmax(lg.detach(), 1).gather(1, lab_all.view(-1, 1)).view(-1)
+        return total.detach(), lt.detach(), conf, lg.grad, (ex.grad if mode != "abmil" else None)
+
+    lg, ex = lg0.clone().requires_grad_(), ex0.clone().requires_grad_()
+    if mode == "clam":
+        total, lt, conf = StepLossFn.apply(lg, lab_all, B, bw, ex, 1 - bw, False)
+    elif mode == "dsmil":
+        total, lt, conf = StepLossFn.apply(lg, lab_all, B, 0.5, ex, 0.5, True)
+    else:
+        total, lt, conf = StepCEMeanFn.apply(lg, lab_all, B)
+    assert total.shape == () and not lt.requires_grad and not conf.requires_grad
+    total.backward(ops.unit_grad(total))
+    rt, rl, rc, rg, rx = ref()
+    np.testing.assert_allclose(total.item(), rt.item(), rtol=1e-5)
+    np.testing.assert_allclose(lt.cpu().numpy(), rl.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(conf.cpu().numpy(), rc.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), rg.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    if mode != "abmil":
+        np.testing.assert_allclose(ex.grad.cpu().numpy(), rx.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    # a non-unit upstream gradient takes the general path
+    lg2, ex2 = lg0.clone().requires_grad_(), ex0.clone().requires_grad_()
+    if mode == "abmil":
+        (StepCEMeanFn.apply(lg2, lab_all, B)[0] * 3.0).backward()
+    else:
+        (StepLossFn.apply(lg2, lab_all, B, bw if mode == "clam" else 0.5, ex2, (1 - bw) if mode == "clam" else 0.5, mode == "dsmil")[0] * 3.0).backward()
+        np.testing.assert_allclose(ex2.grad.cpu().numpy(), 3.0 * rx.cpu().numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(lg2.grad.cpu().numpy(), 3.0 * rg.cpu().numpy(), rtol=1e-4, atol=1e-7)

@@ -19,7 +19,8 @@ stage = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
 B, RAW, K, T_, FS = 64, 8192, 10, 6, 1024
-model, fc = create_model("ABMIL", 512, 2, dev, dtype=torch.bfloat16)
+ARCH = os.environ.get("SUP_ARCH", "ABMIL")
+model, fc = create_model(ARCH, 512, 2, dev, dtype=torch.bfloat16 if ARCH != "DSMIL" else torch.float32)
 model.train() if stage != 2 else model.eval()
 ppo = None
 if stage != 1:
@@ -35,13 +36,13 @@ clusters = []
 for _ in range(B):
     lab = rng.integers(0, K, RAW)
     clusters.append([np.nonzero(lab == k)[0].tolist() for k in range(K)])
-pack = BagPack.from_lists(feats, clusters, dtype=torch.bfloat16)
+pack = BagPack.from_lists(feats, clusters, dtype=torch.bfloat16 if ARCH != "DSMIL" else None)
 labels = torch.from_numpy(rng.integers(0, 2, B)).to(dev)
 mem = rlmil.Memory()
 
 
 def step():
-    return supervised_step("ABMIL", model, fc, ppo, opt, pack, labels, mem, T=T_, feat_size=FS, train_stage=stage)[0]
+    return supervised_step(ARCH, model, fc, ppo, opt, pack, labels, mem, T=T_, feat_size=FS, train_stage=stage)[0]
 
 
 for _ in range(4):
@@ -51,7 +52,7 @@ t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
 torch.cuda.synchronize()
-print(f"supervised stage {stage}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step, loss {loss.item():.5f}")
+print(f"supervised {ARCH} stage {stage}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step, loss {loss.item():.5f}")
 
 if os.environ.get("MURCL_ATEN_WHO") == "1":
     # which Python lines launch ATen kernels?  (torch.profiler: aten ops with device time, their nearest frames inside this repo)
