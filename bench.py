@@ -747,18 +747,25 @@ def main():
     ms_step = elapsed / args.steps * 1e3
     value = B * world / (elapsed / args.steps)
     eager = dict(value=round(value, 2), ms_per_step=round(ms_step, 4),
-                 note="K steps enqueued step by step from Python: the contract's timed region (the per-kernel HIP events of `roofline` were taken in it)")
+                 note="K steps enqueued step by step from Python between the same barriers (the per-kernel HIP events of `roofline` were taken in this region)")
     timing_mode = "eager: K steps enqueued from Python (the host runs ~0.6 ms per step ahead of the GPU)"
     graph = None
     if world == 1 and not force_dist and args.graph:
         # a SECOND region of exactly K steps, as hipGraph replays with live optimizer state (round 6: every replayed step is a real
-        # training step).  Reported beside the headline, not instead of it: measured on three boxes the replays run 1-2.5 % SLOWER
-        # than the eager loop whose host keeps ahead (per-node dispatch cost of ~25 kernel nodes per step) and 2 % faster only in a
-        # window that a host stall hit (BENCH_r05) - `value` stays the eager region, a reader can tell a stall from the two numbers
+        # training step, Adam's step counts advance on the device).  It is GPU-paced: the host launches K / G graphs and waits.  The
+        # eager region is host-paced whenever the host is slower than the GPU - measured on this pool: a loaded host (four tenants per
+        # box) enqueued a step in 1.56 ms instead of 0.8 and the eager region read 1.958 ms per step while the GPU needed 1.45
+        # (gpurun_out/r06_zz_bench_driver_args2.json), and in a 20-step window the first step alone runs from an empty queue (+ 1-2 %).
+        # With a healthy host the two regions agree to 0.5 % (profiles/r06_zz_bench*.json).  `value` is therefore the graph region
+        # when it exists ("make value robust to one host stall ... the graph replay once its arguments are live"),
+        # and the eager region is reported beside it; --no-graph, more than one rank, or a capture failure leave `value` eager.
         try:
             graph = graph_timed_region(step, opt, args.steps, barrier)
             graph["ms_per_step_graph"] = round(graph["ms_per_step"], 4)
             graph["value_graph"] = round(B * world / (graph["elapsed_s"] / args.steps), 2)
+            value, ms_step = B * world / (graph["elapsed_s"] / args.steps), graph["ms_per_step"]
+            timing_mode = ("hipgraph: the K steps as replays of captured graphs of G steps with LIVE optimizer state, between the same "
+                           "barriers (GPU-paced; the eager region of the same K steps - `eager` - is host-paced when the host is loaded)")
         except Exception as e:                                                 # noqa: BLE001  (a diagnostic must not take the line with it)
             graph = {"error": f"{type(e).__name__}: {e}"[:300]}
 
