@@ -460,6 +460,10 @@ int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles, murcl_stre
 /* The same table as a flat grid: first_tile_dev [n_jobs + 1] int32 (device) = ascending first tile index of every job (a job of
  * [rows, cols] has ceil(rows/32) * ceil(cols/32) tiles), total_tiles = its last entry.  For tables whose jobs differ widely in size. */
 int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, murcl_stream_t stream);
+/* ... which also advances tick_dev[0] by one (NULL: no counter): the step counter of a captured optimizer step
+ * (murcl_adam_multi_live_deferred).  -1 when there is nothing to launch and a counter was given. */
+int murcl_cast_batch_flat_tick(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, int* tick_dev,
+                               murcl_stream_t stream);
 
 /* torch.stack of several lists of equally shaped tensors in ONE launch (PPO.update, rlmil.py:163-165: the rollout's states, actions
  * and log-probabilities): job i copies `bytes` (a multiple of 4) from src to dst.  `jobs_host` is a HOST array. */
@@ -486,6 +490,11 @@ int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, flo
  * captured one again (torch.optim.Adam's state['step'], train_MuRCL.py:165-171, kept on the device). */
 int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                           int zero_grad, int* replays_dev, murcl_stream_t stream);
+/* ... without the one-thread launch that advances the counter: the caller's next launch on the stream does it
+ * (murcl_cast_batch_flat_tick - the weight-view refresh that follows every optimizer step - or murcl_replay_tick). */
+int murcl_adam_multi_live_deferred(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
+                                   int zero_grad, int* replays_dev, murcl_stream_t stream);
+int murcl_replay_tick(int* replays_dev, murcl_stream_t stream);
 /* out = a x + b y over n floats: the rewards of a contrastive step, cosine of patch step t-1 minus that of step t
  * (train_MuRCL.py:282-283), for all T-1 steps in one launch; b == 0: out = a x, y is not read (the 1/T of the step loss's mean on
  * the stored NT-Xent gradients, :291). */

@@ -113,11 +113,14 @@ SIGNATURES = {
     "murcl_add_lists": [_P, _I, _P],
     "murcl_cast_batch": [_P, _I, _I, _P],
     "murcl_cast_batch_flat": [_P, _P, _I, _I, _P],
+    "murcl_cast_batch_flat_tick": [_P, _P, _I, _I, _P, _P],
     "murcl_relu_bitmask": [_P, _P, _I, _I, _I, _I, _P],
     "murcl_dropout_relu_bitmask": [_P, _P, _I, _I, _F, _F, ctypes.c_ulonglong, _I, _P],
     "murcl_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "murcl_adam_multi": [_P, _I, _F, _F, _F, _F, _I, _P],
     "murcl_adam_multi_live": [_P, _I, _F, _F, _F, _F, _I, _P, _P],
+    "murcl_adam_multi_live_deferred": [_P, _I, _F, _F, _F, _F, _I, _P, _P],
+    "murcl_replay_tick": [_P, _P],
     "murcl_sgd_step": [_P, _P, _P, _L, _F, _F, _I, _F, _I, _I, _P],
 }
 _RESTYPE = {"murcl_ntxent_workspace_bytes": _L, "murcl_ntxent_xchg_bytes": _L, "murcl_kmeans_workspace_bytes": _L, "murcl_ppo_act_workspace": _L, "murcl_gemm_tn_workspace_bytes": _L, "murcl_gemm_tn_grouped_workspace_bytes": _L,

@@ -110,8 +110,11 @@ extern "C" int murcl_cast_batch(const void* jobs_dev, int n_jobs, int max_tiles,
 // on the device, ascending; a binary search), so tables that mix a 3072 x 1024 matrix with 16-row blocks run as one launch without
 // the (largest tile count) x (jobs) grid of mostly empty workgroups.
 __global__ __launch_bounds__(256) void cast_flat_kernel(const MurclCastJob* __restrict__ jobs, const int* __restrict__ first_tile,
-                                                        int n_jobs) {
+                                                        int n_jobs, int* __restrict__ tick) {
     __shared__ float t[32][33];
+    // (tick: the device-side step counter of a captured optimizer step, murcl_adam_multi_live_deferred - this launch runs behind
+    //  the update that read it and before the next one, so it can advance it for free instead of a one-thread launch of its own)
+    if (tick && blockIdx.x == 0 && threadIdx.x == 0) tick[0] += 1;
     int lo = 0, hi = n_jobs - 1;
     const int w = blockIdx.x;
     while (lo < hi) {
@@ -123,10 +126,14 @@ __global__ __launch_bounds__(256) void cast_flat_kernel(const MurclCastJob* __re
     if (j.dtype_out == MURCL_DTYPE_BF16) cast_job_tile<bf16_t>(j, tile, t);
     else cast_job_tile<float>(j, tile, t);
 }
-extern "C" int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, hipStream_t s) {
-    if (n_jobs <= 0 || total_tiles <= 0) return 0;
-    hipLaunchKernelGGL(cast_flat_kernel, dim3(total_tiles), dim3(256), 0, s, (const MurclCastJob*)jobs_dev, first_tile_dev, n_jobs);
+extern "C" int murcl_cast_batch_flat_tick(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, int* tick_dev,
+                                          hipStream_t s) {
+    if (n_jobs <= 0 || total_tiles <= 0) return tick_dev ? -1 : 0;          // (nothing to launch: the caller must advance the counter itself)
+    hipLaunchKernelGGL(cast_flat_kernel, dim3(total_tiles), dim3(256), 0, s, (const MurclCastJob*)jobs_dev, first_tile_dev, n_jobs, tick_dev);
     return MURCL_CHECK_LAUNCH();
+}
+extern "C" int murcl_cast_batch_flat(const void* jobs_dev, const int* first_tile_dev, int n_jobs, int total_tiles, hipStream_t s) {
+    return murcl_cast_batch_flat_tick(jobs_dev, first_tile_dev, n_jobs, total_tiles, nullptr, s);
 }
 
 // torch.stack of several lists of equally shaped contiguous tensors in ONE launch: job i copies `bytes` (a multiple of 4) from src to
@@ -562,6 +569,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable t, float b1, 
     }
 }
 __global__ void adam_replay_tick_kernel(int* __restrict__ replays) { replays[0] += 1; }
+static thread_local bool g_adam_defer_tick = false;
 extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
                                      int zero_grad, int* replays_dev, hipStream_t s);
 extern "C" int murcl_adam_multi(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps, float weight_decay,
@@ -589,7 +597,21 @@ extern "C" int murcl_adam_multi_live(const MurclAdamJob* jobs_host, int n_jobs, 
     t.first_chunk[t.n_jobs] = (int)chunks;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, weight_decay, zero_grad,
                        replays_dev);
-    if (replays_dev) hipLaunchKernelGGL(adam_replay_tick_kernel, dim3(1), dim3(1), 0, s, replays_dev);
+    if (replays_dev && !g_adam_defer_tick) hipLaunchKernelGGL(adam_replay_tick_kernel, dim3(1), dim3(1), 0, s, replays_dev);
+    return MURCL_CHECK_LAUNCH();
+}
+// the same launch WITHOUT the one-thread tick behind it: the caller advances replays_dev[0] with its next launch on the stream
+// (murcl_cast_batch_flat_tick, the weight-view refresh that follows every optimizer step) or with murcl_replay_tick
+extern "C" int murcl_adam_multi_live_deferred(const MurclAdamJob* jobs_host, int n_jobs, float beta1, float beta2, float eps,
+                                              float weight_decay, int zero_grad, int* replays_dev, hipStream_t s) {
+    g_adam_defer_tick = true;
+    const int rc = murcl_adam_multi_live(jobs_host, n_jobs, beta1, beta2, eps, weight_decay, zero_grad, replays_dev, s);
+    g_adam_defer_tick = false;
+    return rc;
+}
+extern "C" int murcl_replay_tick(int* replays_dev, hipStream_t s) {
+    if (!replays_dev) return -1;
+    hipLaunchKernelGGL(adam_replay_tick_kernel, dim3(1), dim3(1), 0, s, replays_dev);
     return MURCL_CHECK_LAUNCH();
 }
 

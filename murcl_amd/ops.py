@@ -869,10 +869,12 @@ def is_unit_grad(g):
     return t is not None and t.data_ptr() == g.data_ptr()
 
 
-def refresh_views(owned):
+def refresh_views(owned, tick=None):
     """Called by an optimizer right after it rewrote the parameters whose ``data_ptr()`` are in ``owned``: advance
     PARAM_EPOCH and rebuild, in ONE launch, every cached view built from those parameters; views of other optimizers'
-    parameters stay valid."""
+    parameters stay valid.  ``tick`` (a device int32 tensor; a captured optimizer step): that launch also advances ``tick[0]``
+    (the live step counter of ``adam_multi(..., tick=False)``); returns True when it did - False means nothing was launched and the
+    caller has to advance the counter itself (``replay_tick``)."""
     global PARAM_EPOCH
     old = PARAM_EPOCH
     PARAM_EPOCH += 1
@@ -886,7 +888,7 @@ def refresh_views(owned):
         elif st["ver"][0] == old:
             st["ver"] = (PARAM_EPOCH, st["ver"][1])
     if not todo:
-        return
+        return False
     # ONE launch for all of them: a flat grid over the tiles of every job (the (largest tile count) x (jobs) grid of murcl_cast_batch
     # spent 78 us on 400 k almost all empty workgroups when CLAM's 16-row blocks met the GRU's 3072 x 1024)
     mkey = tuple(k for k, _ in todo)
@@ -901,9 +903,10 @@ def refresh_views(owned):
                 acc += t_
                 first.append(acc)
         merged = _MERGED[mkey] = (table, torch.tensor(first, dtype=torch.int32).to(table.device), len(first) - 1, acc)
-    check(_lib.lib().murcl_cast_batch_flat(ptr(merged[0]), ptr(merged[1]), merged[2], merged[3], stream()), "cast_batch_flat")
+    check(_lib.lib().murcl_cast_batch_flat_tick(ptr(merged[0]), ptr(merged[1]), merged[2], merged[3], ptr(tick), stream()), "cast_batch_flat")
     for _, st in todo:
         st["ver"] = (PARAM_EPOCH, tuple(p._version for p in st["keep"]))
+    return tick is not None
 
 
 _MERGED = {}
@@ -1038,7 +1041,12 @@ class _AdamJob(_lib.ctypes.Structure):                 # MurclAdamJob (include/m
 ADAM_MAX_JOBS = 8
 
 
-def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False, replays=None):
+def replay_tick(replays):
+    """Advance the live step counter of a captured optimizer step by one (a one-thread launch; ``adam_multi(..., tick=False)``)."""
+    check(_lib.lib().murcl_replay_tick(ptr(replays), stream()), "replay_tick")
+
+
+def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False, replays=None, tick=True):
     """torch.optim.Adam.step over several flat runs in ONE launch.  ``jobs``: up to ``ADAM_MAX_JOBS`` tuples (p, g, m, v, lr, step) of
     equally long contiguous f32 tensors (each run with its own learning rate and step count).  ``replays``: None, or a device int32[2]
     (zeros) when the launch is being captured into a hipGraph - the step counts then advance on the device with every replay
@@ -1051,8 +1059,10 @@ def adam_multi(jobs, betas, eps, weight_decay, zero_grad=False, replays=None):
         a.p, a.g, a.m, a.v, a.n, a.lr, a.step = ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step)
     if replays is not None:
         assert replays.dtype == torch.int32 and replays.numel() >= 2 and replays.is_contiguous()
-        check(_lib.lib().murcl_adam_multi_live(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
-                                               float(weight_decay), int(bool(zero_grad)), ptr(replays), stream()), "adam_multi_live")
+        # ``tick=False``: the caller advances the counter with its next launch (``refresh_views(tick=)`` / ``replay_tick``)
+        fn = _lib.lib().murcl_adam_multi_live if tick else _lib.lib().murcl_adam_multi_live_deferred
+        check(fn(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
+                 float(weight_decay), int(bool(zero_grad)), ptr(replays), stream()), "adam_multi_live")
         return
     check(_lib.lib().murcl_adam_multi(_lib.ctypes.addressof(arr), len(jobs), float(betas[0]), float(betas[1]), float(eps),
                                       float(weight_decay), int(bool(zero_grad)), stream()), "adam_multi")

@@ -100,7 +100,12 @@ class _FlatOptimizer:
     def _finish_step(self):
         self.step_count += 1
         self._fn._TOUCHED -= self._ids
-        ops.refresh_views(self._owned)             # cached compute-dtype / transposed weight views: one launch
+        pending = getattr(self, "_pending_tick", None)   # a captured Adam step left its live step counter to the next launch
+        ticked = ops.refresh_views(self._owned, tick=pending)   # cached compute-dtype / transposed weight views: one launch
+        if pending is not None:
+            if not ticked:
+                ops.replay_tick(pending)           # (no view to refresh: a one-thread launch advances the counter)
+            self._pending_tick = None
         if self.fused_zero:
             self._maybe_dirty = False
 
@@ -173,7 +178,8 @@ class FlatAdam(_FlatOptimizer):
                 self._launch(g, lo, hi, n)
         else:
             ops.adam_multi([(g["p"][lo:hi], g["g"][lo:hi], g["m"][lo:hi], g["v"][lo:hi], g["lr"], n) for g, lo, hi, n in runs],
-                           self.betas, self.eps, self.weight_decay, zero_grad=self.fused_zero, replays=self.replays)
+                           self.betas, self.eps, self.weight_decay, zero_grad=self.fused_zero, replays=self.replays, tick=False)
+            self._pending_tick = self.replays       # advanced by the view refresh that follows (_finish_step)
         self._finish_step()
 
 
