@@ -843,6 +843,9 @@ def main():
                        f"pass, the rest right up to the barrier that opens the timed region) so that >= {SETTLE_STEPS} steps precede the timed ones: "
                        "the first ~10 steps after an idle GPU run 14 % slower",
         "ms_per_step": round(ms_step, 4), "timing_mode": timing_mode, "eager": eager,
+        # eager slower than the GPU-paced region by more than 3 %: the host, not the GPU, paced the eager region - its per-kernel HIP
+        # events (`roofline`, `roofline_k2`) then include the GPU's wait for late launches and read low
+        "eager_host_paced": (bool(eager["ms_per_step"] > 1.03 * graph["ms_per_step"]) if graph and "ms_per_step" in graph else None),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "precision_note": ("bf16 storage of patch-level tensors, f32 accumulation and f32 bag-level math: checked against the f32 kernels to ~2e-2 "
